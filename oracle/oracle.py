@@ -1,0 +1,162 @@
+"""ctypes wrapper of oracle/libplp_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (polytope_amd/) never does.
+
+Each function mirrors one C entry point of plp_oracle.c, which cites the reference
+file:line it restates (polytope/solvers.py, polytope/polytope.py, polytope/quickhull.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libplp_oracle.so")
+
+RF_EMPTY, RF_EARLY, RF_MINREP, RF_LPFAIL = 1, 2, 4, 8
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (a few hundred ms)."""
+    src = os.path.join(_HERE, "plp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.plpo_lp_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, ip]
+        L.plpo_lp_solve.restype = C.c_int
+        L.plpo_cheby.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, ip]
+        L.plpo_cheby.restype = C.c_int
+        L.plpo_bounding_box.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, ip]
+        L.plpo_bounding_box.restype = C.c_int
+        L.plpo_reduce.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double,
+                                  C.POINTER(C.c_uint64), dp, dp, dp, ip]
+        L.plpo_reduce.restype = C.c_int
+        L.plpo_contains.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int32),
+                                    C.c_int64, dp, C.c_double, C.POINTER(C.c_uint8)]
+        L.plpo_contains.restype = None
+        L.plpo_region_contains.argtypes = L.plpo_contains.argtypes
+        L.plpo_region_contains.restype = None
+        L.plpo_assign.argtypes = [C.c_int64, C.c_int, dp, C.c_int, dp, dp, C.c_double,
+                                  C.POINTER(C.c_int32), dp, C.POINTER(C.c_int64), dp]
+        L.plpo_assign.restype = None
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def lp_solve(c, G, h):
+    """min c'x s.t. Gx<=h, x free -> (status, x or None, fun or None, iters).  solvers.py:149-158."""
+    c, G, h = _d(c).ravel(), _d(G), _d(h).ravel()
+    n = c.size
+    G = G.reshape(-1, n)
+    m = G.shape[0]
+    x = np.empty(n)
+    fun = C.c_double()
+    it = C.c_int()
+    st = lib().plpo_lp_solve(m, n, _p(c), _p(G), _p(h), _p(x), C.byref(fun), C.byref(it))
+    if st != 0:
+        return st, None, None, it.value
+    return st, x, fun.value, it.value
+
+
+def cheby(A, b):
+    """Raw F1 LP of cheby_ball (polytope.py:1283-1288) -> (status, r, xc)."""
+    A, b = _d(A), _d(b).ravel()
+    m, d = A.shape
+    r = C.c_double()
+    xc = np.empty(d)
+    st = lib().plpo_cheby(m, d, _p(A), _p(b), C.byref(r), _p(xc), None)
+    return st, r.value, xc
+
+
+def cheby_ball(A, b):
+    """cheby_ball semantics (polytope.py:1289-1300): (r, xc) or (0.0, None)."""
+    st, r, xc = cheby(A, b)
+    if st != 0 or r < 0:
+        return 0.0, None
+    return r, xc
+
+
+def bounding_box(A, b):
+    """polytope.py:1367-1409 -> (lb, ub, bad_status)."""
+    A, b = _d(A), _d(b).ravel()
+    m, d = A.shape
+    lb, ub = np.empty(d), np.empty(d)
+    nlp = C.c_int(0)
+    bad = lib().plpo_bounding_box(m, d, _p(A), _p(b), _p(lb), _p(ub), C.byref(nlp))
+    return lb, ub, bad
+
+
+def reduce(A, b, abs_tol=1e-7):
+    """polytope.py:1053-1163 on one non-minrep polytope.
+
+    -> dict(keep=bool[m], flags, b=b values after the 0.1 round trip, r, xc, nlp)
+    """
+    A, b = _d(A), _d(b).ravel()
+    m, d = A.shape
+    keep = C.c_uint64(0)
+    bout = np.empty(max(m, 1))
+    r = C.c_double()
+    xc = np.empty(d)
+    nlp = C.c_int()
+    flags = lib().plpo_reduce(m, d, _p(A), _p(b), abs_tol, C.byref(keep), _p(bout),
+                              C.byref(r), _p(xc), C.byref(nlp))
+    mask = np.array([(keep.value >> i) & 1 for i in range(m)], dtype=bool)
+    return dict(keep=mask, mask=keep.value, flags=flags, b=bout[:m], r=r.value, xc=xc, nlp=nlp.value)
+
+
+def contains(A, b, X, abs_tol=1e-7, mrows=None, region=False):
+    """A:[P][m_max][d], b:[P][m_max], X:[N][d] point-major.
+
+    region=False -> uint8 [P][N]  (Polytope.contains, polytope.py:217-218)
+    region=True  -> uint8 [N]     (Region.contains, polytope.py:732-746)
+    """
+    A, b, X = _d(A), _d(b), _d(X)
+    P, m_max, d = A.shape
+    N = X.shape[0]
+    mr = None if mrows is None else np.ascontiguousarray(mrows, dtype=np.int32)
+    mp = None if mr is None else _p(mr, C.c_int32)
+    if region:
+        out = np.empty(N, dtype=np.uint8)
+        lib().plpo_region_contains(P, m_max, d, _p(A), _p(b), mp, N, _p(X), abs_tol, _p(out, C.c_uint8))
+    else:
+        out = np.empty((P, N), dtype=np.uint8)
+        lib().plpo_contains(P, m_max, d, _p(A), _p(b), mp, N, _p(X), abs_tol, _p(out, C.c_uint8))
+    return out
+
+
+def assign(X, normals, offsets, abs_tol=1e-7):
+    """quickhull outside-set assignment + furthest (quickhull.py:87-102,117-121,224-245).
+
+    -> (facet_of_point int32[N], dist f64[N], argmax int64[F], max f64[F])
+    """
+    X, normals, offsets = _d(X), _d(normals), _d(offsets).ravel()
+    N, d = X.shape
+    F = normals.shape[0]
+    fop = np.empty(N, dtype=np.int32)
+    dist = np.empty(N)
+    am = np.empty(F, dtype=np.int64)
+    mx = np.empty(F)
+    lib().plpo_assign(N, d, _p(X), F, _p(normals), _p(offsets), abs_tol,
+                      _p(fop, C.c_int32), _p(dist), _p(am, C.c_int64), _p(mx))
+    return fop, dist, am, mx

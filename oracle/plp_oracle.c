@@ -1,0 +1,482 @@
+/*
+ * plp_oracle.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C, scalar, FP64)
+ * of the batched small-LP hot path of tulip-control/polytope.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (polytope_amd/) never imports, links or calls it.
+ *
+ * What is restated, and from where (paths relative to /root/reference):
+ *
+ *   plpo_lp_solve      polytope/solvers.py:76-106 (lpsolve) and :149-158
+ *                      (_solve_lp_using_scipy):  min c'x  s.t. Gx <= h, x free,
+ *                      status codes 0/1/2/3/4 as scipy.optimize.linprog.
+ *                      The arithmetic of the reference lives in a third-party
+ *                      dependency that is NOT under /root/reference:
+ *                      scipy.optimize.linprog -> HiGHS (requirements/default.txt pins
+ *                      scipy==1.10.0; pyproject.toml:28-32 scipy>=1.10.0; this image has
+ *                      scipy 1.15.3).  HiGHS is a (dual revised) simplex code; the
+ *                      optimal value of an LP is unique, so what is restated here is the
+ *                      published textbook algorithm -- the two-phase primal simplex
+ *                      method in dictionary form (Chvatal, "Linear Programming", ch. 2-3,
+ *                      8: auxiliary variable x0 for phase 1, free variables enter and
+ *                      never leave) with Dantzig pricing and Bland's anti-cycling rule.
+ *                      Parity is pinned on golden vectors generated from the imported
+ *                      reference (tests/golden/make_golden.py).
+ *   plpo_cheby         polytope/polytope.py:1241-1300 (cheby_ball)       LP form F1
+ *   plpo_bounding_box  polytope/polytope.py:1314-1411 (bounding_box)     LP form F3
+ *   plpo_reduce        polytope/polytope.py:1053-1163 (reduce)           LP form F2
+ *   plpo_contains      polytope/polytope.py:206-218, :732-746 (contains)
+ *   plpo_assign        polytope/quickhull.py:117-121 (distance), :224-245 / :311-336
+ *                      (outside-set assignment), :87-102 (get_furthest)
+ *
+ * The pivot rules, tolerances and operation order of plpo_lp_solve are the ones the HIP
+ * kernels use (polytope_amd/csrc/plp_simplex.hpp) so that CPU and GPU walk the same
+ * vertex path; results are nevertheless compared with a tolerance (1e-9), never bitwise.
+ *
+ * Build:  make -C oracle      (gcc -O2 -ffp-contract=off -shared -fPIC)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PLPO_MAXM 64
+#define PLPO_MAXN 18 /* d+1 structural columns (<=17) + phase-1 artificial */
+
+#define TOL_D 1e-9     /* reduced-cost (dual feasibility) tolerance            */
+#define TOL_PIV 1e-9   /* smallest admissible pivot element                    */
+#define TOL_FEAS 1e-7  /* phase-1 infeasibility accepted (HiGHS primal tol)    */
+#define DEGEN_EPS 1e-12 /* step length regarded as degenerate                  */
+#define BLAND_AFTER 6  /* consecutive degenerate pivots before Bland's rule    */
+
+enum { ST_OPT = 0, ST_ITER = 1, ST_INFEAS = 2, ST_UNBND = 3, ST_NUM = 4 };
+
+/* Dictionary:  basic_i = beta[i] - sum_j T[i][j] * nb_j      (i < m, j < nc)
+ *              (-zeta) = negz    - sum_j cost[j] * nb_j      (minimise zeta)
+ * A second cost row (cost2/negz2) can be carried through the pivots (phase 1). */
+typedef struct {
+    int m, n, nc;
+    double T[PLPO_MAXM][PLPO_MAXN];
+    double beta[PLPO_MAXM];
+    double cost[PLPO_MAXN], negz;
+    double cost2[PLPO_MAXN], negz2;
+    int carry;
+    int rowvar[PLPO_MAXM]; /* id of the basic variable of row i            */
+    int colvar[PLPO_MAXN]; /* id of the nonbasic variable of column j      */
+    int rowsgn[PLPO_MAXM]; /* +-1 for a basic free variable                */
+    int colsgn[PLPO_MAXN];
+    int rowact[PLPO_MAXM]; /* row takes part in the ratio test             */
+    int coldead[PLPO_MAXN];
+    int iters, maxit;
+} dict_t;
+
+/* ids: 0..n-1 structural (free) x_j; n..n+m-1 slack of row i; -1 artificial t
+ * (lowest id, so that ties in the ratio test let t leave first, Chvatal p.41) */
+#define ID_T (-1)
+#define ISFREE(D, id) ((unsigned)(id) < (unsigned)(D)->n)
+
+static void pivot(dict_t *D, int r, int e)
+{
+    const int nc = D->nc, m = D->m;
+    double rho[PLPO_MAXN], rhob;
+    const double p = 1.0 / D->T[r][e];
+    for (int j = 0; j < nc; ++j) rho[j] = D->T[r][j] * p;
+    rho[e] = p;
+    rhob = D->beta[r] * p;
+    for (int i = 0; i < m; ++i) {
+        if (i == r) continue;
+        const double f = D->T[i][e];
+        D->T[i][e] = 0.0;
+        for (int j = 0; j < nc; ++j) D->T[i][j] = fma(-f, rho[j], D->T[i][j]);
+        D->beta[i] = fma(-f, rhob, D->beta[i]);
+    }
+    {
+        const double f = D->cost[e];
+        D->cost[e] = 0.0;
+        for (int j = 0; j < nc; ++j) D->cost[j] = fma(-f, rho[j], D->cost[j]);
+        D->negz = fma(-f, rhob, D->negz);
+    }
+    if (D->carry) {
+        const double f = D->cost2[e];
+        D->cost2[e] = 0.0;
+        for (int j = 0; j < nc; ++j) D->cost2[j] = fma(-f, rho[j], D->cost2[j]);
+        D->negz2 = fma(-f, rhob, D->negz2);
+    }
+    for (int j = 0; j < nc; ++j) D->T[r][j] = rho[j];
+    D->beta[r] = rhob;
+    /* swap variable bookkeeping */
+    const int vin = D->colvar[e], vout = D->rowvar[r];
+    const int sin_ = D->colsgn[e], sout = D->rowsgn[r];
+    D->rowvar[r] = vin;  D->rowsgn[r] = sin_;
+    D->colvar[e] = vout; D->colsgn[e] = sout;
+    D->rowact[r] = !ISFREE(D, vin); /* a free variable never leaves again */
+    D->iters++;
+}
+
+/* Primal simplex from a primal-feasible dictionary.  Returns ST_OPT/ST_UNBND/ST_ITER. */
+static int run(dict_t *D)
+{
+    int ndeg = 0;
+    for (;;) {
+        const int bland = (ndeg >= BLAND_AFTER);
+        int e = -1;
+        double best = 0.0;
+        int bestid = 0x7fffffff;
+        for (int j = 0; j < D->nc; ++j) {
+            if (D->coldead[j]) continue;
+            const double dj = D->cost[j];
+            const int isfree = ISFREE(D, D->colvar[j]);
+            const int elig = isfree ? (fabs(dj) > TOL_D) : (dj < -TOL_D);
+            if (!elig) continue;
+            if (bland) {
+                if (D->colvar[j] < bestid) { bestid = D->colvar[j]; e = j; }
+            } else {
+                if (fabs(dj) > best) { best = fabs(dj); e = j; }
+            }
+        }
+        if (e < 0) return ST_OPT;
+        if (D->iters >= D->maxit) return ST_ITER;
+        if (D->cost[e] > 0.0) { /* free variable entering downwards: x := -x */
+            for (int i = 0; i < D->m; ++i) D->T[i][e] = -D->T[i][e];
+            D->cost[e] = -D->cost[e];
+            if (D->carry) D->cost2[e] = -D->cost2[e];
+            D->colsgn[e] = -D->colsgn[e];
+        }
+        /* ratio test: min beta_i/T_ie over active rows with T_ie > TOL_PIV;
+           ties -> lowest basic-variable id */
+        int r = -1;
+        double rmin = INFINITY;
+        for (int i = 0; i < D->m; ++i) {
+            if (!D->rowact[i]) continue;
+            const double a = D->T[i][e];
+            if (!(a > TOL_PIV)) continue;
+            const double bi = D->beta[i] > 0.0 ? D->beta[i] : 0.0;
+            const double q = bi / a;
+            if (r < 0 || q < rmin || (q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
+        }
+        if (r < 0) return ST_UNBND;
+        ndeg = (rmin <= DEGEN_EPS) ? ndeg + 1 : 0;
+        pivot(D, r, e);
+    }
+}
+
+static void dict_init(dict_t *D, int m, int n)
+{
+    memset(D, 0, sizeof(*D));
+    D->m = m; D->n = n; D->nc = n;
+    for (int i = 0; i < m; ++i) { D->rowvar[i] = n + i; D->rowsgn[i] = 1; D->rowact[i] = 1; }
+    for (int j = 0; j < PLPO_MAXN; ++j) { D->colvar[j] = j; D->colsgn[j] = 1; }
+    D->maxit = 50 * (m + n) + 100;
+}
+
+static void extract_x(const dict_t *D, double *x)
+{
+    for (int j = 0; j < D->n; ++j) x[j] = 0.0;
+    for (int i = 0; i < D->m; ++i)
+        if (ISFREE(D, D->rowvar[i])) x[D->rowvar[i]] = D->rowsgn[i] * D->beta[i];
+}
+
+/* min c'x s.t. Gx<=h, x free.  G is m x n row-major.  x/fun written only for status 0
+ * (NaN otherwise).  solvers.py:149-158 semantics. */
+int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *h,
+                  double *x, double *fun, int *iters)
+{
+    static const double qnan = NAN;
+    dict_t D;
+    int st;
+    if (iters) *iters = 0;
+    for (int j = 0; j < n; ++j) x[j] = qnan;
+    *fun = qnan;
+    if (m > PLPO_MAXM || n > PLPO_MAXN - 1 || n < 1 || m < 0) return ST_NUM;
+    for (int j = 0; j < n; ++j) if (!isfinite(c[j])) return ST_NUM;
+    for (int i = 0; i < m; ++i) {
+        if (!isfinite(h[i])) return ST_NUM;
+        for (int j = 0; j < n; ++j) if (!isfinite(G[i * n + j])) return ST_NUM;
+    }
+    dict_init(&D, m, n);
+    int need_p1 = 0;
+    for (int i = 0; i < m; ++i) {
+        int zero = 1;
+        for (int j = 0; j < n; ++j) { D.T[i][j] = G[i * n + j]; if (G[i * n + j] != 0.0) zero = 0; }
+        D.beta[i] = h[i];
+        if (zero) { /* 0 <= h_i : vacuous or infeasible */
+            if (h[i] < -TOL_FEAS) return ST_INFEAS;
+            D.rowact[i] = 0; D.beta[i] = 0.0;
+            continue;
+        }
+        if (h[i] < 0.0) need_p1 = 1;
+    }
+    for (int j = 0; j < n; ++j) D.cost[j] = c[j];
+    if (need_p1) {
+        /* auxiliary problem: min t  s.t. Gx - t <= h, t >= 0 (Chvatal's x0) */
+        const int tc = n;
+        D.nc = n + 1;
+        D.colvar[tc] = ID_T;
+        for (int j = 0; j < n; ++j) { D.cost2[j] = D.cost[j]; D.cost[j] = 0.0; }
+        D.cost2[tc] = 0.0; D.cost[tc] = 1.0; D.carry = 1;
+        int r0 = -1;
+        for (int i = 0; i < m; ++i) {
+            if (!D.rowact[i]) continue;
+            D.T[i][tc] = -1.0;
+            if (r0 < 0 || D.beta[i] < D.beta[r0]) r0 = i;
+        }
+        pivot(&D, r0, tc);
+        st = run(&D);
+        if (st != ST_OPT) { if (iters) *iters = D.iters; return st == ST_ITER ? ST_ITER : ST_NUM; }
+        int rt = -1, ct = -1;
+        for (int i = 0; i < m; ++i) if (D.rowvar[i] == ID_T) rt = i;
+        for (int j = 0; j < D.nc; ++j) if (D.colvar[j] == ID_T) ct = j;
+        if (rt >= 0) {
+            if (D.beta[rt] > TOL_FEAS) { if (iters) *iters = D.iters; return ST_INFEAS; }
+            /* drive t out of the basis (degenerate pivot on the largest element) */
+            int e = -1; double big = TOL_PIV;
+            for (int j = 0; j < D.nc; ++j)
+                if (fabs(D.T[rt][j]) > big) { big = fabs(D.T[rt][j]); e = j; }
+            if (e >= 0) {
+                pivot(&D, rt, e);
+                if (!ISFREE(&D, D.rowvar[rt]) && D.beta[rt] < 0.0) D.beta[rt] = 0.0;
+                ct = e;
+            } else {
+                D.rowact[rt] = 0; /* 0 = t : redundant row */
+            }
+        }
+        if (ct >= 0) D.coldead[ct] = 1;
+        for (int i = 0; i < m; ++i) if (D.rowact[i] && D.beta[i] < 0.0) D.beta[i] = 0.0;
+        for (int j = 0; j < D.nc; ++j) D.cost[j] = D.cost2[j];
+        D.negz = D.negz2; D.carry = 0;
+    }
+    st = run(&D);
+    if (iters) *iters = D.iters;
+    if (st != ST_OPT) return st;
+    extract_x(&D, x);
+    double f = 0.0;
+    for (int j = 0; j < n; ++j) f = fma(c[j], x[j], f);
+    *fun = f;
+    return ST_OPT;
+}
+
+/* F1 (polytope.py:1283-1288): c = -e_{d+1}, G = [A | sqrt(sum(A*A,1))], h = b.
+ * Returns the raw LP status; r = x[-1], xc = x[:-1] (NaN unless status 0). */
+int plpo_cheby(int m, int d, const double *A, const double *b, double *r, double *xc, int *iters)
+{
+    double G[PLPO_MAXM * PLPO_MAXN], c[PLPO_MAXN], x[PLPO_MAXN], fun;
+    const int n = d + 1;
+    if (m > PLPO_MAXM || d > 16) return ST_NUM;
+    for (int i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) { G[i * n + k] = A[i * d + k]; s += A[i * d + k] * A[i * d + k]; }
+        G[i * n + d] = sqrt(s);
+    }
+    for (int k = 0; k < d; ++k) c[k] = 0.0;
+    c[d] = -1.0;
+    const int st = plpo_lp_solve(m, n, c, G, b, x, &fun, iters);
+    *r = x[d];
+    for (int k = 0; k < d; ++k) xc[k] = x[k];
+    return st;
+}
+
+/* F3 (polytope.py:1367-1409).  lb/ub get +-inf on status 3, 0 / lb on status 2.
+ * Returns 0, or the offending LP status (1/4) where the reference raises RuntimeError. */
+int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb, double *ub, int *nlp)
+{
+    double c[PLPO_MAXN], x[PLPO_MAXN], fun;
+    int bad = 0;
+    for (int i = 0; i < d; ++i) {
+        for (int k = 0; k < d; ++k) c[k] = 0.0;
+        c[i] = 1.0;
+        int st = plpo_lp_solve(m, d, c, A, b, x, &fun, NULL);
+        if (nlp) ++*nlp;
+        if (st == ST_OPT) lb[i] = x[i];
+        else if (st == ST_UNBND) lb[i] = -INFINITY;
+        else if (st == ST_INFEAS) lb[i] = 0.0;
+        else { lb[i] = NAN; bad = st; }
+    }
+    for (int i = 0; i < d; ++i) {
+        for (int k = 0; k < d; ++k) c[k] = 0.0;
+        c[i] = -1.0;
+        int st = plpo_lp_solve(m, d, c, A, b, x, &fun, NULL);
+        if (nlp) ++*nlp;
+        if (st == ST_OPT) ub[i] = x[i];
+        else if (st == ST_UNBND) ub[i] = INFINITY;
+        else if (st == ST_INFEAS) ub[i] = lb[i];
+        else { ub[i] = NAN; bad = st; }
+    }
+    return bad;
+}
+
+/* flags returned by plpo_reduce */
+#define RF_EMPTY 1    /* not full-dimensional: reference returns Polytope()       */
+#define RF_EARLY 2    /* returned at neq <= nx+1 (minrep stays False)             */
+#define RF_MINREP 4   /* went through the redundancy LPs (minrep = True)          */
+#define RF_LPFAIL 8   /* a bounding-box LP came back with status 1/4 (RuntimeError) */
+
+/* reduce (polytope.py:1053-1163) on ONE polytope that is not already minrep.
+ * keep: bit i set <=> input row i survives.  bout[i] = b value of row i as the
+ * reference would hand it to Polytope(...) (after the +0.1/-0.1 round trip).
+ * r/xc: the Chebyshev ball computed by is_fulldim (polytope.py:1081). */
+int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
+                uint64_t *keep, double *bout, double *r, double *xc, int *nlp)
+{
+    int idx[PLPO_MAXM], neq = 0, flags = 0;
+    double Aw[PLPO_MAXM * 16], bw[PLPO_MAXM];
+    *keep = 0; *nlp = 0;
+    for (int i = 0; i < m; ++i) bout[i] = b[i];
+    /* :1081 is_fulldim -> cheby_ball -> F1 */
+    int st = plpo_cheby(m, d, A, b, r, xc, NULL);
+    ++*nlp;
+    if (!(st == ST_OPT && *r >= 0.0)) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; }
+    if (!(*r > abs_tol)) return RF_EMPTY;
+    /* :1087-1089 drop rows with b == inf */
+    for (int i = 0; i < m; ++i) if (b[i] != INFINITY) idx[neq++] = i;
+    /* :1094-1110 parallel-row dedupe */
+    {
+        double an[PLPO_MAXM], nrm[PLPO_MAXM * 16];
+        int rem[PLPO_MAXM];
+        for (int p = 0; p < neq; ++p) {
+            const double *a = A + idx[p] * d;
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += a[k] * a[k];
+            an[p] = 1.0 / sqrt(s);
+            for (int k = 0; k < d; ++k) nrm[p * d + k] = a[k] * an[p];
+            rem[p] = 0;
+        }
+        for (int p = 0; p < neq; ++p)
+            for (int q = p + 1; q < neq; ++q) {
+                double dot = 0.0;
+                for (int k = 0; k < d; ++k) dot += nrm[p * d + k] * nrm[q * d + k];
+                if (dot > 1.0 - abs_tol) {
+                    const double bp = b[idx[p]] * an[p], bq = b[idx[q]] * an[q];
+                    if (bp < bq) rem[q] = 1; else rem[p] = 1;
+                }
+            }
+        int k2 = 0;
+        for (int p = 0; p < neq; ++p) if (!rem[p]) idx[k2++] = idx[p];
+        neq = k2;
+    }
+    /* :1114-1116 */
+    if (neq <= d + 1) {
+        for (int p = 0; p < neq; ++p) *keep |= (uint64_t)1 << idx[p];
+        return RF_EARLY;
+    }
+    for (int p = 0; p < neq; ++p) {
+        for (int k = 0; k < d; ++k) Aw[p * d + k] = A[idx[p] * d + k];
+        bw[p] = b[idx[p]];
+    }
+    /* :1118-1134 bounding-box prefilter */
+    if (neq > 3 * d) {
+        double lb[16], ub[16];
+        if (plpo_bounding_box(neq, d, Aw, bw, lb, ub, nlp)) flags |= RF_LPFAIL;
+        int k2 = 0;
+        for (int p = 0; p < neq; ++p) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double a = Aw[p * d + k];
+                const double pa = (a > 0.0 ? 1.0 : 0.0) * a;
+                s1 += pa * (ub[k] - lb[k]);
+                s2 += a * lb[k];
+            }
+            const int out = (s1 - (bw[p] - s2)) < -1e-4;
+            if (!out) {
+                idx[k2] = idx[p];
+                for (int k = 0; k < d; ++k) Aw[k2 * d + k] = Aw[p * d + k];
+                bw[k2] = bw[p];
+                ++k2;
+            }
+        }
+        neq = k2;
+    }
+    /* :1136-1138 */
+    if (neq <= d + 1) {
+        for (int p = 0; p < neq; ++p) *keep |= (uint64_t)1 << idx[p];
+        return flags | RF_EARLY;
+    }
+    /* :1142-1160 one redundancy LP per row; h[k] +0.1 / -0.1 round trip persists */
+    for (int k = 0; k < neq; ++k) {
+        double c[16], x[16], fun;
+        for (int j = 0; j < d; ++j) c[j] = -Aw[k * d + j];
+        bw[k] += 0.1;
+        st = plpo_lp_solve(neq, d, c, Aw, bw, x, &fun, NULL);
+        ++*nlp;
+        bw[k] -= 0.1;
+        if (st == ST_OPT) {
+            const double obj = -fun - bw[k];
+            if (obj > abs_tol) *keep |= (uint64_t)1 << idx[k];
+        } else if (st == ST_UNBND) {
+            *keep |= (uint64_t)1 << idx[k];
+        }
+        bout[idx[k]] = bw[k];
+    }
+    return flags | RF_MINREP;
+}
+
+/* contains (polytope.py:217-218): out[p*N + q] = all_i( A_p[i,:].X[:,q] - b_p[i] < tol ).
+ * X is [N][d] (point-major).  The dot product is a k-ordered fma chain, like the kernel. */
+void plpo_contains(int P, int m_max, int d, const double *A, const double *b, const int32_t *mrows,
+                   int64_t N, const double *X, double abs_tol, uint8_t *out)
+{
+    for (int p = 0; p < P; ++p) {
+        const int m = mrows ? mrows[p] : m_max;
+        const double *Ap = A + (size_t)p * m_max * d, *bp = b + (size_t)p * m_max;
+        for (int64_t q = 0; q < N; ++q) {
+            const double *x = X + q * d;
+            int ok = 1;
+            for (int i = 0; i < m; ++i) {
+                double s = Ap[i * d] * x[0];
+                for (int k = 1; k < d; ++k) s = fma(Ap[i * d + k], x[k], s);
+                if (!(s - bp[i] < abs_tol)) ok = 0;
+            }
+            out[(size_t)p * N + q] = (uint8_t)ok;
+        }
+    }
+}
+
+/* Region.contains (polytope.py:732-746): OR over polytopes. */
+void plpo_region_contains(int P, int m_max, int d, const double *A, const double *b, const int32_t *mrows,
+                          int64_t N, const double *X, double abs_tol, uint8_t *out)
+{
+    for (int64_t q = 0; q < N; ++q) out[q] = 0;
+    for (int p = 0; p < P; ++p) {
+        const int m = mrows ? mrows[p] : m_max;
+        const double *Ap = A + (size_t)p * m_max * d, *bp = b + (size_t)p * m_max;
+        for (int64_t q = 0; q < N; ++q) {
+            if (out[q]) continue;
+            const double *x = X + q * d;
+            int ok = 1;
+            for (int i = 0; i < m && ok; ++i) {
+                double s = Ap[i * d] * x[0];
+                for (int k = 1; k < d; ++k) s = fma(Ap[i * d + k], x[k], s);
+                if (!(s - bp[i] < abs_tol)) ok = 0;
+            }
+            if (ok) out[q] = 1;
+        }
+    }
+}
+
+/* quickhull outside-set assignment + furthest point.
+ * distance (quickhull.py:117-121): sum(n*p) - d0 ; assignment (:224-245, :311-336): a point
+ * goes to the FIRST facet (list order) with dist > abs_tol; get_furthest (:87-102): arg-max
+ * with strict '<' (first maximum wins).  facet_of_point = -1 when inside all facets.
+ * The dot product is accumulated in k order without fma (numpy's sum(n*p)). */
+void plpo_assign(int64_t N, int d, const double *X, int F, const double *normals, const double *offsets,
+                 double abs_tol, int32_t *facet_of_point, double *dist, int64_t *argmax_per_facet,
+                 double *max_per_facet)
+{
+    for (int f = 0; f < F; ++f) { argmax_per_facet[f] = -1; max_per_facet[f] = -INFINITY; }
+    for (int64_t q = 0; q < N; ++q) {
+        const double *x = X + q * d;
+        facet_of_point[q] = -1; dist[q] = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const double *nf = normals + (size_t)f * d;
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += nf[k] * x[k];
+            const double dd = s - offsets[f];
+            if (dd > abs_tol) {
+                facet_of_point[q] = f; dist[q] = dd;
+                if (argmax_per_facet[f] < 0 || max_per_facet[f] < dd) { argmax_per_facet[f] = q; max_per_facet[f] = dd; }
+                break;
+            }
+        }
+    }
+}
+
+int plpo_version(void) { return 1; }

@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports tulip-control/polytope read-only from /root/reference (scipy/HiGHS backend --
+cvxopt/GLPK is not installed in this image), calls the reference's own functions on seeded
+inputs and stores inputs + outputs as small .npz files.  Fixtures are data only; no
+reference source is copied.
+
+Sets:
+  g1_lp.npz        raw lpsolve() triples for the LP forms F1/F2/F3 + generic       (solvers.py:76-106)
+  g2_reduce.npz    reduce(): kept-row masks, reduced (A,b), Chebyshev radius        (polytope.py:1053-1163)
+  g3_edge.npz      edge cases of SURVEY A.4 through cheby_ball / bounding_box / lpsolve
+  g4_contains.npz  Polytope.contains / Region.contains incl. boundary points        (polytope.py:206-218,732-746)
+  g6_quickhull.npz Facet normals/offsets, distance(), first-facet assignment,
+                   get_furthest, and end-to-end hull facet sets                     (quickhull.py)
+  g7_known.npz     the known-answer data of the reference's own tests (tests/polytope_test.py)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import polytope as pc  # noqa: E402  (the reference)
+import polytope.polytope as alg  # noqa: E402
+from polytope import solvers  # noqa: E402
+from polytope import quickhull as qh  # noqa: E402
+from scipy.optimize import linprog  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+assert solvers.default_solver == "scipy", solvers.default_solver
+
+
+def rand_hpoly(rng, m, d, bounded=True):
+    """Rows tangent to spheres of radius 1..2 (origin strictly inside)."""
+    A = rng.standard_normal((m, d))
+    A /= np.linalg.norm(A, axis=1)[:, None]
+    b = 1.0 + rng.random(m)
+    if bounded and m >= 2 * d:
+        A[:2 * d] = np.vstack([np.eye(d), -np.eye(d)])
+        b[:2 * d] = 3.0
+    return A, b
+
+
+def pad(rows, width):
+    out = np.full((len(rows), width), np.nan)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return out
+
+
+# ----------------------------------------------------------------------------- G1
+def gen_g1():
+    rng = np.random.default_rng(20260928)
+    recs = []
+    for (m, d) in [(10, 2), (16, 3), (32, 6), (64, 16), (5, 3), (7, 1)]:
+        for t in range(48):
+            A, b = rand_hpoly(rng, m, d, bounded=(t % 4 != 0))
+            G1 = np.c_[A, np.sqrt(np.sum(A * A, axis=1))]
+            c1 = -np.r_[np.zeros(d), 1.0]
+            k = int(rng.integers(m))
+            h2 = b.copy()
+            h2[k] += 0.1
+            i = int(rng.integers(d))
+            e = np.zeros(d)
+            e[i] = rng.choice([-1.0, 1.0])
+            x0 = rng.standard_normal(d) * 2
+            h4 = A @ x0 + rng.random(m) * rng.choice([1.0, 1.0, 1.0, -0.05])
+            for form, (c, G, h) in enumerate(
+                    [(c1, G1, b), (-A[k], A, h2), (e, A, b), (rng.standard_normal(d), A, h4)]):
+                sol = solvers.lpsolve(c, G, h)
+                s_np = linprog(c, G, h, None, None, bounds=(None, None), options={"presolve": False})
+                recs.append(dict(form=form + 1, m=m, n=G.shape[1], c=c, G=G, h=h,
+                                 status=sol["status"], status_nopresolve=s_np.status,
+                                 fun=np.nan if sol["fun"] is None else sol["fun"],
+                                 x=np.full(G.shape[1], np.nan) if sol["x"] is None else sol["x"]))
+    N = len(recs)
+    out = dict(
+        form=np.array([r["form"] for r in recs], np.int32),
+        m=np.array([r["m"] for r in recs], np.int32),
+        n=np.array([r["n"] for r in recs], np.int32),
+        status=np.array([r["status"] for r in recs], np.int32),
+        status_nopresolve=np.array([r["status_nopresolve"] for r in recs], np.int32),
+        fun=np.array([r["fun"] for r in recs]),
+        c=pad([r["c"] for r in recs], 17),
+        x=pad([r["x"] for r in recs], 17),
+        h=pad([r["h"] for r in recs], 64),
+        G=pad([r["G"].ravel() for r in recs], 64 * 17),
+    )
+    np.savez_compressed(os.path.join(HERE, "g1_lp.npz"), **out)
+    print("g1:", N, "LPs; status histogram", np.bincount(out["status"]))
+
+
+# ----------------------------------------------------------------------------- G2
+def match_rows(Ain, bin_, Aout, bout):
+    """Indices of the input rows the reference kept (see module docstring of the tests:
+    exact duplicates resolve to the LAST index, as the dedupe at polytope.py:1104-1109 does)."""
+    nin = np.sqrt(np.sum(Ain * Ain, axis=1))
+    An = Ain / nin[:, None]
+    bn = bin_ / nin
+    used = []
+    for a, bb in zip(Aout, bout):
+        err = np.abs(An - a).sum(axis=1) + np.abs(bn - bb)
+        cand = np.nonzero(err < 1e-9)[0]
+        cand = [c for c in cand if c not in used]
+        assert len(cand) >= 1, (a, bb, err.min())
+        used.append(cand[-1])
+    return sorted(used)
+
+
+def structured_polys(rng):
+    out = []
+    # the reference's own test_reduce data (tests/polytope_test.py:601-622)
+    out.append((np.array([[1.0, 0.1], [1.0, 0.1], [-1.0, 0.0], [0.0, 1.0], [0.0, -1.0]]),
+                np.array([50.0, 50.5, -40.0, 1.0, 0.0])))
+    # boxes with duplicated / scaled-duplicate rows
+    for d in (2, 3, 4):
+        I = np.vstack([np.eye(d), -np.eye(d)])
+        b = np.r_[np.ones(d), np.zeros(d)]
+        out.append((np.vstack([I, I]), np.r_[b, b]))
+        out.append((np.vstack([I, 2 * I]), np.r_[b, 2 * b + 0.5]))
+        out.append((np.vstack([I, I[::-1]]), np.r_[b, b[::-1] + 1e-9]))
+    # stacked overlapping / touching squares (Polytope.intersect stacks rows, polytope.py:270-273)
+    sq = np.vstack([np.eye(2), -np.eye(2)])
+    for off in (0.0, 0.25, 0.5, 1.0 - 1e-6):
+        out.append((np.vstack([sq, sq]), np.r_[1, 1, 0, 0, 1 + off, 1 + off, -off, -off].astype(float)))
+    # box cut by random redundant and non-redundant planes
+    for d in (2, 3, 5):
+        for _ in range(4):
+            I = np.vstack([np.eye(d), -np.eye(d)])
+            R = rng.standard_normal((3 * d, d))
+            R /= np.linalg.norm(R, axis=1)[:, None]
+            bb = np.r_[np.ones(2 * d), rng.uniform(0.3, 2.5, 3 * d)]
+            out.append((np.vstack([I, R]), bb))
+    # simplex-like polytopes with m <= d+1 and m = d+2
+    for d in (2, 3, 4):
+        A = np.vstack([-np.eye(d), np.ones((1, d))])
+        out.append((A, np.r_[np.zeros(d), 1.0]))
+        out.append((np.vstack([A, np.ones((1, d))]), np.r_[np.zeros(d), 1.0, 2.0]))
+    # empty / flat polytopes
+    out.append((np.vstack([sq]), np.array([1.0, 1.0, -2.0, 0.0])))
+    out.append((np.vstack([sq]), np.array([1.0, 1.0, -1.0, 0.0])))
+    return out
+
+
+def gen_g2():
+    rng = np.random.default_rng(77)
+    polys = []
+    for (m, d, cnt) in [(16, 3, 64), (10, 2, 48), (24, 4, 32), (32, 6, 24), (64, 16, 6), (40, 3, 16)]:
+        for t in range(cnt):
+            polys.append(rand_hpoly(rng, m, d, bounded=(t % 8 != 7)))
+    polys += structured_polys(rng)
+    recs = []
+    for (A, b) in polys:
+        p = pc.Polytope(A.copy(), b.copy())  # normalises (polytope.py:128-138)
+        An, bn = p.A.copy(), p.b.copy()
+        q = pc.reduce(p)
+        m = An.shape[0]
+        if q.A.size == 0:
+            kept = []
+        else:
+            kept = match_rows(An, bn, q.A, q.b)
+        mask = np.zeros(64, bool)
+        mask[kept] = True
+        recs.append(dict(m=m, d=An.shape[1], A=An, b=bn, mask=mask, empty=(q.A.size == 0),
+                         minrep=bool(q.minrep), r=float(p._chebR),
+                         Aout=q.A, bout=q.b))
+    out = dict(
+        m=np.array([r["m"] for r in recs], np.int32),
+        d=np.array([r["d"] for r in recs], np.int32),
+        A=pad([r["A"].ravel() for r in recs], 64 * 16),
+        b=pad([r["b"] for r in recs], 64),
+        mask=np.array([r["mask"] for r in recs]),
+        empty=np.array([r["empty"] for r in recs]),
+        minrep=np.array([r["minrep"] for r in recs]),
+        r=np.array([r["r"] for r in recs]),
+        Aout=pad([r["Aout"].ravel() for r in recs], 64 * 16),
+        bout=pad([r["bout"] for r in recs], 64),
+    )
+    np.savez_compressed(os.path.join(HERE, "g2_reduce.npz"), **out)
+    print("g2:", len(recs), "polytopes; empty", int(out["empty"].sum()), "minrep", int(out["minrep"].sum()),
+          "mean kept", out["mask"].sum(1).mean())
+
+
+# ----------------------------------------------------------------------------- G3
+def gen_g3():
+    cases = {
+        "halfspace": (np.array([[1.0, 0.0]]), np.array([1.0])),
+        "cone": (np.array([[1.0, 0.0], [0.0, 1.0]]), np.array([1.0, 1.0])),
+        "slab": (np.array([[1.0, 0.0], [-1.0, 0.0]]), np.array([1.0, 1.0])),
+        "infeasible_box": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([1.0, -2.0, 1.0, 1.0])),
+        "rectangle": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([2.0, 0.0, 1.0, 0.0])),
+        "unit_square": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([1.0, 0.0, 1.0, 0.0])),
+        "flat": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([1.0, -1.0, 1.0, 0.0])),
+        "triangle": (np.array([[-1.0, 0], [0, -1.0], [1.0, 1.0]]), np.array([0.0, 0.0, 1.0])),
+        "interval_1d": (np.array([[1.0], [-1.0]]), np.array([1.0, 0.0])),
+        "shifted_big": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([1e3 + 1, -1e3, 5e2 + 1, -5e2])),
+        "thin_slab_2e-7": (np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]), np.array([1 + 1e-7, -1 + 1e-7, 1.0, 0.0])),
+    }
+    out = {}
+    names = []
+    for name, (A, b) in cases.items():
+        p = pc.Polytope(A.copy(), b.copy())
+        r, xc = pc.cheby_ball(p)
+        G = np.c_[p.A, np.sqrt(np.sum(p.A * p.A, axis=1))]
+        sol = solvers.lpsolve(-np.r_[np.zeros(p.dim), 1.0], G, p.b)
+        p2 = pc.Polytope(A.copy(), b.copy())
+        lb, ub = pc.bounding_box(p2)
+        names.append(name)
+        out[name + "_A"] = p.A
+        out[name + "_b"] = p.b
+        out[name + "_r"] = np.float64(r)
+        out[name + "_xc"] = np.full(p.dim, np.nan) if xc is None else np.asarray(xc, float)
+        out[name + "_f1status"] = np.int32(sol["status"])
+        out[name + "_lb"] = lb.ravel()
+        out[name + "_ub"] = ub.ravel()
+        out[name + "_fulldim"] = np.bool_(pc.is_fulldim(pc.Polytope(A.copy(), b.copy())))
+    out["names"] = np.array(names)
+    # empty polytope object
+    r, xc = pc.cheby_ball(pc.Polytope())
+    out["emptyobj_r"] = np.float64(r)
+    np.savez_compressed(os.path.join(HERE, "g3_edge.npz"), **out)
+    print("g3:", len(names), "edge cases")
+
+
+# ----------------------------------------------------------------------------- G4
+def gen_g4():
+    rng = np.random.default_rng(4)
+    P, d, m = 16, 3, 12
+    A = np.zeros((P, m, d))
+    b = np.zeros((P, m))
+    for p in range(P):
+        Ap, bp = rand_hpoly(rng, m, d)
+        cen = rng.uniform(-1, 1, d)
+        bp = bp * 0.5 + Ap @ cen
+        pp = pc.Polytope(Ap, bp)
+        A[p], b[p] = pp.A, pp.b
+    N = 4096
+    X = rng.uniform(-2.5, 2.5, (d, N))
+    # boundary points: project some points onto facets exactly-ish
+    for q in range(0, 512):
+        p = q % P
+        i = q % m
+        x = X[:, q]
+        x = x - (A[p, i] @ x - b[p, i]) * A[p, i]
+        X[:, q] = x
+    tols = np.array([0.0, 1e-7, 0.01, 1.2])
+    res = np.zeros((len(tols), P, N), bool)
+    reg = np.zeros((len(tols), N), bool)
+    polys = [pc.Polytope(A[p], b[p], normalize=False) for p in range(P)]
+    region = pc.Region(polys)
+    for ti, tol in enumerate(tols):
+        for p in range(P):
+            res[ti, p] = polys[p].contains(X, abs_tol=tol)
+        reg[ti] = region.contains(X, abs_tol=tol)
+    # axis-aligned box with exact boundary points (region_contains_test, polytope_test.py:261-277)
+    box = pc.box2poly([[0.0, 1.0], [0.0, 2.0]])
+    Xb = np.array([[-1.0, 0.0, 0.5, 1.0, 2.0, 0.0, 1.0, 0.5], [1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 2.0, 2.0 + 1e-7]])
+    boxres = np.array([box.contains(Xb, abs_tol=t) for t in tols])
+    np.savez_compressed(os.path.join(HERE, "g4_contains.npz"), A=A, b=b, X=X, tols=tols, res=res, reg=reg,
+                        boxA=box.A, boxb=box.b, Xb=Xb, boxres=boxres)
+    print("g4: contains", res.shape, "inside fraction", res.mean())
+
+
+# ----------------------------------------------------------------------------- G6
+def gen_g6():
+    rng = np.random.default_rng(6)
+    out = {}
+    for d in (2, 3, 5, 8):
+        # a reference-style start simplex: d+1 points, centred, one Facet per omitted vertex (quickhull.py:188-199)
+        S = rng.standard_normal((d + 1, d))
+        xc = S.mean(axis=0)
+        S0 = S - xc
+        normals, offsets = [], []
+        facets = []
+        for i in range(d + 1):
+            ind = np.setdiff1d(np.arange(d + 1), [i])
+            f = qh.Facet(S0[ind, :])
+            facets.append(f)
+            normals.append(np.asarray(f.normal).ravel())
+            offsets.append(float(np.asarray(f.distance).ravel()[0]))
+        normals, offsets = np.array(normals), np.array(offsets)
+        N = 2048
+        X = rng.standard_normal((N, d)) * 1.5 - xc
+        dist_all = np.array([[float(qh.distance(X[q], f)) for f in facets] for q in range(N)])
+        # first-facet assignment (quickhull.py:224-245) and get_furthest (:87-102)
+        fop = np.full(N, -1, np.int32)
+        dist = np.zeros(N)
+        for q in range(N):
+            for fi in range(d + 1):
+                if dist_all[q, fi] > 1e-7:
+                    fop[q] = fi
+                    dist[q] = dist_all[q, fi]
+                    break
+        argmax = np.full(d + 1, -1, np.int64)
+        for fi, f in enumerate(facets):
+            f.outside = [qh.Outside_point(X[q], dist[q]) for q in range(N) if fop[q] == fi]
+            idx = [q for q in range(N) if fop[q] == fi]
+            if idx:
+                pfar = f.get_furthest()
+                # identify by coordinates
+                hit = [q for q in idx if np.array_equal(X[q], pfar.coordinates)]
+                argmax[fi] = hit[0]
+        out[f"d{d}_simplex"] = S0
+        out[f"d{d}_normals"] = normals
+        out[f"d{d}_offsets"] = offsets
+        out[f"d{d}_X"] = X
+        out[f"d{d}_distall"] = dist_all
+        out[f"d{d}_fop"] = fop
+        out[f"d{d}_dist"] = dist
+        out[f"d{d}_argmax"] = argmax
+    # end-to-end hulls (facet sets canonicalised by sorting rounded [A|b] rows)
+    for (d, n) in [(2, 200), (3, 300), (4, 120)]:
+        P = rng.random((n, d))
+        np.random.seed(123)
+        A, b, V = qh.quickhull(P)
+        Ab = np.c_[A, b]
+        Ab = Ab[np.lexsort(np.round(Ab, 9).T[::-1])]
+        out[f"hull{d}_P"] = P
+        out[f"hull{d}_Ab"] = Ab
+        out[f"hull{d}_V"] = V
+    np.savez_compressed(os.path.join(HERE, "g6_quickhull.npz"), **out)
+    print("g6: quickhull vectors for d=2,3,5,8 and hulls d=2,3,4")
+
+
+# ----------------------------------------------------------------------------- G7
+def gen_g7():
+    out = {}
+    # test_lpsolve / test_lpsolve_solver_selection_scipy (polytope_test.py:510-548)
+    r = solvers.lpsolve(np.array([1.0]), np.array([[-1.0]]), np.array([1.0]), solver="scipy")
+    out["lp1d_x"] = r["x"]
+    r = solvers.lpsolve(np.array([1.0, 1.0]), np.array([[-1.0, 0], [0, -1.0]]), np.array([1.0, 1.0]))
+    out["lp2d_x"] = r["x"]
+    # test_reduce (polytope_test.py:601-622)
+    a = np.array([[1.0, 0.1], [1.0, 0.1], [-1.0, 0.0], [0.0, 1.0], [0.0, -1.0]])
+    b = np.array([50.0, 50.5, -40.0, 1.0, 0.0])
+    p2 = pc.reduce(pc.Polytope(a, b))
+    l, u = p2.bounding_box
+    out["reduce_a"], out["reduce_b"], out["reduce_l"], out["reduce_u"] = a, b, l, u
+    out["reduce_Aout"], out["reduce_bout"] = p2.A, p2.b
+    # operations_test fixtures (polytope_test.py:57-88): unit squares; fulldim / intersect
+    A = np.array([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0], [0.0, -1.0]])
+    bb = np.array([1.0, 1.0, 0.0, 0.0])
+    Ab2 = np.array([[-1.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 1.0], [0.0, -1.0, 0.0]])
+    p1 = pc.Polytope(A, bb)
+    p2 = pc.Polytope(Ab2[:, 0:2], Ab2[:, 2])
+    p3 = p1.intersect(p2)
+    p4 = pc.Polytope(np.array([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0], [0.0, -1.0]]), np.array([0.5, 0.5, 0.5, 0.5]))
+    p5 = p2.intersect(p4)
+    out["sq_A"], out["sq_b"], out["sq_Ab2"] = A, bb, Ab2
+    out["sq_fulldim"] = np.array([pc.is_fulldim(p1), pc.is_fulldim(p2), pc.is_fulldim(pc.Polytope()),
+                                  pc.is_fulldim(pc.Polytope(A, bb - 1e3)), pc.is_fulldim(p3),
+                                  pc.is_fulldim(p4), pc.is_fulldim(p5)])
+    out["sq_p5_A"], out["sq_p5_b"] = p5.A, p5.b
+    out["sq_cheb"] = np.r_[p1.chebR, p1.chebXc, p2.chebR, p2.chebXc, p4.chebR, p4.chebXc]
+    # is_inside_test (polytope_test.py:279-296)
+    box = pc.Polytope.from_box([[0.0, 1.0], [0.0, 2.0]])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out["inside"] = np.array([
+            pc.is_inside(box, np.array([0.0, 1.0])), pc.is_inside(box, np.array([0.0, 1.0]), 0.01),
+            pc.is_inside(box, np.array([2.0, 0.0])), pc.is_inside(box, np.array([2.0, 0.0]), 0.01),
+            pc.is_inside(box, np.array([2.0, 0.0]), 1.2)])
+    # test_bounding_box_to_polytope boxes (polytope_test.py:299-312)
+    for i, iv in enumerate([[[0, 1]], [[0, 1], [0, 2]], [[-1, 2], [3, 5], [-5, -3]]]):
+        p = pc.box2poly(iv)
+        l, u = p.bounding_box
+        out[f"bbox{i}_A"], out[f"bbox{i}_b"], out[f"bbox{i}_l"], out[f"bbox{i}_u"] = p.A, p.b, l, u
+    np.savez_compressed(os.path.join(HERE, "g7_known.npz"), **out)
+    print("g7: known-answer data")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    for w in which:
+        globals()["gen_" + w]()
