@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- LP solves/sec of the fused reduce() hot path on N MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+    batch of 100 000 random H-polytopes, d=3, m=16 facets; one step = one pass of
+    reduce() over the whole batch = for every polytope 1 Chebyshev LP (F1) + 2d bounding-box
+    LPs (F3) + one redundancy LP (F2) per row that survives dedupe/prefilter
+    (reference: polytope/polytope.py:1053-1163).  value = LPs solved per second; the LP
+    count is the number of lpsolve() calls the reference would issue on the same input
+    (returned by the kernel as nlp[] and checked against the oracle in tests/).
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]; for N>1 under
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU; every rank reduces its own 100k-polytope shard (weak scaling) and the
+step ends with the RCCL all-gather of the packed results (24 B per polytope).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_PER_GPU, M_ROWS, DIM = 100000, 16, 3
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(A, b, nlp_per_poly):
+    """Rank 0, N=1 only.  (i) the C oracle ('port') on a bounded sample of the same batch,
+    one core; (ii) scipy.optimize.linprog called exactly as polytope/solvers.py:152-154 on
+    the redundancy LPs of a smaller sample, 1 process and all cores."""
+    import numpy as np
+    from oracle import oracle as O
+    O.build()
+    n = 4000
+    t0 = time.perf_counter()
+    lps = 0
+    for k in range(n):
+        lps += O.reduce(A[k], b[k])["nlp"]
+    t_or = time.perf_counter() - t0
+    out = {"value": lps / t_or, "unit": "LP/s", "cores": 1, "kind": "port",
+           "sample": "oracle/plp_oracle.c reduce() on the first %d polytopes of the same batch (%d LPs, %.1f s)"
+                     % (n, lps, t_or)}
+    try:
+        from scipy.optimize import linprog
+        ns = 40
+        t0 = time.perf_counter()
+        cnt = 0
+        for k in range(ns):
+            Ak, bk = A[k], b[k].copy()
+            for row in range(M_ROWS):
+                h = bk.copy()
+                h[row] += 0.1
+                linprog(-Ak[row], Ak, h, None, None, bounds=(None, None))
+                cnt += 1
+        t1 = time.perf_counter() - t0
+        out["scipy_linprog_1proc_lp_per_s"] = cnt / t1
+        import multiprocessing as mp
+        ncpu = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", "1")
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+        chunks = [(A[k], b[k]) for k in range(ns, ns + 8 * ncpu)]
+        with mp.get_context("fork").Pool(ncpu) as pool:
+            t0 = time.perf_counter()
+            res = pool.map(_scipy_chunk, chunks, chunksize=1)
+            t2 = time.perf_counter() - t0
+        out["scipy_linprog_allcores_lp_per_s"] = sum(res) / t2
+        out["scipy_cores"] = ncpu
+        out["sample"] += "; scipy.optimize.linprog (HiGHS) on the F2 LPs of %d (1 proc) / %d (%d procs) polytopes" % (
+            ns, len(chunks), ncpu)
+    except Exception as e:  # scipy is the reference's own backend; report, never fail the bench on it
+        out["scipy_error"] = repr(e)
+    return out
+
+
+def _scipy_chunk(args):
+    from scipy.optimize import linprog
+    Ak, bk = args
+    cnt = 0
+    for row in range(Ak.shape[0]):
+        h = bk.copy()
+        h[row] += 0.1
+        linprog(-Ak[row], Ak, h, None, None, bounds=(None, None))
+        cnt += 1
+    return cnt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import polytope_amd as pa
+    from polytope_amd import _lib
+    from polytope_amd.dist import pack_results, allgather_packed
+    from polytope_amd.synth import random_hpolytopes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available() or not _lib.available():
+        raise SystemExit("bench.py needs a MI355X and polytope_amd/libplp_hip.so (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    A, b = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=0, stream=rank)
+    At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+    counts = [B_PER_GPU] * world
+
+    def step():
+        res = pa.reduce_batch(At, bt)  # one fused kernel on torch's current stream
+        if world > 1:
+            return res, allgather_packed(torch, dist, pack_results(torch, res), counts)
+        return res, None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        res = pa.reduce_batch(At, bt)
+        ev[k][1].record()  # brackets exactly the reduce kernel on the stream it is launched on
+        if world > 1:
+            gathered = allgather_packed(torch, dist, pack_results(torch, res), counts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / args.steps
+    nlp_local = int(res["nlp"].sum().item())
+    nlp_total = nlp_local
+    if world > 1:
+        t = torch.tensor([nlp_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        nlp_total = int(t.item())
+        assert gathered.shape[0] == world * B_PER_GPU
+
+    if rank == 0:
+        alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "LP solves/sec (batched Chebyshev + redundancy)",
+            "value": nlp_total * args.steps / elapsed,
+            "unit": "LP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1])"
+                                   % (B_PER_GPU, DIM, M_ROWS),
+                       "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU,
+                       "parallelism": "batch-sharded x%d + all-gather of packed results" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "reduce_kernel<3>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "FP64-VALU/latency bound: %.3g LP/s inside the kernel"
+                                 % (nlp_local / (kern_ms * 1e-3))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(A, b, None)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

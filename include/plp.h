@@ -1,0 +1,140 @@
+/*
+ * plp.h -- C ABI of libplp_hip.so: the MI355X (gfx950) engine for the batched small-LP hot
+ * path of tulip-control/polytope.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference is pure Python and has no FFI of its own; the boundary this library sits
+ * behind is the reference's solver plug-in surface and the numpy kernels listed below
+ * (paths relative to the reference checkout).  Each entry point cites what it replaces.
+ *
+ * Conventions
+ *   - all floating point data is IEEE binary64 ("double"), C-contiguous, caller-owned;
+ *     nothing is retained after a call returns (reduce() passes aliases of arrays it
+ *     mutates around the call: polytope/polytope.py:1146-1151).
+ *   - a batch of polytopes is packed as A[B][m_max][d], b[B][m_max] with an optional
+ *     int32 m[B] (rows actually used, <= m_max; NULL = all m_max).  m_max <= 64, d <= 16.
+ *   - per-LP status codes are scipy.optimize.linprog's, as returned by
+ *     polytope.solvers.lpsolve (polytope/solvers.py:76-106, 155-158):
+ *        0 optimal, 1 iteration limit, 2 infeasible, 3 unbounded, 4 numerical trouble.
+ *     An LP that fails is NOT an error of the call: it is status != 0 with x/fun = NaN.
+ *   - function return value: PLP_OK, or PLP_E* for API misuse / HIP errors
+ *     (plp_last_error() has the text).  Nothing throws across this boundary.
+ *   - "_dev" variants take DEVICE pointers and a HIP stream (void* = hipStream_t, NULL =
+ *     default stream), enqueue the work and return without synchronising.  The plain
+ *     variants take HOST pointers, copy in/out through the context's scratch buffers and
+ *     block until results are host-visible.
+ *   - a plp_ctx is not thread safe; use one per thread (the reference is single-threaded).
+ */
+#ifndef PLP_H
+#define PLP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLP_OK 0
+#define PLP_EINVAL 1       /* bad argument (NULL pointer, negative size, ...)            */
+#define PLP_EUNSUPPORTED 2 /* size outside the engine's envelope (m_max > 64, d > 16)    */
+#define PLP_EHIP 3         /* HIP runtime error                                          */
+#define PLP_ENODEVICE 4    /* no gfx950 device visible                                   */
+
+/* flags[] bits written by plp_reduce_batch (see polytope/polytope.py:1053-1163) */
+#define PLP_RF_EMPTY 1  /* not full-dimensional: reduce() returns Polytope()       (:1081-1082) */
+#define PLP_RF_EARLY 2  /* returned at neq <= nx+1, minrep stays False             (:1114-1116, :1136-1138) */
+#define PLP_RF_MINREP 4 /* all redundancy LPs done, minrep = True                  (:1161-1163) */
+#define PLP_RF_LPFAIL 8 /* a bounding-box LP ended 1/4: reference raises RuntimeError (:1378-1384) */
+
+typedef struct plp_ctx plp_ctx;
+
+int plp_version(void);
+/* number of visible HIP devices whose architecture is gfx950 (0 if none / no runtime) */
+int plp_device_count(void);
+const char *plp_last_error(void);
+
+int plp_ctx_create(int device, plp_ctx **out);
+int plp_ctx_destroy(plp_ctx *ctx);
+/* block until everything enqueued on `stream` by this context has finished */
+int plp_ctx_synchronize(plp_ctx *ctx, void *stream);
+
+/*
+ * Batched lpsolve():  B independent LPs   min c'x  s.t.  G x <= h,  x free.
+ * Replaces: polytope.solvers.lpsolve / _solve_lp_using_scipy
+ *           (polytope/solvers.py:76-106, :149-158) called in Python loops at
+ *           polytope/polytope.py:1150, :1288, :1371, :1393.
+ * c[B][n], G[B][m_max][n], h[B][m_max], m[B] or NULL;  n <= 17.
+ * Out: x[B][n], fun[B] (NaN unless status 0), status[B], iters[B] (may be NULL).
+ */
+int plp_lp_solve_batch(plp_ctx *ctx, int64_t B, int m_max, int n, const double *c, const double *G,
+                       const double *h, const int32_t *m, double *x, double *fun, int32_t *status,
+                       int32_t *iters);
+int plp_lp_solve_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int n, const double *c,
+                           const double *G, const double *h, const int32_t *m, double *x, double *fun,
+                           int32_t *status, int32_t *iters);
+
+/*
+ * Batched Chebyshev ball, LP form F1:  max r  s.t.  a_i.x + ||a_i|| r <= b_i.
+ * Replaces: cheby_ball (polytope/polytope.py:1241-1300; G,h,c built at :1283-1287) and
+ *           therefore is_fulldim (:962-985).
+ * Out: r[B] = x[-1] of the LP (may be negative: the caller applies ":1291 r < 0 -> empty"),
+ *      xc[B][d], status[B] raw LP status.
+ */
+int plp_cheby_batch(plp_ctx *ctx, int64_t B, int m_max, int d, const double *A, const double *b,
+                    const int32_t *m, double *r, double *xc, int32_t *status);
+int plp_cheby_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d, const double *A,
+                        const double *b, const int32_t *m, double *r, double *xc, int32_t *status);
+
+/*
+ * Fused reduce() of a batch of polytopes (none of them minrep):  F1, parallel-row dedupe,
+ * bounding-box prefilter (2d LPs F3, when rows > 3d) and one redundancy LP F2 per row.
+ * Replaces: reduce (polytope/polytope.py:1053-1163), including the is_fulldim/cheby_ball
+ *           call at :1081 and the bounding_box call at :1119 (:1314-1411).
+ * Out: keep[B]  bit i set <=> input row i is kept;
+ *      flags[B] PLP_RF_* ;  r[B], xc[B][d] the Chebyshev ball of the INPUT polytope
+ *      (r = 0, xc = NaN when cheby_ball would return (0, None));
+ *      nlp[B]   number of LPs the reference would have issued (= LPs solved here).
+ */
+int plp_reduce_batch(plp_ctx *ctx, int64_t B, int m_max, int d, const double *A, const double *b,
+                     const int32_t *m, double abs_tol, uint64_t *keep, int32_t *flags, double *r,
+                     double *xc, int32_t *nlp);
+int plp_reduce_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d, const double *A,
+                         const double *b, const int32_t *m, double abs_tol, uint64_t *keep,
+                         int32_t *flags, double *r, double *xc, int32_t *nlp);
+
+/*
+ * Containment of N points in P polytopes:  all_i( A_p[i,:].x - b_p[i] < abs_tol ).
+ * Replaces: Polytope.contains (polytope/polytope.py:206-218), Region.contains (:732-746),
+ *           is_inside (:1017-1029), __contains__ (:191-204, :723-730).
+ * X[d][N]: column vectors exactly as the reference takes them.
+ * mode 0 (Region.contains): out[N]    = OR over the P polytopes (all P*N tests evaluated)
+ * mode 1 (per polytope)   : out[P][N] = Polytope.contains of each polytope
+ */
+int plp_contains(plp_ctx *ctx, int P, int m_max, int d, const double *A, const double *b, const int32_t *m,
+                 int64_t N, const double *X, double abs_tol, int mode, uint8_t *out);
+int plp_contains_dev(plp_ctx *ctx, void *stream, int P, int m_max, int d, const double *A, const double *b,
+                     const int32_t *m, int64_t N, const double *X, double abs_tol, int mode, uint8_t *out);
+
+/*
+ * quickhull outside-set assignment and furthest point.
+ * Replaces: distance() (polytope/quickhull.py:117-121), the assignment loops (:224-245,
+ *           :311-336: a point goes to the FIRST facet with distance > abs_tol) and
+ *           Facet.get_furthest (:87-102: first maximum wins).
+ * X[N][d] (rows = points, as quickhull takes them), normals[F][d], offsets[F].
+ * Out: facet_of_point[N] (-1 = inside every facet), dist[N] (0 when unassigned),
+ *      argmax[F] (index of the furthest point assigned to facet f, -1 if none), maxd[F].
+ */
+int plp_assign(plp_ctx *ctx, int64_t N, int d, const double *X, int F, const double *normals,
+               const double *offsets, double abs_tol, int32_t *facet_of_point, double *dist,
+               int64_t *argmax, double *maxd);
+int plp_assign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const double *X, int F,
+                   const double *normals, const double *offsets, double abs_tol, int32_t *facet_of_point,
+                   double *dist, int64_t *argmax, double *maxd);
+
+/* cross-lane primitive self-test (group size 8/16/32/64); host out_d[128], out_u[128] */
+int plp_selftest(plp_ctx *ctx, int group_size, double *out_d, uint32_t *out_u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLP_H */

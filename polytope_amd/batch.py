@@ -1,0 +1,253 @@
+"""Batched entry points of the MI355X engine (no counterpart in the reference, which loops
+in Python: polytope/polytope.py:1142-1151, :1367-1409, :2148-2152, prop2partition.py:57-61).
+
+Every function takes either numpy arrays (host path: the C ABI copies in and out and
+blocks) or torch CUDA tensors (device path: pointers are handed to the `_dev` entry points
+on torch's current stream, results come back as CUDA tensors, nothing synchronises).
+
+Packing: A[B, m_max, d], b[B, m_max], optional int32 m[B] (rows used per polytope).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+MAX_M, MAX_D = 64, 16
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _np(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _finite_or_raise(what, *arrays):
+    for a in arrays:
+        if a is not None and not np.all(np.isfinite(a)):
+            # same exception class scipy.optimize.linprog raises on inf/nan input
+            raise ValueError("%s: input must not contain values inf, nan, or None" % what)
+
+
+def _torch_stream_ctx(t):
+    import torch
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    ctx = _lib.context(dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return torch, ctx, stream
+
+
+def _tprep(torch, t, dtype):
+    if t is None:
+        return None
+    if t.dtype != dtype or not t.is_contiguous():
+        t = t.to(dtype).contiguous()
+    return t
+
+
+# --------------------------------------------------------------------------------------
+def lpsolve_batch(c, G, h, m=None):
+    """B independent LPs  min c'x s.t. Gx <= h, x free  (solvers.py:76-106 semantics per LP).
+
+    c[B,n], G[B,m_max,n], h[B,m_max] -> dict(status int32[B], x[B,n], fun[B], iters int32[B]);
+    x/fun are NaN where status != 0.
+    """
+    lib = _lib.load()
+    if _is_torch(G):
+        torch, ctx, stream = _torch_stream_ctx(G)
+        G = _tprep(torch, G, torch.float64)
+        c = _tprep(torch, c, torch.float64)
+        h = _tprep(torch, h, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        B, m_max, n = G.shape
+        x = torch.empty((B, n), dtype=torch.float64, device=G.device)
+        fun = torch.empty((B,), dtype=torch.float64, device=G.device)
+        status = torch.empty((B,), dtype=torch.int32, device=G.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=G.device)
+        _lib.check(lib.plp_lp_solve_batch_dev(ctx.handle, stream, B, m_max, n, _ptr(c), _ptr(G), _ptr(h), _ptr(m),
+                                              _ptr(x), _ptr(fun), _ptr(status), _ptr(iters)), "plp_lp_solve_batch_dev")
+        return dict(status=status, x=x, fun=fun, iters=iters)
+    G = _np(G)
+    if G.ndim != 3:
+        raise ValueError("G must be [B, m_max, n]")
+    B, m_max, n = G.shape
+    c = _np(c).reshape(B, n)
+    h = _np(h).reshape(B, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(B)
+    _finite_or_raise("lpsolve_batch", c, G, h)
+    x = np.empty((B, n))
+    fun = np.empty(B)
+    status = np.empty(B, np.int32)
+    iters = np.empty(B, np.int32)
+    _lib.check(lib.plp_lp_solve_batch(_lib.context().handle, B, m_max, n, _ptr(c), _ptr(G), _ptr(h), _ptr(mm),
+                                      _ptr(x), _ptr(fun), _ptr(status), _ptr(iters)), "plp_lp_solve_batch")
+    return dict(status=status, x=x, fun=fun, iters=iters)
+
+
+def cheby_ball_batch(A, b, m=None):
+    """Chebyshev-ball LP (F1, polytope.py:1283-1288) of B polytopes.
+
+    -> dict(r[B] raw x[-1], xc[B,d], status[B]).  cheby_ball's own post-processing
+    (status != 0 or r < 0 -> (0, None), :1289-1297) is left to the caller.
+    """
+    lib = _lib.load()
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        B, m_max, d = A.shape
+        r = torch.empty((B,), dtype=torch.float64, device=A.device)
+        xc = torch.empty((B, d), dtype=torch.float64, device=A.device)
+        status = torch.empty((B,), dtype=torch.int32, device=A.device)
+        _lib.check(lib.plp_cheby_batch_dev(ctx.handle, stream, B, m_max, d, _ptr(A), _ptr(b), _ptr(m), _ptr(r),
+                                           _ptr(xc), _ptr(status)), "plp_cheby_batch_dev")
+        return dict(r=r, xc=xc, status=status)
+    A = _np(A)
+    if A.ndim != 3:
+        raise ValueError("A must be [B, m_max, d]")
+    B, m_max, d = A.shape
+    b = _np(b).reshape(B, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(B)
+    _finite_or_raise("cheby_ball_batch", A, b)
+    r = np.empty(B)
+    xc = np.empty((B, d))
+    status = np.empty(B, np.int32)
+    _lib.check(lib.plp_cheby_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), _ptr(r),
+                                   _ptr(xc), _ptr(status)), "plp_cheby_batch")
+    return dict(r=r, xc=xc, status=status)
+
+
+def reduce_batch(A, b, m=None, abs_tol=1e-7):
+    """Fused reduce() (polytope.py:1053-1163) of B non-minrep polytopes.
+
+    -> dict(keep uint64[B] (bit i = input row i kept), flags int32[B] (RF_*), r[B], xc[B,d],
+            nlp int32[B] = LPs the reference would have issued for that polytope)
+    """
+    lib = _lib.load()
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        B, m_max, d = A.shape
+        keep = torch.empty((B,), dtype=torch.int64, device=A.device)
+        flags = torch.empty((B,), dtype=torch.int32, device=A.device)
+        r = torch.empty((B,), dtype=torch.float64, device=A.device)
+        xc = torch.empty((B, d), dtype=torch.float64, device=A.device)
+        nlp = torch.empty((B,), dtype=torch.int32, device=A.device)
+        _lib.check(lib.plp_reduce_batch_dev(ctx.handle, stream, B, m_max, d, _ptr(A), _ptr(b), _ptr(m), float(abs_tol),
+                                            _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)),
+                   "plp_reduce_batch_dev")
+        return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
+    A = _np(A)
+    if A.ndim != 3:
+        raise ValueError("A must be [B, m_max, d]")
+    B, m_max, d = A.shape
+    b = _np(b).reshape(B, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(B)
+    _finite_or_raise("reduce_batch", A, b)
+    keep = np.empty(B, np.uint64)
+    flags = np.empty(B, np.int32)
+    r = np.empty(B)
+    xc = np.empty((B, d))
+    nlp = np.empty(B, np.int32)
+    _lib.check(lib.plp_reduce_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
+                                    _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)), "plp_reduce_batch")
+    return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
+
+
+def keep_to_bool(keep, m_max):
+    """uint64 keep masks -> bool[B, m_max]."""
+    keep = np.asarray(keep).astype(np.uint64)
+    return ((keep[:, None] >> np.arange(m_max, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+
+
+def contains_batch(A, b, X, abs_tol=1e-7, m=None, region=True):
+    """Containment of the N column vectors X[d, N] in P polytopes (polytope.py:206-218, :732-746).
+
+    region=True  -> uint8[N]    OR over the polytopes (Region.contains; all P*N tests evaluated)
+    region=False -> uint8[P, N] one row per polytope (Polytope.contains)
+    """
+    lib = _lib.load()
+    mode = 0 if region else 1
+    if _is_torch(X):
+        torch, ctx, stream = _torch_stream_ctx(X)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        X = _tprep(torch, X, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        P, m_max, d = A.shape
+        if X.shape[0] != d:
+            raise ValueError("points should be column vectors")
+        N = X.shape[1]
+        out = torch.empty((N,) if region else (P, N), dtype=torch.uint8, device=X.device)
+        _lib.check(lib.plp_contains_dev(ctx.handle, stream, P, m_max, d, _ptr(A), _ptr(b), _ptr(m), N, _ptr(X),
+                                        float(abs_tol), mode, _ptr(out)), "plp_contains_dev")
+        return out
+    A = _np(A)
+    P, m_max, d = A.shape
+    b = _np(b).reshape(P, m_max)
+    X = _np(X)
+    if X.ndim != 2 or X.shape[0] != d:
+        raise ValueError("points should be column vectors")
+    N = X.shape[1]
+    mm = None if m is None else _np(m, np.int32).reshape(P)
+    out = np.zeros((N,) if region else (P, N), np.uint8)
+    _lib.check(lib.plp_contains(_lib.context().handle, P, m_max, d, _ptr(A), _ptr(b), _ptr(mm), N, _ptr(X),
+                                float(abs_tol), mode, _ptr(out)), "plp_contains")
+    return out
+
+
+def assign_batch(X, normals, offsets, abs_tol=1e-7):
+    """quickhull outside-set assignment + furthest point (quickhull.py:87-102,117-121,224-245).
+
+    X[N, d] points (rows), normals[F, d], offsets[F]
+    -> dict(facet int32[N] (-1 inside), dist[N], argmax int64[F] (-1 none), maxd[F])
+    """
+    lib = _lib.load()
+    if _is_torch(X):
+        torch, ctx, stream = _torch_stream_ctx(X)
+        X = _tprep(torch, X, torch.float64)
+        normals = _tprep(torch, normals, torch.float64)
+        offsets = _tprep(torch, offsets, torch.float64)
+        N, d = X.shape
+        F = normals.shape[0]
+        fop = torch.empty((N,), dtype=torch.int32, device=X.device)
+        dist = torch.empty((N,), dtype=torch.float64, device=X.device)
+        am = torch.empty((F,), dtype=torch.int64, device=X.device)
+        mx = torch.empty((F,), dtype=torch.float64, device=X.device)
+        _lib.check(lib.plp_assign_dev(ctx.handle, stream, N, d, _ptr(X), F, _ptr(normals), _ptr(offsets),
+                                      float(abs_tol), _ptr(fop), _ptr(dist), _ptr(am), _ptr(mx)), "plp_assign_dev")
+        return dict(facet=fop, dist=dist, argmax=am, maxd=mx)
+    X = _np(X)
+    N, d = X.shape
+    normals = _np(normals).reshape(-1, d)
+    F = normals.shape[0]
+    offsets = _np(offsets).reshape(F)
+    fop = np.empty(N, np.int32)
+    dist = np.empty(N)
+    am = np.empty(F, np.int64)
+    mx = np.empty(F)
+    _lib.check(lib.plp_assign(_lib.context().handle, N, d, _ptr(X), F, _ptr(normals), _ptr(offsets), float(abs_tol),
+                              _ptr(fop), _ptr(dist), _ptr(am), _ptr(mx)), "plp_assign")
+    return dict(facet=fop, dist=dist, argmax=am, maxd=mx)
+
+
+def selftest(group_size):
+    """Cross-lane primitive self-test -> (out_d[128], out_u[128]) (see plp_points.hip)."""
+    lib = _lib.load()
+    od = np.empty(128)
+    ou = np.empty(128, np.uint32)
+    _lib.check(lib.plp_selftest(_lib.context().handle, int(group_size), _ptr(od), _ptr(ou)), "plp_selftest")
+    return od, ou

@@ -1,0 +1,395 @@
+// plp_capi.hip -- extern "C" boundary of libplp_hip.so (declared in include/plp.h).
+// Host-pointer entry points stage through a grow-only device scratch arena owned by the
+// context, call the *_dev entry point on the context's stream and synchronise.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/plp.h"
+#include "plp_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(PLP_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+struct plp_ctx {
+    int device;
+    hipStream_t stream;
+    char* arena;
+    size_t arena_bytes;
+};
+
+namespace {
+
+struct Arena {
+    plp_ctx* ctx;
+    size_t off;
+    explicit Arena(plp_ctx* c) : ctx(c), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(ctx->arena + off);
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+
+size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+int ensure_arena(plp_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->arena_bytes) return PLP_OK;
+    if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_bytes = 0;
+    size_t want = bytes + bytes / 4;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->arena), want));
+    ctx->arena_bytes = want;
+    return PLP_OK;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PLP_EHIP, "%s launch: %s", what, hipGetErrorString(e));
+    return PLP_OK;
+}
+
+bool is_gfx950(int dev) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plp_version(void) { return 100; }
+
+int plp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int k = 0;
+    for (int i = 0; i < n; ++i) k += is_gfx950(i) ? 1 : 0;
+    return k;
+}
+
+const char* plp_last_error(void) { return g_err; }
+
+int plp_ctx_create(int device, plp_ctx** out) {
+    if (!out) return fail(PLP_EINVAL, "plp_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(PLP_ENODEVICE, "no HIP device visible");
+    }
+    if (device < 0 || device >= n) return fail(PLP_EINVAL, "device %d out of range [0,%d)", device, n);
+    if (!is_gfx950(device)) return fail(PLP_ENODEVICE, "device %d is not gfx950 (MI355X)", device);
+    HIP_TRY(hipSetDevice(device));
+    plp_ctx* ctx = new plp_ctx();
+    ctx->device = device;
+    ctx->arena = nullptr;
+    ctx->arena_bytes = 0;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(PLP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return PLP_OK;
+}
+
+int plp_ctx_destroy(plp_ctx* ctx) {
+    if (!ctx) return PLP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PLP_OK;
+}
+
+int plp_ctx_synchronize(plp_ctx* ctx, void* stream) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- lp_solve
+int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int n, const double* c,
+                           const double* G, const double* h, const int32_t* m, double* x, double* fun,
+                           int32_t* status, int32_t* iters) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || n < 1) return fail(PLP_EINVAL, "bad sizes B=%lld m_max=%d n=%d", (long long)B, m_max, n);
+    if (B == 0) return PLP_OK;
+    if (!c || !h || !x || !fun || !status || (!G && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (m_max > plp::MAX_M || n > plp::MAX_D + 1)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d n=%d outside envelope (m<=64, n<=17)", m_max, n);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (plp::launch_lp(B, m_max, n, c, G, h, m, x, fun, status, iters, st))
+        return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
+    return check_launch("lp_kernel");
+}
+
+int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* c, const double* G,
+                       const double* h, const int32_t* m, double* x, double* fun, int32_t* status,
+                       int32_t* iters) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || n < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!c || !h || !x || !fun || !status || (!G && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nc = (size_t)B * n, nG = (size_t)B * m_max * n, nh = (size_t)B * m_max;
+    size_t need = pad(nc * 8) * 2 + pad(nG * 8) + pad(nh * 8) + pad(B * 8) + pad(B * 4) * 3 + 4096;
+    int rc = ensure_arena(ctx, need);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dc = a.take<double>(nc);
+    double* dG = a.take<double>(nG ? nG : 1);
+    double* dh = a.take<double>(nh ? nh : 1);
+    int32_t* dm = a.take<int32_t>(B);
+    double* dx = a.take<double>(nc);
+    double* dfun = a.take<double>(B);
+    int32_t* dst = a.take<int32_t>(B);
+    int32_t* dit = a.take<int32_t>(B);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dc, c, nc * 8, hipMemcpyHostToDevice, st));
+    if (nG) HIP_TRY(hipMemcpyAsync(dG, G, nG * 8, hipMemcpyHostToDevice, st));
+    if (nh) HIP_TRY(hipMemcpyAsync(dh, h, nh * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(x, dx, nc * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(fun, dfun, B * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, dit, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- cheby
+int plp_cheby_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, const double* A,
+                        const double* b, const int32_t* m, double* r, double* xc, int32_t* status) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!r || !xc || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (plp::launch_cheby(B, m_max, d, A, b, m, r, xc, status, st))
+        return fail(PLP_EUNSUPPORTED, "cheby kernel: unsupported size");
+    return check_launch("cheby_kernel");
+}
+
+int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b,
+                    const int32_t* m, double* r, double* xc, int32_t* status) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!r || !xc || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)B * m_max * d, nb = (size_t)B * m_max, nx = (size_t)B * d;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nx * 8) + pad(B * 8) + pad(B * 4) * 2 + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA ? nA : 1);
+    double* db = a.take<double>(nb ? nb : 1);
+    int32_t* dm = a.take<int32_t>(B);
+    double* dr = a.take<double>(B);
+    double* dxc = a.take<double>(nx);
+    int32_t* dst = a.take<int32_t>(B);
+    hipStream_t st = ctx->stream;
+    if (nA) HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    if (nb) HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = plp_cheby_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dr, dxc, dst);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(r, dr, B * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(xc, dxc, nx * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- reduce
+int plp_reduce_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, const double* A,
+                         const double* b, const int32_t* m, double abs_tol, uint64_t* keep, int32_t* flags,
+                         double* r, double* xc, int32_t* nlp) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!keep || !flags || !r || !xc || !nlp || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (plp::launch_reduce(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r, xc,
+                           nlp, st))
+        return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
+    return check_launch("reduce_kernel");
+}
+
+int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b,
+                     const int32_t* m, double abs_tol, uint64_t* keep, int32_t* flags, double* r, double* xc,
+                     int32_t* nlp) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!keep || !flags || !r || !xc || !nlp || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)B * m_max * d, nb = (size_t)B * m_max, nx = (size_t)B * d;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nx * 8) + pad(B * 8) * 2 + pad(B * 4) * 3 + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA ? nA : 1);
+    double* db = a.take<double>(nb ? nb : 1);
+    int32_t* dm = a.take<int32_t>(B);
+    uint64_t* dkeep = a.take<uint64_t>(B);
+    int32_t* dfl = a.take<int32_t>(B);
+    double* dr = a.take<double>(B);
+    double* dxc = a.take<double>(nx);
+    int32_t* dnlp = a.take<int32_t>(B);
+    hipStream_t st = ctx->stream;
+    if (nA) HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    if (nb) HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(keep, dkeep, B * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags, dfl, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(r, dr, B * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(xc, dxc, nx * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(nlp, dnlp, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- contains
+int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const double* A, const double* b,
+                     const int32_t* m, int64_t N, const double* X, double abs_tol, int mode, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (P < 0 || m_max < 0 || d < 1 || N < 0 || (mode != 0 && mode != 1)) return fail(PLP_EINVAL, "bad sizes/mode");
+    if (N == 0) return PLP_OK;
+    if (!X || !out || ((!A || !b) && P > 0 && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (plp::launch_contains(P, m_max, d, A, b, m, N, X, abs_tol, mode, out, st))
+        return fail(PLP_EUNSUPPORTED, "contains kernel: unsupported size");
+    return check_launch("contains_kernel");
+}
+
+int plp_contains(plp_ctx* ctx, int P, int m_max, int d, const double* A, const double* b, const int32_t* m,
+                 int64_t N, const double* X, double abs_tol, int mode, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (P < 0 || m_max < 0 || d < 1 || N < 0 || (mode != 0 && mode != 1)) return fail(PLP_EINVAL, "bad sizes/mode");
+    if (N == 0) return PLP_OK;
+    if (!X || !out || ((!A || !b) && P > 0 && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)P * m_max * d, nb = (size_t)P * m_max, nX = (size_t)N * d;
+    const size_t nout = mode == 1 ? (size_t)P * N : (size_t)N;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nX * 8) + pad(nout) + pad((size_t)P * 4) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA ? nA : 1);
+    double* db = a.take<double>(nb ? nb : 1);
+    int32_t* dm = a.take<int32_t>(P ? P : 1);
+    double* dX = a.take<double>(nX);
+    uint8_t* dout = a.take<uint8_t>(nout ? nout : 1);
+    hipStream_t st = ctx->stream;
+    if (nA) HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    if (nb) HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m && P) HIP_TRY(hipMemcpyAsync(dm, m, (size_t)P * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dX, X, nX * 8, hipMemcpyHostToDevice, st));
+    rc = plp_contains_dev(ctx, st, P, m_max, d, dA, db, m ? dm : nullptr, N, dX, abs_tol, mode, dout);
+    if (rc) return rc;
+    if (nout) HIP_TRY(hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- assign
+int plp_assign_dev(plp_ctx* ctx, void* stream, int64_t N, int d, const double* X, int F, const double* normals,
+                   const double* offsets, double abs_tol, int32_t* fop, double* dist, int64_t* argmax,
+                   double* maxd) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (N < 0 || d < 1 || F < 1 || !(abs_tol >= 0.0)) return fail(PLP_EINVAL, "bad sizes (need F>=1, abs_tol>=0)");
+    if (!normals || !offsets || !argmax || !maxd || (N > 0 && (!X || !fop || !dist)))
+        return fail(PLP_EINVAL, "NULL pointer");
+    if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (plp::launch_assign(N, d, X, F, normals, offsets, abs_tol, fop, dist, reinterpret_cast<long long*>(argmax),
+                           maxd, nullptr, 0, st))
+        return fail(PLP_EUNSUPPORTED, "assign kernel: unsupported size");
+    return check_launch("assign_kernel");
+}
+
+int plp_assign(plp_ctx* ctx, int64_t N, int d, const double* X, int F, const double* normals,
+               const double* offsets, double abs_tol, int32_t* fop, double* dist, int64_t* argmax, double* maxd) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (N < 0 || d < 1 || F < 1 || !(abs_tol >= 0.0)) return fail(PLP_EINVAL, "bad sizes (need F>=1, abs_tol>=0)");
+    if (!normals || !offsets || !argmax || !maxd || (N > 0 && (!X || !fop || !dist)))
+        return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nX = (size_t)N * d, nF = (size_t)F * d;
+    int rc = ensure_arena(ctx, pad(nX * 8) + pad(nF * 8) + pad((size_t)F * 8) * 3 + pad((size_t)N * 4) +
+                                   pad((size_t)N * 8) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dX = a.take<double>(nX ? nX : 1);
+    double* dn = a.take<double>(nF);
+    double* dof = a.take<double>(F);
+    int32_t* dfop = a.take<int32_t>(N ? N : 1);
+    double* ddist = a.take<double>(N ? N : 1);
+    int64_t* dam = a.take<int64_t>(F);
+    double* dmx = a.take<double>(F);
+    hipStream_t st = ctx->stream;
+    if (nX) HIP_TRY(hipMemcpyAsync(dX, X, nX * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dn, normals, nF * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dof, offsets, (size_t)F * 8, hipMemcpyHostToDevice, st));
+    rc = plp_assign_dev(ctx, st, N, d, dX, F, dn, dof, abs_tol, dfop, ddist, dam, dmx);
+    if (rc) return rc;
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(fop, dfop, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(dist, ddist, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipMemcpyAsync(argmax, dam, (size_t)F * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(maxd, dmx, (size_t)F * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+int plp_selftest(plp_ctx* ctx, int group_size, double* out_d, uint32_t* out_u) {
+    if (!ctx || !out_d || !out_u) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ensure_arena(ctx, 128 * 8 + 128 * 4 + 1024);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dd = a.take<double>(128);
+    unsigned* du = a.take<unsigned>(128);
+    if (plp::launch_selftest(group_size, dd, du, ctx->stream)) return fail(PLP_EINVAL, "group size must be 8/16/32/64");
+    rc = check_launch("selftest_kernel");
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_d, dd, 128 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_u, du, 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLP_OK;
+}
+
+}  // extern "C"

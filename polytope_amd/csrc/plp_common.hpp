@@ -1,0 +1,34 @@
+// plp_common.hpp -- constants shared by the HIP kernels and the C-ABI (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plp {
+
+// LP status codes = scipy.optimize.linprog's (reference: polytope/solvers.py:76-106,155-158)
+enum : int { ST_OPT = 0, ST_ITER = 1, ST_INFEAS = 2, ST_UNBND = 3, ST_NUM = 4 };
+
+// flags written by the fused reduce kernel (reference: polytope/polytope.py:1053-1163)
+enum : int {
+    RF_EMPTY = 1,   // not full-dimensional -> reference returns Polytope()      (:1081-1082)
+    RF_EARLY = 2,   // returned at neq <= nx+1, minrep stays False               (:1114-1116,:1136-1138)
+    RF_MINREP = 4,  // went through the redundancy LPs, minrep = True            (:1161-1163)
+    RF_LPFAIL = 8   // a bounding-box LP ended with status 1/4 (RuntimeError)    (:1378-1384)
+};
+
+// tolerances of the simplex core (identical in oracle/plp_oracle.c)
+constexpr double TOL_D = 1e-9;      // reduced-cost tolerance
+constexpr double TOL_PIV = 1e-9;    // smallest admissible pivot
+constexpr double TOL_FEAS = 1e-7;   // phase-1 infeasibility accepted (HiGHS primal tolerance)
+constexpr double DEGEN_EPS = 1e-12; // step length regarded as degenerate
+constexpr int BLAND_AFTER = 6;      // consecutive degenerate pivots before Bland's rule
+
+constexpr int MAX_M = 64;  // rows per LP  (one lane per row, one LP per <=64-lane group)
+constexpr int MAX_D = 16;  // space dimension
+constexpr int WAVE = 64;   // CDNA wavefront
+constexpr int BLOCK = 256; // 4 waves per workgroup
+
+// ids of variables: 0..n-1 structural free x_j ; n+i slack of row i ; -1 phase-1 artificial
+constexpr int ID_T = -1;
+
+}  // namespace plp

@@ -1,0 +1,37 @@
+// plp_kernels.hpp -- host-side launchers of the HIP kernels (internal to libplp_hip.so).
+// Every launcher returns 0, or 2 for an unsupported size; launches are asynchronous on `st`.
+#pragma once
+#include "plp_common.hpp"
+
+namespace plp {
+
+// lanes per LP group for polytopes with up to m_max rows (-1: unsupported)
+static inline int group_size_for(int m_max) {
+    if (m_max < 0 || m_max > MAX_M) return -1;
+    if (m_max <= 8) return 8;
+    if (m_max <= 16) return 16;
+    if (m_max <= 32) return 32;
+    return 64;
+}
+
+int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+              double* x, double* fun, int* status, int* iters, hipStream_t st);
+
+int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                 double* xc, int* status, hipStream_t st);
+
+int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                  double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                  hipStream_t st);
+
+int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
+                    const double* X, double abs_tol, int mode, unsigned char* out, hipStream_t st);
+
+int launch_assign(long long N, int d, const double* X, int F, const double* normals, const double* offsets,
+                  double abs_tol, int* facet_of_point, double* dist, long long* argmax, double* maxd,
+                  void* scratch, size_t scratch_bytes, hipStream_t st);
+size_t assign_scratch_bytes(long long N, int F);
+
+int launch_selftest(int gs, double* out_d, unsigned* out_u, hipStream_t st);
+
+}  // namespace plp

@@ -1,0 +1,225 @@
+// plp_lp.hip -- batched stand-alone LP kernels (gfx950).
+//
+//   lp_kernel<N>    : B independent LPs  min c'x s.t. Gx<=h, x free   (solvers.py:76-106,149-158)
+//   cheby_kernel<D> : B Chebyshev-ball LPs (form F1, polytope.py:1283-1288):
+//                     c = -e_{d+1}, G = [A | sqrt(sum(A*A,1))], h = b
+//
+// One LP per lane group (GS lanes, GS >= rows), 64/GS LPs per wavefront, 256-thread
+// workgroups, grid-stride over the batch.
+#include "plp_kernels.hpp"
+#include "plp_simplex.hpp"
+
+namespace plp {
+
+template <int N>
+__global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int gs,
+                                                   const double* __restrict__ c,
+                                                   const double* __restrict__ G,
+                                                   const double* __restrict__ h,
+                                                   const int* __restrict__ mrows,
+                                                   double* __restrict__ x, double* __restrict__ fun,
+                                                   int* __restrict__ status, int* __restrict__ iters) {
+    constexpr int NC = N + 1;  // + phase-1 artificial
+    const Grp g(gs);
+    const int gpb = BLOCK / gs;
+    const int gib = threadIdx.x / gs;
+    for (long long base = (long long)blockIdx.x * gpb; base < B; base += (long long)gridDim.x * gpb) {
+        const long long lp = base + gib;
+        const bool valid = lp < B;
+        const int m = valid ? (mrows ? mrows[lp] : m_max) : 0;
+        const int i = g.gl;
+        const bool has_row = valid && i < m;
+        Simplex<NC, true> S;
+        S.reset(N, m, i);
+        double cc[N];
+        bool finite = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            cc[j] = valid ? c[lp * N + j] : 0.0;
+            finite = finite && isfinite(cc[j]);
+        }
+        bool zero = true;
+        double hi = 0.0;
+        if (has_row) {
+            const double* Gr = G + (lp * m_max + i) * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                S.T[j] = Gr[j];
+                zero = zero && (S.T[j] == 0.0);
+                finite = finite && isfinite(S.T[j]);
+            }
+            hi = h[lp * m_max + i];
+            finite = finite && isfinite(hi);
+        }
+        S.beta = hi;
+        S.rowact = has_row && !zero;
+        const bool infeasible0 = grp_ballot(has_row && zero && hi < -TOL_FEAS, g) != 0;  // 0 <= h_i < 0
+        if (has_row && zero) S.beta = 0.0;
+        const bool bad = grp_ballot(!finite, g) != 0 || m > gs;
+        const bool need_p1 = grp_ballot(S.rowact && hi < 0.0, g) != 0;
+        S.colvar[N] = ID_T;
+        if (need_p1) {
+            S.T[N] = S.rowact ? -1.0 : 0.0;
+            S.cost[N] = 1.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) S.cost2[j] = cc[j];
+            S.mode = M_INIT;
+            S.init_col = N;
+            S.init_q = S.beta;
+            S.init_elig = S.rowact;
+            S.mode_after_init = M_P1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) S.cost[j] = cc[j];
+            S.dead = 1u << N;
+            S.mode = M_P2;
+        }
+        if (!valid) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (bad) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+
+        S.run(g);
+
+        // gather x: variable j sits in the row whose basic id is j (0 when nonbasic)
+        const bool ok = S.status == ST_OPT;
+        const double mine = S.x_value();
+        const bool holds = S.holds_x();
+        double f = 0.0;
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint64_t ob = grp_ballot(holds && S.rowvar == j, g);
+            const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+            const double xj = ob ? v : 0.0;
+            f = fma(cc[j], xj, f);
+            if (valid && g.gl == 0) x[lp * N + j] = ok ? xj : qnan;
+        }
+        if (valid && g.gl == 0) {
+            fun[lp] = ok ? f : qnan;
+            status[lp] = S.status;
+            if (iters) iters[lp] = S.iters;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(BLOCK) void cheby_kernel(long long B, int m_max, int gs,
+                                                      const double* __restrict__ A,
+                                                      const double* __restrict__ b,
+                                                      const int* __restrict__ mrows,
+                                                      double* __restrict__ r, double* __restrict__ xc,
+                                                      int* __restrict__ status) {
+    constexpr int NC = D + 1;
+    const Grp g(gs);
+    const int gpb = BLOCK / gs;
+    const int gib = threadIdx.x / gs;
+    for (long long base = (long long)blockIdx.x * gpb; base < B; base += (long long)gridDim.x * gpb) {
+        const long long p = base + gib;
+        const bool valid = p < B;
+        const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
+        const int i = g.gl;
+        const bool has_row = valid && i < m;
+        Simplex<NC, false> S;
+        S.reset(NC, m, i);
+        bool finite = true;
+        double bi = 0.0, nrm2 = 0.0;
+        if (has_row) {
+            const double* Ar = A + (p * m_max + i) * D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                S.T[k] = Ar[k];
+                nrm2 = nrm2 + S.T[k] * S.T[k];
+                finite = finite && isfinite(S.T[k]);
+            }
+            bi = b[p * m_max + i];
+            finite = finite && isfinite(bi);
+        }
+        const double nrm = sqrt(nrm2);
+        S.T[D] = nrm;
+        S.beta = bi;
+        const bool zero = !(nrm > 0.0);
+        S.rowact = has_row && !zero;
+        if (!S.rowact) { S.beta = 0.0; S.T[D] = 0.0; }
+        const bool infeasible0 = grp_ballot(has_row && zero && bi < -TOL_FEAS, g) != 0;
+        const bool bad = grp_ballot(!finite, g) != 0 || m > gs;
+        S.cost[D] = -1.0;
+        S.mode = M_INIT;
+        S.init_col = D;
+        S.init_q = bi / nrm;
+        S.init_elig = S.rowact;
+        S.mode_after_init = M_P2;
+        if (!valid || bad) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+
+        S.run(g);
+
+        const bool ok = S.status == ST_OPT;
+        const double mine = S.x_value();
+        const bool holds = S.holds_x();
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const uint64_t ob = grp_ballot(holds && S.rowvar == j, g);
+            const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+            const double xj = ok ? (ob ? v : 0.0) : qnan;
+            if (valid && g.gl == 0) {
+                if (j < D) xc[p * D + j] = xj; else r[p] = xj;
+            }
+        }
+        if (valid && g.gl == 0) status[p] = S.status;
+    }
+}
+
+static inline int pick_grid(long long B, int gs) {
+    const long long gpb = BLOCK / gs;
+    long long blocks = (B + gpb - 1) / gpb;
+    const long long cap = 256ll * 16;  // 256 CUs x up to 8 blocks, x2 so the tail balances
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <int N>
+static void launch_lp_n(long long B, int m_max, int gs, const double* c, const double* G, const double* h,
+                        const int* mrows, double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    hipLaunchKernelGGL(lp_kernel<N>, dim3(pick_grid(B, gs)), dim3(BLOCK), 0, st, B, m_max, gs, c, G, h, mrows, x,
+                       fun, status, iters);
+}
+
+template <int D>
+static void launch_cheby_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
+                           double* r, double* xc, int* status, hipStream_t st) {
+    hipLaunchKernelGGL(cheby_kernel<D>, dim3(pick_grid(B, gs)), dim3(BLOCK), 0, st, B, m_max, gs, A, b, mrows, r,
+                       xc, status);
+}
+
+#define PLP_CASE_N(K) case K: launch_lp_n<K>(B, m_max, gs, c, G, h, mrows, x, fun, status, iters, st); break;
+#define PLP_CASE_D(K) case K: launch_cheby_d<K>(B, m_max, gs, A, b, mrows, r, xc, status, st); break;
+
+int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+              double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    const int gs = group_size_for(m_max);
+    if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
+    switch (n) {
+        PLP_CASE_N(1) PLP_CASE_N(2) PLP_CASE_N(3) PLP_CASE_N(4) PLP_CASE_N(5) PLP_CASE_N(6)
+        PLP_CASE_N(7) PLP_CASE_N(8) PLP_CASE_N(9) PLP_CASE_N(10) PLP_CASE_N(11) PLP_CASE_N(12)
+        PLP_CASE_N(13) PLP_CASE_N(14) PLP_CASE_N(15) PLP_CASE_N(16) PLP_CASE_N(17)
+        default: return 2;
+    }
+    return 0;
+}
+
+int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                 double* xc, int* status, hipStream_t st) {
+    const int gs = group_size_for(m_max);
+    if (gs < 0 || d < 1 || d > MAX_D) return 2;
+    switch (d) {
+        PLP_CASE_D(1) PLP_CASE_D(2) PLP_CASE_D(3) PLP_CASE_D(4) PLP_CASE_D(5) PLP_CASE_D(6)
+        PLP_CASE_D(7) PLP_CASE_D(8) PLP_CASE_D(9) PLP_CASE_D(10) PLP_CASE_D(11) PLP_CASE_D(12)
+        PLP_CASE_D(13) PLP_CASE_D(14) PLP_CASE_D(15) PLP_CASE_D(16)
+        default: return 2;
+    }
+    return 0;
+}
+
+}  // namespace plp

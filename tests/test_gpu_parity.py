@@ -1,0 +1,288 @@
+"""GPU parity tests (run with `pytest -m gpu` on a MI355X): the HIP path, called through the
+C ABI (include/plp.h), against
+  * the golden vectors generated from the imported reference (tests/golden/*.npz),
+  * the CPU oracle (oracle/plp_oracle.c) on seeded inputs,
+  * scipy.optimize.linprog called exactly as polytope/solvers.py:152-154 does,
+and, at the full BASELINE sizes, size-independent properties.
+
+Bars: status / keep masks / booleans / indices exact; Chebyshev radii and objective values
+within 1e-9 (north_star); centres only validated as feasible (not unique).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import polytope_amd as pa
+    from polytope_amd import _lib
+    assert _lib.available(), "libplp_hip.so did not load or no gfx950 device: the HIP path is mandatory"
+    return pa
+
+
+# ------------------------------------------------------------------------------ primitives
+@pytest.mark.parametrize("gs", [8, 16, 32, 64])
+def test_group_primitives(pa, gs):
+    from polytope_amd.batch import selftest
+    od, ou = selftest(gs)
+    lanes = np.arange(64)
+    d = ((lanes * 37) % 64 - 20) * 0.5
+    u = (lanes * 29) % 61
+    for l in range(64):
+        base = l - l % gs
+        grp = slice(base, base + gs)
+        assert od[l] == d[grp].min(), (gs, l)
+        assert ou[l] == u[grp].min(), (gs, l)
+        assert od[64 + l] == d[base + (l * 7) % gs], (gs, l)
+        bal = sum(1 << i for i in range(min(gs, 32)) if (base + i) % 3 == 0)
+        assert ou[64 + l] == bal, (gs, l)
+
+
+# ------------------------------------------------------------------------------ raw LPs
+def _g1_groups():
+    g = load_golden("g1_lp.npz")
+    groups = {}
+    for i in range(len(g["m"])):
+        groups.setdefault((int(g["m"][i]), int(g["n"][i])), []).append(i)
+    return g, groups
+
+
+def test_lp_golden(pa):
+    g, groups = _g1_groups()
+    worst = 0.0
+    for (m, n), idx in groups.items():
+        idx = np.array(idx)
+        c = g["c"][idx, :n]
+        G = g["G"][idx, :m * n].reshape(-1, m, n)
+        h = g["h"][idx, :m]
+        res = pa.lpsolve_batch(c, G, h)
+        st_ref = np.where(g["status"][idx] == g["status_nopresolve"][idx], g["status"][idx],
+                          g["status_nopresolve"][idx])  # HiGHS presolve quirk, see test_oracle_golden
+        assert np.array_equal(res["status"], st_ref), (m, n, np.nonzero(res["status"] != st_ref))
+        ok = st_ref == 0
+        err = np.abs(res["fun"][ok] - g["fun"][idx][ok])
+        assert np.all(err <= TOL * np.maximum(1.0, np.abs(g["fun"][idx][ok]))), (m, n, err.max())
+        worst = max(worst, err.max() if err.size else 0.0)
+        # returned x is feasible and attains fun
+        x = res["x"][ok]
+        viol = np.einsum("bij,bj->bi", G[ok], x) - h[ok]
+        assert viol.max() <= 1e-7
+        assert np.all(np.isnan(res["fun"][~ok])) and np.all(np.isnan(res["x"][~ok]))
+    print("worst |fun - scipy| over g1:", worst)
+
+
+def test_lp_vs_oracle_and_scipy(pa, oracle):
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(5)
+    for (m, n, B) in [(16, 3, 256), (16, 4, 256), (8, 2, 128), (40, 7, 96), (64, 17, 48), (3, 5, 64)]:
+        G = rng.standard_normal((B, m, n))
+        G /= np.linalg.norm(G, axis=2, keepdims=True)
+        x0 = rng.standard_normal((B, n))
+        h = np.einsum("bij,bj->bi", G, x0) + rng.random((B, m)) * rng.choice([1.0, 1.0, -0.02], (B, 1))
+        if m >= 2 * n:
+            G[:, :2 * n] = np.vstack([np.eye(n), -np.eye(n)])[None]
+            h[:, :2 * n] = 4.0
+        c = rng.standard_normal((B, n))
+        mrows = rng.integers(max(1, m - 3), m + 1, B).astype(np.int32)
+        res = pa.lpsolve_batch(c, G, h, m=mrows)
+        for k in range(B):
+            mk = mrows[k]
+            so, xo, fo, _ = oracle.lp_solve(c[k], G[k, :mk], h[k, :mk])
+            assert res["status"][k] == so, (m, n, k, res["status"][k], so)
+            if so == 0:
+                assert abs(res["fun"][k] - fo) <= TOL * max(1.0, abs(fo)), (m, n, k)
+            if k < 24:
+                sp = linprog(c[k], G[k, :mk], h[k, :mk], None, None, bounds=(None, None), options={"presolve": False})
+                assert sp.status == res["status"][k], (m, n, k, sp.status, res["status"][k])
+                if sp.status == 0:
+                    assert abs(sp.fun - res["fun"][k]) <= TOL * max(1.0, abs(sp.fun))
+
+
+def test_lp_edge_inputs(pa):
+    # known-answer cases of the reference's tests (polytope_test.py:510-548)
+    r = pa.lpsolve_batch(np.array([[1.0]]), np.array([[[-1.0]]]), np.array([[1.0]]))
+    assert r["status"][0] == 0 and r["x"][0, 0] == -1.0
+    r = pa.lpsolve_batch(np.array([[1.0, 1.0]]), np.array([[[-1.0, 0], [0, -1.0]]]), np.array([[1.0, 1.0]]))
+    assert r["status"][0] == 0 and np.array_equal(r["x"][0], [-1.0, -1.0])
+    # empty batch, zero rows, zero-row constraints, unbounded, infeasible
+    r = pa.lpsolve_batch(np.zeros((0, 2)), np.zeros((0, 4, 2)), np.zeros((0, 4)))
+    assert r["status"].shape == (0,)
+    r = pa.lpsolve_batch(np.array([[1.0]]), np.zeros((1, 0, 1)), np.zeros((1, 0)))
+    assert r["status"][0] == 3
+    r = pa.lpsolve_batch(np.array([[1.0], [1.0]]), np.array([[[0.0], [-1.0]], [[0.0], [-1.0]]]),
+                         np.array([[-1.0, 1.0], [1.0, 1.0]]))
+    assert list(r["status"]) == [2, 0] and r["x"][1, 0] == -1.0
+    r = pa.lpsolve_batch(np.array([[1.0, 0.0]]), np.array([[[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]]),
+                         np.array([[1.0, -2.0, 1.0, 1.0]]))
+    assert r["status"][0] == 2
+    with pytest.raises(ValueError):
+        pa.lpsolve_batch(np.array([[1.0]]), np.array([[[1.0], [-1.0]]]), np.array([[np.inf, 1.0]]))
+    with pytest.raises(ValueError):
+        pa.lpsolve_batch(np.zeros((1, 2)), np.zeros((1, 65, 2)), np.zeros((1, 65)))
+
+
+# ------------------------------------------------------------------------------ Chebyshev
+def test_cheby_golden_edges(pa, oracle):
+    g = load_golden("g3_edge.npz")
+    for name in g["names"]:
+        A, b = g[f"{name}_A"], g[f"{name}_b"]
+        res = pa.cheby_ball_batch(A[None], b[None])
+        st, r, xc = int(res["status"][0]), float(res["r"][0]), res["xc"][0]
+        rr = r if (st == 0 and r >= 0) else 0.0
+        assert abs(rr - float(g[f"{name}_r"])) <= TOL, name
+        assert (st == 0) == (int(g[f"{name}_f1status"]) == 0), name
+        if st == 0 and r > 0:
+            nrm = np.sqrt((A * A).sum(1))
+            assert np.max(A @ xc + nrm * r - b) <= 1e-9, name
+
+
+def test_cheby_vs_oracle(pa, oracle):
+    from polytope_amd.synth import random_hpolytopes
+    for (m, d, B) in [(16, 3, 512), (10, 2, 256), (32, 6, 128), (64, 16, 64), (7, 5, 128), (24, 9, 64)]:
+        A, b = random_hpolytopes(B, m, d, seed=11, bounded=False)
+        mrows = np.random.default_rng(3).integers(max(1, m - 4), m + 1, B).astype(np.int32)
+        res = pa.cheby_ball_batch(A, b, m=mrows)
+        for k in range(B):
+            so, ro, xo = oracle.cheby(A[k, :mrows[k]], b[k, :mrows[k]])
+            assert res["status"][k] == so, (m, d, k)
+            if so == 0:
+                assert abs(res["r"][k] - ro) <= TOL, (m, d, k, res["r"][k], ro)
+                Ak = A[k, :mrows[k]]
+                assert np.max(Ak @ res["xc"][k] + res["r"][k] - b[k, :mrows[k]]) <= 1e-9
+
+
+# ------------------------------------------------------------------------------ reduce
+def test_reduce_golden(pa):
+    from polytope_amd import _lib
+    g = load_golden("g2_reduce.npz")
+    for i in range(len(g["m"])):
+        m, d = int(g["m"][i]), int(g["d"][i])
+        A = g["A"][i, :m * d].reshape(1, m, d)
+        b = g["b"][i, :m].reshape(1, m)
+        res = pa.reduce_batch(A, b)
+        fl = int(res["flags"][0])
+        assert bool(fl & _lib.RF_EMPTY) == bool(g["empty"][i]), i
+        if g["empty"][i]:
+            continue
+        mask = pa.keep_to_bool(res["keep"], m)[0]
+        assert np.array_equal(mask, g["mask"][i, :m]), (i, m, d, mask, g["mask"][i, :m])
+        assert bool(fl & _lib.RF_MINREP) == bool(g["minrep"][i]), i
+        assert abs(res["r"][0] - g["r"][i]) <= TOL, i
+
+
+def test_reduce_vs_oracle_batches(pa, oracle):
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(9)
+    for (m, d, B) in [(16, 3, 1024), (16, 3, 37), (10, 2, 256), (24, 4, 192), (32, 6, 96), (64, 16, 12),
+                      (8, 3, 200), (40, 3, 64), (5, 4, 40)]:
+        A, b = random_hpolytopes(B, m, d, seed=100 + m + d, bounded=True)
+        # make some polytopes degenerate: duplicated rows, unbounded, empty
+        for k in range(0, B, 7):
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.1])
+        for k in range(3, B, 11):
+            b[k, 0] = -5.0  # cuts everything away -> empty or tiny
+        mrows = rng.integers(max(2, m - 5), m + 1, B).astype(np.int32)
+        res = pa.reduce_batch(A, b, m=mrows)
+        masks = pa.keep_to_bool(res["keep"], m)
+        nlp_total = 0
+        for k in range(B):
+            mk = mrows[k]
+            o = oracle.reduce(A[k, :mk], b[k, :mk])
+            assert int(res["flags"][k]) == o["flags"], (m, d, k, int(res["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k, :mk], o["keep"]), (m, d, k, masks[k, :mk], o["keep"])
+            assert not masks[k, mk:].any()
+            assert abs(res["r"][k] - o["r"]) <= TOL
+            assert int(res["nlp"][k]) == o["nlp"], (m, d, k, int(res["nlp"][k]), o["nlp"])
+            nlp_total += o["nlp"]
+        assert nlp_total > B
+
+
+def test_reduce_properties_full_config(pa):
+    """BASELINE config 2 at full size (100k polytopes, m=16, d=3): size-independent properties.
+    idempotence: reducing the reduced polytope keeps every row; the Chebyshev radius is unchanged;
+    every dropped row is redundant at the Chebyshev centre (strictly inactive)."""
+    from polytope_amd import _lib
+    from polytope_amd.synth import random_hpolytopes
+    B, m, d = 100000, 16, 3
+    A, b = random_hpolytopes(B, m, d, seed=0)
+    res = pa.reduce_batch(A, b)
+    masks = pa.keep_to_bool(res["keep"], m)
+    assert np.all(res["flags"] == _lib.RF_MINREP)
+    assert np.all(res["r"] >= 1.0 - 1e-12)
+    cnt = masks.sum(1)
+    assert cnt.min() >= d + 1
+    # pack the reduced polytopes (ragged) and reduce again
+    A2 = np.zeros_like(A)
+    b2 = np.zeros_like(b)
+    order = np.argsort(~masks, axis=1, kind="stable")  # kept rows first, original order
+    A2 = np.take_along_axis(A, order[:, :, None], axis=1)
+    b2 = np.take_along_axis(b, order, axis=1)
+    res2 = pa.reduce_batch(A2, b2, m=cnt.astype(np.int32))
+    masks2 = pa.keep_to_bool(res2["keep"], m)
+    assert np.array_equal(masks2.sum(1), cnt), "reduce is not idempotent"
+    assert np.allclose(res2["r"], res["r"], atol=1e-9, rtol=0)
+    # LP count bookkeeping: 1 F1 + 2d F3 + one F2 per row that survived dedupe/prefilter
+    assert np.all(res["nlp"] >= 1 + 2 * d + cnt) and np.all(res["nlp"] <= 1 + 2 * d + m)
+    # checksum of checksums, pinned by the oracle on a sample
+    print("kept rows total", int(cnt.sum()), "LPs", int(res["nlp"].sum()))
+
+
+# ------------------------------------------------------------------------------ contains
+def test_contains_golden(pa):
+    g = load_golden("g4_contains.npz")
+    A, b, X = g["A"], g["b"], g["X"]
+    for ti, tol in enumerate(g["tols"]):
+        out = pa.contains_batch(A, b, X, abs_tol=float(tol), region=False)
+        assert np.array_equal(out.astype(bool), g["res"][ti]), tol
+        reg = pa.contains_batch(A, b, X, abs_tol=float(tol), region=True)
+        assert np.array_equal(reg.astype(bool), g["reg"][ti]), tol
+        ob = pa.contains_batch(g["boxA"][None], g["boxb"][None], g["Xb"], abs_tol=float(tol), region=False)
+        assert np.array_equal(ob[0].astype(bool), g["boxres"][ti]), tol
+
+
+def test_contains_vs_oracle(pa, oracle):
+    from polytope_amd.synth import containment_workload
+    for (P, N, d, m) in [(64, 20000, 6, 16), (7, 1000, 2, 5), (33, 4099, 9, 20), (5, 513, 16, 40), (20, 3000, 1, 2)]:
+        A, b, X = containment_workload(P, N, d=d, m=m, seed=d)
+        mrows = np.random.default_rng(d).integers(max(1, m - 3), m + 1, P).astype(np.int32)
+        for tol in (1e-7, 0.0):
+            o = oracle.contains(A, b, np.ascontiguousarray(X.T), abs_tol=tol, mrows=mrows)
+            out = pa.contains_batch(A, b, X, abs_tol=tol, m=mrows, region=False)
+            assert np.array_equal(out, o), (P, N, d, m, tol, int((out != o).sum()))
+            oreg = oracle.contains(A, b, np.ascontiguousarray(X.T), abs_tol=tol, mrows=mrows, region=True)
+            reg = pa.contains_batch(A, b, X, abs_tol=tol, m=mrows, region=True)
+            assert np.array_equal(reg, oreg)
+            assert np.array_equal(reg.astype(bool), out.astype(bool).any(axis=0))
+    with pytest.raises(ValueError):
+        pa.contains_batch(A, b, np.zeros((3, 4)))
+
+
+# ------------------------------------------------------------------------------ quickhull kernels
+@pytest.mark.parametrize("d", [2, 3, 5, 8])
+def test_assign_golden(pa, d):
+    g = load_golden("g6_quickhull.npz")
+    res = pa.assign_batch(g[f"d{d}_X"], g[f"d{d}_normals"], g[f"d{d}_offsets"], 1e-7)
+    assert np.array_equal(res["facet"], g[f"d{d}_fop"])
+    assert np.allclose(res["dist"], g[f"d{d}_dist"], atol=1e-13, rtol=0)
+    assert np.array_equal(res["argmax"], g[f"d{d}_argmax"])
+
+
+def test_assign_vs_oracle(pa, oracle):
+    from polytope_amd.synth import quickhull_workload
+    for (N, d, F) in [(100000, 8, 9), (5000, 3, 4), (30000, 8, 64), (20000, 4, 600), (1000, 16, 17)]:
+        X, nrm, off = quickhull_workload(N, d=d, F=F, seed=F)
+        X[N // 2] = X[N // 3]  # exact tie of distances: the first maximum must win
+        fo, do_, am, mx = oracle.assign(X, nrm, off, 1e-7)
+        res = pa.assign_batch(X, nrm, off, 1e-7)
+        assert np.array_equal(res["facet"], fo), (N, d, F)
+        assert np.array_equal(res["dist"], do_), (N, d, F)  # same operation order -> bitwise
+        assert np.array_equal(res["argmax"], am), (N, d, F)
+        has = am >= 0
+        assert np.array_equal(res["maxd"][has], mx[has])
