@@ -55,7 +55,7 @@ const char *plp_last_error(void);
 
 int plp_ctx_create(int device, plp_ctx **out);
 int plp_ctx_destroy(plp_ctx *ctx);
-/* block until everything enqueued on `stream` by this context has finished */
+/* block until everything enqueued on `stream` (NULL = default stream) has finished */
 int plp_ctx_synchronize(plp_ctx *ctx, void *stream);
 
 /*

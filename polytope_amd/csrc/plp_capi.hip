@@ -128,7 +128,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
 
 int plp_ctx_synchronize(plp_ctx* ctx, void* stream) {
     if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
-    HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return PLP_OK;
 }
 
@@ -142,7 +142,7 @@ int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int
     if (!c || !h || !x || !fun || !status || (!G && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (m_max > plp::MAX_M || n > plp::MAX_D + 1)
         return fail(PLP_EUNSUPPORTED, "m_max=%d n=%d outside envelope (m<=64, n<=17)", m_max, n);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_lp(B, m_max, n, c, G, h, m, x, fun, status, iters, st))
         return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
     return check_launch("lp_kernel");
@@ -193,7 +193,7 @@ int plp_cheby_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d,
     if (!r || !xc || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (m_max > plp::MAX_M || d > plp::MAX_D)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_cheby(B, m_max, d, A, b, m, r, xc, status, st))
         return fail(PLP_EUNSUPPORTED, "cheby kernel: unsupported size");
     return check_launch("cheby_kernel");
@@ -239,7 +239,7 @@ int plp_reduce_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d
     if (!keep || !flags || !r || !xc || !nlp || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (m_max > plp::MAX_M || d > plp::MAX_D)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_reduce(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r, xc,
                            nlp, st))
         return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
@@ -289,7 +289,7 @@ int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const 
     if (N == 0) return PLP_OK;
     if (!X || !out || ((!A || !b) && P > 0 && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_contains(P, m_max, d, A, b, m, N, X, abs_tol, mode, out, st))
         return fail(PLP_EUNSUPPORTED, "contains kernel: unsupported size");
     return check_launch("contains_kernel");
@@ -333,7 +333,7 @@ int plp_assign_dev(plp_ctx* ctx, void* stream, int64_t N, int d, const double* X
     if (!normals || !offsets || !argmax || !maxd || (N > 0 && (!X || !fop || !dist)))
         return fail(PLP_EINVAL, "NULL pointer");
     if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_assign(N, d, X, F, normals, offsets, abs_tol, fop, dist, reinterpret_cast<long long*>(argmax),
                            maxd, nullptr, 0, st))
         return fail(PLP_EUNSUPPORTED, "assign kernel: unsupported size");

@@ -14,8 +14,24 @@ echo "== bench"
 timeout 600 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee gpurun_out/bench.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel trace"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o reduce -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o reduce -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
   tail -2 gpurun_out/prof_bench.log
   find gpurun_out/prof -name "*kernel_stats*" | head -3
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
+fi
+if [ "${1:-}" != "quick" ]; then
+  echo "== rocprofv3 PMC passes (separate runs, counters only)"
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_$ctr" -o reduce -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$ctr.log" 2>&1)
+    f=$(find gpurun_out/pmc_$ctr -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python - "$f" $ctr <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(list)
+for r in rows:
+    acc[r.get("Kernel_Name", "?")[:60]].append(float(r.get("Counter_Value", 0)))
+for k, v in acc.items():
+    print(sys.argv[2], k, "dispatches", len(v), "mean", sum(v) / len(v))
+PY
+  done
 fi
