@@ -1,0 +1,1023 @@
+"""Polytope / Region and the set operations on the LP hot path -- host-side mirror of the
+reference's public interface for that path (polytope/polytope.py of tulip-control/polytope).
+
+Same names, argument meaning, caches and error behaviour as the reference; the difference is
+where the linear programs go.  Wherever the reference issues LPs one at a time from a Python
+loop, this module collects them and issues ONE batched call into the HIP engine
+(polytope_amd.batch) when `solvers.default_solver == 'hip'`:
+
+    cheby_ball / is_fulldim     1 LP (F1) per polytope; Regions -> one batch      (ref :1241-1300, :962-985)
+    bounding_box                2d LPs (F3) -> one batch                           (ref :1314-1411)
+    reduce                      fused kernel: F1 + dedupe + 2d F3 + m F2           (ref :1053-1163)
+    Region.intersect            all pair stacks reduced in one batch               (ref :815-830)
+    region_diff                 pre-scan and every level scan = one batch of F1    (ref :2117-2282)
+    envelope                    all (facet, other polytope) F1 LPs in one batch    (ref :1414-1464)
+    is_adjacent_pairs           all pair LPs in one batch                          (ref :1827-1866)
+    contains                    dense kernel                                       (ref :206-218, :732-746)
+
+With any other backend name the LPs go through `solvers.lpsolve` one by one, as in the
+reference.  There is no silent fallback between backends.
+
+Out of scope here: projection, extreme/qhull vertex enumeration,
+rotation, plotting, grid helpers.
+"""
+import logging
+import warnings
+
+import numpy as np
+
+from . import solvers
+from .solvers import lpsolve
+
+logger = logging.getLogger(__name__)
+
+# global default absolute tolerance (module global so the magic methods can use it; ref :83)
+ABS_TOL = 1e-7
+
+_RF_EMPTY, _RF_EARLY, _RF_MINREP, _RF_LPFAIL = 1, 2, 4, 8
+_MAX_ROWS, _MAX_DIM = 64, 16
+
+
+def _use_hip():
+    return solvers.default_solver == "hip"
+
+
+def _fits(m, d):
+    return 1 <= d <= _MAX_DIM and m <= _MAX_ROWS
+
+
+# ======================================================================================
+class Polytope(object):
+    """Convex polytope {x | A x <= b} (H-representation).
+
+    Attributes `A`, `b`, `minrep`, `bbox`, `fulldim`, `vertices`, and the cached Chebyshev
+    ball `chebR` / `chebXc` behave as in the reference (polytope/polytope.py:89-148).
+    With `normalize=True` rows are scaled to unit norm and rows with norm <= 1e-10 dropped.
+    """
+
+    def __init__(self, A=np.array([]), b=np.array([]), minrep=False, chebR=0, chebX=None,
+                 fulldim=None, volume=None, vertices=None, normalize=True):
+        self.A = A.astype(float)
+        self.b = b.astype(float).flatten()
+        if A.size > 0 and normalize:
+            norms = np.sqrt(np.sum(A * A, 1)).flatten()
+            rows = np.nonzero(norms > 1e-10)[0]
+            scale = 1 / norms[rows]
+            self.A = self.A[rows, :] * scale[:, None]   # row-wise multiply by the reciprocal norm
+            self.b = self.b[rows].flatten() * scale
+        self.minrep = minrep
+        self._chebXc = chebX
+        self._chebR = chebR
+        self.bbox = None
+        self.fulldim = fulldim
+        self._volume = None
+        if volume is not None:
+            self._set_volume(volume)
+        self.vertices = vertices
+
+    def __str__(self):
+        rows = ["  %s | %s" % (np.array2string(a, precision=5, suppress_small=True), np.format_float_positional(
+            bb, precision=5)) for a, bb in zip(self.A, self.b)]
+        return "Single polytope \n" + "\n".join(rows) + "\n"
+
+    def __len__(self):
+        return 0
+
+    def __copy__(self):
+        twin = Polytope(self.A.copy(), self.b.copy())
+        twin._chebXc, twin._chebR = self._chebXc, self._chebR
+        twin.minrep, twin.bbox, twin.fulldim = self.minrep, self.bbox, self.fulldim
+        return twin
+
+    def copy(self):
+        return self.__copy__()
+
+    def __contains__(self, point):
+        """`point in self`, boundary included up to the module tolerance ABS_TOL (ref :191-204)."""
+        if not isinstance(point, np.ndarray):
+            point = np.array(point)
+        return bool(self.contains(point.flatten()[:, np.newaxis], ABS_TOL)[0])
+
+    def contains(self, points, abs_tol=ABS_TOL):
+        """Boolean array: which column vectors of `points` satisfy A x - b < abs_tol row-wise
+        (strict; abs_tol=0 excludes the boundary).  ref :206-218."""
+        return _contains_many([self], points, abs_tol, region=True)
+
+    def __eq__(self, other):
+        return self <= other and other <= self
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __le__(self, other):
+        return is_subset(self, other)
+
+    def __ge__(self, other):
+        return is_subset(other, self)
+
+    def __bool__(self):
+        return bool(self.volume > 0)
+
+    __nonzero__ = __bool__
+    __hash__ = object.__hash__
+
+    def union(self, other, check_convex=False):
+        return union(self, other, check_convex)
+
+    def diff(self, other):
+        return mldivide(self, other)
+
+    def intersect(self, other, abs_tol=ABS_TOL):
+        """Intersection with a Polytope (-> Polytope) or a Region (-> Region).  ref :255-275."""
+        if isinstance(other, Region):
+            return other.intersect(self, abs_tol=abs_tol)
+        if not isinstance(other, Polytope):
+            raise Exception("Polytope intersection defined only with other Polytope. Got instead: "
+                            + str(type(other)))
+        if (not is_fulldim(self)) or (not is_fulldim(other)):
+            return Polytope()
+        if self.dim != other.dim:
+            raise Exception("polytopes have different dimension")
+        return reduce(Polytope(np.vstack([self.A, other.A]), np.hstack([self.b, other.b])), abs_tol=abs_tol)
+
+    def translation(self, d):
+        """Copy of self moved by the vector d (ref :277-286, :449-466): b += A d."""
+        out = self.copy()
+        out.b = out.b + out.A.dot(np.asarray(d, dtype=float).flatten())
+        if out._chebXc is not None:
+            out._chebXc = out._chebXc + np.asarray(d, dtype=float).flatten()
+        out.bbox = None
+        return out
+
+    @classmethod
+    def from_box(cls, intervals=[]):
+        """Hyperrectangle from [[x0_min, x0_max], ...] (ref :311-354)."""
+        if not isinstance(intervals, np.ndarray):
+            try:
+                intervals = np.array(intervals)
+            except Exception:
+                raise Exception("Polytope.from_box:intervals must be a numpy ndarray or "
+                                "convertible as arg to numpy.array")
+        if intervals.ndim != 2:
+            raise Exception("Polytope.from_box: intervals must be 2 dimensional")
+        if intervals.shape[1] != 2:
+            raise Exception("Polytope.from_box: intervals must have 2 columns")
+        if (intervals[:, 0] > intervals[:, 1]).any():
+            raise Exception("Polytope.from_box: Invalid interval in from_box method.\n"
+                            "First element of an interval must not be larger than the second.")
+        n = intervals.shape[0]
+        return cls(np.vstack([np.eye(n), -np.eye(n)]), np.hstack([intervals[:, 1], -intervals[:, 0]]), minrep=True)
+
+    def scale(self, factor):
+        self.b = factor * self.b
+
+    @property
+    def dim(self):
+        try:
+            return np.shape(self.A)[1]
+        except Exception:
+            return 0.0
+
+    @property
+    def volume(self):
+        if self._volume is None:
+            self._volume = volume(self)
+        return self._volume
+
+    def _set_volume(self, polytope_volume):
+        if polytope_volume < 0.0:
+            raise ValueError("`polytope_volume` must be >= 0, given:  {v}".format(v=polytope_volume))
+        self._volume = float(polytope_volume)
+
+    @property
+    def chebR(self):
+        cheby_ball(self)
+        return self._chebR
+
+    @property
+    def chebXc(self):
+        cheby_ball(self)
+        return self._chebXc
+
+    @property
+    def cheby(self):
+        return cheby_ball(self)
+
+    @property
+    def bounding_box(self):
+        if self.bbox is None:
+            self.bbox = bounding_box(self)
+        return self.bbox
+
+
+# ======================================================================================
+class Region(object):
+    """Possibly non-convex set: a list of convex polytopes (ref :650-936)."""
+
+    def __init__(self, list_poly=None, props=None):
+        if list_poly is None:
+            list_poly = []
+        if props is None:
+            props = set()
+        if isinstance(list_poly, str):
+            # the reference's hack for discrete problems (ref :681-685)
+            self.list_poly = list_poly
+            self.props = set(props)
+            return
+        if isinstance(list_poly, Region):
+            dim = list_poly[0].dim
+            for poly in list_poly:
+                if poly.dim != dim:
+                    raise Exception("Region error: Polytopes must be of same dimension!")
+        self.list_poly = [p for p in list_poly if not is_empty(p)]
+        self.props = set(props)
+        self.bbox = None
+        self.fulldim = None
+        self._volume = None
+        self._chebXc = None
+        self._chebR = None
+
+    def __iter__(self):
+        return iter(self.list_poly)
+
+    def __getitem__(self, key):
+        return self.list_poly[key]
+
+    def __str__(self):
+        out = ""
+        for i, p in enumerate(self.list_poly):
+            out += "\t Polytope number %d:\n\t %s\n" % (i + 1, str(p).replace("\n", "\n\t\t"))
+        return out + "\n"
+
+    def __len__(self):
+        return len(self.list_poly)
+
+    def __contains__(self, point):
+        if not isinstance(point, np.ndarray):
+            point = np.array(point)
+        return any(point in u for u in self.list_poly)
+
+    def contains(self, points, abs_tol=ABS_TOL):
+        """OR over the polytopes of Polytope.contains (ref :732-746)."""
+        if not isinstance(points, np.ndarray):
+            points = np.array(points)
+        if points.shape[0] != self.dim:
+            raise ValueError("points should be column vectors")
+        return _contains_many(self.list_poly, points, abs_tol, region=True)
+
+    def __eq__(self, other):
+        return self <= other and other <= self
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __le__(self, other):
+        return is_subset(self, other)
+
+    def __ge__(self, other):
+        return is_subset(other, self)
+
+    __hash__ = object.__hash__
+
+    def __add__(self, other):
+        return union(self, other, check_convex=True)
+
+    def __bool__(self):
+        return bool(self.volume > 0)
+
+    __nonzero__ = __bool__
+
+    def union(self, other, check_convex=False):
+        return union(self, other, check_convex)
+
+    def __sub__(self, other):
+        return mldivide(self, other)
+
+    def diff(self, other):
+        return mldivide(self, other)
+
+    def __and__(self, other):
+        return intersect(self, other)
+
+    def intersect(self, other, abs_tol=ABS_TOL):
+        """Pairwise intersections, kept when their Chebyshev radius exceeds abs_tol and merged
+        with union(check_convex=True) in pair order (ref :815-830)."""
+        if isinstance(other, Polytope):
+            other = [other]
+        pairs = [(p0, p1) for p0 in self for p1 in other]
+        pieces = _intersect_pairs(pairs, abs_tol)
+        out = Region()
+        for piece in pieces:
+            rp, _ = piece.cheby
+            if rp > abs_tol:
+                out = union(out, piece, check_convex=True)
+        return out
+
+    def translation(self, d):
+        return Region([p.translation(d) for p in self.list_poly], self.props.copy())
+
+    def __copy__(self):
+        return Region(list_poly=self.list_poly[:], props=self.props.copy())
+
+    def copy(self):
+        return self.__copy__()
+
+    @property
+    def dim(self):
+        return np.shape(self.list_poly[0].A)[1]
+
+    @property
+    def volume(self):
+        if self._volume is None:
+            self._volume = volume(self)
+        return self._volume
+
+    def _set_volume(self, region_volume):
+        if region_volume < 0.0:
+            raise ValueError("`region_volume` must be >= 0, given:  {v}".format(v=region_volume))
+        self._volume = float(region_volume)
+
+    @property
+    def chebR(self):
+        cheby_ball(self)
+        return self._chebR
+
+    @property
+    def chebXc(self):
+        cheby_ball(self)
+        return self._chebXc
+
+    @property
+    def cheby(self):
+        return cheby_ball(self)
+
+    @property
+    def bounding_box(self):
+        if self.bbox is None:
+            self.bbox = bounding_box(self)
+        return self.bbox
+
+
+# ====================================================================================== helpers
+def _pack(polys):
+    """[Polytope] -> A[B, m_max, d], b[B, m_max], m[B] (rows zero-padded)."""
+    B = len(polys)
+    d = polys[0].A.shape[1]
+    ms = np.array([p.A.shape[0] for p in polys], dtype=np.int32)
+    m_max = max(int(ms.max()), 1)
+    A = np.zeros((B, m_max, d))
+    b = np.zeros((B, m_max))
+    for k, p in enumerate(polys):
+        A[k, :ms[k]] = p.A
+        b[k, :ms[k]] = p.b
+    return A, b, ms
+
+
+def _contains_many(polys, points, abs_tol, region=True):
+    points = np.asarray(points, dtype=float)
+    if _use_hip() and polys and all(p.A.size > 0 for p in polys) and points.ndim == 2 \
+            and points.shape[1] > 0 and polys[0].A.shape[1] <= _MAX_DIM:
+        from .batch import contains_batch
+        A, b, ms = _pack(polys)
+        return contains_batch(A, b, np.ascontiguousarray(points), abs_tol, m=ms, region=True).astype(bool)
+    if _use_hip():
+        solvers._require("hip")
+    inside = np.full(points.shape[1], False, dtype=bool)
+    for p in polys:
+        inside |= np.all(p.A.dot(points) - p.b[:, np.newaxis] < abs_tol, axis=0)
+    return inside
+
+
+def _ball_from_lp(status, r, xc):
+    """cheby_ball's reading of the LP result (ref :1289-1297): (r, xc) or None for 'empty'."""
+    if status != 0 or r < 0:
+        return None
+    return np.double(r), np.array(xc)
+
+
+def _cheby_raw(polys):
+    """Chebyshev LP (F1) of each non-empty polytope -> list of (r, xc) or None."""
+    if not polys:
+        return []
+    d = polys[0].A.shape[1]
+    if _use_hip() and all(_fits(p.A.shape[0], p.A.shape[1]) and p.A.shape[1] == d for p in polys):
+        from .batch import cheby_ball_batch
+        A, b, ms = _pack(polys)
+        res = cheby_ball_batch(A, b, m=ms)
+        return [_ball_from_lp(int(res["status"][k]), float(res["r"][k]), res["xc"][k]) for k in range(len(polys))]
+    out = []
+    for p in polys:
+        n = p.A.shape[1]
+        c = np.negative(np.r_[np.zeros(n), 1])
+        G = np.c_[p.A, np.sqrt(np.sum(p.A * p.A, axis=1))]
+        sol = lpsolve(c, G, p.b)
+        out.append(_ball_from_lp(sol["status"], sol["x"][-1], sol["x"][0:-1]) if sol["status"] == 0 else None)
+    return out
+
+
+def _cheby_fill(polys):
+    """Compute and cache the Chebyshev ball of every polytope of the list that lacks one."""
+    todo = [p for p in polys
+            if not (p._chebXc is not None and p._chebR is not None) and not is_empty(p)]
+    for p, ball in zip(todo, _cheby_raw(todo)):
+        if ball is not None:
+            p._chebR, p._chebXc = ball
+
+
+# ====================================================================================== predicates
+def is_empty(polyreg):
+    """True if the DESCRIPTION is empty (no rows / no non-empty member), ref :939-959."""
+    n = len(polyreg)
+    if n == 0:
+        try:
+            return len(polyreg.A) == 0
+        except Exception:
+            return True
+    return all(is_empty(p) for p in polyreg.list_poly)
+
+
+def cheby_ball(poly1):
+    """Chebyshev radius and a centre of a Polytope; for a Region the largest ball of its
+    members (first maximum wins).  Returns cached values when present (ref :1241-1300)."""
+    if (poly1._chebXc is not None) and (poly1._chebR is not None):
+        return poly1._chebR, poly1._chebXc
+    if isinstance(poly1, Region):
+        _cheby_fill(poly1.list_poly)
+        maxr, maxx = 0, None
+        for p in poly1.list_poly:
+            rc, xc = cheby_ball(p)
+            if rc > maxr:
+                maxr, maxx = rc, xc
+        poly1._chebXc, poly1._chebR = maxx, maxr
+        return maxr, maxx
+    if is_empty(poly1):
+        return 0, None
+    ball = _cheby_raw([poly1])[0]
+    if ball is None:
+        return 0, None
+    poly1._chebR, poly1._chebXc = ball
+    return poly1._chebR, poly1._chebXc
+
+
+def is_fulldim(polyreg, abs_tol=ABS_TOL):
+    """True if the polytope / some member of the region has interior points (ref :962-985)."""
+    if polyreg.fulldim is not None:
+        return polyreg.fulldim
+    if len(polyreg) == 0:
+        rc, _ = cheby_ball(polyreg)
+        status = rc > abs_tol
+    else:
+        _cheby_fill(polyreg.list_poly)
+        status = any(cheby_ball(p)[0] > abs_tol for p in polyreg.list_poly)
+    polyreg.fulldim = status
+    return status
+
+
+def is_inside(polyreg, point, abs_tol=ABS_TOL):
+    """Deprecated spelling of `point in polyreg` with an explicit tolerance (ref :1017-1029)."""
+    warnings.warn("Write `point in polyreg` instead of calling this function.", DeprecationWarning)
+    if not isinstance(point, np.ndarray):
+        point = np.array(point)
+    return polyreg.contains(point[:, np.newaxis], abs_tol)[0]
+
+
+def is_subset(small, big, abs_tol=ABS_TOL):
+    r"""small \subseteq big, decided by the volume of small \ big (ref :1032-1050)."""
+    for x in [small, big]:
+        if not isinstance(x, (Polytope, Region)):
+            raise TypeError("Not a Polytope or Region, got instead:\n\t" + str(type(x)))
+    return bool(small.diff(big).volume < abs_tol)
+
+
+# ====================================================================================== bounding box
+def _bbox_raw(polys):
+    """Bounding boxes of non-empty Polytopes via 2d LPs each (F3), all in one batch."""
+    cs, Gs, hs = [], [], []
+    for p in polys:
+        n = p.A.shape[1]
+        eye = np.eye(n)
+        for i in range(n):
+            cs.append(eye[:, i]); Gs.append(p.A); hs.append(p.b)
+        for i in range(n):
+            cs.append(-eye[:, i]); Gs.append(p.A); hs.append(p.b)
+    if _use_hip() and len({c.size for c in cs}) > 1:
+        sols = [solvers.lpsolve(c, G, h) for c, G, h in zip(cs, Gs, hs)]
+    else:
+        sols = solvers.lpsolve_many(cs, Gs, hs)
+    out, pos = [], 0
+    for p in polys:
+        n = p.A.shape[1]
+        lo, hi = np.zeros([n, 1]), np.zeros([n, 1])
+        for i in range(n):
+            sol = sols[pos + i]
+            if sol["status"] == 0:
+                lo[i] = sol["x"][i]
+            elif sol["status"] == 3:
+                lo[i] = -np.inf
+            elif sol["status"] == 2:
+                lo[i] = 0
+            else:
+                raise RuntimeError("bounding_box (lower corner): `polytope.solvers.lpsolve` returned:  "
+                                   "{v}\nits docstring describes return values".format(v=sol))
+        for i in range(n):
+            sol = sols[pos + n + i]
+            if sol["status"] == 0:
+                hi[i] = sol["x"][i]
+            elif sol["status"] == 3:
+                hi[i] = np.inf
+            elif sol["status"] == 2:
+                hi[i] = lo[i]
+            else:
+                raise RuntimeError("bounding_box (upper corner): `polytope.solvers.lpsolve` returned:  "
+                                   "{v}\nits docstring describes return values".format(v=sol))
+        out.append((lo, hi))
+        pos += 2 * n
+    return out
+
+
+def bounding_box(polyreg):
+    """Smallest axis-aligned box (l, u), each a (d,1) array; cached in `.bbox` (ref :1314-1411)."""
+    if polyreg.bbox is not None:
+        return polyreg.bbox
+    if isinstance(polyreg, Region):
+        members = polyreg.list_poly
+        todo = [p for p in members if p.bbox is None]
+        for p, box in zip(todo, _bbox_raw(todo)):
+            p.bbox = box
+        lows = np.array([p.bbox[0].ravel() for p in members])
+        highs = np.array([p.bbox[1].ravel() for p in members])
+        l = lows.min(axis=0).reshape(-1, 1)
+        u = highs.max(axis=0).reshape(-1, 1)
+        polyreg.bbox = l, u
+        return l, u
+    polyreg.bbox = _bbox_raw([polyreg])[0]
+    return polyreg.bbox
+
+
+def _bounding_box_to_polytope(lower, upper):
+    return box2poly([(a[0], b[0]) for a, b in zip(lower, upper)])
+
+
+def box2poly(box):
+    """Polytope from [[x1min, x1max], [x2min, x2max], ...] (ref :2293-2299)."""
+    return Polytope.from_box(box)
+
+
+# ====================================================================================== reduce
+def _reduce_lp_loop(poly, nonEmptyBounded, abs_tol):
+    """reduce() with the LPs issued one by one through lpsolve (non-'hip' backends, and the
+    little-used nonEmptyBounded=0 variant).  Steps as ref :1084-1163."""
+    A_arr, b_arr = poly.A, poly.b
+    rows = np.nonzero(poly.b != np.inf)
+    A_arr, b_arr = A_arr[rows], b_arr[rows]
+    neq = A_arr.shape[0]
+    inv = 1 / np.sqrt(np.sum(A_arr.T ** 2, 0))
+    unit = np.dot(A_arr.T, np.diag(inv)).T
+    drop = set()
+    for i in range(neq):
+        for j in range(i + 1, neq):
+            if np.dot(unit[i].T, unit[j]) > 1 - abs_tol:
+                drop.add(j if b_arr[i] * inv[i] < b_arr[j] * inv[j] else i)
+    keep = [i for i in range(neq) if i not in drop]
+    A_arr, b_arr = A_arr[keep], b_arr[keep]
+    neq, nx = A_arr.shape
+    if nonEmptyBounded and neq <= nx + 1:
+        return Polytope(A_arr, b_arr)
+    if neq > 3 * nx:
+        lb, ub = Polytope(A_arr, b_arr).bounding_box
+        cand = ~(np.dot((A_arr > 0) * A_arr, ub - lb) - (np.array([b_arr]).T - np.dot(A_arr, lb)) < -1e-4)
+        A_arr, b_arr = A_arr[cand.squeeze()], b_arr[cand.squeeze()]
+    neq, nx = A_arr.shape
+    if nonEmptyBounded and neq <= nx + 1:
+        return Polytope(A_arr, b_arr)
+    kept = []
+    for k in range(neq):
+        b_arr[k] += 0.1
+        sol = lpsolve(-A_arr[k, :], A_arr, b_arr)
+        b_arr[k] -= 0.1
+        if sol["status"] == 0:
+            if -sol["fun"] - b_arr[k] > abs_tol:
+                kept.append(k)
+        elif sol["status"] == 3:
+            kept.append(k)
+    out = Polytope(A_arr[kept], b_arr[kept])
+    out.minrep = True
+    return out
+
+
+def _reduce_many(polys, abs_tol):
+    """Fused reduce of Polytopes that are neither minrep nor known to be flat -> list of Polytope.
+
+    Side effects as in the reference: the Chebyshev ball and `fulldim` of each INPUT polytope
+    are cached (is_fulldim at ref :1081)."""
+    from .batch import reduce_batch, keep_to_bool
+    A, b, ms = _pack(polys)
+    res = reduce_batch(A, b, m=ms, abs_tol=abs_tol)
+    masks = keep_to_bool(res["keep"], A.shape[1])
+    out = []
+    for k, p in enumerate(polys):
+        fl = int(res["flags"][k])
+        if fl & _RF_LPFAIL:
+            raise RuntimeError("bounding_box: an LP of the box prefilter of `reduce` ended with status 1 or 4")
+        r = float(res["r"][k])
+        if not np.isnan(res["xc"][k]).any():
+            if p._chebXc is None or p._chebR is None:
+                p._chebR, p._chebXc = np.double(r), res["xc"][k].copy()
+        if p.fulldim is None:
+            p.fulldim = bool(r > abs_tol) if abs_tol == ABS_TOL else p.fulldim
+        if fl & _RF_EMPTY:
+            out.append(Polytope())
+            continue
+        rows = np.nonzero(masks[k, :ms[k]])[0]
+        if fl & _RF_MINREP:
+            bk = (p.b[rows] + 0.1) - 0.1   # the h[k] += 0.1; h[k] -= 0.1 round trip of ref :1149-1151
+            q = Polytope(p.A[rows], bk)
+            q.minrep = True
+        else:
+            q = Polytope(p.A[rows], p.b[rows])
+        out.append(q)
+    return out
+
+
+def reduce(poly, nonEmptyBounded=1, abs_tol=ABS_TOL):
+    """Remove redundant inequalities from the H-representation, one LP per facet
+    (ref :1053-1163).  A Region is reduced member-wise; members that end up flat are dropped."""
+    if isinstance(poly, Region):
+        members = poly.list_poly
+        results = [None] * len(members)
+        if _use_hip() and nonEmptyBounded:
+            todo = [k for k, p in enumerate(members)
+                    if not p.minrep and p.fulldim is not False and p.A.size > 0
+                    and _fits(p.A.shape[0], p.A.shape[1]) and np.all(np.isfinite(p.b))]
+            if todo and len({members[k].A.shape[1] for k in todo}) == 1:
+                for k, q in zip(todo, _reduce_many([members[k] for k in todo], ABS_TOL)):
+                    results[k] = q
+        lst = []
+        for k, p in enumerate(members):
+            red = results[k] if results[k] is not None else reduce(p)
+            if is_fulldim(red):
+                lst.append(red)
+        return Region(lst, poly.props) if lst else Polytope()
+    if poly.minrep:
+        return poly
+    if _use_hip() and nonEmptyBounded and poly.A.size > 0 and _fits(poly.A.shape[0], poly.A.shape[1]) \
+            and np.all(np.isfinite(poly.b)) and poly.fulldim is not False:
+        return _reduce_many([poly], abs_tol)[0]
+    if not is_fulldim(poly):
+        return Polytope()
+    return _reduce_lp_loop(poly, nonEmptyBounded, abs_tol)
+
+
+def _intersect_pairs(pairs, abs_tol):
+    """Polytope.intersect for a list of (Polytope, Polytope) pairs; the stacked polytopes of all
+    full-dimensional pairs are reduced in one batch."""
+    involved = []
+    for p0, p1 in pairs:
+        involved += [p0, p1]
+    _cheby_fill([p for p in involved if p.fulldim is None])
+    out = [None] * len(pairs)
+    stacks, where = [], []
+    for k, (p0, p1) in enumerate(pairs):
+        if not isinstance(p1, Polytope):
+            raise Exception("Polytope intersection defined only with other Polytope. Got instead: " + str(type(p1)))
+        if (not is_fulldim(p0)) or (not is_fulldim(p1)):
+            out[k] = Polytope()
+            continue
+        if p0.dim != p1.dim:
+            raise Exception("polytopes have different dimension")
+        stacks.append(Polytope(np.vstack([p0.A, p1.A]), np.hstack([p0.b, p1.b])))
+        where.append(k)
+    if stacks:
+        batchable = _use_hip() and all(_fits(s.A.shape[0], s.A.shape[1]) for s in stacks) \
+            and len({s.A.shape[1] for s in stacks}) == 1
+        reduced = _reduce_many(stacks, abs_tol) if batchable else [reduce(s, abs_tol=abs_tol) for s in stacks]
+        for k, q in zip(where, reduced):
+            out[k] = q
+    _cheby_fill([q for q in out if q.A.size > 0])
+    return out
+
+
+def intersect(poly1, poly2, abs_tol=ABS_TOL):
+    """Intersection of two polytopes or regions (ref :1508-1526)."""
+    if isinstance(poly1, Region):
+        return poly1.intersect(poly2, abs_tol=abs_tol)
+    if isinstance(poly2, Region):
+        return poly2.intersect(poly1, abs_tol=abs_tol)
+    if not isinstance(poly1, Polytope):
+        raise Exception("poly1 not Region nor Polytope.Got instead: " + str(type(poly1)))
+    return poly1.intersect(poly2, abs_tol)
+
+
+# ====================================================================================== union / convexity
+def _members(s):
+    if len(s) == 0:
+        return [] if is_empty(s) else [s]
+    return [p for p in s.list_poly if not is_empty(p)]
+
+
+def union(polyreg1, polyreg2, check_convex=False):
+    """Union as a Region of non-overlapping polytopes; with check_convex the pieces are greedily
+    merged whenever their union is convex (ref :1166-1238)."""
+    if is_empty(polyreg1):
+        return polyreg2
+    if is_empty(polyreg2):
+        return polyreg1
+    if check_convex:
+        common = intersect(polyreg1, polyreg2)
+        if is_fulldim(common):
+            parts = [common, polyreg2.diff(polyreg1), polyreg1.diff(polyreg2)]
+        else:
+            parts = [common, polyreg1, polyreg2]
+    else:
+        parts = [polyreg1, polyreg2]
+    lst = []
+    for s in parts:
+        lst += _members(s)
+    if not check_convex:
+        return Region(lst)
+    if len(lst) <= 1:
+        return Region(lst)
+    final = []
+    while lst:
+        group = [lst[0]]
+        for cand in lst[1:]:
+            group.append(cand)
+            convex, _ = is_convex(Region(group))
+            if not convex:
+                group.pop()
+        lst = [p for p in lst if not any(p is q for q in group)]
+        hull = reduce(envelope(Region(group)))
+        if not is_empty(hull):
+            final.append(reduce(hull))
+    return Region(final)
+
+
+def is_convex(reg, abs_tol=ABS_TOL):
+    """(True, envelope) if the region is convex, else (False, None) (ref :988-1014)."""
+    if len(reg) == 0:
+        return True, None
+    outer = envelope(reg)
+    if is_empty(outer):
+        return False, None
+    Pl, Pu = reg.bounding_box
+    Ol, Ou = outer.bounding_box
+    if np.any(abs(Pl - Ol) > abs_tol) or np.any(abs(Pu - Ou) > abs_tol):
+        return False, None
+    if is_fulldim(outer.diff(reg)):
+        return False, None
+    return True, outer
+
+
+def envelope(reg, abs_tol=ABS_TOL):
+    """Polytope of all 'outer' inequalities of a region: facet ii of member i is outer when no
+    other member reaches beyond it (one Chebyshev LP per (facet, other member)); empty Polytope
+    when the envelope is not full-dimensional (ref :1414-1464)."""
+    members = reg.list_poly
+    tests, owner = [], []
+    for i, p1 in enumerate(members):
+        for ii in range(p1.A.shape[0]):
+            for j, p2 in enumerate(members):
+                if i == j:
+                    continue
+                tests.append(Polytope(np.vstack([p2.A, -p1.A[ii, :]]), np.hstack([p2.b, -p1.b[ii]])))
+                owner.append((i, ii))
+    crossed = set()
+    balls = _cheby_raw(tests) if tests else []
+    for (i, ii), ball in zip(owner, balls):
+        if ball is not None and ball[0] > abs_tol:
+            crossed.add((i, ii))
+    Ae, be = [], []
+    for i, p1 in enumerate(members):
+        rows = [ii for ii in range(p1.A.shape[0]) if (i, ii) not in crossed]
+        Ae.append(p1.A[rows, :])
+        be.append(p1.b[rows])
+    ret = reduce(Polytope(np.vstack(Ae), np.hstack(be)), abs_tol=abs_tol)
+    return ret if is_fulldim(ret) else Polytope()
+
+
+# ====================================================================================== difference
+def mldivide(a, b, save=False):
+    r"""Set difference a \ b as a Region (ref :1470-1505)."""
+    if isinstance(b, Polytope):
+        b = Region([b])
+    if isinstance(a, Region):
+        out = Region()
+        for poly in a:
+            rest = poly
+            for sub in b:
+                rest = mldivide(rest, sub, save=save)
+            out = union(out, rest, check_convex=True)
+        return out
+    if isinstance(a, Polytope):
+        return region_diff(a, b)
+    raise Exception("a neither Region nor Polytope")
+
+
+def _radii(polys):
+    """Chebyshev radius of freshly built polytopes (0 when the ball LP fails), one batch."""
+    out = []
+    for p, ball in zip(polys, _cheby_raw(polys)):
+        if ball is None:
+            out.append(0)
+        else:
+            p._chebR, p._chebXc = ball
+            out.append(ball[0])
+    return out
+
+
+def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
+    """poly minus the union of the polytopes of reg, as non-overlapping pieces.
+
+    Depth-first enumeration of the sign patterns of the subtrahends' new constraints, one
+    Chebyshev LP per node (the algorithm of ref :2117-2282, same visiting order and the same
+    tests).  The N LPs of the initial scan and the LPs of every level scan are independent and
+    are issued as one batch each.
+    """
+    if not isinstance(poly, Polytope):
+        raise Exception("poly not a Polytope, but: " + str(type(poly)))
+    poly = poly.copy()
+    if isinstance(reg, Polytope):
+        reg = Region([reg])
+    if not isinstance(reg, Region):
+        raise Exception("reg not a Region, but: " + str(type(reg)))
+    N = len(reg)
+    if N == 0:
+        reg = Region([reg])
+        N = 1
+    if is_empty(reg):
+        return poly
+    if is_empty(poly):
+        return Polytope()
+    cells = reg.list_poly
+    # which cells meet the polytope at all
+    Rc = np.array(_radii([Polytope(np.vstack([poly.A, c.A]), np.hstack([poly.b, c.b])) for c in cells]), dtype=float)
+    N = int(np.sum(Rc >= intersect_tol))
+    if N == 0:
+        logger.debug("no Polytope in the Region intersects the given Polytope")
+        return poly
+    order = np.argsort(-Rc)
+    m = poly.A.shape[0]
+    A = poly.A.copy()
+    B = poly.b.copy()
+    base = np.hstack([poly.A, poly.b[:, None]])
+    _cheby_fill([cells[order[ii]] for ii in range(N) if cells[order[ii]].fulldim is None])
+    mi = np.zeros(N, dtype=int)
+    for ii in range(N):
+        cell = cells[order[ii]]
+        if not is_fulldim(cell):
+            continue
+        for j in range(cell.A.shape[0]):
+            row = np.hstack([cell.A[j, :], cell.b[j]])
+            if np.all(np.sum(np.abs(base - row), axis=1) >= abs_tol):  # constraint not already in poly
+                mi[ii] += 1
+                A = np.vstack([A, cell.A[j, :]])
+                B = np.hstack([B, cell.b[j]])
+    if np.any(mi == 0):
+        return Polytope()  # some cell covers the polytope
+    M = int(np.sum(mi))
+    beg = m + np.concatenate([[0], np.cumsum(mi[:-1])]).astype(int)
+    A = np.vstack([A, -A[m:m + M, :]])
+    B = np.hstack([B, -B[m:m + M]])
+    counter = [0] * N   # python list: negative `level` wraps around exactly as the reference's array does
+    idx = list(range(m))
+    level = 0
+    res = Polytope()
+
+    def poly_of(rows):
+        return Polytope(A[rows, :], B[rows])
+
+    while level != -1:
+        if counter[level] == 0:
+            scan = [poly_of(idx + list(range(beg[j], beg[j] + mi[j]))) for j in range(level, N)]
+            radii = _radii(scan)
+            R = radii[-1]
+            for off, Rj in enumerate(radii):
+                if Rj > abs_tol:
+                    R = Rj
+                    level = level + off
+                    counter[level] = 1
+                    idx = idx + [beg[level] + M]
+                    break
+            if R < abs_tol:
+                level = level - 1
+                res = union(res, poly_of(idx), False)
+                nz = [k for k in range(N) if counter[k] != 0]
+                for _ in range(len(nz)):
+                    if counter[level] <= mi[level]:
+                        idx[-1] = idx[-1] - M
+                        idx = idx + [beg[level] + counter[level] + M]
+                        break
+                    counter[level] = 0
+                    idx = idx[0:m + sum(counter)]
+                    if level == -1:
+                        logger.debug("returning res from 1st point")
+                        return res
+        else:
+            nz = [k for k in range(N) if counter[k] != 0]
+            for jj in range(len(nz) - 1, -1, -1):
+                level = nz[jj]
+                counter[level] += 1
+                if counter[level] <= mi[level]:
+                    idx[-1] = idx[-1] - M
+                    idx = idx + [beg[level] + counter[level] + M - 1]
+                    break
+                counter[level] = 0
+                idx = idx[0:m + sum(counter)]
+                level = level - 1
+                if level == -1:
+                    logger.debug("returning res from 2nd point")
+                    return res
+        test_poly = poly_of(idx)
+        rc, _ = cheby_ball(test_poly)
+        if rc > abs_tol:
+            if level == N - 1:
+                res = union(res, reduce(test_poly), False)
+            else:
+                level = level + 1
+    logger.debug("returning res from end")
+    return res
+
+
+# ====================================================================================== volume
+def volume(polyreg, nsamples=None, seed=None):
+    """Monte-Carlo volume: uniform samples in the bounding box, fraction strictly inside
+    (ref :1529-1594).  Region: sum over its members."""
+    if not is_fulldim(polyreg):
+        return 0.0
+    if isinstance(polyreg, Region):
+        tot = 0.0
+        for p in polyreg.list_poly:
+            tot += volume(p)
+        polyreg._set_volume(tot)
+        return tot
+    n = polyreg.A.shape[1]
+    N = {1: 50, 2: 500, 3: 3000}.get(n, 10000)
+    if nsamples is not None and nsamples < 1:
+        raise ValueError("`nsamples` must be >= 1, given:  {v}".format(v=nsamples))
+    if nsamples is not None:
+        N = nsamples
+    if N != int(N):
+        raise ValueError("it appears that a noninteger number of samples has been given, namely:  {v}".format(
+            v=nsamples))
+    l_b, u_b = polyreg.bounding_box
+    x = np.tile(l_b, (1, N)) + np.random.default_rng(seed).random((n, N)) * np.tile(u_b - l_b, (1, N))
+    aux = np.dot(polyreg.A, x) - np.tile(np.array([polyreg.b]).T, (1, N))
+    hits = np.nonzero(np.all(aux < 0, 0))[0].shape[0]
+    vol = np.prod(u_b - l_b) * hits / N
+    polyreg._set_volume(vol)
+    return vol
+
+
+# ====================================================================================== adjacency
+def _adjacency_stack(poly1, poly2, overlap, abs_tol):
+    """The slightly inflated stacked polytope whose full-dimensionality decides adjacency
+    (ref :1855-1885); None when the non-overlap branch can answer False without an LP."""
+    A1, A2 = poly1.A.copy(), poly2.A.copy()
+    b1, b2 = poly1.b.copy(), poly2.b.copy()
+    if overlap:
+        b1 += abs_tol
+        b2 += abs_tol
+    else:
+        M1 = np.concatenate((poly1.A, np.array([poly1.b]).T), 1).T
+        M1n = np.dot(M1, np.diag(1 / np.sqrt(np.sum(M1 ** 2, 0))))
+        M2 = np.concatenate((poly2.A, np.array([poly2.b]).T), 1).T
+        M2n = np.dot(M2, np.diag(1 / np.sqrt(np.sum(M2 ** 2, 0))))
+        gram = np.dot(M1n.T, M2n)
+        if not np.any(gram < -0.99):
+            return None
+        row, col = np.nonzero(np.isclose(gram, gram.min()))
+        for i, j in zip(row, col):
+            b1[i] += abs_tol
+            b2[j] += abs_tol
+    return Polytope(np.concatenate((A1, A2)), np.concatenate((b1, b2)))
+
+
+def is_adjacent(poly1, poly2, overlap=True, abs_tol=ABS_TOL):
+    """True if two polytopes / regions touch (or overlap, with overlap=True): both are inflated
+    by abs_tol and the intersection must have Chebyshev radius > abs_tol/10 (ref :1827-1885)."""
+    if poly1.dim != poly2.dim:
+        raise Exception("is_adjacent: polytopes do not have the same dimension")
+    return bool(is_adjacent_pairs([(poly1, poly2)], overlap=overlap, abs_tol=abs_tol)[0])
+
+
+def is_adjacent_pairs(pairs, overlap=True, abs_tol=ABS_TOL):
+    """is_adjacent for many (polytope-or-region, polytope-or-region) pairs; every pair of member
+    polytopes contributes one Chebyshev LP and all of them go down as one batch
+    (the O(n^2) loop of prop2partition.py:57-61)."""
+    stacks, owner = [], []
+    result = np.zeros(len(pairs), dtype=bool)
+    for k, (pa, pb) in enumerate(pairs):
+        if pa.dim != pb.dim:
+            raise Exception("is_adjacent: polytopes do not have the same dimension")
+        la = pa.list_poly if isinstance(pa, Region) else [pa]
+        lb = pb.list_poly if isinstance(pb, Region) else [pb]
+        for p in la:
+            for q in lb:
+                st = _adjacency_stack(p, q, overlap, abs_tol)
+                if st is not None:
+                    stacks.append(st)
+                    owner.append(k)
+    for k, r in zip(owner, _radii(stacks) if stacks else []):
+        if r > abs_tol / 10:
+            result[k] = True
+    return result
