@@ -15,6 +15,8 @@ Sets:
   g2_reduce.npz    reduce(): kept-row masks, reduced (A,b), Chebyshev radius        (polytope.py:1053-1163)
   g3_edge.npz      edge cases of SURVEY A.4 through cheby_ball / bounding_box / lpsolve
   g4_contains.npz  Polytope.contains / Region.contains incl. boundary points        (polytope.py:206-218,732-746)
+  g5_setops.npz    region_diff / Region.intersect pieces and is_adjacent matrices on box grids
+                   (polytope.py:2117-2282, :815-830, :1827-1866)
   g6_quickhull.npz Facet normals/offsets, distance(), first-facet assignment,
                    get_furthest, and end-to-end hull facet sets                     (quickhull.py)
   g7_known.npz     the known-answer data of the reference's own tests (tests/polytope_test.py)
@@ -268,6 +270,60 @@ def gen_g4():
     print("g4: contains", res.shape, "inside fraction", res.mean())
 
 
+
+# ----------------------------------------------------------------------------- G5
+def grid_cells(shape, lo=0.0, hi=1.0):
+    import itertools
+    d = len(shape)
+    cells = []
+    for idx in itertools.product(*[range(n) for n in shape]):
+        iv = [[lo + (hi - lo) * idx[k] / shape[k], lo + (hi - lo) * (idx[k] + 1) / shape[k]] for k in range(d)]
+        cells.append(pc.box2poly(iv))
+    return cells
+
+
+def pieces_of(x):
+    if isinstance(x, pc.Region):
+        return list(x.list_poly)
+    return [] if x.A.size == 0 else [x]
+
+
+def gen_g5():
+    rng = np.random.default_rng(55)
+    out = {}
+    cases = []
+    for name, shape in [("g2x2", (2, 2)), ("g3x3", (3, 3)), ("g2x2x2", (2, 2, 2)), ("g2x2x2x2", (2, 2, 2, 2)),
+                        ("g3x2x2x1", (3, 2, 2, 1))]:
+        d = len(shape)
+        cells = grid_cells(shape)
+        # minuend: bounded random polytope scaled to radius ~0.3 around the grid centre
+        A, b = rand_hpoly(rng, 4 * d, d, bounded=False)
+        P = pc.Polytope(A, 0.3 * b + A @ (0.5 * np.ones(d)))
+        sub = pc.Region(cells[: max(1, len(cells) // 2)])  # subtract half of the cells
+        D = alg.region_diff(P.copy(), sub)
+        I = pc.Region(cells).intersect(P.copy())
+        adj = np.zeros((len(cells), len(cells)), np.int8)
+        for i, a in enumerate(cells):
+            adj[i, i] = 1
+            for j, bb in enumerate(cells[:i]):
+                adj[i, j] = adj[j, i] = pc.is_adjacent(a, bb)
+        out[name + "_cellsA"] = np.array([c.A for c in cells])
+        out[name + "_cellsb"] = np.array([c.b for c in cells])
+        out[name + "_PA"], out[name + "_Pb"] = P.A, P.b
+        out[name + "_nsub"] = np.int32(len(sub))
+        for tag, X in (("diff", D), ("isect", I)):
+            ps = pieces_of(X)
+            out[f"{name}_{tag}_n"] = np.int32(len(ps))
+            out[f"{name}_{tag}_r"] = np.array([float(pc.cheby_ball(q)[0]) for q in ps])
+            out[f"{name}_{tag}_m"] = np.array([q.A.shape[0] for q in ps], np.int32)
+            out[f"{name}_{tag}_A"] = pad([q.A.ravel() for q in ps], 64 * d) if ps else np.zeros((0, 64 * d))
+            out[f"{name}_{tag}_b"] = pad([q.b for q in ps], 64) if ps else np.zeros((0, 64))
+        out[name + "_adj"] = adj
+        cases.append(name)
+        print("g5", name, "diff pieces", len(pieces_of(D)), "isect pieces", len(pieces_of(I)), "adj pairs", int(adj.sum()))
+    out["names"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "g5_setops.npz"), **out)
+
 # ----------------------------------------------------------------------------- G6
 def gen_g6():
     rng = np.random.default_rng(6)
@@ -377,6 +433,6 @@ def gen_g7():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:
         globals()["gen_" + w]()
