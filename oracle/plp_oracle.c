@@ -142,8 +142,7 @@ static int run(dict_t *D)
             if (D->carry) D->cost2[e] = -D->cost2[e];
             D->colsgn[e] = -D->colsgn[e];
         }
-        /* ratio test: min beta_i/T_ie over active rows with T_ie > TOL_PIV;
-           ties -> lowest basic-variable id */
+        /* ratio test: min beta_i/T_ie over active rows with T_ie > TOL_PIV */
         int r = -1;
         double rmin = INFINITY;
         for (int i = 0; i < D->m; ++i) {
@@ -151,8 +150,9 @@ static int run(dict_t *D)
             const double a = D->T[i][e];
             if (!(a > TOL_PIV)) continue;
             const double bi = D->beta[i] > 0.0 ? D->beta[i] : 0.0;
-            const double q = bi / a;
-            if (r < 0 || q < rmin || (q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
+            const double q = bi * (1.0 / a);
+            /* ties: Dantzig mode keeps the first (lowest) row, Bland mode the lowest variable id */
+            if (r < 0 || q < rmin || (bland && q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
         }
         if (r < 0) return ST_UNBND;
         ndeg = (rmin <= DEGEN_EPS) ? ndeg + 1 : 0;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int g
         if (has_row && zero) S.beta = 0.0;
         const bool bad = grp_ballot(!finite, g) != 0 || m > gs;
         const bool need_p1 = grp_ballot(S.rowact && hi < 0.0, g) != 0;
-        S.colvar[N] = ID_T;
+        S.set_col(N, ID_T);
         if (need_p1) {
             S.T[N] = S.rowact ? -1.0 : 0.0;
             S.cost[N] = 1.0;

@@ -9,42 +9,26 @@
 //   6. one redundancy LP F2 per remaining row k (h[k] += 0.1 ... -= 0.1)  (:1142-1160)
 // Output: 64-bit keep mask over the INPUT rows, flags, Chebyshev ball, number of LPs solved.
 //
-// Mapping: a 256-thread workgroup takes a tile of NG = 256/GS polytopes (GS lanes per LP
-// group, GS >= rows).  The tile's rows are read from HBM once, coalesced, into LDS; every LP
-// of the tile is then solved out of LDS by whichever group is free:
-//   phase A  group p solves F1 of polytope p, then dedupes              (NG LPs)
-//   phase B  the 2*nx F3 LPs of all polytopes that need a box           (work list, NG at a time)
-//   phase C  the F2 LPs of all surviving rows                           (work list, NG at a time)
-// F2/F3 start from the dictionary shifted to the Chebyshev centre (b - A xc > 0), so they
-// need no phase 1.  HBM traffic = 8 m (d+1) bytes in + 12 + 8(d+1) + 4 bytes out per polytope.
+// Mapping: a 256-thread workgroup takes a tile of NG = 256/GS polytopes (GS lanes per group,
+// GS >= rows).  The tile's rows are read from HBM once, coalesced, into LDS.  Group p then runs
+// the whole pipeline of polytope p: lane i keeps row i (a_i, b_i) in VGPRs for the entire
+// sequence F1 -> dedupe -> 2d F3 -> prefilter -> one F2 per surviving row; the 64/GS groups of a
+// wavefront advance in lockstep, LP by LP.  The LPs of one polytope share everything but the
+// objective and one right-hand side entry, so setting one up is a handful of register moves:
+//   * F2/F3 start from the dictionary translated to the Chebyshev centre (b - A xc > 0), which is
+//     primal feasible: no phase 1;
+//   * the optimal value is read off the dictionary (zeta = -negz), not recomputed from x.
+// LDS is only read after the staging barrier (row k's coefficients = objective of F2(k), other
+// rows for the dedupe), so the groups never synchronise with each other.
+// HBM traffic = 8 m (d+1) bytes in + 24 + 8 d bytes out per polytope.
 #include "plp_kernels.hpp"
 #include "plp_simplex.hpp"
 
 namespace plp {
 
-struct ReduceSmem {
-    double* A;    // [NG][gs][D]
-    double* b;    // [NG][gs]
-    double* an;   // [NG][gs]   1/||a_i||
-    double* xc;   // [NG][D]
-    double* lb;   // [NG][D]
-    double* ub;   // [NG][D]
-    double* r;    // [NG]
-    unsigned long long* live;  // [NG]
-    unsigned long long* keep;  // [NG]
-    int* flags;   // [NG]
-    int* nlp;     // [NG]
-    int* stage;   // [NG] 0 done, 1 needs box, 2 needs F2
-    int* list;    // [NG*max(gs,2D)]
-    int* count;   // [1]
-};
-
 static inline size_t reduce_smem_bytes(int gs, int D) {
     const int NG = BLOCK / gs;
-    const int per = gs > 2 * D ? gs : 2 * D;
-    size_t dbl = (size_t)NG * gs * D + 2 * (size_t)NG * gs + 3 * (size_t)NG * D + NG;
-    size_t bytes = dbl * 8 + 2 * (size_t)NG * 8 + 3 * (size_t)NG * 4 + (size_t)NG * per * 4 + 16;
-    return (bytes + 15) & ~(size_t)15;
+    return ((size_t)NG * gs * (D + 1) * 8 + 15) & ~(size_t)15;
 }
 
 template <int D>
@@ -62,30 +46,17 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(long long B, int m_max, i
     const int NG = BLOCK / gs;
     const int gib = threadIdx.x / gs;
     const int i = g.gl;
-    ReduceSmem sm;
-    {
-        double* p = reinterpret_cast<double*>(smem_raw);
-        sm.A = p;  p += (size_t)NG * gs * D;
-        sm.b = p;  p += (size_t)NG * gs;
-        sm.an = p; p += (size_t)NG * gs;
-        sm.xc = p; p += (size_t)NG * D;
-        sm.lb = p; p += (size_t)NG * D;
-        sm.ub = p; p += (size_t)NG * D;
-        sm.r = p;  p += NG;
-        sm.live = reinterpret_cast<unsigned long long*>(p);
-        sm.keep = sm.live + NG;
-        sm.flags = reinterpret_cast<int*>(sm.keep + NG);
-        sm.nlp = sm.flags + NG;
-        sm.stage = sm.nlp + NG;
-        sm.list = sm.stage + NG;
-        sm.count = sm.list + NG * (gs > 2 * D ? gs : 2 * D);
-    }
+    double* sA = reinterpret_cast<double*>(smem_raw);   // [NG][gs][D]
+    double* sb = sA + (size_t)NG * gs * D;               // [NG][gs]
+    const double* myA = sA + (size_t)gib * gs * D;       // rows of my polytope
+    const double* myb = sb + (size_t)gib * gs;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
     for (long long tile = (long long)blockIdx.x * NG; tile < B; tile += (long long)gridDim.x * NG) {
         const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
         // ---------------------------------------------------------------- stage rows in LDS
+        __syncthreads();  // the previous tile's readers are done
         {
             const int rowsz = m_max * D;
             const int totA = ntile * rowsz;
@@ -93,39 +64,43 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(long long B, int m_max, i
             for (int idx = threadIdx.x; idx < totA; idx += BLOCK) {
                 const int p = idx / rowsz, rem = idx - p * rowsz;
                 const int row = rem / D, k = rem - row * D;
-                sm.A[((size_t)p * gs + row) * D + k] = src[idx];
+                sA[((size_t)p * gs + row) * D + k] = src[idx];
             }
             const int totb = ntile * m_max;
             const double* srcb = bg + tile * m_max;
             for (int idx = threadIdx.x; idx < totb; idx += BLOCK) {
                 const int p = idx / m_max, row = idx - p * m_max;
-                sm.b[p * gs + row] = srcb[idx];
+                sb[p * gs + row] = srcb[idx];
             }
         }
         __syncthreads();
-        // ---------------------------------------------------------------- phase A: F1 + dedupe
         const long long pg = tile + gib;
         const bool valid = gib < ntile;
         const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
         const bool has_row = valid && i < m && m <= gs;
+        // ---------------------------------------------------------------- my row
         double a[D];
-        double bi = 0.0, an_i = 0.0;
-        {
-            Simplex<D + 1, false> S;
-            S.reset(D + 1, m, i);
-            bool finite = true;
-            double nrm2 = 0.0;
+        bool finite = true;
+        double nrm2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                a[k] = has_row ? sm.A[((size_t)gib * gs + i) * D + k] : 0.0;
-                S.T[k] = a[k];
-                nrm2 = nrm2 + a[k] * a[k];
-                finite = finite && isfinite(a[k]);
-            }
-            bi = has_row ? sm.b[gib * gs + i] : 0.0;
-            finite = finite && isfinite(bi);
-            const double nrm = sqrt(nrm2);
-            an_i = 1.0 / nrm;
+        for (int k = 0; k < D; ++k) {
+            a[k] = has_row ? myA[i * D + k] : 0.0;
+            nrm2 = nrm2 + a[k] * a[k];
+            finite = finite && isfinite(a[k]);
+        }
+        const double bi = has_row ? myb[i] : 0.0;
+        finite = finite && isfinite(bi);
+        const double nrm = sqrt(nrm2);
+        const double an_i = 1.0 / nrm;
+        // ---------------------------------------------------------------- F1: Chebyshev ball
+        double xc[D];
+        double rr = 0.0;
+        bool ball, fulldim;
+        {
+            Simplex<D + 1, false, true> S;
+            S.reset(D + 1, m, i);
+#pragma unroll
+            for (int k = 0; k < D; ++k) S.T[k] = a[k];
             const bool zero = !(nrm > 0.0);
             S.T[D] = nrm;
             S.beta = bi;
@@ -142,38 +117,24 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(long long B, int m_max, i
             if (!valid || bad) { S.mode = M_DONE; S.status = ST_NUM; }
             else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
             S.run(g);
-
             const bool ok = S.status == ST_OPT;
             const double mine = S.x_value();
             const bool holds = S.holds_x();
-            double rr = 0.0;
 #pragma unroll
             for (int j = 0; j <= D; ++j) {
                 const uint64_t ob = grp_ballot(holds && S.rowvar == j, g);
                 const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
                 const double xj = ob ? v : 0.0;
-                if (j < D) { if (valid && i == 0) sm.xc[gib * D + j] = xj; }
-                else rr = xj;
+                if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
             }
-            const bool ball = ok && rr >= 0.0;  // cheby_ball: status 0 and r >= 0 (:1289-1293)
-            const bool fulldim = ball && rr > abs_tol;
-            if (valid && i == 0) {
-                sm.r[gib] = ball ? rr : 0.0;
-                sm.flags[gib] = fulldim ? 0 : RF_EMPTY;
-                sm.nlp[gib] = 1;
-                sm.keep[gib] = 0ull;
-                sm.stage[gib] = fulldim ? -1 : 0;  // -1: decided after dedupe
-                if (!ball) {
-#pragma unroll
-                    for (int j = 0; j < D; ++j) sm.xc[gib * D + j] = qnan;
-                }
-            }
-            if (has_row) sm.an[gib * gs + i] = an_i;
+            ball = ok && rr >= 0.0;        // cheby_ball: status 0 and r >= 0 (:1289-1293)
+            fulldim = ball && rr > abs_tol;
         }
-        __syncthreads();
+        // ---------------------------------------------------------------- dedupe (:1094-1110)
+        // unit rows with dot > 1 - abs_tol are the same hyperplane; of a pair (p<q) the one with the
+        // larger normalised offset goes, ties drop p.
+        uint64_t live;
         {
-            // dedupe (:1094-1110): unit rows with dot > 1 - abs_tol are the same hyperplane;
-            // of a pair (p<q) the one with the larger normalised offset goes, ties drop p.
             bool removed = false;
             double ni[D];
 #pragma unroll
@@ -181,173 +142,126 @@ __global__ __launch_bounds__(BLOCK) void reduce_kernel(long long B, int m_max, i
             const double bin_ = bi * an_i;
             for (int j = 0; j < m_max; ++j) {
                 const bool jrow = valid && j < m;
-                const double an_j = jrow ? sm.an[gib * gs + j] : 0.0;
+                const double an_j = bcast(an_i, g.gbase + (j & (gs - 1)));
                 double dot = 0.0;
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const double ajk = jrow ? sm.A[((size_t)gib * gs + j) * D + k] : 0.0;
-                    dot = dot + ni[k] * (ajk * an_j);
-                }
-                const double bjn = (jrow ? sm.b[gib * gs + j] : 0.0) * an_j;
+                for (int k = 0; k < D; ++k) dot = dot + ni[k] * (myA[j * D + k] * an_j);
+                const double bjn = myb[j] * an_j;
                 const bool par = has_row && jrow && j != i && (dot > 1.0 - abs_tol);
-                if (par) {
-                    if (i < j) removed = removed || !(bin_ < bjn);
-                    else removed = removed || (bjn < bin_);
-                }
+                removed = removed || (par && ((i < j) ? !(bin_ < bjn) : (bjn < bin_)));
             }
-            const uint64_t live = grp_ballot(has_row && !removed, g);
-            const int neq = __popcll(live);
-            if (valid && i == 0 && sm.stage[gib] == -1) {
-                if (neq <= D + 1) { sm.flags[gib] = RF_EARLY; sm.keep[gib] = live; sm.stage[gib] = 0; }
-                else sm.stage[gib] = (neq > 3 * D) ? 1 : 2;
-            }
-            if (valid && i == 0) sm.live[gib] = live;
-            if (!valid && i == 0) { sm.stage[gib] = 0; sm.live[gib] = 0ull; }
+            live = grp_ballot(has_row && !removed, g);
         }
-        __syncthreads();
-        // ---------------------------------------------------------------- phase B: bounding boxes
-        {
-            unsigned need = 0u;
-            for (int p = 0; p < NG; ++p) need |= (sm.stage[p] == 1 ? 1u : 0u) << p;
-            const int total = 2 * D * __popc(need);
-            if (sm.stage[gib] == 1) {
-                const int off = 2 * D * __popc(need & ((1u << gib) - 1u));
-                for (int k = i; k < 2 * D; k += gs) sm.list[off + k] = (gib << 8) | k;
-            }
-            __syncthreads();
-            for (int it = 0; it * NG < total; ++it) {
-                const int item = it * NG + gib;
-                const bool iv = item < total;
-                const int code = iv ? sm.list[item] : 0;
-                const int p = code >> 8, k = code & 255;
-                const uint64_t live = iv ? sm.live[p] : 0ull;
-                const bool lrow = (live >> i) & 1ull;
-                Simplex<D, false> S;
+        int flags = fulldim ? 0 : RF_EMPTY;
+        int nlp = 1;
+        uint64_t keep = 0ull;
+        int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
+        if (fulldim) {
+            const int neq = __popcll(live);
+            if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
+            else stage = (neq > 3 * D) ? 1 : 2;
+        }
+        // dictionary translated to the Chebyshev centre: beta_i = b_i - a_i.xc
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fma(a[k], ball ? xc[k] : 0.0, s);
+        // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
+        if (__any(stage == 1)) {
+            double s1 = 0.0, s2 = 0.0;
+            bool lpfail = false;
+            const bool lrow = (live >> i) & 1ull;
+            const double bsh = bi - s;
+            const bool go = stage == 1;
+            double lbk = 0.0;
+            for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
+                const int k = it >> 1;
+                const bool up = it & 1;
+                double aik = 0.0, xck = 0.0;
+                Simplex<D, false, false> S;
                 S.reset(D, __popcll(live), i);
-                double s = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) {
-                    const double av = lrow ? sm.A[((size_t)p * gs + i) * D + kk] : 0.0;
-                    S.T[kk] = av;
-                    s = fma(av, iv ? sm.xc[p * D + kk] : 0.0, s);
-                    S.cost[kk] = iv ? ((kk == (k < D ? k : k - D)) ? (k < D ? 1.0 : -1.0) : 0.0) : 0.0;
+                    aik = (kk == k) ? a[kk] : aik;
+                    xck = (kk == k) ? xc[kk] : xck;
+                    S.T[kk] = lrow ? a[kk] : 0.0;
+                    S.cost[kk] = (kk == k) ? (up ? -1.0 : 1.0) : 0.0;
                 }
-                const double bsh = (lrow ? sm.b[p * gs + i] : 0.0) - s;
-                S.beta = bsh > 0.0 ? bsh : 0.0;
+                S.beta = (lrow && bsh > 0.0) ? bsh : 0.0;
                 S.rowact = lrow;
-                S.mode = iv ? M_P2 : M_DONE;
+                S.mode = go ? M_P2 : M_DONE;
                 S.run(g);
-                const int kk = k < D ? k : k - D;
-                const uint64_t ob = grp_ballot(S.holds_x() && S.rowvar == kk, g);
-                const double v = bcast(S.x_value(), g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
-                if (iv && i == 0) {
-                    double val;
-                    if (S.status == ST_OPT) val = sm.xc[p * D + kk] + (ob ? v : 0.0);
-                    else if (S.status == ST_UNBND) val = (k < D) ? -pinf : pinf;
-                    else { val = qnan; atomicOr(&sm.flags[p], RF_LPFAIL); }
-                    if (k < D) sm.lb[p * D + kk] = val; else sm.ub[p * D + kk] = val;
+                // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
+                double val;
+                if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+                else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+                else { val = qnan; lpfail = lpfail || go; }
+                if (!up) {
+                    lbk = val;
+                } else {  // prefilter sums, accumulated in k order (:1131-1134)
+                    const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                    s1 = s1 + pa * (val - lbk);
+                    s2 = s2 + aik * lbk;
                 }
-            }
-        }
-        __syncthreads();
-        // ---------------------------------------------------------------- prefilter (:1131-1134)
-        if (sm.stage[gib] == 1) {
-            const uint64_t live = sm.live[gib];
-            const bool lrow = (live >> i) & 1ull;
-            double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double lbk = sm.lb[gib * D + k], ubk = sm.ub[gib * D + k];
-                const double pa = (a[k] > 0.0 ? 1.0 : 0.0) * a[k];
-                s1 = s1 + pa * (ubk - lbk);
-                s2 = s2 + a[k] * lbk;
             }
             const bool out = (s1 - (bi - s2)) < -1e-4;
-            const uint64_t live2 = live & ~grp_ballot(lrow && out, g);
-            if (i == 0) {
-                sm.nlp[gib] += 2 * D;
-                sm.live[gib] = live2;
-                if (__popcll(live2) <= D + 1) {
-                    sm.flags[gib] |= RF_EARLY; sm.keep[gib] = live2; sm.stage[gib] = 0;
-                } else sm.stage[gib] = 2;
+            const uint64_t outb = grp_ballot(go && lrow && out, g);
+            if (go) {
+                live = live & ~outb;
+                nlp += 2 * D;
+                if (lpfail) flags |= RF_LPFAIL;
+                if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
+                else stage = 2;
             }
         }
-        __syncthreads();
-        // ---------------------------------------------------------------- phase C: redundancy LPs
-        {
-            int myoff = 0, total = 0;
-            for (int p = 0; p < NG; ++p) {
-                const int c = (sm.stage[p] == 2) ? __popcll(sm.live[p]) : 0;
-                if (p < gib) myoff += c;
-                total += c;
-            }
-            if (sm.stage[gib] == 2) {
-                const uint64_t live = sm.live[gib];
-                if ((live >> i) & 1ull) sm.list[myoff + __popcll(live & ((1ull << i) - 1ull))] = (gib << 8) | i;
-            }
-            __syncthreads();
-            for (int it = 0; it * NG < total; ++it) {
-                const int item = it * NG + gib;
-                const bool iv = item < total;
-                const int code = iv ? sm.list[item] : 0;
-                const int p = code >> 8, k = code & 255;
-                const uint64_t live = iv ? sm.live[p] : 0ull;
-                const bool lrow = (live >> i) & 1ull;
-                Simplex<D, false> S;
+        // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+        if (__any(stage == 2)) {
+            const bool lrow = (live >> i) & 1ull;
+            // h[k] += 0.1 for LP k; rows k' < k carry the (+0.1, -0.1) round trip (:1149-1151)
+            const double bup = bi + 0.1;
+            const double brt = bup - 0.1;
+            const double sh_plain = bi - s, sh_up = bup - s, sh_rt = brt - s;
+            uint64_t todo = (stage == 2) ? live : 0ull;
+            if (stage == 2) nlp += __popcll(live);
+            while (__any(todo != 0ull)) {
+                const bool go = todo != 0ull;
+                const int k = go ? __ffsll((long long)todo) - 1 : 0;
+                todo &= todo - 1ull;
+                Simplex<D, false, false> S;
                 S.reset(D, __popcll(live), i);
-                double s = 0.0, cxc = 0.0;
-                double cc[D];
+                double cxc = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) {
-                    const double av = lrow ? sm.A[((size_t)p * gs + i) * D + kk] : 0.0;
-                    S.T[kk] = av;
-                    s = fma(av, iv ? sm.xc[p * D + kk] : 0.0, s);
-                    cc[kk] = iv ? -sm.A[((size_t)p * gs + k) * D + kk] : 0.0;  // f = -A[k,:]  (:1145)
-                    S.cost[kk] = cc[kk];
+                    const double ck = -myA[k * D + kk];  // f = -A[k,:]  (:1145)
+                    S.T[kk] = lrow ? a[kk] : 0.0;
+                    S.cost[kk] = ck;
+                    cxc = fma(ck, xc[kk], cxc);
                 }
-                // h[k] += 0.1 for this LP; rows k' < k carry the (+0.1, -0.1) round trip (:1149-1151)
-                const double b0 = lrow ? sm.b[p * gs + i] : 0.0;
-                const double bup = b0 + 0.1;
-                const double brt = bup - 0.1;
-                const double beff = (i < k) ? brt : ((i == k) ? bup : b0);
-                const double bsh = beff - s;
-                S.beta = bsh > 0.0 ? bsh : 0.0;
+                const double bsh = (i < k) ? sh_rt : ((i == k) ? sh_up : sh_plain);
+                S.beta = (lrow && bsh > 0.0) ? bsh : 0.0;
                 S.rowact = lrow;
-                S.mode = iv ? M_P2 : M_DONE;
+                S.mode = go ? M_P2 : M_DONE;
                 S.run(g);
-                const double mine = S.x_value();
-                const bool holds = S.holds_x();
-                double fun = 0.0;
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    const uint64_t ob = grp_ballot(holds && S.rowvar == j, g);
-                    const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
-                    const double xj = (iv ? sm.xc[p * D + j] : 0.0) + (ob ? v : 0.0);
-                    fun = fma(cc[j], xj, fun);
-                }
-                (void)cxc;
-                const double bk = iv ? sm.b[p * gs + k] : 0.0;
+                const double fun = cxc - S.negz;        // c.xc + zeta, zeta = -negz
+                const double bk = myb[k];
                 const double hk = (bk + 0.1) - 0.1;
-                const double obj = -fun - hk;  // (:1156)
-                const bool keepk = (S.status == ST_OPT && obj > abs_tol) || S.status == ST_UNBND;
-                if (iv && i == 0 && keepk) atomicOr(&sm.keep[p], 1ull << k);
+                const double obj = -fun - hk;           // (:1156)
+                const bool keepk = go && ((S.status == ST_OPT && obj > abs_tol) || S.status == ST_UNBND);
+                keep |= keepk ? (1ull << k) : 0ull;
             }
+            if (stage == 2) flags |= RF_MINREP;
         }
-        __syncthreads();
         // ---------------------------------------------------------------- results
         if (valid && i == 0) {
-            int fl = sm.flags[gib];
-            int nl = sm.nlp[gib];
-            if (sm.stage[gib] == 2) { fl |= RF_MINREP; nl += __popcll(sm.live[gib]); }
-            keep_out[pg] = sm.keep[gib];
-            flags_out[pg] = fl;
-            nlp_out[pg] = nl;
-            r_out[pg] = sm.r[gib];
+            keep_out[pg] = keep;
+            flags_out[pg] = flags;
+            nlp_out[pg] = nlp;
+            r_out[pg] = ball ? rr : 0.0;
         }
         if (valid) {
-            for (int k = i; k < D; k += gs) xc_out[pg * D + k] = sm.xc[gib * D + k];
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (i == (k & (gs - 1)) ) xc_out[pg * D + k] = ball ? xc[k] : qnan;
         }
-        __syncthreads();
     }
 }
 

@@ -91,6 +91,13 @@ __device__ __forceinline__ unsigned grp_min(unsigned v, int gs) {
 __device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int bcast(int v, int src) { return __shfl(v, src, 64); }
 
+// same with the byte address (lane << 2) precomputed: one pivot broadcasts NC+2 values from one lane
+__device__ __forceinline__ double bcast_addr(double v, int addr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // ballot restricted to my group, bit i = lane gbase+i
 __device__ __forceinline__ uint64_t grp_ballot(bool p, const Grp& g) {
     return (__ballot(p) >> g.gbase) & g.gmask;
