@@ -165,6 +165,16 @@ def main():
     if rank == 0:
         alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
+        # passes (scripts/gpu_check.sh), whose summary is committed by scripts/summarize_profiles.py
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+                tj = json.load(f)
+            traffic = tj["hbm_bytes_per_launch"]
+            traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+        except Exception:
+            pass
         line = {
             "metric": "LP solves/sec (batched Chebyshev + redundancy)",
             "value": nlp_total * args.steps / elapsed,
@@ -183,7 +193,7 @@ def main():
                        "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU,
                        "parallelism": "batch-sharded x%d + all-gather of packed results" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_kernel<3>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "FP64-VALU/latency bound: %.3g LP/s inside the kernel"

@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplp_hip.so")
+# PLP_LIB overrides the path (A/B runs of kernel variants); it must still be a libplp_hip build
+LIB_PATH = os.environ.get("PLP_LIB") or os.path.join(_HERE, "libplp_hip.so")
 
 PLP_OK, PLP_EINVAL, PLP_EUNSUPPORTED, PLP_EHIP, PLP_ENODEVICE = 0, 1, 2, 3, 4
 RF_EMPTY, RF_EARLY, RF_MINREP, RF_LPFAIL = 1, 2, 4, 8

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void cheby_kernel(long long B, int m_max, in
 static inline int pick_grid(long long B, int gs) {
     const long long gpb = BLOCK / gs;
     long long blocks = (B + gpb - 1) / gpb;
-    const long long cap = 256ll * 16;  // 256 CUs x up to 8 blocks, x2 so the tail balances
+    const long long cap = 1ll << 20;  // one LP tile per block: the dispatcher balances uneven pivot counts
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;

@@ -31,8 +31,18 @@ static inline size_t reduce_smem_bytes(int gs, int D) {
     return ((size_t)NG * gs * (D + 1) * 8 + 15) & ~(size_t)15;
 }
 
+// Waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument).
+// Measured on MI355X at d=3 (100k polytopes, m=16): 3 waves 0.820 ms, 4 waves 0.719 ms,
+// 5 waves 0.703 ms (24 VGPRs spilled outside the pivot loop), 6 waves 0.706 ms: the kernel is
+// VALU-issue bound from ~4 waves on, and the 5/6-wave builds pay for their spills with scratch
+// traffic (WRITE_SIZE 4.7 MB -> 132 MB per launch).  Larger d needs the registers more than the
+// occupancy.
+#ifndef PLP_REDUCE_WAVES
+#define PLP_REDUCE_WAVES(D) ((D) <= 4 ? 4 : ((D) <= 8 ? 3 : 2))
+#endif
+
 template <int D>
-__global__ __launch_bounds__(BLOCK) void reduce_kernel(long long B, int m_max, int gs,
+__global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long long B, int m_max, int gs,
                                                        const double* __restrict__ Ag,
                                                        const double* __restrict__ bg,
                                                        const int* __restrict__ mrows, double abs_tol,
@@ -272,7 +282,7 @@ static int launch_reduce_d(long long B, int m_max, int gs, const double* A, cons
     const size_t smem = reduce_smem_bytes(gs, D);
     const long long NG = BLOCK / gs;
     long long blocks = (B + NG - 1) / NG;
-    if (blocks > 256ll * 16) blocks = 256ll * 16;
+    if (blocks > (1ll << 20)) blocks = 1ll << 20;  // one tile per block: the dispatcher balances the tail
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
                        abs_tol, keep, flags, r, xc, nlp);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Copy the judged summaries from gpurun_out/ (scratch) into profiles/<round>/ (tracked):
+kernel stats of the rocprofv3 --kernel-trace --stats run, the two PMC passes, the bench line,
+and traffic.json = HBM bytes per launch of the dominant kernel
+(FETCH_SIZE [KB] x 1024 x 2 -- gfx950 counts 64 B per 128 B read request, MI355X_MICROARCH.md
+section HBM -- plus WRITE_SIZE [KB] x 1024)."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd, tag = sys.argv[1], sys.argv[2]
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "prof", "reduce_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.log"), os.path.join(dst, tag + "_bench.json"))
+vals = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    rows = list(csv.DictReader(open(os.path.join(src, "pmc_" + ctr, "reduce_counter_collection.csv"))))
+    mine = [r for r in rows if "plp::" in r["Kernel_Name"]]
+    with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, ctr)), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Dispatch_Id", "Counter_Name", "Counter_Value", "VGPR_Count", "LDS_Block_Size", "Scratch_Size"])
+        for r in mine:
+            w.writerow([r["Kernel_Name"].split("(")[0], r["Dispatch_Id"], r["Counter_Name"], r["Counter_Value"],
+                        r.get("VGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")])
+    v = [float(r["Counter_Value"]) for r in mine if "reduce_kernel" in r["Kernel_Name"]]
+    vals[ctr] = sum(v) / len(v)
+stats = list(csv.DictReader(open(os.path.join(src, "prof", "reduce_kernel_stats.csv"))))
+k = [r for r in stats if "plp::reduce_kernel" in r["Name"]][0]
+traffic = {
+    "kernel": "plp::reduce_kernel<3>",
+    "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one rocprofv3 --pmc run per counter)",
+    "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+    "hbm_read_bytes": vals["FETCH_SIZE"] * 1024 * 2, "hbm_write_bytes": vals["WRITE_SIZE"] * 1024,
+    "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
+    "rocprof_avg_kernel_ns": float(k["AverageNs"]), "rocprof_calls": int(k["Calls"]),
+}
+json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic))
