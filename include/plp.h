@@ -122,7 +122,8 @@ int plp_contains_dev(plp_ctx *ctx, void *stream, int P, int m_max, int d, const 
  *           Facet.get_furthest (:87-102: first maximum wins).
  * X[N][d] (rows = points, as quickhull takes them), normals[F][d], offsets[F].
  * Out: facet_of_point[N] (-1 = inside every facet), dist[N] (0 when unassigned),
- *      argmax[F] (index of the furthest point assigned to facet f, -1 if none), maxd[F].
+ *      argmax[F] (index of the furthest point assigned to facet f, -1 if none), maxd[F] (its
+ *      distance; 0 if none).
  */
 int plp_assign(plp_ctx *ctx, int64_t N, int d, const double *X, int F, const double *normals,
                const double *offsets, double abs_tol, int32_t *facet_of_point, double *dist,

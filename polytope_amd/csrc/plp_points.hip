@@ -37,14 +37,19 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
         bool any_in[PPL];
 #pragma unroll
         for (int t = 0; t < PPL; ++t) any_in[t] = false;
-        for (int p = 0; p < P; ++p) {
+        // blockIdx.y selects a contiguous chunk of the polytopes (more waves in flight than one
+        // pass over the points alone would give)
+        const int pchunk = (P + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int p_lo = (int)blockIdx.y * pchunk;
+        const int p_hi = (p_lo + pchunk < P) ? p_lo + pchunk : P;
+        for (int p = p_lo; p < p_hi; ++p) {
             const int m = mrows ? mrows[p] : m_max;
             const double* Ap = A + (size_t)p * m_max * D;
             const double* bp = b + (size_t)p * m_max;
             bool ok[PPL];
 #pragma unroll
             for (int t = 0; t < PPL; ++t) ok[t] = true;
-            for (int i = 0; i < m; ++i) {
+            for (int i = 0; i < m; ++i) {  // rows are wave-uniform: scalar loads, SGPR operands
                 double ar[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) ar[k] = Ap[i * D + k];
@@ -69,10 +74,12 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
             }
         }
         if (mode == 0) {
+            // Region.contains = OR over polytopes: `out` was zeroed by the launcher and every chunk
+            // that found the point inside stores the same value 1 (a benign same-value race)
 #pragma unroll
             for (int t = 0; t < PPL; ++t) {
                 const long long q = q0 + t * stride;
-                if (inb[t]) out[q] = any_in[t] ? 1 : 0;
+                if (inb[t] && any_in[t]) out[q] = 1;
             }
         }
     }
@@ -85,8 +92,14 @@ static void launch_contains_d(int P, int m_max, const double* A, const double* b
     long long blocks = (N + (long long)BLOCK * PPL - 1) / ((long long)BLOCK * PPL);
     if (blocks > 256ll * 32) blocks = 256ll * 32;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((contains_kernel<D, PPL>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, P, m_max, A, b, mrows,
-                       N, X, tol, mode, out);
+    // aim at >= 16 wavefronts per SIMD over the launch (256 CUs x 4 SIMDs) so that the tail is short
+    // and the scalar-load latency of the row fetches hides behind other waves; >= 32 polytopes per chunk
+    long long chunks = (16ll * 1024 + blocks * 4 - 1) / (blocks * 4);
+    if (chunks > (P + 31) / 32) chunks = (P + 31) / 32;
+    if (chunks < 1) chunks = 1;
+    if (mode == 0) (void)hipMemsetAsync(out, 0, (size_t)N, st);
+    hipLaunchKernelGGL((contains_kernel<D, PPL>), dim3((unsigned)blocks, (unsigned)chunks), dim3(BLOCK), 0, st, P,
+                       m_max, A, b, mrows, N, X, tol, mode, out);
 }
 
 #define PLP_CASE_C(K) case K: launch_contains_d<K>(P, m_max, A, b, mrows, N, X, abs_tol, mode, out, st); break;
@@ -107,15 +120,26 @@ int launch_contains(int P, int m_max, int d, const double* A, const double* b, c
 // ------------------------------------------------------------------------------------------
 constexpr int FCHUNK = 256;  // facets staged in LDS at a time
 
+constexpr int SMAX_CAP = 8192;  // per-facet maxima kept in LDS for the first SMAX_CAP facets
+
 template <int D>
 __global__ __launch_bounds__(BLOCK) void assign_kernel(long long N, const double* __restrict__ X, int F,
                                                        const double* __restrict__ normals,
                                                        const double* __restrict__ offsets, double tol,
                                                        int* __restrict__ fop_out, double* __restrict__ dist_out,
                                                        unsigned long long* __restrict__ maxbits) {
-    __shared__ double sn[FCHUNK * D];
-    __shared__ double so[FCHUNK];
-    __shared__ unsigned long long smax[FCHUNK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sn = reinterpret_cast<double*>(smem_raw);                    // [FCHUNK][D]
+    double* so = sn + FCHUNK * D;                                        // [FCHUNK]
+    unsigned long long* smax = reinterpret_cast<unsigned long long*>(so + FCHUNK);  // [min(F, SMAX_CAP)]
+    const int FS = F < SMAX_CAP ? F : SMAX_CAP;
+    const bool single = F <= FCHUNK;  // all facets fit one staging: stage them once per block
+    for (int idx = threadIdx.x; idx < FS; idx += BLOCK) smax[idx] = 0ull;
+    if (single) {
+        for (int idx = threadIdx.x; idx < F * D; idx += BLOCK) sn[idx] = normals[idx];
+        for (int idx = threadIdx.x; idx < F; idx += BLOCK) so[idx] = offsets[idx];
+    }
+    __syncthreads();
     const long long stride = (long long)gridDim.x * BLOCK;
     const long long nloop = (N + stride - 1) / stride;
     for (long long it = 0; it < nloop; ++it) {
@@ -128,10 +152,12 @@ __global__ __launch_bounds__(BLOCK) void assign_kernel(long long N, const double
         double dd = 0.0;
         for (int f0 = 0; f0 < F; f0 += FCHUNK) {
             const int fc = (F - f0) < FCHUNK ? (F - f0) : FCHUNK;
-            __syncthreads();
-            for (int idx = threadIdx.x; idx < fc * D; idx += BLOCK) sn[idx] = normals[(size_t)f0 * D + idx];
-            for (int idx = threadIdx.x; idx < fc; idx += BLOCK) { so[idx] = offsets[f0 + idx]; smax[idx] = 0ull; }
-            __syncthreads();
+            if (!single) {
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < fc * D; idx += BLOCK) sn[idx] = normals[(size_t)f0 * D + idx];
+                for (int idx = threadIdx.x; idx < fc; idx += BLOCK) so[idx] = offsets[f0 + idx];
+                __syncthreads();
+            }
             if (!__all(fop >= 0 || !inb)) {
                 for (int f = 0; f < fc; ++f) {
                     double s = 0.0;
@@ -141,38 +167,35 @@ __global__ __launch_bounds__(BLOCK) void assign_kernel(long long N, const double
                     if (inb && fop < 0 && dist > tol) { fop = f0 + f; dd = dist; }
                 }
             }
-            // furthest point of each facet of this chunk: block max, then one global atomic per facet
-            if (fop >= f0 && fop < f0 + fc) atomicMax(&smax[fop - f0], (unsigned long long)__double_as_longlong(dd));
-            __syncthreads();
-            for (int idx = threadIdx.x; idx < fc; idx += BLOCK)
-                if (smax[idx] != 0ull) atomicMax(&maxbits[f0 + idx], smax[idx]);
+        }
+        // furthest point per facet: LDS max over everything this block sees, flushed once at the end
+        if (fop >= 0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(dd);
+            if (fop < FS) atomicMax(&smax[fop], bits); else atomicMax(&maxbits[fop], bits);
         }
         if (inb) { fop_out[q] = fop; dist_out[q] = dd; }
     }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < FS; idx += BLOCK)
+        if (smax[idx] != 0ull) atomicMax(&maxbits[idx], smax[idx]);  // one global atomic per (block, facet)
 }
 
 __global__ __launch_bounds__(BLOCK) void argmax_kernel(long long N, const int* __restrict__ fop,
                                                        const double* __restrict__ dist,
                                                        const unsigned long long* __restrict__ maxbits,
-                                                       long long* __restrict__ argmax) {
+                                                       unsigned long long* __restrict__ argmax) {
     const long long stride = (long long)gridDim.x * BLOCK;
     for (long long q = (long long)blockIdx.x * BLOCK + threadIdx.x; q < N; q += stride) {
         const int f = fop[q];
         if (f >= 0 && (unsigned long long)__double_as_longlong(dist[q]) == maxbits[f])
-            atomicMin(&argmax[f], q);  // first maximum wins (quickhull.py:97-100, strict '<')
+            atomicMin(&argmax[f], (unsigned long long)q);  // first maximum wins (quickhull.py:97-100, strict '<')
     }
 }
 
-__global__ void assign_init_kernel(int F, unsigned long long* maxbits, long long* argmax) {
+// maxd = 0.0 and argmax = -1 (all ones: the identity of the unsigned atomicMin) for "no point"
+__global__ void assign_init_kernel(int F, unsigned long long* maxbits, unsigned long long* argmax) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < F) { maxbits[f] = 0ull; argmax[f] = 0x7fffffffffffffffll; }
-}
-
-__global__ void assign_fini_kernel(int F, double* maxd, long long* argmax) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < F) {
-        if (argmax[f] == 0x7fffffffffffffffll) { argmax[f] = -1; maxd[f] = -__longlong_as_double(0x7ff0000000000000ll); }
-    }
+    if (f < F) { maxbits[f] = 0ull; argmax[f] = ~0ull; }
 }
 
 size_t assign_scratch_bytes(long long, int) { return 0; }
@@ -181,14 +204,21 @@ template <int D>
 static void launch_assign_d(long long N, const double* X, int F, const double* normals, const double* offsets,
                             double tol, int* fop, double* dist, long long* argmax, double* maxd, hipStream_t st) {
     long long blocks = (N + BLOCK - 1) / BLOCK;
-    if (blocks > 256ll * 16) blocks = 256ll * 16;
+    // few blocks when there are few facets (HBM/atomic bound: one global atomic per (block, facet));
+    // more when the per-point facet scan dominates (VALU bound from F ~ 32 on)
+    long long cap = 256ll * 4 * (F <= 16 ? 1 : (F <= 128 ? F / 16 : 8));
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     unsigned long long* mb = reinterpret_cast<unsigned long long*>(maxd);
-    hipLaunchKernelGGL(assign_init_kernel, dim3((F + 255) / 256), dim3(256), 0, st, F, mb, argmax);
-    hipLaunchKernelGGL(assign_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), 0, st, N, X, F, normals, offsets, tol,
+    unsigned long long* am = reinterpret_cast<unsigned long long*>(argmax);
+    const size_t smem = ((size_t)FCHUNK * (D + 1) + (size_t)(F < SMAX_CAP ? F : SMAX_CAP)) * 8;
+    hipLaunchKernelGGL(assign_init_kernel, dim3((F + 255) / 256), dim3(256), 0, st, F, mb, am);
+    hipLaunchKernelGGL(assign_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, N, X, F, normals, offsets, tol,
                        fop, dist, mb);
-    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, st, N, fop, dist, mb, argmax);
-    hipLaunchKernelGGL(assign_fini_kernel, dim3((F + 255) / 256), dim3(256), 0, st, F, maxd, argmax);
+    long long blocks2 = (N + BLOCK - 1) / BLOCK;
+    if (blocks2 > 256ll * 8) blocks2 = 256ll * 8;
+    if (blocks2 < 1) blocks2 = 1;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)blocks2), dim3(BLOCK), 0, st, N, fop, dist, mb, am);
 }
 
 #define PLP_CASE_A(K) case K: launch_assign_d<K>(N, X, F, normals, offsets, abs_tol, fop, dist, argmax, maxd, st); break;

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Secondary measurements at the BASELINE.json config sizes (bench.py stays the headline):
+
+  C3  containment: 1M points x 10k polytopes (d=6, m=16), Region.contains semantics
+  C5  quickhull assignment/furthest: 1M points, d=8, F in {9, 64, 512}
+  LP  stand-alone batches: Chebyshev F1 (100k x (16,3)), generic lpsolve batch F2 (100k x (16,3)),
+      (64,16) Chebyshev
+
+One JSON line per measurement: time per launch from HIP events on the launch stream, roofline
+(algorithmic bytes or flops of SURVEY.md 8(d) / peak) and a bounded CPU baseline
+(numpy as the reference computes it, polytope/polytope.py:217-218, quickhull.py:117-121).
+Usage (GPU box): python scripts/bench_configs.py [c3 c5 lp]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import polytope_amd as pa  # noqa: E402
+from polytope_amd import synth  # noqa: E402
+
+HBM_PEAK = 8000.0   # GB/s   (MI355X_MICROARCH.md)
+FP64_PEAK = 78.6    # TFLOP/s vector = matrix on MI355X
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return ms[len(ms) // 2]
+
+
+def c3():
+    P, N, d, m = 10000, 1000000, 6, 16
+    A, b, X = synth.containment_workload(P, N, d=d, m=m, seed=0)
+    At, bt, Xt = (torch.as_tensor(v).to(dev) for v in (A, b, X))
+    out = pa.contains_batch(At, bt, Xt, 1e-7)
+    ms = timeit(lambda: pa.contains_batch(At, bt, Xt, 1e-7), reps=5, warm=1)
+    inside = int(out.sum().item())
+    flops = 2.0 * m * d * N * P
+    # CPU: numpy exactly as Polytope.contains on a 16-polytope sample, extrapolated
+    t0 = time.perf_counter()
+    acc = np.zeros(N, bool)
+    for p in range(16):
+        acc |= np.all(A[p].dot(X) - b[p][:, None] < 1e-7, axis=0)
+    tcpu = (time.perf_counter() - t0) / 16 * P
+    # spot parity at full size: first 64 polytopes on the first 200k points vs numpy
+    ref = np.zeros(200000, bool)
+    for p in range(P):
+        if p < 64:
+            ref |= np.all(A[p].dot(X[:, :200000]) - b[p][:, None] < 1e-7, axis=0)
+    sub = pa.contains_batch(At[:64], bt[:64], Xt[:, :200000].contiguous(), 1e-7).cpu().numpy().astype(bool)
+    print(json.dumps({"config": "C3 contains 1M points x 10k polytopes d=6 m=16", "ms": ms,
+                      "tests_per_s": N * P / (ms * 1e-3), "points_inside": inside,
+                      "roofline": {"bound": "fp64-valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_PEAK,
+                                   "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP64_PEAK},
+                      "hbm_algorithmic_GBs": (8 * d * N + 8 * P * m * (d + 1) + N) / (ms * 1e-3) / 1e9,
+                      "cpu_baseline": {"numpy_1thread_s_extrapolated": tcpu, "speedup": tcpu / (ms * 1e-3)},
+                      "spot_parity_equal": bool(np.array_equal(sub, ref))}), flush=True)
+
+
+def c5():
+    N, d = 1000000, 8
+    for F in (9, 64, 512):
+        X, nrm, off = synth.quickhull_workload(N, d=d, F=F, seed=0)
+        Xt, nt, ot = (torch.as_tensor(v).to(dev) for v in (X, nrm, off))
+        res = pa.assign_batch(Xt, nt, ot, 1e-7)
+        ms = timeit(lambda: pa.assign_batch(Xt, nt, ot, 1e-7))
+        bytes_alg = 8 * d * N + 12 * N + 8 * F * (d + 1)
+        t0 = time.perf_counter()
+        D = X @ nrm.T - off  # numpy baseline: all distances, first facet over tol, per-facet argmax
+        hit = D > 1e-7
+        fop = np.where(hit.any(1), hit.argmax(1), -1)
+        tcpu = time.perf_counter() - t0
+        same = bool(np.array_equal(res["facet"].cpu().numpy(), fop))
+        print(json.dumps({"config": "C5 assign/furthest 1M points d=8 F=%d" % F, "ms": ms,
+                          "point_facet_evals_per_s": N * F / (ms * 1e-3),
+                          "assigned": int((res["facet"] >= 0).sum().item()),
+                          "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
+                                       "unit": "GB/s", "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK},
+                          "cpu_baseline": {"numpy_matmul_s": tcpu, "speedup": tcpu / (ms * 1e-3)},
+                          "facet_ids_equal_numpy": same}), flush=True)
+
+
+def lp():
+    for (B, m, d) in [(100000, 16, 3), (20000, 64, 16)]:
+        A, b = synth.random_hpolytopes(B, m, d, seed=1)
+        At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+        ms = timeit(lambda: pa.cheby_ball_batch(At, bt))
+        by = B * (8 * (m * (d + 1) + m + d + 1) + 8 * (d + 2) + 4)
+        print(json.dumps({"config": "F1 cheby batch B=%d m=%d d=%d" % (B, m, d), "ms": ms, "lp_per_s": B / (ms * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
+                                       "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
+        # generic lpsolve batch on the F2 form of row 0 (h[0] += 0.1)
+        c = torch.as_tensor(-A[:, 0, :].copy()).to(dev)
+        h = b.copy()
+        h[:, 0] += 0.1
+        ht = torch.as_tensor(h).to(dev)
+        ms = timeit(lambda: pa.lpsolve_batch(c, At, ht))
+        by = B * (8 * (m * d + m + d) + 8 * (d + 1) + 4)
+        print(json.dumps({"config": "lpsolve batch (F2 form) B=%d m=%d n=%d" % (B, m, d), "ms": ms,
+                          "lp_per_s": B / (ms * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
+                                       "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c5", "lp"]
+    for w in which:
+        globals()[w]()

@@ -288,3 +288,26 @@ def test_assign_vs_oracle(pa, oracle):
         assert np.array_equal(res["argmax"], am), (N, d, F)
         has = am >= 0
         assert np.array_equal(res["maxd"][has], mx[has])
+
+
+def test_degenerate_lps(pa, oracle):
+    """Bland's rule / phase-1 corner cases on the device: same status as the oracle and as
+    scipy (presolve off), objective within 1e-9."""
+    from scipy.optimize import linprog
+    from degenerate_cases import degenerate_lps
+    cases = degenerate_lps()
+    by_shape = {}
+    for k, (tag, c, G, h) in enumerate(cases):
+        by_shape.setdefault(G.shape, []).append(k)
+    for (m, n), idx in by_shape.items():
+        c = np.array([cases[k][1] for k in idx])
+        G = np.array([cases[k][2] for k in idx])
+        h = np.array([cases[k][3] for k in idx])
+        res = pa.lpsolve_batch(c, G, h)
+        for j, k in enumerate(idx):
+            so, xo, fo, _ = oracle.lp_solve(c[j], G[j], h[j])
+            sp = linprog(c[j], G[j], h[j], None, None, bounds=(None, None), options={"presolve": False})
+            assert res["status"][j] == so == sp.status, (cases[k][0], m, n, res["status"][j], so, sp.status)
+            if so == 0:
+                assert abs(res["fun"][j] - sp.fun) <= TOL * max(1.0, abs(sp.fun)), (cases[k][0], m, n)
+            assert res["iters"][j] <= 50 * (m + n) + 100
