@@ -104,8 +104,9 @@ struct Simplex {
         for (int j = 0; j < NC; ++j) {
             const double c = cost[j];
             const double ac = fabs(c);
-            const bool elig = (ac > TOL_D) && (((cfree >> j) & 1u) || c < 0.0) && !((dead >> j) & 1u);
-            const bool take = elig && (ac > best);
+            // bitwise, not short-circuit: '&&' chains compile to s_and_saveexec control flow
+            const bool elig = (ac > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0)) & (((dead >> j) & 1u) == 0u);
+            const bool take = elig & (ac > best);
             e = take ? j : e;
             best = take ? ac : best;
             epos = take ? (c > 0.0) : epos;
@@ -118,8 +119,8 @@ struct Simplex {
             for (int j = 0; j < NC; ++j) {
                 const double c = cost[j];
                 const double ac = fabs(c);
-                const bool elig = (ac > TOL_D) && (((cfree >> j) & 1u) || c < 0.0) && !((dead >> j) & 1u);
-                const bool take = elig && (cv[j] < bid);
+                const bool elig = (ac > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0)) & (((dead >> j) & 1u) == 0u);
+                const bool take = elig & (cv[j] < bid);
                 eb = take ? j : eb;
                 bid = take ? cv[j] : bid;
                 bb = take ? ac : bb;
@@ -128,9 +129,11 @@ struct Simplex {
             if (bland) { e = eb; best = bb; epos = bp; }
         }
         int fin = -1;  // status this group finishes with in this iteration
-        bool normal = running && (mode == M_P1 || mode == M_P2);
-        if (normal && e < 0) { fin = ST_OPT; normal = false; }
-        if (normal && iters >= maxit) { fin = ST_ITER; normal = false; }
+        bool normal = running & ((mode == M_P1) | (mode == M_P2));
+        fin = (normal & (e < 0)) ? ST_OPT : fin;
+        normal = normal & (e >= 0);
+        fin = (normal & (iters >= maxit)) ? ST_ITER : fin;
+        normal = normal & (iters < maxit);
         // ------------------------------------------------ special pivots (rare)
         bool init = false, drive = false;
         int rt = 0;
@@ -161,7 +164,7 @@ struct Simplex {
             }
         }
         if (init) e = init_col;
-        bool act = normal || init || drive;
+        bool act = normal | init | drive;
         e = act ? e : -1;
         if (__any(act)) {  // wave-uniform: the step that only detects optimality skips the pivot
             // ------------------------------------------------ selected column
@@ -175,7 +178,7 @@ struct Simplex {
                 if constexpr (CARRY) ce2 = mj ? cost2[j] : ce2;
             }
             double ce = -best;  // normal mode: the (sign-flipped if necessary) reduced cost is -|c_e|
-            const bool flip = normal && epos;  // free variable entering downwards: x := -x
+            const bool flip = normal & epos;  // free variable entering downwards: x := -x
             if (flip) { a = -a; ce2 = -ce2; }
             if constexpr (INITM || CARRY) {
                 if (__any(init || drive)) {
@@ -191,7 +194,7 @@ struct Simplex {
             const double x0 = __builtin_amdgcn_rcp(a);
             const double x1 = fma(x0, fma(-a, x0, 1.0), x0);
             const double pinv = fma(x1, fma(-a, x1, 1.0), x1);
-            bool erow = normal && rowact && (a > TOL_PIV);
+            bool erow = normal & rowact & (a > TOL_PIV);
             double q = (beta > 0.0 ? beta : 0.0) * pinv;
             if constexpr (INITM) { if (init) { erow = init_elig; q = init_q; } }
             if constexpr (CARRY) { if (drive) { erow = (g.lane == rt); q = 0.0; } }
@@ -209,7 +212,7 @@ struct Simplex {
                 act = false;
                 e = -1;
             }
-            const bool tie = erow && (kh == mh) && (kl == ml);
+            const bool tie = erow & (kh == mh) & (kl == ml);
             const uint64_t tbal = grp_ballot(tie, g);
             int rl = tbal ? __ffsll((long long)tbal) - 1 : 0;  // Dantzig mode: lowest row among ties
             if (__any(bland && act)) {                          // Bland mode: lowest basic-variable id
@@ -218,7 +221,7 @@ struct Simplex {
                 const uint64_t kb = grp_ballot(tie && key == kmin, g);
                 if (bland) rl = kb ? __ffsll((long long)kb) - 1 : 0;
             }
-            const bool is_r = act && (g.gl == rl);
+            const bool is_r = act & (g.gl == rl);
             const int r = g.gbase + rl;
             if (normal && act) {
                 const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);
@@ -229,7 +232,7 @@ struct Simplex {
                 const int raddr = r << 2;
                 const double p = act ? bcast_addr(pinv, raddr) : 0.0;
                 const double rhob = bcast_addr(beta, raddr) * p;
-                const double f = (act && !is_r) ? a : 0.0;
+                const double f = (act & !is_r) ? a : 0.0;
                 const double fc = act ? ce : 0.0;
                 const double fc2 = act ? ce2 : 0.0;
                 const double ecol = is_r ? p : -(f * p);

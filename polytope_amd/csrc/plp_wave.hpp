@@ -69,12 +69,19 @@ __device__ __forceinline__ double grp_min(double v, int gs) {
     return v;
 }
 
+// v_min_u32 with a DPP source operand: dst = min(dpp(v), dst).  hipcc does not fold v_mov_dpp
+// into the consumer here, so the instruction is written out; the s_nop covers the "VALU write ->
+// DPP read" hazard (2 wait states) that the compiler cannot see inside an asm statement.  dst is
+// tied to the input, so a lane whose DPP source is disabled keeps its own value (the identity).
+#define PLP_MIN_U32_DPP(v, CTRL) \
+    asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+
 __device__ __forceinline__ unsigned grp_min(unsigned v, int gs) {
 #if PLP_USE_DPP
-    v = min_u(v, (unsigned)dpp_i<PLP_DPP_XOR1>((int)v));
-    v = min_u(v, (unsigned)dpp_i<PLP_DPP_XOR2>((int)v));
-    v = min_u(v, (unsigned)dpp_i<PLP_DPP_HMIRROR>((int)v));
-    if (gs > 8) v = min_u(v, (unsigned)dpp_i<PLP_DPP_MIRROR>((int)v));
+    PLP_MIN_U32_DPP(v, "quad_perm:[1,0,3,2]");
+    PLP_MIN_U32_DPP(v, "quad_perm:[2,3,0,1]");
+    PLP_MIN_U32_DPP(v, "row_half_mirror");
+    if (gs > 8) PLP_MIN_U32_DPP(v, "row_mirror");
 #else
     v = min_u(v, (unsigned)__shfl_xor((int)v, 1, 64));
     v = min_u(v, (unsigned)__shfl_xor((int)v, 2, 64));

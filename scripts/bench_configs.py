@@ -118,6 +118,43 @@ def lp():
                                        "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
 
 
+def c4():
+    """Config 4: 1000-cell Region in d=4 (10x10x5x2 grid of boxes on [0,1]^4): adjacency of all
+    499 500 cell pairs (one batch of (16,5) Chebyshev LPs) and region_diff of a polytope against
+    the whole Region (host DFS, every scan one batch)."""
+    import itertools
+    import polytope_amd.polytope as pc
+    from polytope_amd import prop2partition as p2p
+    shape = (10, 10, 5, 2)
+    cells, index = [], []
+    for idx in itertools.product(*[range(n) for n in shape]):
+        cells.append(pc.box2poly([[idx[k] / shape[k], (idx[k] + 1) / shape[k]] for k in range(4)]))
+        index.append(idx)
+    index = np.array(index)
+    t0 = time.perf_counter()
+    adj = p2p.adjacency_matrix_dense(cells)
+    t_adj = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    adj = p2p.adjacency_matrix_dense(cells)
+    t_adj2 = time.perf_counter() - t0
+    want = (np.abs(index[:, None, :] - index[None, :, :]).max(axis=2) <= 1).astype(np.int8)
+    npairs = len(cells) * (len(cells) - 1) // 2
+    print(json.dumps({"config": "C4 find_adjacent_regions 1000 cells d=4", "pairs": npairs, "s_first": t_adj,
+                      "s": t_adj2, "pair_lps_per_s": npairs / t_adj2,
+                      "equals_grid_neighbourhood": bool(np.array_equal(adj, want))}), flush=True)
+    A, b = synth.random_hpolytopes(1, 12, 4, seed=4, bounded=True)
+    P = pc.Polytope(A[0], 0.1 * b[0] + A[0] @ (0.5 * np.ones(4)))
+    t0 = time.perf_counter()
+    half = [c for c, idx in zip(cells, index) if idx[0] < 5]  # the 500 cells with x0 < 0.5
+    D = pc.region_diff(P.copy(), pc.Region(half))
+    t_diff = time.perf_counter() - t0
+    r, _ = pc.cheby_ball(P)
+    print(json.dumps({"config": "C4 region_diff P(m=12,d=4) minus the 500 cells with x0<0.5 of the 1000-cell grid",
+                      "s": t_diff,
+                      "pieces": len(D) if isinstance(D, pc.Region) else int(D.A.size > 0), "P_radius": float(r)}),
+          flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c5", "lp"]
     for w in which:

@@ -288,3 +288,19 @@ def test_mldivide_and_subset(pc):
     assert v == pytest.approx(2.0, rel=0.1)
     with pytest.raises(ValueError):
         pc.volume(a, nsamples=0)
+
+
+@pytest.mark.parametrize("name", ["g3x3", "g2x2x2x2"])
+def test_find_adjacent_regions(pc, name):
+    """prop2partition.find_adjacent_regions (prop2partition.py:46-63): all pair LPs in one batch."""
+    from polytope_amd import prop2partition as p2p
+    g = load_golden("g5_setops.npz")
+    cells = [pc.Polytope(A, b, normalize=False) for A, b in zip(g[name + "_cellsA"], g[name + "_cellsb"])]
+    adj = p2p.find_adjacent_regions([pc.Region([c]) for c in cells])
+    assert adj.shape == (len(cells), len(cells)) and adj.dtype == np.int8
+    assert np.array_equal(adj.toarray(), g[name + "_adj"])
+    # mixed shapes take the general path
+    mixed = [pc.Region([cells[0], cells[1]]), cells[2], pc.Region([cells[3]])]
+    adj2 = p2p.find_adjacent_regions(mixed).toarray()
+    want01 = int(g[name + "_adj"][0, 2] or g[name + "_adj"][1, 2])
+    assert adj2[0, 1] == want01 == adj2[1, 0] and adj2[2, 2] == 1
