@@ -375,13 +375,19 @@ def _pack(polys):
 
 def _contains_many(polys, points, abs_tol, region=True):
     points = np.asarray(points, dtype=float)
-    if _use_hip() and polys and all(p.A.size > 0 for p in polys) and points.ndim == 2 \
-            and points.shape[1] > 0 and polys[0].A.shape[1] <= _MAX_DIM:
+    if _use_hip():
+        solvers._require("hip")
+        if points.ndim != 2:
+            raise ValueError("points should be column vectors")
+        polys = [p for p in polys if p.A.size > 0]  # an empty description contains nothing here
+        if not polys or points.shape[1] == 0:
+            return np.full(points.shape[1], False, dtype=bool)
+        if polys[0].A.shape[1] > _MAX_DIM:
+            raise ValueError("the 'hip' backend handles dimension <= %d, got %d" % (_MAX_DIM, polys[0].A.shape[1]))
         from .batch import contains_batch
         A, b, ms = _pack(polys)
         return contains_batch(A, b, np.ascontiguousarray(points), abs_tol, m=ms, region=True).astype(bool)
-    if _use_hip():
-        solvers._require("hip")
+    # explicitly selected non-'hip' backend: the reference's own numpy expression (ref :217-218)
     inside = np.full(points.shape[1], False, dtype=bool)
     for p in polys:
         inside |= np.all(p.A.dot(points) - p.b[:, np.newaxis] < abs_tol, axis=0)
@@ -961,8 +967,8 @@ def volume(polyreg, nsamples=None, seed=None):
             v=nsamples))
     l_b, u_b = polyreg.bounding_box
     x = np.tile(l_b, (1, N)) + np.random.default_rng(seed).random((n, N)) * np.tile(u_b - l_b, (1, N))
-    aux = np.dot(polyreg.A, x) - np.tile(np.array([polyreg.b]).T, (1, N))
-    hits = np.nonzero(np.all(aux < 0, 0))[0].shape[0]
+    # all(A x - b < 0) per sample (ref :1590-1591) == contains(x, abs_tol=0): the containment kernel
+    hits = int(np.count_nonzero(_contains_many([polyreg], x, 0.0)))
     vol = np.prod(u_b - l_b) * hits / N
     polyreg._set_volume(vol)
     return vol
