@@ -24,6 +24,16 @@ int launch_reduce(long long B, int m_max, int d, const double* A, const double* 
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                   hipStream_t st);
 
+// four dictionary rows per lane (d <= 8); returns 1 when it does not apply
+int launch_reduce_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                    double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                    hipStream_t st);
+
+// small polytopes (rows <= 16, d <= 3): one polytope per lane; returns 1 when it does not apply
+int launch_reduce_tpl(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                      hipStream_t st);
+
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
                     const double* X, double abs_tol, int mode, unsigned char* out, hipStream_t st);
 

@@ -21,6 +21,8 @@
 // LDS is only read after the staging barrier (row k's coefficients = objective of F2(k), other
 // rows for the dedupe), so the groups never synchronise with each other.
 // HBM traffic = 8 m (d+1) bytes in + 24 + 8 d bytes out per polytope.
+#include <stdlib.h>
+
 #include "plp_kernels.hpp"
 #include "plp_simplex.hpp"
 
@@ -296,6 +298,18 @@ int launch_reduce(long long B, int m_max, int d, const double* A, const double* 
                   unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
     const int gs = group_size_for(m_max);
     if (gs < 0 || d < 1 || d > MAX_D) return 2;
+    // PLP_TPL=1 sends small polytopes (rows <= 16, d <= 3) to the one-polytope-per-lane kernel
+    // (plp_reduce_tpl.hip).  Measured on MI355X it only pays off for very large batches: at 100k
+    // polytopes it has 1563 wavefronts for 1024 SIMDs at one wave per SIMD (0.72 ms vs 0.69 ms here).
+    const char* tpl = getenv("PLP_TPL");
+    if (tpl && tpl[0] == '1' &&
+        launch_reduce_tpl(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
+        return 0;
+    // default for d <= 8: four rows per lane (plp_reduce_r.hip); PLP_REDUCE_1ROW=1 keeps this kernel
+    const char* one = getenv("PLP_REDUCE_1ROW");
+    if (!(one && one[0] == '1') &&
+        launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
+        return 0;
     switch (d) {
         PLP_CASE_R(1) PLP_CASE_R(2) PLP_CASE_R(3) PLP_CASE_R(4) PLP_CASE_R(5) PLP_CASE_R(6)
         PLP_CASE_R(7) PLP_CASE_R(8) PLP_CASE_R(9) PLP_CASE_R(10) PLP_CASE_R(11) PLP_CASE_R(12)

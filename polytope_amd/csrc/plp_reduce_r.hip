@@ -1,0 +1,348 @@
+// plp_reduce_r.hip -- fused reduce() (polytope/polytope.py:1053-1163) with R = 4 rows per lane.
+//
+// Same pipeline and the same reference steps as plp_reduce.hip (F1 -> dedupe -> 2d F3 -> prefilter
+// -> one F2 per surviving row, all LPs of a polytope solved by one lane group out of registers),
+// but built on SimplexR (plp_simplex_r.hpp): a polytope with up to 16 / 32 / 64 rows occupies a
+// group of 4 / 8 / 16 lanes, lane l holding rows 4l..4l+3.  A wavefront therefore advances 16 / 8 / 4
+// polytopes per instruction instead of 4 / 2 / 1, and the per-pivot reductions are DPP quad steps.
+// A 256-thread workgroup takes NG = 256/GS polytopes per tile; their rows are read from HBM once,
+// coalesced, into LDS (rows of F2's objective and the dedupe partners are read back from there).
+#include <stdlib.h>
+
+#include "plp_kernels.hpp"
+#include "plp_simplex_r.hpp"
+
+namespace plp {
+
+constexpr int RR = 4;  // rows per lane
+
+static inline int group_size_r(int m_max) {
+    if (m_max <= 16) return 4;
+    if (m_max <= 32) return 8;
+    return 16;
+}
+
+static inline size_t reduce_r_smem_bytes(int gs, int D) {
+    const int NG = BLOCK / gs;
+    return ((size_t)NG * gs * RR * (D + 2) * 8 + 15) & ~(size_t)15;  // A rows, b, 1/||a||
+}
+
+// bit l of x (l < 16)  ->  bit 4l
+__device__ __forceinline__ uint64_t spread4(uint64_t x) {
+    x = (x | (x << 24)) & 0x000000ff000000ffull;
+    x = (x | (x << 12)) & 0x000f000f000f000full;
+    x = (x | (x << 6)) & 0x0303030303030303ull;
+    x = (x | (x << 3)) & 0x1111111111111111ull;
+    return x;
+}
+
+#ifndef PLP_REDUCE_R_WAVES
+// measured at d=3 (100k polytopes, m=16): 2 waves/SIMD (212 VGPRs, no spill) 0.628 ms,
+// 3 waves (168 VGPRs, 152 B/lane spilled outside the pivot loop) 0.524 ms, 4 waves 0.532 ms
+#define PLP_REDUCE_R_WAVES(D) ((D) <= 4 ? 3 : 1)
+#endif
+
+template <int D>
+__global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
+    long long B, int m_max, int gs, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    constexpr int R = RR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Grp g(gs);
+    const int NG = BLOCK / gs;
+    const int rows = gs * R;  // row slots per polytope
+    const int gib = threadIdx.x / gs;
+    const int row0 = g.gl * R;  // my first row
+    double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
+    double* sb = sA + (size_t)NG * rows * D;            // [NG][rows]
+    double* san = sb + (size_t)NG * rows;               // [NG][rows]
+    const double* myA = sA + (size_t)gib * rows * D;
+    const double* myb = sb + (size_t)gib * rows;
+    double* myan = san + (size_t)gib * rows;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+
+    {  // one tile per workgroup (grid.x = number of tiles: no values kept live across a tile loop)
+        const long long tile = (long long)blockIdx.x * NG;
+        const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
+        __syncthreads();
+        {
+            const int rowsz = m_max * D;
+            const double* src = Ag + tile * rowsz;
+            for (int idx = threadIdx.x; idx < ntile * rowsz; idx += BLOCK) {
+                const int p = idx / rowsz, rem = idx - p * rowsz;
+                sA[(size_t)p * rows * D + rem] = src[idx];
+            }
+            const double* srcb = bg + tile * m_max;
+            for (int idx = threadIdx.x; idx < ntile * m_max; idx += BLOCK) {
+                const int p = idx / m_max, row = idx - p * m_max;
+                sb[p * rows + row] = srcb[idx];
+            }
+        }
+        __syncthreads();
+        const long long pg = tile + gib;
+        const bool valid = gib < ntile;
+        const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
+        double xc[D];
+        double rr = 0.0;
+        bool ball, fulldim;
+        uint64_t live = 0ull;
+        unsigned has = 0u;
+        // ---------------------------------------------------------------- F1: Chebyshev ball
+        {
+            SimplexR<D + 1, R, true> S;
+            S.reset(D + 1, m, row0);
+            unsigned actb = 0u;
+            bool inf0 = false, finite = true;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const bool h = valid & (row0 + k < m) & (m <= rows);
+                has |= h ? (1u << k) : 0u;
+                double nrm2 = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) {
+                    const double v = h ? myA[(row0 + k) * D + kk] : 0.0;
+                    S.T[k][kk] = v;
+                    nrm2 = nrm2 + v * v;
+                    finite = finite & isfinite(v);
+                }
+                const double bk = h ? myb[row0 + k] : 0.0;
+                finite = finite & isfinite(bk);
+                const double nrm = sqrt(nrm2);
+                myan[row0 + k] = 1.0 / nrm;
+                const bool zero = !(nrm > 0.0);
+                const bool on = h & !zero;
+                S.T[k][D] = on ? nrm : 0.0;
+                S.beta[k] = on ? bk : 0.0;
+                S.init_q[k] = bk / nrm;
+                actb |= on ? (1u << k) : 0u;
+                inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
+            }
+            S.ract = actb;
+            S.init_elig = actb;
+            const bool infeasible0 = grp_ballot(inf0, g) != 0;
+            const bool bad = (grp_ballot(!finite, g) != 0) | (m > rows);
+            S.cost[D] = -1.0;
+            S.mode = M_INIT;
+            S.init_col = D;
+            S.mode_after_init = M_P2;
+            if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
+            else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+            S.run(g);
+            const bool ok = S.status == ST_OPT;
+#pragma unroll
+            for (int j = 0; j <= D; ++j) {
+                bool found;
+                const double mine = S.x_of(j, found);
+                const uint64_t ob = grp_ballot(found, g);
+                const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+                const double xj = ob ? v : 0.0;
+                if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
+            }
+            ball = ok & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+            fulldim = ball & (rr > abs_tol);
+        }
+        __syncthreads();  // 1/||a|| of every row is in LDS
+        // ---------------------------------------------------------------- dedupe (:1094-1110)
+        // (rows are re-read from LDS: the register file limits the occupancy of this kernel, LDS is idle)
+        {
+            unsigned removed = 0u;
+            double ni[R][D], bin_[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double an_i = myan[row0 + k];
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) ni[k][kk] = myA[(row0 + k) * D + kk] * an_i;
+                bin_[k] = myb[row0 + k] * an_i;
+            }
+            for (int j = 0; j < m_max; ++j) {
+                const bool jrow = valid & (j < m);
+                const double an_j = myan[j];
+                double nj[D];
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) nj[kk] = myA[j * D + kk] * an_j;
+                const double bjn = myb[j] * an_j;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    double dot = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) dot = dot + ni[k][kk] * nj[kk];
+                    const int i = row0 + k;
+                    const bool par = (((has >> k) & 1u) != 0u) & jrow & (j != i) & (dot > 1.0 - abs_tol);
+                    const bool rem = par & ((i < j) ? !(bin_[k] < bjn) : (bjn < bin_[k]));
+                    removed |= rem ? (1u << k) : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                live |= spread4(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
+        }
+        // dictionary translated to the Chebyshev centre: beta_i = b_i - a_i.xc.  s_i = a_i.xc replaces
+        // 1/||a_i|| in LDS (only the owner lane touches its rows' slots from here on).
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            double sk = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk)
+                sk = fma(((has >> k) & 1u) ? myA[(row0 + k) * D + kk] : 0.0, ball ? xc[kk] : 0.0, sk);
+            myan[row0 + k] = sk;
+        }
+        int flags = fulldim ? 0 : RF_EMPTY;
+        int nlp = 1;
+        uint64_t keep = 0ull;
+        int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
+        if (fulldim) {
+            const int neq = __popcll(live);
+            if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
+            else stage = (neq > 3 * D) ? 1 : 2;
+        }
+        // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
+        if (__any(stage == 1)) {
+            const bool go = stage == 1;
+            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            double s1[R], s2[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+            bool lpfail = false;
+            double lbk = 0.0;
+            for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
+                const int kx = it >> 1;
+                const bool up = it & 1;
+                double xck = 0.0;
+                SimplexR<D, R, false> S;
+                S.reset(D, __popcll(live), row0);
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) {
+                    xck = (kk == kx) ? xc[kk] : xck;
+                    S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const bool l = (lloc >> k) & 1u;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = l ? myA[(row0 + k) * D + kk] : 0.0;
+                    const double bsh = myb[row0 + k] - myan[row0 + k];
+                    S.beta[k] = (l & (bsh > 0.0)) ? bsh : 0.0;
+                }
+                S.ract = lloc;
+                S.mode = go ? M_P2 : M_DONE;
+                S.run(g);
+                // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
+                double val;
+                if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+                else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+                else { val = qnan; lpfail = lpfail | go; }
+                if (!up) {
+                    lbk = val;
+                } else {  // prefilter sums, accumulated in k order (:1131-1134)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const double aik = ((lloc >> k) & 1u) ? myA[(row0 + k) * D + kx] : 0.0;
+                        const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                        s1[k] = s1[k] + pa * (val - lbk);
+                        s2[k] = s2[k] + aik * lbk;
+                    }
+                }
+            }
+            uint64_t outb = 0ull;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (myb[row0 + k] - s2[k])) < -1e-4);
+                outb |= spread4(grp_ballot(out, g)) << k;
+            }
+            if (go) {
+                live = live & ~outb;
+                nlp += 2 * D;
+                if (lpfail) flags |= RF_LPFAIL;
+                if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
+                else stage = 2;
+            }
+        }
+        // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+        if (__any(stage == 2)) {
+            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            // h[k] += 0.1 for LP k; rows k' < k carry the (+0.1, -0.1) round trip (:1149-1151)
+            uint64_t todo = (stage == 2) ? live : 0ull;
+            if (stage == 2) nlp += __popcll(live);
+            while (__any(todo != 0ull)) {
+                const bool go = todo != 0ull;
+                const int kr = go ? __ffsll((long long)todo) - 1 : 0;
+                todo &= todo - 1ull;
+                SimplexR<D, R, false> S;
+                S.reset(D, __popcll(live), row0);
+                double cxc = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) {
+                    const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
+                    S.cost[kk] = ck;
+                    cxc = fma(ck, xc[kk], cxc);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const bool l = (lloc >> k) & 1u;
+                    const int i = row0 + k;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = l ? myA[(row0 + k) * D + kk] : 0.0;
+                    const double b0 = myb[row0 + k];
+                    const double bup = b0 + 0.1;
+                    const double brt = bup - 0.1;
+                    const double bsh = ((i < kr) ? brt : ((i == kr) ? bup : b0)) - myan[row0 + k];
+                    S.beta[k] = (l & (bsh > 0.0)) ? bsh : 0.0;
+                }
+                S.ract = lloc;
+                S.mode = go ? M_P2 : M_DONE;
+                S.run(g);
+                const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
+                const double bk = myb[kr];
+                const double hk = (bk + 0.1) - 0.1;
+                const double obj = -fun - hk;     // (:1156)
+                const bool keepk = go & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
+                keep |= keepk ? (1ull << kr) : 0ull;
+            }
+            if (stage == 2) flags |= RF_MINREP;
+        }
+        // ---------------------------------------------------------------- results
+        if (valid & (g.gl == 0)) {
+            keep_out[pg] = keep;
+            flags_out[pg] = flags;
+            nlp_out[pg] = nlp;
+            r_out[pg] = ball ? rr : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
+        }
+    }
+}
+
+template <int D>
+static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
+                             double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                             hipStream_t st) {
+    const size_t smem = reduce_r_smem_bytes(gs, D);
+    const long long NG = BLOCK / gs;
+    long long blocks = (B + NG - 1) / NG;
+    if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_r_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
+                       abs_tol, keep, flags, r, xc, nlp);
+    return 0;
+}
+
+#define PLP_CASE_RR(K) \
+    case K: return launch_reduce_r_d<K>(B, m_max, gs, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+
+// returns 0 when launched, 1 when this kernel does not apply (caller falls through to reduce_kernel)
+int launch_reduce_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                    double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                    hipStream_t st) {
+    if (m_max < 1 || m_max > MAX_M || d < 1 || d > 8) return 1;
+    const int gs = group_size_r(m_max);
+    switch (d) {
+        PLP_CASE_RR(1) PLP_CASE_RR(2) PLP_CASE_RR(3) PLP_CASE_RR(4)
+        PLP_CASE_RR(5) PLP_CASE_RR(6) PLP_CASE_RR(7) PLP_CASE_RR(8)
+        default: return 1;
+    }
+}
+
+}  // namespace plp

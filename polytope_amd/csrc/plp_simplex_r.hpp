@@ -1,0 +1,326 @@
+// plp_simplex_r.hpp -- dense simplex with R dictionary rows per lane (gfx950).
+//
+// plp_simplex.hpp gives every row of the dictionary its own lane: a 16-row LP occupies a 16-lane
+// group and one wavefront instruction advances only 4 LPs; measured on MI355X the fused reduce
+// kernel built on it is VALU-issue bound (SQ_ACTIVE_INST_VALU ~96 %).  Here lane l of a group owns
+// the R consecutive rows l*R .. l*R+R-1 (T[R][NC], beta[R] in VGPRs), the group is GS = rows/R
+// lanes, and a wavefront carries 64/GS LPs: 16 for 16-row polytopes at R = 4.  Per pivot
+//   * the entering-column scan runs on the replicated reduced costs (no cross-lane traffic),
+//   * every lane finds the best of its own R rows by cross-multiplication (no division), takes one
+//     reciprocal (v_rcp_f64 + 2 Newton steps) and the group minimum is an exact f64 min done as two
+//     u32 min all-reduces on an order-preserving key -- for GS = 4 these are two DPP quad_perm steps,
+//   * the pivot row travels by NC+2 ds_bpermute broadcasts, and each lane updates its R rows.
+// Pivot rules are those of plp_simplex.hpp / oracle/plp_oracle.c: free variables enter in either
+// direction and never leave, Dantzig pricing, ties of the ratio test go to the lowest row; after
+// BLAND_AFTER consecutive degenerate pivots Bland's rule (lowest variable id) takes over behind a
+// wave-uniform branch.  No phase 1 here: the callers start from primal-feasible dictionaries
+// (forced first pivot for the Chebyshev LP, translation to the Chebyshev centre for F2/F3).
+#pragma once
+#include "plp_simplex.hpp"
+
+namespace plp {
+
+template <int NC, int R, bool INITM>
+struct SimplexR {
+    // ---- my R rows
+    double T[R][NC];
+    double beta[R];
+    int rv[R];        // id of the basic variable of my row k (0..n-1 structural, n+i slack)
+    unsigned rneg;    // bit k: the basic free variable of row k is stored negated
+    unsigned ract;    // bit k: row k takes part in ratio tests
+    // ---- replicated per group
+    double cost[NC], negz;
+    int cv[NC];       // id of the nonbasic variable of column j
+    unsigned cneg;    // bit j: column j holds -x
+    unsigned cfree;   // bit j: column j holds a free (structural) variable
+    int n, ndeg, iters, maxit;
+    int mode, status;
+    // ---- INIT pivot request: forced entering column, caller-supplied signed ratios of my rows
+    int init_col;
+    double init_q[INITM ? R : 1];
+    unsigned init_elig;
+    int mode_after_init;
+
+    __device__ __forceinline__ void reset(int n_, int m_rows, int first_row) {
+        n = n_;
+        rneg = 0u;
+        ract = 0u;
+        negz = 0.0;
+        cneg = 0u;
+        cfree = n_ >= 32 ? 0xffffffffu : ((1u << n_) - 1u);
+        ndeg = 0;
+        iters = 0;
+        maxit = 50 * (m_rows + n_) + 100;
+        status = -1;
+        mode = M_P2;
+        init_col = -1;
+        init_elig = 0u;
+        mode_after_init = M_P2;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { cv[j] = j; cost[j] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            rv[k] = n_ + first_row + k;
+            beta[k] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) T[k][j] = 0.0;
+        }
+    }
+
+    __device__ __forceinline__ void step(const Grp& g) {
+        const bool running = mode != M_DONE;
+        const bool bland = ndeg >= BLAND_AFTER;
+        // ------------------------------------------------ entering column (Dantzig)
+        int e = -1;
+        double best = 0.0;
+        bool epos = false;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const double c = cost[j];
+            const double ac = fabs(c);
+            const bool elig = (ac > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0));
+            const bool take = elig & (ac > best);
+            e = take ? j : e;
+            best = take ? ac : best;
+            epos = take ? (c > 0.0) : epos;
+        }
+        if (__any(bland & running)) {  // Bland: lowest variable id among the eligible columns
+            int eb = -1, bid = 0x7fffffff;
+            double bb = 0.0;
+            bool bp = false;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double c = cost[j];
+                const double ac = fabs(c);
+                const bool elig = (ac > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0));
+                const bool take = elig & (cv[j] < bid);
+                eb = take ? j : eb;
+                bid = take ? cv[j] : bid;
+                bb = take ? ac : bb;
+                bp = take ? (c > 0.0) : bp;
+            }
+            if (bland) { e = eb; best = bb; epos = bp; }
+        }
+        int fin = -1;
+        bool normal = running & (mode == M_P2);
+        fin = (normal & (e < 0)) ? ST_OPT : fin;
+        normal = normal & (e >= 0);
+        fin = (normal & (iters >= maxit)) ? ST_ITER : fin;
+        normal = normal & (iters < maxit);
+        bool init = false;
+        if constexpr (INITM) init = running & (mode == M_INIT);
+        if (init) e = init_col;
+        bool act = normal | init;
+        e = act ? e : -1;
+        if (__any(act)) {  // wave-uniform: a step that only detects optimality skips the pivot
+            // ------------------------------------------------ entering column of my rows
+            const bool flip = normal & epos;  // free variable entering downwards: x := -x
+            double a[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) v = (j == e) ? T[k][j] : v;
+                a[k] = flip ? -v : v;
+            }
+            double ce = -best;  // normal mode: the (sign-flipped) reduced cost of the entering column
+            if constexpr (INITM) {
+                if (__any(init)) {
+                    double cr = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) cr = (j == e) ? cost[j] : cr;
+                    if (init) ce = cr;
+                }
+            }
+            const unsigned efree = (cfree >> (e & 31)) & 1u;
+            const unsigned eneg = ((cneg >> (e & 31)) & 1u) ^ (flip ? 1u : 0u);
+            int vin = 0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) vin = (j == e) ? cv[j] : vin;
+            // ------------------------------------------------ ratio test, my rows first
+            // b_k / a_k < b_n / a_n  <=>  b_k a_n < b_n a_k  (a > 0): the first (lowest) row wins ties
+            int kb = -1;
+            double bn = 0.0, an = 1.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const bool elig = normal & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
+                const double bi = beta[k] > 0.0 ? beta[k] : 0.0;
+                const bool better = elig & ((kb < 0) | (bi * an < bn * a[k]));
+                kb = better ? k : kb;
+                bn = better ? bi : bn;
+                an = better ? a[k] : an;
+            }
+            double qinit = 0.0;
+            if constexpr (INITM) {
+                if (__any(init)) {
+                    int ki = -1;
+                    double qi = 0.0, ai = 1.0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const bool elig = init & (((init_elig >> k) & 1u) != 0u);
+                        const bool better = elig & ((ki < 0) | (init_q[k] < qi));
+                        ki = better ? k : ki;
+                        qi = better ? init_q[k] : qi;
+                        ai = better ? a[k] : ai;
+                    }
+                    if (init) { kb = ki; an = ai; qinit = qi; }
+                }
+            }
+            const double x0 = __builtin_amdgcn_rcp(an);
+            const double x1 = fma(x0, fma(-an, x0, 1.0), x0);
+            double pinv = fma(x1, fma(-an, x1, 1.0), x1);  // 1/a of my best row = the pivot's 1/a_re
+            double q = bn * pinv;
+            if constexpr (INITM) q = init ? qinit : q;
+            const bool erow = kb >= 0;
+            q = erow ? q : __longlong_as_double(0x7ff0000000000000ll);
+            // ------------------------------------------------ group minimum (exact, on a u64 key)
+            const int qh = __double2hiint(q), ql = __double2loint(q);
+            const int sm = qh >> 31;
+            const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
+            const unsigned kl = (unsigned)(ql ^ sm);
+            const unsigned mh = grp_min(kh, g.gs);
+            const unsigned klm = (kh == mh) ? kl : 0xffffffffu;
+            const unsigned ml = grp_min(klm, g.gs);
+            if (act & (mh >= 0xfff00000u)) {  // +inf: no eligible row (or NaN)
+                fin = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM;
+                act = false;
+                e = -1;
+            }
+            const bool tie = erow & (kh == mh) & (kl == ml);
+            const uint64_t tbal = grp_ballot(tie, g);
+            int rl = tbal ? __ffsll((long long)tbal) - 1 : 0;  // lowest lane = lowest row among ties
+            if (__any(bland & act & !init)) {
+                // Bland mode: among ALL rows attaining the minimum, the lowest basic-variable id.
+                // Needs every row's own ratio: one reciprocal per row, rare path.
+                const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);
+                unsigned idb = 0xffffffffu;
+                int kbl = -1;
+                double pinvb = 1.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const bool elig = normal & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
+                    const double y0 = __builtin_amdgcn_rcp(a[k]);
+                    const double y1 = fma(y0, fma(-a[k], y0, 1.0), y0);
+                    const double y2 = fma(y1, fma(-a[k], y1, 1.0), y1);
+                    const double qk = (beta[k] > 0.0 ? beta[k] : 0.0) * y2;
+                    const bool t2 = elig & (qk <= qmin);
+                    const bool take = t2 & ((unsigned)rv[k] < idb);
+                    idb = take ? (unsigned)rv[k] : idb;
+                    kbl = take ? k : kbl;
+                    pinvb = take ? y2 : pinvb;
+                }
+                const unsigned idmin = grp_min(idb, g.gs);
+                const uint64_t kbal = grp_ballot((idb == idmin) & (idb != 0xffffffffu), g);
+                if (bland & (kbal != 0)) {
+                    rl = __ffsll((long long)kbal) - 1;
+                    if (g.gl == rl) { kb = kbl; pinv = pinvb; }
+                }
+            }
+            const bool is_r = act & (g.gl == rl);
+            const int raddr = (g.gbase + rl) << 2;
+            if (normal & act) {
+                const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);
+                ndeg = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
+            }
+            // ------------------------------------------------ pivot row: latch in its lane, broadcast
+            double prow[NC], pb = 0.0;
+            int prv = 0;
+            unsigned prneg = 0u;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) prow[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (k == kb) {
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) prow[j] = T[k][j];
+                    pb = beta[k];
+                    prv = rv[k];
+                    prneg = (rneg >> k) & 1u;
+                }
+            }
+            const double p = act ? bcast_addr(pinv, raddr) : 0.0;
+            const double rhob = bcast_addr(pb, raddr) * p;
+            double rho[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) rho[j] = bcast_addr(prow[j], raddr) * p;
+            const int rpack = __builtin_amdgcn_ds_bpermute(raddr, (prv << 1) | (int)prneg);
+            const int krow = __builtin_amdgcn_ds_bpermute(raddr, kb);
+            // ------------------------------------------------ update my rows
+            const double fc = act ? ce : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double c = fma(-fc, rho[j], cost[j]);
+                cost[j] = (j == e) ? -(fc * p) : c;
+            }
+            negz = fma(-fc, rhob, negz);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const bool piv = is_r & (k == krow);
+                const double f = (act & !piv) ? a[k] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) T[k][j] = fma(-f, rho[j], T[k][j]);
+                beta[k] = fma(-f, rhob, beta[k]);
+                a[k] = f;
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (j == e) {  // entering column: T[k][e] = -a_k p
+#pragma unroll
+                    for (int k = 0; k < R; ++k) T[k][j] = -(a[k] * p);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) rho[j] = (j == e) ? p : rho[j];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (is_r & (k == krow)) {  // the pivot row itself
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) T[k][j] = rho[j];
+                    beta[k] = rhob;
+                    rv[k] = vin;
+                    rneg = (rneg & ~(1u << k)) | (eneg << k);
+                    if (efree) ract &= ~(1u << k);  // a free variable never leaves again
+                }
+            }
+            // ------------------------------------------------ bookkeeping of the column
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cv[j] = (j == e) ? (rpack >> 1) : cv[j];
+            if (act) {
+                cneg = (cneg & ~(1u << e)) | ((unsigned)(rpack & 1) << e);
+                cfree &= ~(1u << e);
+                iters += 1;
+            }
+        }
+        // ------------------------------------------------ mode transitions
+        if (INITM && init) {
+            mode = (fin >= 0) ? M_DONE : mode_after_init;
+            if (fin >= 0) status = fin;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if (((ract >> k) & 1u) && beta[k] < 0.0) beta[k] = 0.0;  // rounding of the forced pivot
+        } else if (running & (fin >= 0)) {
+            mode = M_DONE;
+            status = fin;
+        }
+    }
+
+    __device__ __forceinline__ void run(const Grp& g) {
+        while (__any(mode != M_DONE)) step(g);
+    }
+
+    // value of structural variable j if one of my rows holds it (found = true)
+    __device__ __forceinline__ double x_of(int j, bool& found) const {
+        double v = 0.0;
+        found = false;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool h = rv[k] == j;
+            const double xv = ((rneg >> k) & 1u) ? -beta[k] : beta[k];
+            v = h ? xv : v;
+            found = found | h;
+        }
+        return v;
+    }
+};
+
+}  // namespace plp

@@ -80,12 +80,12 @@ __device__ __forceinline__ unsigned grp_min(unsigned v, int gs) {
 #if PLP_USE_DPP
     PLP_MIN_U32_DPP(v, "quad_perm:[1,0,3,2]");
     PLP_MIN_U32_DPP(v, "quad_perm:[2,3,0,1]");
-    PLP_MIN_U32_DPP(v, "row_half_mirror");
+    if (gs > 4) PLP_MIN_U32_DPP(v, "row_half_mirror");
     if (gs > 8) PLP_MIN_U32_DPP(v, "row_mirror");
 #else
     v = min_u(v, (unsigned)__shfl_xor((int)v, 1, 64));
     v = min_u(v, (unsigned)__shfl_xor((int)v, 2, 64));
-    v = min_u(v, (unsigned)__shfl_xor((int)v, 4, 64));
+    if (gs > 4) v = min_u(v, (unsigned)__shfl_xor((int)v, 4, 64));
     if (gs > 8) v = min_u(v, (unsigned)__shfl_xor((int)v, 8, 64));
 #endif
     if (gs > 16) v = min_u(v, (unsigned)__shfl_xor((int)v, 16, 64));
