@@ -323,6 +323,9 @@ static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, co
     const long long NG = BLOCK / gs;
     long long blocks = (B + NG - 1) / NG;
     if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
+    if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(reduce_r_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
                        abs_tol, keep, flags, r, xc, nlp);

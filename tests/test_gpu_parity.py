@@ -179,6 +179,7 @@ def test_reduce_vs_oracle_batches(pa, oracle):
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(9)
     for (m, d, B) in [(16, 3, 1024), (16, 3, 37), (10, 2, 256), (24, 4, 192), (32, 6, 96), (64, 16, 12),
+                      (64, 8, 40), (17, 5, 70), (33, 7, 30), (48, 9, 20), (1, 1, 16), (2, 1, 33),
                       (8, 3, 200), (40, 3, 64), (5, 4, 40)]:
         A, b = random_hpolytopes(B, m, d, seed=100 + m + d, bounded=True)
         # make some polytopes degenerate: duplicated rows, unbounded, empty
@@ -188,7 +189,7 @@ def test_reduce_vs_oracle_batches(pa, oracle):
             b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.1])
         for k in range(3, B, 11):
             b[k, 0] = -5.0  # cuts everything away -> empty or tiny
-        mrows = rng.integers(max(2, m - 5), m + 1, B).astype(np.int32)
+        mrows = rng.integers(max(min(2, m), m - 5), m + 1, B).astype(np.int32)
         res = pa.reduce_batch(A, b, m=mrows)
         masks = pa.keep_to_bool(res["keep"], m)
         nlp_total = 0
@@ -202,6 +203,31 @@ def test_reduce_vs_oracle_batches(pa, oracle):
             assert int(res["nlp"][k]) == o["nlp"], (m, d, k, int(res["nlp"][k]), o["nlp"])
             nlp_total += o["nlp"]
         assert nlp_total >= B
+
+
+@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_TPL"])
+def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
+    """The three mappings of the fused reduce (4 rows per lane = default, 1 row per lane, 1 polytope
+    per lane) must agree with the oracle; the non-default ones are selected by environment."""
+    from polytope_amd.synth import random_hpolytopes
+    monkeypatch.setenv(variant, "1")
+    rng = np.random.default_rng(21)
+    for (m, d, B) in [(16, 3, 700), (10, 2, 130), (8, 3, 65), (13, 1, 40)]:
+        A, b = random_hpolytopes(B, m, d, seed=7 * m + d, bounded=True)
+        for k in range(0, B, 5):
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.05])
+        for k in range(2, B, 9):
+            b[k, 0] = -4.0
+        mrows = rng.integers(max(2, m - 4), m + 1, B).astype(np.int32)
+        res = pa.reduce_batch(A, b, m=mrows)
+        masks = pa.keep_to_bool(res["keep"], m)
+        for k in range(B):
+            o = oracle.reduce(A[k, :mrows[k]], b[k, :mrows[k]])
+            assert int(res["flags"][k]) == o["flags"], (variant, m, d, k)
+            assert np.array_equal(masks[k, :mrows[k]], o["keep"]), (variant, m, d, k)
+            assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
 def test_reduce_properties_full_config(pa):
