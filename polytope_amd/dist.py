@@ -86,3 +86,83 @@ def reduce_batch_sharded(A, b, m=None, abs_tol=1e-7, reduce_fn=None, device=None
     if world > 1:
         packed = allgather_packed(torch, dist, packed, counts)
     return unpack_results(torch, packed)
+
+
+# ------------------------------------------------------------------------------------------
+# Containment: every rank holds all polytopes (a few MB, replicated) and a
+# contiguous slice of the points; the exchange step is one all-gather of the uint8 results.
+def contains_sharded(A, b, X, abs_tol=1e-7, m=None, contains_fn=None, device=None):
+    """X[d, N] column vectors, known to every rank -> uint8[N] on every rank (Region.contains)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    N = X.shape[1]
+    lo, hi = shard_bounds(N, rank, world)
+    counts = [shard_bounds(N, r, world)[1] - shard_bounds(N, r, world)[0] for r in range(world)]
+    if contains_fn is None:
+        from .batch import contains_batch
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+        def contains_fn(A_, b_, Xs, tol, m_):
+            t = lambda v, dt=None: None if v is None else torch.as_tensor(np.ascontiguousarray(v, dtype=dt)).to(dev)
+            return contains_batch(t(A_), t(b_), t(Xs), tol, m=t(m_, np.int32), region=True)
+    mine = contains_fn(A, b, np.ascontiguousarray(X[:, lo:hi]), abs_tol, m)
+    mine = mine.to(torch.uint8).reshape(-1, 1)
+    if world > 1:
+        mine = allgather_packed(torch, dist, mine, counts)
+    return mine.reshape(-1)
+
+
+# Quickhull outside-set assignment / furthest point (SURVEY 8e, config C5): shard the points; the
+# per-point results stay with (or are gathered from) their owner, the per-facet furthest point needs
+# one exchange: all-gather of F x (max distance, global index), then "first maximum wins" = the
+# lowest global index among the ranks that attain the maximum (quickhull.py:97-100).
+def assign_sharded(X, normals, offsets, abs_tol=1e-7, assign_fn=None, device=None, gather_points=True):
+    """X[N, d] rows, known to every rank -> dict(facet[N], dist[N], argmax[F], maxd[F]) on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    N = X.shape[0]
+    lo, hi = shard_bounds(N, rank, world)
+    counts = [shard_bounds(N, r, world)[1] - shard_bounds(N, r, world)[0] for r in range(world)]
+    if assign_fn is None:
+        from .batch import assign_batch
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+        def assign_fn(Xs, nrm, off, tol):
+            t = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to(dev)
+            return assign_batch(t(Xs), t(nrm), t(off), tol)
+    res = assign_fn(np.ascontiguousarray(X[lo:hi]), normals, offsets, abs_tol)
+    am = res["argmax"].to(torch.int64)
+    mx = res["maxd"].to(torch.float64)
+    big = torch.iinfo(torch.int64).max
+    gidx = torch.where(am >= 0, am + lo, torch.full_like(am, big))   # global point index, "none" = +inf
+    mxv = torch.where(am >= 0, mx, torch.full_like(mx, -1.0))          # distances are > abs_tol >= 0
+    if world > 1:
+        pack = torch.stack([mxv.contiguous().view(torch.int64), gidx], dim=1).contiguous()   # [F, 2]
+        F = pack.shape[0]
+        allp = torch.empty((world * F, 2), dtype=torch.int64, device=pack.device)
+        dist.all_gather_into_tensor(allp, pack)
+        allp = allp.reshape(world, F, 2)
+        dd = allp[:, :, 0].contiguous().view(torch.float64)            # [world, F]
+        ii = allp[:, :, 1]
+        best = dd.max(dim=0).values
+        cand = torch.where(dd == best[None, :], ii, torch.full_like(ii, big))
+        gidx = cand.min(dim=0).values
+        mxv = best
+    argmax = torch.where(gidx == big, torch.full_like(gidx, -1), gidx)
+    maxd = torch.where(gidx == big, torch.zeros_like(mxv), mxv)
+    out = dict(argmax=argmax, maxd=maxd)
+    if gather_points:
+        fac = res["facet"].to(torch.int64).reshape(-1, 1)
+        dst = res["dist"].to(torch.float64).contiguous().view(torch.int64).reshape(-1, 1)
+        both = torch.cat([fac, dst], dim=1).contiguous()
+        if world > 1:
+            both = allgather_packed(torch, dist, both, counts)
+        out["facet"] = both[:, 0].to(torch.int32)
+        out["dist"] = both[:, 1].contiguous().view(torch.float64)
+    else:
+        out["facet"], out["dist"], out["lo"], out["hi"] = res["facet"], res["dist"], lo, hi
+    return out

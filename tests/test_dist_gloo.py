@@ -75,6 +75,63 @@ def test_sharded_reduce_allgather(world, B):
     assert covered.all()
 
 
+def _worker_points(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from polytope_amd import dist as pdist
+    from polytope_amd.synth import containment_workload, quickhull_workload
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b, X = containment_workload(12, 1001, d=3, m=8, seed=2)
+
+    def cpu_contains(A_, b_, Xs, tol, m_):
+        return torch.as_tensor(O.contains(A_, b_, np.ascontiguousarray(Xs.T), abs_tol=tol, mrows=m_, region=True))
+
+    got = pdist.contains_sharded(A, b, X, 1e-7, contains_fn=cpu_contains)
+    Xq, nrm, off = quickhull_workload(777, d=3, F=9, seed=5)
+    Xq[500] = Xq[100]  # exact tie across ranks: the lower global index must win
+
+    def cpu_assign(Xs, n_, o_, tol):
+        fo, dd, am, mx = O.assign(Xs, n_, o_, tol)
+        return dict(facet=torch.as_tensor(fo), dist=torch.as_tensor(dd), argmax=torch.as_tensor(am),
+                    maxd=torch.as_tensor(np.where(am >= 0, mx, 0.0)))
+
+    res = pdist.assign_sharded(Xq, nrm, off, 1e-7, assign_fn=cpu_assign)
+    q.put((rank, got.numpy(), res["facet"].numpy(), res["dist"].numpy(), res["argmax"].numpy(), res["maxd"].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_contains_and_assign(world):
+    import torch.multiprocessing as mp
+    from polytope_amd.synth import containment_workload, quickhull_workload
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_points, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    A, b, X = containment_workload(12, 1001, d=3, m=8, seed=2)
+    want = O.contains(A, b, np.ascontiguousarray(X.T), abs_tol=1e-7, region=True)
+    Xq, nrm, off = quickhull_workload(777, d=3, F=9, seed=5)
+    Xq[500] = Xq[100]
+    fo, dd, am, mx = O.assign(Xq, nrm, off, 1e-7)
+    for rank, got, facet, dist_, argmax, maxd in outs:
+        assert np.array_equal(got, want)
+        assert np.array_equal(facet, fo) and np.array_equal(dist_, dd)
+        assert np.array_equal(argmax, am), (rank, argmax, am)
+        assert np.array_equal(maxd[am >= 0], mx[am >= 0])
+
+
 def test_shard_bounds_and_packing():
     import torch
     from polytope_amd import dist as pdist
