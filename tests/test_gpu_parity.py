@@ -262,6 +262,42 @@ def test_reduce_properties_full_config(pa):
     print("kept rows total", int(cnt.sum()), "LPs", int(res["nlp"].sum()))
 
 
+def test_fuzz_random_shapes(pa, oracle):
+    """Random (rows, dimension) over the whole envelope m <= 64, d <= 16, ragged row counts:
+    lpsolve / cheby / reduce against the oracle (status, masks, flags exact; values 1e-9)."""
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        d = int(rng.integers(1, 17))
+        m = int(rng.integers(1, 65))
+        B = int(rng.integers(1, 40))
+        A = rng.standard_normal((B, m, d))
+        A /= np.linalg.norm(A, axis=2, keepdims=True)
+        b = 0.5 + rng.random((B, m))
+        if m >= 2 * d and trial % 3:
+            A[:, :2 * d] = np.vstack([np.eye(d), -np.eye(d)])[None]
+            b[:, :2 * d] = 2.0
+        mrows = rng.integers(max(1, m - 6), m + 1, B).astype(np.int32)
+        ch = pa.cheby_ball_batch(A, b, m=mrows)
+        rd = pa.reduce_batch(A, b, m=mrows)
+        masks = pa.keep_to_bool(rd["keep"], m)
+        c = rng.standard_normal((B, d))
+        lp = pa.lpsolve_batch(c, A, b, m=mrows)
+        for k in range(B):
+            Ak, bk = A[k, :mrows[k]], b[k, :mrows[k]]
+            so, ro, _ = oracle.cheby(Ak, bk)
+            assert ch["status"][k] == so, (trial, m, d, k)
+            if so == 0:
+                assert abs(ch["r"][k] - ro) <= TOL, (trial, m, d, k)
+            o = oracle.reduce(Ak, bk)
+            assert int(rd["flags"][k]) == o["flags"], (trial, m, d, k, int(rd["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k, :mrows[k]], o["keep"]), (trial, m, d, k)
+            assert int(rd["nlp"][k]) == o["nlp"]
+            s2, x2, f2, _ = oracle.lp_solve(c[k], Ak, bk)
+            assert lp["status"][k] == s2, (trial, m, d, k)
+            if s2 == 0:
+                assert abs(lp["fun"][k] - f2) <= TOL * max(1.0, abs(f2)), (trial, m, d, k)
+
+
 # ------------------------------------------------------------------------------ contains
 def test_contains_golden(pa):
     g = load_golden("g4_contains.npz")
