@@ -268,6 +268,16 @@ struct Simplex {
                     rowact = !efree;  // a free variable never leaves again
                 }
             }
+            // Optimal right after this pivot?  Checking the fresh cost row here saves the extra lock-step
+            // iteration that would otherwise only discover "no entering column".
+            bool more = false;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double c = cost[j];
+                more = more | ((fabs(c) > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0)) &
+                               (((dead >> j) & 1u) == 0u));
+            }
+            if (normal & act & !more) fin = ST_OPT;
         }
         // ------------------------------------------------ mode transitions
         if (INITM && init) {

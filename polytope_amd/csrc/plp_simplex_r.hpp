@@ -290,6 +290,15 @@ struct SimplexR {
                 cfree &= ~(1u << e);
                 iters += 1;
             }
+            // Optimal right after this pivot?  Checking the fresh cost row here saves the whole extra
+            // lock-step iteration that would otherwise only discover "no entering column".
+            bool more = false;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const double c = cost[j];
+                more = more | ((fabs(c) > TOL_D) & ((((cfree >> j) & 1u) != 0u) | (c < 0.0)));
+            }
+            if (normal & act & !more) fin = ST_OPT;
         }
         // ------------------------------------------------ mode transitions
         if (INITM && init) {
