@@ -132,6 +132,20 @@ int plp_assign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const double *X
                    const double *normals, const double *offsets, double abs_tol, int32_t *facet_of_point,
                    double *dist, int64_t *argmax, double *maxd);
 
+/*
+ * Adjacency of all pairs of n cells (one polytope each): adj[i][j] = 1 iff the two cells, both
+ * inflated by abs_tol, have an intersection with Chebyshev radius > abs_tol/10.
+ * Replaces: the O(n^2) loop of find_adjacent_regions (polytope/prop2partition.py:46-63) over
+ *           is_adjacent(a, b, overlap=True) (polytope/polytope.py:1843-1866): one Chebyshev LP per
+ *           pair on the stacked rows [A_i; A_j], [b_i + abs_tol; b_j + abs_tol].
+ * A[n][m_max][d], b[n][m_max], m[n] or NULL; 2*m_max <= 64, d <= 8.  Out: adj[n][n] (symmetric,
+ * ones on the diagonal).  The n(n-1)/2 pair LPs are formed on the device from the resident cells.
+ */
+int plp_adjacent_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, const double *b,
+                       const int32_t *m, double abs_tol, uint8_t *adj);
+int plp_adjacent_pairs_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
+                           const double *b, const int32_t *m, double abs_tol, uint8_t *adj);
+
 /* cross-lane primitive self-test (group size 8/16/32/64); host out_d[128], out_u[128] */
 int plp_selftest(plp_ctx *ctx, int group_size, double *out_d, uint32_t *out_u);
 

@@ -244,6 +244,32 @@ def assign_batch(X, normals, offsets, abs_tol=1e-7):
     return dict(facet=fop, dist=dist, argmax=am, maxd=mx)
 
 
+def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
+    """Adjacency matrix of n single-polytope cells (prop2partition.py:46-63 over polytope.py:1843-1866):
+    uint8[n, n], symmetric, ones on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 8.
+    The n(n-1)/2 stacked, abs_tol-inflated pair LPs are formed on the device."""
+    lib = _lib.load()
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        n, m_max, d = A.shape
+        adj = torch.empty((n, n), dtype=torch.uint8, device=A.device)
+        _lib.check(lib.plp_adjacent_pairs_dev(ctx.handle, stream, n, m_max, d, _ptr(A), _ptr(b), _ptr(m),
+                                              float(abs_tol), _ptr(adj)), "plp_adjacent_pairs_dev")
+        return adj
+    A = _np(A)
+    n, m_max, d = A.shape
+    b = _np(b).reshape(n, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(n)
+    _finite_or_raise("adjacent_pairs", A, b)
+    adj = np.zeros((n, n), np.uint8)
+    _lib.check(lib.plp_adjacent_pairs(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
+                                      _ptr(adj)), "plp_adjacent_pairs")
+    return adj
+
+
 def selftest(group_size):
     """Cross-lane primitive self-test -> (out_d[128], out_u[128]) (see plp_points.hip)."""
     lib = _lib.load()

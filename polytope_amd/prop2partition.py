@@ -30,12 +30,12 @@ def _uniform_single_cells(regions):
     if len(shapes) != 1:
         return None
     m, d = next(iter(shapes))
-    if 2 * m > 64 or d > 16:
+    if 2 * m > 64 or d > 8 or m < 1:
         return None
     return cells
 
 
-def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL, chunk=1 << 19):
+def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL):
     """n x n int8 adjacency (1 on the diagonal) -- is_adjacent(a, b, overlap=True) for every pair."""
     n = len(regions)
     adj = np.eye(n, dtype=np.int8)
@@ -44,19 +44,11 @@ def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL, chunk=1 << 19):
     ii, jj = np.tril_indices(n, -1)
     cells = _uniform_single_cells(regions) if solvers.default_solver == "hip" else None
     if cells is not None:
-        # vectorised stacking: rows of cell i and cell j, both inflated by abs_tol (polytope.py:1860-1864)
-        from .batch import cheby_ball_batch
+        # the n(n-1)/2 stacked, abs_tol-inflated pair LPs (polytope.py:1860-1866) are formed on the device
+        from .batch import adjacent_pairs
         A = np.stack([c.A for c in cells])
-        b = np.stack([c.b for c in cells]) + abs_tol
-        for s in range(0, ii.size, chunk):
-            i_, j_ = ii[s:s + chunk], jj[s:s + chunk]
-            Ap = np.concatenate([A[i_], A[j_]], axis=1)
-            bp = np.concatenate([b[i_], b[j_]], axis=1)
-            res = cheby_ball_batch(Ap, bp)
-            ok = (res["status"] == 0) & (res["r"] > abs_tol / 10)  # is_fulldim(dummy, abs_tol / 10)
-            adj[i_[ok], j_[ok]] = 1
-            adj[j_[ok], i_[ok]] = 1
-        return adj
+        b = np.stack([c.b for c in cells])
+        return adjacent_pairs(A, b, abs_tol=abs_tol).astype(np.int8)
     flags = pc.is_adjacent_pairs([(regions[i], regions[j]) for i, j in zip(ii, jj)], abs_tol=abs_tol)
     adj[ii[flags], jj[flags]] = 1
     adj[jj[flags], ii[flags]] = 1
