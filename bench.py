@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "exercise the N>1 code path with several ranks on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,13 +114,17 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available() or not _lib.available():
         raise SystemExit("bench.py needs a MI355X and polytope_amd/libplp_hip.so (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     A, b = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=0, stream=rank)
     At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
@@ -150,14 +156,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / args.steps
     nlp_local = int(res["nlp"].sum().item())
     nlp_total = nlp_local
     if world > 1:
-        t = torch.tensor([nlp_local], dtype=torch.int64, device=dev)
+        t = torch.tensor([nlp_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t)
         nlp_total = int(t.item())
         assert gathered.shape[0] == world * B_PER_GPU

@@ -49,8 +49,14 @@ def allgather_packed(torch, dist, packed, counts):
     if packed.shape[0] != cmax:
         pad = torch.zeros((cmax - packed.shape[0], cols), dtype=packed.dtype, device=packed.device)
         packed = torch.cat([packed, pad], dim=0)
-    out = torch.empty((world * cmax, cols), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed.contiguous())
+    if dist.get_backend() == "gloo" and packed.is_cuda:  # test-only path: gloo gathers on the host
+        host = packed.contiguous().cpu()
+        out = torch.empty((world * cmax, cols), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        out = out.to(packed.device)
+    else:
+        out = torch.empty((world * cmax, cols), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed.contiguous())
     if all(c == cmax for c in counts):
         return out
     parts = [out[r * cmax: r * cmax + counts[r]] for r in range(world)]
