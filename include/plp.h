@@ -133,6 +133,38 @@ int plp_assign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const double *X
                    double *dist, int64_t *argmax, double *maxd);
 
 /*
+ * quickhull main loop: outside sets kept on the device for the whole run.
+ * Replaces: the per-iteration pooling of the visible facets' outside points and their
+ *           re-assignment to the new facets (polytope/quickhull.py:273-283, :311-336), the initial
+ *           assignment (:224-245) and Facet.get_furthest (:87-102).
+ * A plp_hull holds the N points ([N][d] rows, uploaded once), one int32 owner per point (facet id;
+ * -1 = not outside any facet) and the point's distance to its owner.  Facet ids are handed out by
+ * the session in creation order; id 0 is the virtual facet that owns every point at creation.
+ *
+ * plp_hull_reassign: flag the n_dead facets dead_ids[] (the visible set) dead; every point they own
+ *   goes to the FIRST of the n_new facets normals[n_new][d], offsets[n_new] (creation order) with
+ *   n.p - offset > abs_tol, else to -1.  The new facets get ids *new_id0 .. *new_id0 + n_new - 1.
+ *   Out (per new facet): count[] points received, argmax[] the point furthest from it (-1 if none;
+ *   lowest point index among exactly equal distances), maxd[] that distance (0 if none).
+ * plp_hull_drop: owner[idx[i]] = -1 (start-simplex members, the apex just taken from its facet).
+ * plp_hull_read: copy owner[N] / dist[N] to the host (either may be NULL).
+ * The "_dev" form is stateless: device pointers X, owner, dist, dead[new_id0] (uint8 per facet id),
+ * normals, offsets, argmax, maxd, count; it enqueues on `stream` and returns.
+ */
+typedef struct plp_hull plp_hull;
+int plp_hull_create(plp_ctx *ctx, int64_t N, int d, const double *X, plp_hull **out);
+int plp_hull_destroy(plp_hull *h);
+int plp_hull_drop(plp_hull *h, int64_t n, const int64_t *idx);
+int plp_hull_reassign(plp_hull *h, int n_dead, const int32_t *dead_ids, int n_new, const double *normals,
+                      const double *offsets, double abs_tol, int32_t *new_id0, int64_t *argmax,
+                      double *maxd, int64_t *count);
+int plp_hull_read(plp_hull *h, int32_t *owner, double *dist);
+int plp_hull_reassign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const double *X, int32_t *owner,
+                          double *dist, const uint8_t *dead, int new_id0, int n_new, const double *normals,
+                          const double *offsets, double abs_tol, int64_t *argmax, double *maxd,
+                          int64_t *count);
+
+/*
  * Adjacency of all pairs of n cells (one polytope each): adj[i][j] = 1 iff the two cells, both
  * inflated by abs_tol, have an intersection with Chebyshev radius > abs_tol/10.
  * Replaces: the O(n^2) loop of find_adjacent_regions (polytope/prop2partition.py:46-63) over

@@ -52,6 +52,10 @@ def lib():
         L.plpo_assign.argtypes = [C.c_int64, C.c_int, dp, C.c_int, dp, dp, C.c_double,
                                   C.POINTER(C.c_int32), dp, C.POINTER(C.c_int64), dp]
         L.plpo_assign.restype = None
+        L.plpo_hull_reassign.argtypes = [C.c_int64, C.c_int, dp, C.POINTER(C.c_int32), dp, C.POINTER(C.c_uint8),
+                                         C.c_int, C.c_int, dp, dp, C.c_double, C.POINTER(C.c_int64), dp,
+                                         C.POINTER(C.c_int64)]
+        L.plpo_hull_reassign.restype = None
         _lib = L
     return _lib
 
@@ -160,3 +164,53 @@ def assign(X, normals, offsets, abs_tol=1e-7):
     lib().plpo_assign(N, d, _p(X), F, _p(normals), _p(offsets), abs_tol,
                       _p(fop, C.c_int32), _p(dist), _p(am, C.c_int64), _p(mx))
     return fop, dist, am, mx
+
+
+def hull_reassign(X, owner, dist, dead, new_id0, normals, offsets, abs_tol=1e-7):
+    """One quickhull outside-set update (quickhull.py:273-283, :311-336, :87-102); owner/dist in place.
+
+    -> (count int64[n_new], argmax int64[n_new], maxd f64[n_new])
+    """
+    X, normals, offsets = _d(X), _d(normals), _d(offsets).ravel()
+    N, d = X.shape
+    n_new = normals.shape[0]
+    assert owner.dtype == np.int32 and dist.dtype == np.float64 and dead.dtype == np.uint8
+    am = np.empty(n_new, dtype=np.int64)
+    mx = np.empty(n_new)
+    cnt = np.empty(n_new, dtype=np.int64)
+    lib().plpo_hull_reassign(N, d, _p(X), _p(owner, C.c_int32), _p(dist), _p(dead, C.c_uint8), int(new_id0), n_new,
+                             _p(normals), _p(offsets), abs_tol, _p(am, C.c_int64), _p(mx), _p(cnt, C.c_int64))
+    return cnt, am, mx
+
+
+class HullSession:
+    """CPU stand-in with the interface of polytope_amd.batch.HullSession (tests drive the host-side
+    quickhull logic with it where no GPU is present, and compare the two step by step on the GPU)."""
+
+    def __init__(self, X):
+        self.X = _d(X)
+        self.N, self.d = self.X.shape
+        self.owner = np.zeros(self.N, np.int32)
+        self.dist = np.zeros(self.N)
+        self.dead = np.zeros(4096, np.uint8)
+        self.next_id = 1
+
+    def drop(self, idx):
+        self.owner[np.asarray(idx, dtype=np.int64)] = -1
+
+    def reassign(self, dead_ids, normals, offsets, abs_tol=1e-7):
+        normals = _d(normals).reshape(-1, self.d)
+        n_new = normals.shape[0]
+        while self.dead.size < self.next_id + n_new:
+            self.dead = np.concatenate([self.dead, np.zeros_like(self.dead)])
+        self.dead[np.asarray(dead_ids, dtype=np.int64)] = 1
+        id0 = self.next_id
+        cnt, am, mx = hull_reassign(self.X, self.owner, self.dist, self.dead, id0, normals, offsets, abs_tol)
+        self.next_id += n_new
+        return id0, cnt, am, mx
+
+    def read(self):
+        return self.owner.copy(), self.dist.copy()
+
+    def close(self):
+        pass

@@ -479,4 +479,33 @@ void plpo_assign(int64_t N, int d, const double *X, int F, const double *normals
     }
 }
 
+/* One iteration of quickhull's outside-set bookkeeping (polytope/quickhull.py:273-283 pooling of
+ * the visible facets' points, :311-336 re-assignment to the new facets in creation order, :87-102
+ * furthest point), on index arrays instead of Python lists: owner[q] is the facet id owning point
+ * q (-1: none), dead[id] != 0 marks the visible facets.  New facets get ids new_id0 + j.
+ * Ties of the furthest point go to the lowest point index. */
+void plpo_hull_reassign(int64_t N, int d, const double *X, int32_t *owner, double *dist,
+                        const uint8_t *dead, int new_id0, int n_new, const double *normals,
+                        const double *offsets, double abs_tol, int64_t *argmax, double *maxd, int64_t *count)
+{
+    for (int f = 0; f < n_new; ++f) { argmax[f] = -1; maxd[f] = 0.0; count[f] = 0; }
+    for (int64_t q = 0; q < N; ++q) {
+        const int own = owner[q];
+        if (own < 0 || own >= new_id0 || !dead[own]) continue;
+        const double *x = X + q * d;
+        owner[q] = -1; dist[q] = 0.0;
+        for (int f = 0; f < n_new; ++f) {
+            const double *nf = normals + (size_t)f * d;
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += nf[k] * x[k];
+            const double dd = s - offsets[f];
+            if (dd > abs_tol) {
+                owner[q] = new_id0 + f; dist[q] = dd; count[f] += 1;
+                if (argmax[f] < 0 || maxd[f] < dd) { argmax[f] = q; maxd[f] = dd; }
+                break;
+            }
+        }
+    }
+}
+
 int plpo_version(void) { return 1; }

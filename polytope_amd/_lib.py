@@ -39,6 +39,13 @@ SIGNATURES = {
     "plp_contains_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_double, C.c_int, _vp]),
     "plp_assign": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "plp_assign_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "plp_hull_create": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, C.POINTER(_vp)]),
+    "plp_hull_destroy": (C.c_int, [_vp]),
+    "plp_hull_drop": (C.c_int, [_vp, C.c_int64, _vp]),
+    "plp_hull_reassign": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_double, _ip, _vp, _vp, _vp]),
+    "plp_hull_read": (C.c_int, [_vp, _vp, _vp]),
+    "plp_hull_reassign_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp,
+                                        C.c_double, _vp, _vp, _vp]),
     "plp_adjacent_pairs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "plp_adjacent_pairs_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "plp_selftest": (C.c_int, [_vp, C.c_int, _vp, _vp]),

@@ -244,6 +244,79 @@ def assign_batch(X, normals, offsets, abs_tol=1e-7):
     return dict(facet=fop, dist=dist, argmax=am, maxd=mx)
 
 
+class HullSession:
+    """Outside sets of one quickhull run, resident on the device (include/plp.h: plp_hull_*).
+
+    The N points are uploaded once; per iteration `reassign` moves the points owned by the dead
+    (visible) facets to the new facets and returns, per new facet, how many points it received and
+    which one is furthest (quickhull.py:273-283, :311-336, :87-102).
+    """
+
+    def __init__(self, X):
+        lib = _lib.load()
+        X = _np(X)
+        if X.ndim != 2:
+            raise ValueError("points must be an (N, d) array")
+        _finite_or_raise("HullSession", X)
+        self.N, self.d = X.shape
+        self._ctx = _lib.context()
+        h = C.c_void_p()
+        _lib.check(lib.plp_hull_create(self._ctx.handle, self.N, self.d, _ptr(X), C.byref(h)), "plp_hull_create")
+        self._h = h
+
+    def drop(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64).ravel()
+        _lib.check(_lib.load().plp_hull_drop(self._h, idx.size, _ptr(idx)), "plp_hull_drop")
+
+    def reassign(self, dead_ids, normals, offsets, abs_tol=1e-7):
+        """-> (new_id0, count int64[n_new], argmax int64[n_new] (-1 none), maxd[n_new])"""
+        dead = np.ascontiguousarray(dead_ids, dtype=np.int32).ravel()
+        normals = _np(normals).reshape(-1, self.d)
+        n_new = normals.shape[0]
+        offsets = _np(offsets).reshape(n_new)
+        am = np.empty(n_new, np.int64)
+        mx = np.empty(n_new)
+        cnt = np.empty(n_new, np.int64)
+        id0 = C.c_int32(0)
+        _lib.check(_lib.load().plp_hull_reassign(self._h, dead.size, _ptr(dead), n_new, _ptr(normals), _ptr(offsets),
+                                                 float(abs_tol), C.byref(id0), _ptr(am), _ptr(mx), _ptr(cnt)),
+                   "plp_hull_reassign")
+        return int(id0.value), cnt, am, mx
+
+    def read(self):
+        """-> (owner int32[N], dist[N]) copied to the host"""
+        owner = np.empty(self.N, np.int32)
+        dist = np.empty(self.N)
+        _lib.check(_lib.load().plp_hull_read(self._h, _ptr(owner), _ptr(dist)), "plp_hull_read")
+        return owner, dist
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().plp_hull_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def hull_reassign_dev(X, owner, dist, dead, new_id0, normals, offsets, abs_tol=1e-7):
+    """Stateless form on torch CUDA tensors (updates owner/dist in place) -> dict(count, argmax, maxd)."""
+    lib = _lib.load()
+    torch, ctx, stream = _torch_stream_ctx(X)
+    N, d = X.shape
+    n_new = normals.shape[0]
+    am = torch.empty((n_new,), dtype=torch.int64, device=X.device)
+    mx = torch.empty((n_new,), dtype=torch.float64, device=X.device)
+    cnt = torch.empty((n_new,), dtype=torch.int64, device=X.device)
+    _lib.check(lib.plp_hull_reassign_dev(ctx.handle, stream, N, d, _ptr(X), _ptr(owner), _ptr(dist), _ptr(dead),
+                                         int(new_id0), n_new, _ptr(normals), _ptr(offsets), float(abs_tol),
+                                         _ptr(am), _ptr(mx), _ptr(cnt)), "plp_hull_reassign_dev")
+    return dict(count=cnt, argmax=am, maxd=mx)
+
+
 def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
     """Adjacency matrix of n single-polytope cells (prop2partition.py:46-63 over polytope.py:1843-1866):
     uint8[n, n], symmetric, ones on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 8.

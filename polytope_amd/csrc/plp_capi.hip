@@ -375,6 +375,184 @@ int plp_assign(plp_ctx* ctx, int64_t N, int d, const double* X, int F, const dou
     return PLP_OK;
 }
 
+// ------------------------------------------------------------------------------- hull session
+int plp_hull_reassign_dev(plp_ctx* ctx, void* stream, int64_t N, int d, const double* X, int32_t* owner, double* dist,
+                          const uint8_t* dead, int new_id0, int n_new, const double* normals, const double* offsets,
+                          double abs_tol, int64_t* argmax, double* maxd, int64_t* count) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (N < 0 || d < 1 || n_new < 1 || new_id0 < 0 || !(abs_tol >= 0.0))
+        return fail(PLP_EINVAL, "bad sizes (need n_new>=1, new_id0>=0, abs_tol>=0)");
+    if (!normals || !offsets || !argmax || !maxd || !count || (new_id0 > 0 && !dead) ||
+        (N > 0 && (!X || !owner || !dist)))
+        return fail(PLP_EINVAL, "NULL pointer");
+    if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
+    if (plp::launch_hull_reassign(N, d, X, owner, dist, dead, new_id0, n_new, normals, offsets, abs_tol,
+                                  reinterpret_cast<long long*>(argmax), maxd, reinterpret_cast<long long*>(count),
+                                  (hipStream_t)stream))
+        return fail(PLP_EUNSUPPORTED, "hull kernel: unsupported size");
+    return check_launch("hull_reassign_kernel");
+}
+
+}  // extern "C"
+
+struct plp_hull {
+    plp_ctx* ctx;
+    int64_t N;
+    int d;
+    double* X;
+    int32_t* owner;
+    double* dist;
+    uint8_t* dead;     // one byte per facet id handed out so far (grow-only)
+    size_t dead_cap;
+    int next_id;       // next facet id to hand out
+    char* io;          // per-call staging: dead ids / facets in, argmax / maxd / count out (grow-only)
+    size_t io_bytes;
+};
+
+namespace {
+
+int hull_ensure(plp_hull* h, size_t ids_needed, size_t io_needed) {
+    if (ids_needed > h->dead_cap) {
+        size_t want = h->dead_cap ? h->dead_cap : 4096;
+        while (want < ids_needed) want *= 2;
+        uint8_t* nd = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&nd), want));
+        HIP_TRY(hipMemsetAsync(nd, 0, want, h->ctx->stream));
+        if (h->dead) {
+            HIP_TRY(hipMemcpyAsync(nd, h->dead, h->dead_cap, hipMemcpyDeviceToDevice, h->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+            HIP_TRY(hipFree(h->dead));
+        }
+        h->dead = nd;
+        h->dead_cap = want;
+    }
+    if (io_needed > h->io_bytes) {
+        if (h->io) HIP_TRY(hipFree(h->io));
+        h->io = nullptr;
+        h->io_bytes = 0;
+        const size_t want = io_needed * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->io), want));
+        h->io_bytes = want;
+    }
+    return PLP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plp_hull_destroy(plp_hull* h) {
+    if (!h) return PLP_OK;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->X) (void)hipFree(h->X);
+    if (h->owner) (void)hipFree(h->owner);
+    if (h->dist) (void)hipFree(h->dist);
+    if (h->dead) (void)hipFree(h->dead);
+    if (h->io) (void)hipFree(h->io);
+    delete h;
+    return PLP_OK;
+}
+
+int plp_hull_create(plp_ctx* ctx, int64_t N, int d, const double* X, plp_hull** out) {
+    if (!out) return fail(PLP_EINVAL, "plp_hull_create: out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (N < 0 || d < 1 || (N > 0 && !X)) return fail(PLP_EINVAL, "bad sizes / NULL points");
+    if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
+    HIP_TRY(hipSetDevice(ctx->device));
+    plp_hull* h = new plp_hull();
+    memset(h, 0, sizeof(*h));
+    h->ctx = ctx;
+    h->N = N;
+    h->d = d;
+    h->next_id = 1;  // id 0: the virtual facet owning every point (owner[] is zero-filled)
+    const size_t n1 = N > 0 ? (size_t)N : 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->X), n1 * d * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->owner), n1 * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->dist), n1 * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(h->owner, 0, n1 * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->dist, 0, n1 * 8, ctx->stream);
+    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(h->X, X, (size_t)N * d * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        plp_hull_destroy(h);
+        return fail(PLP_EHIP, "plp_hull_create: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return PLP_OK;
+}
+
+int plp_hull_drop(plp_hull* h, int64_t n, const int64_t* idx) {
+    if (!h) return fail(PLP_EINVAL, "hull is NULL");
+    if (n < 0 || (n > 0 && !idx)) return fail(PLP_EINVAL, "bad index list");
+    if (n == 0) return PLP_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= h->N) return fail(PLP_EINVAL, "point index %lld out of range", (long long)idx[i]);
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    int rc = hull_ensure(h, 0, (size_t)n * 8);
+    if (rc) return rc;
+    hipStream_t st = h->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(h->io, idx, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    plp::launch_hull_drop(n, reinterpret_cast<const long long*>(h->io), h->owner, st);
+    rc = check_launch("hull_drop_kernel");
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
+int plp_hull_reassign(plp_hull* h, int n_dead, const int32_t* dead_ids, int n_new, const double* normals,
+                      const double* offsets, double abs_tol, int32_t* new_id0, int64_t* argmax, double* maxd,
+                      int64_t* count) {
+    if (!h) return fail(PLP_EINVAL, "hull is NULL");
+    if (n_dead < 0 || n_new < 1 || !(abs_tol >= 0.0)) return fail(PLP_EINVAL, "bad sizes (need n_new>=1, abs_tol>=0)");
+    if ((n_dead > 0 && !dead_ids) || !normals || !offsets || !new_id0 || !argmax || !maxd || !count)
+        return fail(PLP_EINVAL, "NULL pointer");
+    for (int i = 0; i < n_dead; ++i)
+        if (dead_ids[i] < 0 || dead_ids[i] >= h->next_id)
+            return fail(PLP_EINVAL, "dead facet id %d was never handed out", dead_ids[i]);
+    if ((long long)h->next_id + n_new > 0x7fffffffll) return fail(PLP_EUNSUPPORTED, "facet ids exhausted");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    const int id0 = h->next_id;
+    const int d = h->d;
+    const size_t b_ids = pad((size_t)(n_dead ? n_dead : 1) * 4), b_n = pad((size_t)n_new * d * 8),
+                 b_f = pad((size_t)n_new * 8);
+    int rc = hull_ensure(h, (size_t)id0 + n_new, b_ids + b_n + 4 * b_f);
+    if (rc) return rc;
+    char* p = h->io;
+    int32_t* d_ids = reinterpret_cast<int32_t*>(p); p += b_ids;
+    double* d_n = reinterpret_cast<double*>(p); p += b_n;
+    double* d_o = reinterpret_cast<double*>(p); p += b_f;
+    int64_t* d_am = reinterpret_cast<int64_t*>(p); p += b_f;
+    double* d_mx = reinterpret_cast<double*>(p); p += b_f;
+    int64_t* d_cn = reinterpret_cast<int64_t*>(p);
+    hipStream_t st = h->ctx->stream;
+    if (n_dead) HIP_TRY(hipMemcpyAsync(d_ids, dead_ids, (size_t)n_dead * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_n, normals, (size_t)n_new * d * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_o, offsets, (size_t)n_new * 8, hipMemcpyHostToDevice, st));
+    plp::launch_hull_mark(n_dead, d_ids, h->dead, st);
+    rc = plp_hull_reassign_dev(h->ctx, st, h->N, d, h->X, h->owner, h->dist, h->dead, id0, n_new, d_n, d_o, abs_tol,
+                               d_am, d_mx, d_cn);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(argmax, d_am, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(maxd, d_mx, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(count, d_cn, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->next_id = id0 + n_new;
+    *new_id0 = id0;
+    return PLP_OK;
+}
+
+int plp_hull_read(plp_hull* h, int32_t* owner, double* dist) {
+    if (!h) return fail(PLP_EINVAL, "hull is NULL");
+    HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    if (owner && h->N) HIP_TRY(hipMemcpyAsync(owner, h->owner, (size_t)h->N * 4, hipMemcpyDeviceToHost, st));
+    if (dist && h->N) HIP_TRY(hipMemcpyAsync(dist, h->dist, (size_t)h->N * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
 // ------------------------------------------------------------------------------- adjacency
 int plp_adjacent_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, const double* A, const double* b,
                            const int32_t* m, double abs_tol, uint8_t* adj) {

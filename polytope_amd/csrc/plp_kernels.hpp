@@ -46,6 +46,13 @@ int launch_assign(long long N, int d, const double* X, int F, const double* norm
                   void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t assign_scratch_bytes(long long N, int F);
 
+// quickhull outside sets on resident points (plp_hull.hip)
+int launch_hull_reassign(long long N, int d, const double* X, int* owner, double* dist, const unsigned char* dead,
+                         int new_id0, int n_new, const double* normals, const double* offsets, double abs_tol,
+                         long long* argmax, double* maxd, long long* count, hipStream_t st);
+void launch_hull_mark(int n, const int* ids, unsigned char* dead, hipStream_t st);
+void launch_hull_drop(long long n, const long long* idx, int* owner, hipStream_t st);
+
 int launch_selftest(int gs, double* out_d, unsigned* out_u, hipStream_t st);
 
 }  // namespace plp

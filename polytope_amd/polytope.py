@@ -1027,3 +1027,61 @@ def is_adjacent_pairs(pairs, overlap=True, abs_tol=ABS_TOL):
         if r > abs_tol / 10:
             result[k] = True
     return result
+
+
+# ======================================================================================
+# Vertex enumeration: qhull / extreme on top of the device-resident
+# quickhull of polytope_amd.quickhull and the fused reduce kernel.
+def qhull(vertices, abs_tol=ABS_TOL):
+    """Convex hull of the rows of `vertices` (N x d) as a Polytope (ref :1685-1695)."""
+    from .quickhull import quickhull
+    A, b, vert = quickhull(vertices, abs_tol=abs_tol)
+    if A.size == 0:
+        return Polytope()
+    return Polytope(A, b, minrep=True, vertices=vert)
+
+
+def extreme(poly1):
+    """Vertices of a bounded polytope as an (N x d) array, None if it is flat (ref :1597-1682).
+
+    d = 1: b_i / a_i.  d = 2: rows sorted by the angle of their normal, consecutive pairs
+    intersected (all 2x2 systems in one batched solve).  d > 2: the facets of the hull of the
+    polar dual about the Chebyshev centre are the vertices: qhull of a_i / (b_i - a_i.xc), reduce,
+    map back.  Caches the result in `poly1.vertices`.
+    """
+    if poly1.vertices is not None:
+        return poly1.vertices
+    if isinstance(poly1, Region):
+        raise Exception("extreme: not executable for regions")
+    poly1 = reduce(poly1)  # the H-representation must be irredundant
+    if not is_fulldim(poly1):
+        return None
+    A, b = poly1.A.copy(), poly1.b.copy()
+    nc, nx = A.shape
+    if nx == 1:
+        if nc == 1:
+            raise Exception("extreme: polytope is unbounded")
+        V = b / A[:, 0]
+    elif nx == 2:
+        order = np.argsort(np.angle(A[:, 0] + 1j * A[:, 1]))
+        nxt = np.roll(order, -1)
+        HH = np.stack([A[order], A[nxt]], axis=1)   # [nc][2][2]: a facet and its angular successor
+        KK = np.stack([b[order], b[nxt]], axis=1)
+        if np.any(np.isinf(np.linalg.cond(HH))):
+            raise Exception("extreme: polytope is unbounded")
+        try:
+            V = np.linalg.solve(HH, KK[:, :, None])[:, :, 0]
+        except Exception:
+            raise Exception("Finding extreme points failed, Check if any unbounded Polytope is causing this.")
+    else:
+        rmid, xmid = cheby_ball(poly1)
+        Ai = A / (b - np.dot(A, xmid))[:, None]
+        Q = reduce(qhull(Ai))
+        if not is_fulldim(Q):
+            return None
+        V = Q.A / Q.b[:, None] + np.asarray(xmid).ravel()[None, :]
+    a = V.size / nx
+    if not float(a).is_integer():
+        raise AssertionError(a)
+    poly1.vertices = np.asarray(V, dtype=float).reshape((int(a), nx))
+    return poly1.vertices

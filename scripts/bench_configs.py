@@ -155,6 +155,44 @@ def c4():
           flush=True)
 
 
+def hull():
+    """End-to-end quickhull with device-resident outside sets (polytope_amd.quickhull) beside qhull's C
+    library (scipy.spatial.ConvexHull) on the same points; per-iteration cost = one plp_hull_reassign."""
+    from scipy.spatial import ConvexHull
+    from polytope_amd.quickhull import quickhull
+    for (N, d) in [(1000000, 3), (1000000, 2), (200000, 4), (1000000, 8)]:
+        rng = np.random.default_rng(N + d)
+        P = rng.standard_normal((N, d))
+        if d == 8:  # a full d=8 hull of 1M Gaussian points has ~1e6 facets: time single passes instead
+            from polytope_amd.batch import HullSession
+            h = HullSession(P)
+            nrm = rng.standard_normal((9, d))
+            nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+            t0 = time.perf_counter()
+            id0, cnt, am, mx = h.reassign([0], nrm, np.full(9, 1.0))
+            t1 = time.perf_counter()
+            _, cnt2, _, _ = h.reassign([id0], nrm, np.full(9, 1.5))
+            t2 = time.perf_counter()
+            h.close()
+            print(json.dumps({"config": "C5 hull pass N=%d d=%d F=9 (host call incl. sync + D2H of results)" % (N, d),
+                              "first_pass_ms": (t1 - t0) * 1e3, "repool_pass_ms": (t2 - t1) * 1e3,
+                              "assigned": int(cnt.sum()), "repooled": int(cnt2.sum())}))
+            continue
+        np.random.seed(0)
+        quickhull(P[:1000])  # warm the library
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        A, b, V = quickhull(P)
+        t1 = time.perf_counter()
+        ch = ConvexHull(P)
+        t2 = time.perf_counter()
+        same = np.array_equal(np.sort(V, axis=0), np.sort(P[np.unique(ch.vertices)], axis=0))
+        print(json.dumps({"config": "quickhull N=%d d=%d" % (N, d), "facets": int(A.shape[0]), "vertices": int(V.shape[0]),
+                          "hip_s": t1 - t0, "us_per_facet": (t1 - t0) / A.shape[0] * 1e6,
+                          "cpu_baseline": {"kind": "scipy.spatial.ConvexHull (qhull C library, 1 core)", "s": t2 - t1},
+                          "same_vertex_set": bool(same)}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c5", "lp"]
     for w in which:

@@ -20,6 +20,9 @@ Sets:
   g6_quickhull.npz Facet normals/offsets, distance(), first-facet assignment,
                    get_furthest, and end-to-end hull facet sets                     (quickhull.py)
   g7_known.npz     the known-answer data of the reference's own tests (tests/polytope_test.py)
+  g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
+                   qhull() and extreme() vertex sets                                (quickhull.py:141-359,
+                   polytope.py:1597-1695)
 """
 import os
 import sys
@@ -432,7 +435,61 @@ def gen_g7():
     print("g7: known-answer data")
 
 
+# ----------------------------------------------------------------------------- G8
+def gen_g8():
+    rng = np.random.default_rng(8)
+    out = {}
+    # end-to-end hulls, rows kept in the order the reference returns them (global RNG seeded)
+    cases = [(2, 150, 11), (3, 400, 12), (4, 150, 13), (5, 60, 14), (3, 4, 15), (2, 3, 16)]
+    for k, (d, n, seed) in enumerate(cases):
+        P = rng.standard_normal((n, d)) if k % 2 else rng.random((n, d))
+        np.random.seed(seed)
+        A, b, V = qh.quickhull(P)
+        out[f"hull{k}_P"], out[f"hull{k}_seed"] = P, np.array(seed)
+        out[f"hull{k}_A"], out[f"hull{k}_b"], out[f"hull{k}_V"] = A, b, V
+    out["hull_ncases"] = np.array(len(cases))
+    # degenerate: unit cube corners + interior points (coplanar points: facets are triangulated);
+    # compared as the set of distinct hyperplanes
+    corners = np.array([[i, j, k] for i in (0.0, 1.0) for j in (0.0, 1.0) for k in (0.0, 1.0)])
+    P = np.vstack([corners, 0.2 + 0.6 * rng.random((40, 3))])
+    np.random.seed(21)
+    A, b, V = qh.quickhull(P)
+    out["cube_P"], out["cube_A"], out["cube_b"], out["cube_V"] = P, A, b, V
+    # too few points / flat input -> empty
+    A, b, V = qh.quickhull(rng.random((3, 3)))
+    out["few_Asize"] = np.array(A.size)
+    flat = np.c_[rng.random((20, 2)), np.zeros(20)]
+    A, b, V = qh.quickhull(flat)
+    out["flat_P"], out["flat_Asize"] = flat, np.array(A.size)
+    # extreme(): d = 1, 2 (angle sort), 3, 4 (dual hull) on seeded bounded polytopes
+    ext = []
+    for (d, m, seed) in [(1, 2, 0), (2, 7, 1), (2, 12, 2), (3, 10, 3), (3, 16, 4), (4, 14, 5)]:
+        r2 = np.random.default_rng(100 + seed)
+        if d == 1:
+            Ap, bp = np.array([[1.0], [-1.0]]), np.array([2.0, 1.0])
+        else:
+            G = r2.standard_normal((m - 2 * d, d))
+            G /= np.linalg.norm(G, axis=1)[:, None]
+            Ap = np.vstack([np.eye(d), -np.eye(d), G])
+            bp = np.r_[np.full(2 * d, 3.0), 1.0 + r2.random(m - 2 * d)]
+        np.random.seed(50 + seed)
+        poly = pc.Polytope(Ap, bp)
+        V = pc.extreme(poly)
+        V = V[np.lexsort(np.round(V, 9).T[::-1])]
+        k = len(ext)
+        out[f"ext{k}_A"], out[f"ext{k}_b"], out[f"ext{k}_V"] = Ap, bp, V
+        ext.append(k)
+    out["ext_ncases"] = np.array(len(ext))
+    # qhull(): Polytope of a point cloud; the known square of the reference's tests
+    sq = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0], [0.5, 0.5]])
+    np.random.seed(3)
+    q = pc.qhull(sq)
+    out["qsq_P"], out["qsq_A"], out["qsq_b"], out["qsq_V"] = sq, q.A, q.b, q.vertices
+    np.savez_compressed(os.path.join(HERE, "g8_hull.npz"), **out)
+    print("g8: ordered hulls, degenerate cube, extreme() d=1..4, qhull square")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,255 @@
+"""quickhull / qhull / extreme (polytope_amd.quickhull, polytope_amd.polytope) against the reference.
+
+  * g8_hull.npz holds hulls the reference computed with a seeded global RNG: the mirror consumes the
+    RNG the same way, so its rows must come out bit-identical AND in the same order;
+  * g6_quickhull.npz holds facet sets (sorted) of three more hulls;
+  * scipy.spatial.ConvexHull gives the vertex set for inputs larger than the reference can handle.
+
+backend 'scipy' : CPU; host facet graph + numpy point passes (the reference's arithmetic)
+backend 'hip'   : gpu; the same host code with every point pass on the device (plp_hull_*)
+The oracle's C restatement of one outside-set update is checked against both.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+@pytest.fixture(params=["scipy", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    from polytope_amd import solvers
+    old = solvers.default_solver
+    if request.param == "hip":
+        assert "hip" in solvers.installed_solvers, "HIP backend not installed on a GPU box"
+    solvers.default_solver = request.param
+    yield request.param
+    solvers.default_solver = old
+
+
+def rows_sorted(A, b):
+    Ab = np.c_[A, b]
+    return Ab[np.lexsort(np.round(Ab, 9).T[::-1])]
+
+
+def planes(A, b):
+    return np.unique(np.round(np.c_[A, b], 9) + 0.0, axis=0)
+
+
+# ------------------------------------------------------------------ end-to-end hulls
+def test_hull_rows_in_reference_order(backend):
+    from polytope_amd.quickhull import quickhull
+    g = load_golden("g8_hull.npz")
+    for k in range(int(g["hull_ncases"])):
+        np.random.seed(int(g[f"hull{k}_seed"]))
+        A, b, V = quickhull(g[f"hull{k}_P"])
+        assert A.shape == g[f"hull{k}_A"].shape, k
+        assert np.array_equal(A, g[f"hull{k}_A"]), k          # same facets, same order, same bits
+        assert np.allclose(b, g[f"hull{k}_b"], rtol=0, atol=1e-12), k
+        assert np.allclose(V, g[f"hull{k}_V"], rtol=0, atol=1e-12), k
+
+
+def test_hull_facet_sets_g6(backend):
+    from polytope_amd.quickhull import quickhull
+    g = load_golden("g6_quickhull.npz")
+    for d in (2, 3, 4):
+        np.random.seed(7)  # a different start simplex than the reference used: same facet SET
+        A, b, V = quickhull(g[f"hull{d}_P"])
+        assert np.allclose(rows_sorted(A, b), g[f"hull{d}_Ab"], rtol=0, atol=1e-9)
+        assert np.allclose(V, g[f"hull{d}_V"], rtol=0, atol=1e-12)
+
+
+def test_hull_degenerate_and_empty(backend):
+    from polytope_amd.quickhull import quickhull
+    g = load_golden("g8_hull.npz")
+    np.random.seed(21)
+    A, b, V = quickhull(g["cube_P"])
+    assert np.array_equal(planes(A, b), planes(g["cube_A"], g["cube_b"]))  # 6 distinct hyperplanes
+    assert planes(A, b).shape == (6, 4)
+    assert np.allclose(V, g["cube_V"], rtol=0, atol=1e-12)
+    A, b, V = quickhull(np.random.default_rng(0).random((3, 3)))   # npt <= dim  (quickhull.py:153-155)
+    assert A.size == 0 and b.size == 0 and V is None and int(g["few_Asize"]) == 0
+    A, b, V = quickhull(g["flat_P"])                               # rank deficient (:157-163)
+    assert A.size == 0 and V is None and int(g["flat_Asize"]) == 0
+
+
+@pytest.mark.parametrize("n,d", [(2000, 2), (3000, 3), (800, 4), (300, 5)])
+def test_hull_vs_scipy_convexhull(backend, n, d):
+    from scipy.spatial import ConvexHull
+    from polytope_amd.quickhull import quickhull
+    P = np.random.default_rng(n + d).standard_normal((n, d))
+    np.random.seed(1)
+    A, b, V = quickhull(P)
+    ref = P[np.unique(ConvexHull(P).vertices)]
+    ref = ref[np.lexsort(ref.T[::-1])]
+    assert V.shape == ref.shape and np.array_equal(V, ref)
+    assert np.all(A @ P.T - b[:, None] < 1e-7)                    # every point inside every facet
+    assert np.allclose(np.linalg.norm(A, axis=1), 1.0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ qhull / extreme (polytope.py:1597-1695)
+def test_qhull_and_extreme(backend):
+    import polytope_amd.polytope as pc
+    g = load_golden("g8_hull.npz")
+    np.random.seed(3)
+    q = pc.qhull(g["qsq_P"])
+    assert q.minrep and np.array_equal(q.A, g["qsq_A"]) and np.allclose(q.b, g["qsq_b"], rtol=0, atol=1e-12)
+    assert np.allclose(q.vertices, g["qsq_V"], rtol=0, atol=1e-12)
+    assert pc.qhull(np.zeros((2, 3))).A.size == 0               # too few points -> Polytope()
+    for k in range(int(g["ext_ncases"])):
+        poly = pc.Polytope(g[f"ext{k}_A"], g[f"ext{k}_b"])
+        np.random.seed(50 + k)
+        V = pc.extreme(poly)
+        # the cache lands on the reduced copy (:1611 rebinds poly1), so only a minrep input keeps it
+        assert poly.vertices is None
+        pm = pc.reduce(poly)
+        if pm.minrep:
+            assert pc.extreme(pm) is pm.vertices and pm.vertices.shape == V.shape
+        V = V[np.lexsort(np.round(V, 9).T[::-1])]
+        assert V.shape == g[f"ext{k}_V"].shape, k
+        assert np.allclose(V, g[f"ext{k}_V"], rtol=0, atol=1e-9), k
+    with pytest.raises(Exception):  # AttributeError in the reference too: Region has no .vertices (:1604)
+        pc.extreme(pc.Region([pc.box2poly([[0, 1], [0, 1]])]))
+    assert pc.extreme(pc.Polytope(np.array([[1.0, 0], [-1.0, 0], [0, 1.0], [0, -1.0]]),
+                                  np.array([1.0, -1.0, 1.0, 0.0]))) is None   # flat
+
+
+def test_extreme_roundtrip(backend):
+    """qhull(extreme(P)) == P for a random bounded polytope (vertices <-> facets)."""
+    import polytope_amd.polytope as pc
+    rng = np.random.default_rng(5)
+    for d in (2, 3, 4):
+        G = rng.standard_normal((10, d))
+        G /= np.linalg.norm(G, axis=1)[:, None]
+        P = pc.reduce(pc.Polytope(np.vstack([np.eye(d), -np.eye(d), G]), np.r_[np.full(2 * d, 2.0), 1 + rng.random(10)]))
+        np.random.seed(d)
+        V = pc.extreme(P)
+        np.random.seed(d + 10)
+        Q = pc.qhull(V)                        # facets with > d vertices come out triangulated ...
+        Q = pc.reduce(pc.Polytope(Q.A, Q.b))   # ... and qhull() marks its result minrep: rebuild, then reduce
+        assert np.allclose(rows_sorted(Q.A, Q.b), rows_sorted(P.A, P.b), rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------ one outside-set update
+def _random_rounds(rng, N, d, rounds, n_new_max):
+    """A sequence of (dead ids, normals, offsets) whose dead ids always exist."""
+    X = rng.standard_normal((N, d))
+    steps, next_id, alive = [], 1, [0]
+    for r in range(rounds):
+        n_new = int(rng.integers(1, n_new_max + 1))
+        nd = int(rng.integers(1, max(2, len(alive) // 2 + 1)))
+        dead = [alive.pop(int(rng.integers(len(alive)))) for _ in range(min(nd, len(alive)))]
+        nrm = rng.standard_normal((n_new, d))
+        nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+        off = rng.random(n_new) * (1.5 if r else 0.8)
+        steps.append((dead, nrm, off))
+        alive += list(range(next_id, next_id + n_new))
+        next_id += n_new
+    return X, steps
+
+
+def test_oracle_hull_step_vs_numpy(oracle):
+    """C restatement == numpy restatement of one outside-set update, step by step."""
+    from polytope_amd.quickhull import _NumpySession
+    rng = np.random.default_rng(42)
+    for d in (2, 3, 5):
+        X, steps = _random_rounds(rng, 5000, d, 12, 9)
+        a, b = oracle.HullSession(X), _NumpySession(X)
+        a.drop([1, 7, 9]); b.drop([1, 7, 9])
+        for dead, nrm, off in steps:
+            ra, rb = a.reassign(dead, nrm, off, 1e-7), b.reassign(dead, nrm, off, 1e-7)
+            assert ra[0] == rb[0]
+            for u, v in zip(ra[1:], rb[1:]):
+                assert np.array_equal(u, v)
+            oa, da = a.read(); ob, db = b.read()
+            assert np.array_equal(oa, ob) and np.array_equal(da, db)
+
+
+def test_hull_host_logic_on_oracle_session(oracle, monkeypatch):
+    """The host facet graph driven by the oracle's C outside-set update reproduces the reference rows."""
+    import polytope_amd.quickhull as q
+    monkeypatch.setattr(q, "_open_session", lambda X: oracle.HullSession(X))
+    g = load_golden("g8_hull.npz")
+    for k in range(int(g["hull_ncases"])):
+        np.random.seed(int(g[f"hull{k}_seed"]))
+        A, b, V = q.quickhull(g[f"hull{k}_P"])
+        assert np.array_equal(A, g[f"hull{k}_A"]) and np.allclose(b, g[f"hull{k}_b"], rtol=0, atol=1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,N,n_new_max", [(2, 20000, 6), (3, 100000, 40), (5, 30000, 300), (8, 50000, 17),
+                                           (16, 4000, 5), (3, 30000, 2600)])
+def test_hip_hull_step_vs_oracle(oracle, d, N, n_new_max):
+    """plp_hull_* (device-resident session) == oracle, bit for bit, over a sequence of updates;
+    n_new beyond the LDS staging chunk (256) and beyond the LDS maxima cap (2048) included."""
+    from polytope_amd.batch import HullSession
+    rng = np.random.default_rng(1000 + d)
+    X, steps = _random_rounds(rng, N, d, 10, n_new_max)
+    steps[0] = (steps[0][0], steps[0][1][:max(1, n_new_max)], steps[0][2][:max(1, n_new_max)])
+    a, h = oracle.HullSession(X), HullSession(X)
+    try:
+        a.drop([0, 5, N - 1]); h.drop([0, 5, N - 1])
+        for dead, nrm, off in steps:
+            ra, rh = a.reassign(dead, nrm, off, 1e-7), h.reassign(dead, nrm, off, 1e-7)
+            assert ra[0] == rh[0]
+            assert np.array_equal(ra[1], rh[1])          # counts
+            assert np.array_equal(ra[2], rh[2])          # furthest point per new facet (lowest index on ties)
+            assert np.array_equal(ra[3], rh[3])          # its distance, bitwise
+            oa, da = a.read(); oh, dh = h.read()
+            assert np.array_equal(oa, oh) and np.array_equal(da, dh)
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
+def test_hip_hull_step_dev_variant(oracle):
+    """Stateless _dev entry point on torch tensors == oracle."""
+    import torch
+    from polytope_amd.batch import hull_reassign_dev
+    rng = np.random.default_rng(77)
+    N, d = 60000, 4
+    X, steps = _random_rounds(rng, N, d, 6, 30)
+    a = oracle.HullSession(X)
+    Xd = torch.tensor(X, device="cuda")
+    owner = torch.zeros(N, dtype=torch.int32, device="cuda")
+    dist = torch.zeros(N, dtype=torch.float64, device="cuda")
+    dead = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    next_id = 1
+    for dd, nrm, off in steps:
+        ra = a.reassign(dd, nrm, off, 1e-7)
+        dead[torch.tensor(dd, device="cuda", dtype=torch.long)] = 1
+        out = hull_reassign_dev(Xd, owner, dist, dead, next_id, torch.tensor(nrm, device="cuda"),
+                                torch.tensor(off, device="cuda"), 1e-7)
+        next_id += nrm.shape[0]
+        assert np.array_equal(ra[1], out["count"].cpu().numpy())
+        assert np.array_equal(ra[2], out["argmax"].cpu().numpy())
+        assert np.array_equal(ra[3], out["maxd"].cpu().numpy())
+        assert np.array_equal(a.owner, owner.cpu().numpy()) and np.array_equal(a.dist, dist.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_hip_hull_large(oracle):
+    """1e6 points in d=3: vertex set equals scipy's; every point inside the hull."""
+    from scipy.spatial import ConvexHull
+    from polytope_amd import solvers
+    from polytope_amd.quickhull import quickhull
+    old, solvers.default_solver = solvers.default_solver, "hip"
+    try:
+        P = np.random.default_rng(9).standard_normal((1000000, 3))
+        np.random.seed(2)
+        A, b, V = quickhull(P)
+    finally:
+        solvers.default_solver = old
+    ref = P[np.unique(ConvexHull(P).vertices)]
+    ref = ref[np.lexsort(ref.T[::-1])]
+    assert np.array_equal(V, ref)
+    assert np.max(A @ P.T - b[:, None]) < 1e-7
+
+
+def test_hull_abi_errors_without_device():
+    """HullSession must raise without the library / a device: no CPU stand-in in the product."""
+    from polytope_amd import _lib
+    if _lib.available():
+        pytest.skip("GPU present")
+    from polytope_amd.batch import HullSession
+    with pytest.raises(Exception):
+        HullSession(np.zeros((10, 3)))
