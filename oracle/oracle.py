@@ -203,7 +203,9 @@ class HullSession:
         n_new = normals.shape[0]
         while self.dead.size < self.next_id + n_new:
             self.dead = np.concatenate([self.dead, np.zeros_like(self.dead)])
-        self.dead[np.asarray(dead_ids, dtype=np.int64)] = 1
+        dead_ids = np.asarray(dead_ids, dtype=np.int64).ravel()
+        assert np.all(dead_ids >= 0) and np.all(dead_ids < self.next_id), "dead facet id was never handed out"
+        self.dead[dead_ids] = 1
         id0 = self.next_id
         cnt, am, mx = hull_reassign(self.X, self.owner, self.dist, self.dead, id0, normals, offsets, abs_tol)
         self.next_id += n_new

@@ -53,8 +53,11 @@ class _NumpySession:
         offsets = np.asarray(offsets, dtype=float).ravel()
         n_new = normals.shape[0]
         id0 = self.next_id
+        dead_ids = np.asarray(dead_ids, dtype=np.int32).ravel()
+        if np.any(dead_ids < 0) or np.any(dead_ids >= id0):
+            raise ValueError("dead facet id was never handed out")
         self.next_id += n_new
-        pooled = np.nonzero(np.isin(self.owner, np.asarray(dead_ids, dtype=np.int32)))[0]
+        pooled = np.nonzero(np.isin(self.owner, dead_ids))[0]
         count = np.zeros(n_new, np.int64)
         argmax = np.full(n_new, -1, np.int64)
         maxd = np.zeros(n_new)
@@ -271,7 +274,7 @@ def quickhull(POINTS, abs_tol=1e-7):
             for f in new:
                 facets[id(f)] = f
             if pooled > 0:
-                hand_out([f.fid for f in visible], new)
+                hand_out([f.fid for f in visible if f.count > 0], new)  # facets without points own nothing
             for f1 in visible:
                 for f2 in f1.neighbors:
                     f2.neighbors.remove(f1)
