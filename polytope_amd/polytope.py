@@ -18,8 +18,9 @@ loop, this module collects them and issues ONE batched call into the HIP engine
 With any other backend name the LPs go through `solvers.lpsolve` one by one, as in the
 reference.  There is no silent fallback between backends.
 
-Out of scope here: projection, extreme/qhull vertex enumeration,
-rotation, plotting, grid helpers.
+    qhull / extreme             quickhull with device-resident outside sets        (ref :1597-1695, quickhull.py)
+
+Out of scope here: projection, rotation, plotting, grid helpers.
 """
 import logging
 import warnings
