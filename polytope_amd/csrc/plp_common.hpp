@@ -7,13 +7,17 @@ namespace plp {
 
 // LP status codes = scipy.optimize.linprog's (reference: polytope/solvers.py:76-106,155-158)
 enum : int { ST_OPT = 0, ST_ITER = 1, ST_INFEAS = 2, ST_UNBND = 3, ST_NUM = 4 };
+// internal: the fast pivot path met a dictionary that needs Bland's rule; the LP is redone by the
+// general engine (never leaves the library)
+constexpr int ST_RETRY = 5;
 
 // flags written by the fused reduce kernel (reference: polytope/polytope.py:1053-1163)
 enum : int {
     RF_EMPTY = 1,   // not full-dimensional -> reference returns Polytope()      (:1081-1082)
     RF_EARLY = 2,   // returned at neq <= nx+1, minrep stays False               (:1114-1116,:1136-1138)
     RF_MINREP = 4,  // went through the redundancy LPs, minrep = True            (:1161-1163)
-    RF_LPFAIL = 8   // a bounding-box LP ended with status 1/4 (RuntimeError)    (:1378-1384)
+    RF_LPFAIL = 8,  // a bounding-box LP ended with status 1/4 (RuntimeError)    (:1378-1384)
+    RF_RETRY = 16   // internal: redo this polytope with the general engine (second pass of launch_reduce)
 };
 
 // tolerances of the simplex core (identical in oracle/plp_oracle.c)

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
                                                        const double* __restrict__ Ag,
                                                        const double* __restrict__ bg,
                                                        const int* __restrict__ mrows, double abs_tol,
+                                                       int retry_only,
                                                        unsigned long long* __restrict__ keep_out,
                                                        int* __restrict__ flags_out,
                                                        double* __restrict__ r_out,
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
 
     for (long long tile = (long long)blockIdx.x * NG; tile < B; tile += (long long)gridDim.x * NG) {
         const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
+        // second pass after reduce_r_kernel: only polytopes it flagged RF_RETRY (tiles without one are skipped)
+        bool mine = true;
+        if (retry_only) {
+            mine = (gib < ntile) && (flags_out[tile + gib] & RF_RETRY) != 0;
+            if (!__syncthreads_or(mine)) continue;
+        }
         // ---------------------------------------------------------------- stage rows in LDS
         __syncthreads();  // the previous tile's readers are done
         {
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
         }
         __syncthreads();
         const long long pg = tile + gib;
-        const bool valid = gib < ntile;
+        const bool valid = gib < ntile && mine;
         const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
         const bool has_row = valid && i < m && m <= gs;
         // ---------------------------------------------------------------- my row
@@ -281,20 +288,21 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
 
 template <int D>
 static int launch_reduce_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
-                           double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
-                           hipStream_t st) {
+                           double abs_tol, int retry_only, unsigned long long* keep, int* flags, double* r,
+                           double* xc, int* nlp, hipStream_t st) {
     const size_t smem = reduce_smem_bytes(gs, D);
     const long long NG = BLOCK / gs;
     long long blocks = (B + NG - 1) / NG;
     if (blocks > (1ll << 20)) blocks = 1ll << 20;  // one tile per block: the dispatcher balances the tail
     if (blocks < 1) blocks = 1;
+    if (retry_only && blocks > 256 * 8) blocks = 256 * 8;  // mostly flag reads: a grid-stride sweep
     hipLaunchKernelGGL(reduce_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
-                       abs_tol, keep, flags, r, xc, nlp);
+                       abs_tol, retry_only, keep, flags, r, xc, nlp);
     return 0;
 }
 
 #define PLP_CASE_R(K) \
-    case K: return launch_reduce_d<K>(B, m_max, gs, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    case K: return launch_reduce_d<K>(B, m_max, gs, A, b, mrows, abs_tol, retry, keep, flags, r, xc, nlp, st);
 
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
                   unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
@@ -308,10 +316,13 @@ int launch_reduce(long long B, int m_max, int d, const double* A, const double* 
         launch_reduce_tpl(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
         return 0;
     // default for d <= 8: four rows per lane (plp_reduce_r.hip); PLP_REDUCE_1ROW=1 keeps this kernel
+    // Its F2/F3 LPs run on the fast pivot path, which hands a polytope back (RF_RETRY) when an LP
+    // needs Bland's rule; the second launch below redoes exactly those with this file's kernel.
     const char* one = getenv("PLP_REDUCE_1ROW");
+    int retry = 0;
     if (!(one && one[0] == '1') &&
         launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
-        return 0;
+        retry = 1;
     switch (d) {
         PLP_CASE_R(1) PLP_CASE_R(2) PLP_CASE_R(3) PLP_CASE_R(4) PLP_CASE_R(5) PLP_CASE_R(6)
         PLP_CASE_R(7) PLP_CASE_R(8) PLP_CASE_R(9) PLP_CASE_R(10) PLP_CASE_R(11) PLP_CASE_R(12)

@@ -42,17 +42,22 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 #define PLP_REDUCE_R_WAVES(D) ((D) <= 4 ? 3 : 1)
 #endif
 
-template <int D>
+#ifndef PLP_R_FAST
+#define PLP_R_FAST 1  // F2/F3 on SimplexR::run_fast (0: the general step(), for A/B runs)
+#endif
+
+template <int D, int GS>
 __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
-    long long B, int m_max, int gs, const double* __restrict__ Ag, const double* __restrict__ bg,
-    const int* __restrict__ mrows, double abs_tol, unsigned long long* __restrict__ keep_out,
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
     int* __restrict__ nlp_out) {
     constexpr int R = RR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int gs = GS;
     const Grp g(gs);
-    const int NG = BLOCK / gs;
-    const int rows = gs * R;  // row slots per polytope
+    constexpr int NG = BLOCK / gs;
+    constexpr int rows = gs * R;  // row slots per polytope
     const int gib = threadIdx.x / gs;
     const int row0 = g.gl * R;  // my first row
     double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
@@ -90,6 +95,9 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
         bool ball, fulldim;
         uint64_t live = 0ull;
         unsigned has = 0u;
+        // an F2/F3 LP needed Bland's rule: the whole polytope goes to the general kernel
+        // (force_retry: test hook, PLP_REDUCE_RETRY_ALL=1 sends every polytope through that second pass)
+        bool retry = force_retry != 0;
         // ---------------------------------------------------------------- F1: Chebyshev ball
         {
             SimplexR<D + 1, R, true> S;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 const int kx = it >> 1;
                 const bool up = it & 1;
                 double xck = 0.0;
-                SimplexR<D, R, false> S;
+                SimplexR<D, R, false, false> S;
                 S.reset(D, __popcll(live), row0);
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) {
@@ -228,7 +236,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 }
                 S.ract = lloc;
                 S.mode = go ? M_P2 : M_DONE;
+#if PLP_R_FAST
+                S.template run_fast<GS>(g);
+                retry = retry | (go & (S.status == ST_RETRY));
+#else
                 S.run(g);
+#endif
                 // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
                 double val;
                 if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 const bool go = todo != 0ull;
                 const int kr = go ? __ffsll((long long)todo) - 1 : 0;
                 todo &= todo - 1ull;
-                SimplexR<D, R, false> S;
+                SimplexR<D, R, false, false> S;
                 S.reset(D, __popcll(live), row0);
                 double cxc = 0.0;
 #pragma unroll
@@ -293,7 +306,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 }
                 S.ract = lloc;
                 S.mode = go ? M_P2 : M_DONE;
+#if PLP_R_FAST
+                S.template run_fast<GS>(g);
+                retry = retry | (go & (S.status == ST_RETRY));
+#else
                 S.run(g);
+#endif
                 const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
                 const double bk = myb[kr];
                 const double hk = (bk + 0.1) - 0.1;
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
         // ---------------------------------------------------------------- results
         if (valid & (g.gl == 0)) {
             keep_out[pg] = keep;
-            flags_out[pg] = flags;
+            flags_out[pg] = retry ? (int)RF_RETRY : flags;
             nlp_out[pg] = nlp;
             r_out[pg] = ball ? rr : 0.0;
 #pragma unroll
@@ -315,21 +333,31 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
     }
 }
 
+template <int D, int GS>
+static int launch_reduce_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows,
+                             double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                             hipStream_t st) {
+    const size_t smem = reduce_r_smem_bytes(GS, D);
+    const long long NG = BLOCK / GS;
+    long long blocks = (B + NG - 1) / NG;
+    if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
+    if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D, GS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (blocks < 1) blocks = 1;
+    const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
+    hipLaunchKernelGGL((reduce_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, A, b, mrows,
+                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+    return 0;
+}
+
 template <int D>
 static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
                              double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                              hipStream_t st) {
-    const size_t smem = reduce_r_smem_bytes(gs, D);
-    const long long NG = BLOCK / gs;
-    long long blocks = (B + NG - 1) / NG;
-    if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
-    if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(reduce_r_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
-                       abs_tol, keep, flags, r, xc, nlp);
-    return 0;
+    if (gs == 4) return launch_reduce_r_dg<D, 4>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    if (gs == 8) return launch_reduce_r_dg<D, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    return launch_reduce_r_dg<D, 16>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
 }
 
 #define PLP_CASE_RR(K) \

@@ -20,7 +20,9 @@
 
 namespace plp {
 
-template <int NC, int R, bool INITM>
+// TRACKX = false drops the sign bookkeeping of the free variables (rneg / cneg): callers that only
+// read the optimal VALUE off the dictionary (F2, F3) never ask for x.
+template <int NC, int R, bool INITM, bool TRACKX = true>
 struct SimplexR {
     // ---- my R rows
     double T[R][NC];
@@ -278,7 +280,7 @@ struct SimplexR {
                     for (int j = 0; j < NC; ++j) T[k][j] = rho[j];
                     beta[k] = rhob;
                     rv[k] = vin;
-                    rneg = (rneg & ~(1u << k)) | (eneg << k);
+                    if constexpr (TRACKX) rneg = (rneg & ~(1u << k)) | (eneg << k);
                     if (efree) ract &= ~(1u << k);  // a free variable never leaves again
                 }
             }
@@ -286,7 +288,7 @@ struct SimplexR {
 #pragma unroll
             for (int j = 0; j < NC; ++j) cv[j] = (j == e) ? (rpack >> 1) : cv[j];
             if (act) {
-                cneg = (cneg & ~(1u << e)) | ((unsigned)(rpack & 1) << e);
+                if constexpr (TRACKX) cneg = (cneg & ~(1u << e)) | ((unsigned)(rpack & 1) << e);
                 cfree &= ~(1u << e);
                 iters += 1;
             }
@@ -317,8 +319,186 @@ struct SimplexR {
         while (__any(mode != M_DONE)) step(g);
     }
 
+    // ------------------------------------------------------------------------------------------
+    // Fast path (no forced pivot, Dantzig mode): the same pivot rules as step(), written so that a
+    // pivot costs ~half the VALU instructions:
+    //   * the entering column for the NEXT pivot is chosen right after the update (that scan doubles
+    //     as the optimality test), on an order-preserving key: for a free column |c|, otherwise -c, so
+    //     that "eligible and larger than the best so far" is one compare and one v_max_f64;
+    //   * the pivot row is latched inside the ratio-test scan (one exec-masked block of moves per row)
+    //     instead of in a second pass; the lowest tied lane comes from a DPP min, not a ballot;
+    //   * column-e / row-r fix-ups are exec-masked 64-bit moves, not pairs of selects.
+    // An LP that reaches Bland mode (>= BLAND_AFTER consecutive degenerate pivots) ends with status
+    // ST_RETRY and is redone by step(); both walk the same vertex path (checked against the oracle).
+    template <int GS>
+    static __device__ __forceinline__ unsigned gmin(unsigned v) {
+        PLP_MIN_U32_DPP(v, "quad_perm:[1,0,3,2]");
+        PLP_MIN_U32_DPP(v, "quad_perm:[2,3,0,1]");
+        if constexpr (GS > 4) PLP_MIN_U32_DPP(v, "row_half_mirror");
+        if constexpr (GS > 8) PLP_MIN_U32_DPP(v, "row_mirror");
+        if constexpr (GS > 16) v = min_u(v, (unsigned)__shfl_xor((int)v, 16, 64));
+        if constexpr (GS > 32) v = min_u(v, (unsigned)__shfl_xor((int)v, 32, 64));
+        return v;
+    }
+
+    // Dantzig choice on the current cost row: e = -1 when the dictionary is optimal; chi = high word
+    // of cost[e] (its sign tells the direction a free variable enters)
+    __device__ __forceinline__ void scan_enter(int& e, double& best, int& chi) const {
+        e = -1;
+        best = TOL_D;
+        chi = 0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int hi = __double2hiint(cost[j]);
+            // free column: clear the sign (|c|); bounded column: flip it (-c)
+            const int khi = (hi ^ (int)0x80000000) & ~((int)(cfree << (31 - j)) & (int)0x80000000);
+            const double key = __hiloint2double(khi, __double2loint(cost[j]));
+            const bool take = key > best;
+            e = take ? j : e;
+            chi = take ? hi : chi;
+            best = fmax(best, key);
+        }
+    }
+
+    template <int GS>
+    __device__ __forceinline__ void pivot_fast(const Grp& g, int& e, double& best, int& chi) {
+        const bool running = mode != M_DONE;
+        const bool over = running & (iters >= maxit);
+        if (over) { status = ST_ITER; mode = M_DONE; }
+        bool act = running & !over;  // e >= 0 here: an optimal dictionary was retired by the last scan
+        // ------------------------------------------------ entering column of my rows
+        double a[R];
+        int vin = cv[0];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = T[k][0];
+#pragma unroll
+        for (int j = 1; j < NC; ++j) {
+            if (e == j) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) a[k] = T[k][j];
+                vin = cv[j];
+            }
+        }
+        const int sgn = (chi >= 0) ? (int)0x80000000 : 0;  // c > 0: the free variable enters downwards, x := -x
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = __hiloint2double(__double2hiint(a[k]) ^ sgn, __double2loint(a[k]));
+        const unsigned efree = (cfree >> (e & 31)) & 1u;
+        // ------------------------------------------------ ratio test over my rows, pivot row latched on the way
+        int kb = 0, prv = 0;
+        double bn = __longlong_as_double(0x7ff0000000000000ll), an = 1.0, pb = 0.0;
+        double prow[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) prow[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool elig = act & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
+            const double bi = fmax(beta[k], 0.0);
+            if (elig & (bi * an < bn * a[k])) {  // strict: the first (lowest) row keeps a tie
+                kb = k;
+                bn = bi;
+                an = a[k];
+                pb = beta[k];
+                prv = rv[k];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) prow[j] = T[k][j];
+            }
+        }
+        const double x0 = __builtin_amdgcn_rcp(an);
+        const double x1 = fma(x0, fma(-an, x0, 1.0), x0);
+        const double pinv = fma(x1, fma(-an, x1, 1.0), x1);
+        const double q = bn * pinv;  // +inf when no row of mine is eligible
+        // ------------------------------------------------ group minimum (exact, on a u64 key)
+        const int qh = __double2hiint(q), ql = __double2loint(q);
+        const int sm = qh >> 31;
+        const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
+        const unsigned kl = (unsigned)(ql ^ sm);
+        const unsigned mh = gmin<GS>(kh);
+        const unsigned ml = gmin<GS>((kh == mh) ? kl : 0xffffffffu);
+        if (act & (mh >= 0xfff00000u)) {  // +inf: unbounded (or NaN: numerical trouble)
+            status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM;
+            mode = M_DONE;
+            act = false;
+        }
+        const unsigned rl = gmin<GS>(((kh == mh) & (kl == ml)) ? (unsigned)g.gl : 0xffu);  // lowest tied lane
+        const bool is_r = act & ((unsigned)g.gl == rl);
+        const int raddr = (g.gbase + (int)rl) << 2;
+        {
+            const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);  // q >= 0 here
+            const int nd = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
+            ndeg = act ? nd : ndeg;
+        }
+        // ------------------------------------------------ broadcast the pivot row
+        const double p = bcast_addr(pinv, raddr);
+        const double rhob = bcast_addr(pb, raddr) * p;
+        double rho[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) rho[j] = bcast_addr(prow[j], raddr) * p;
+        const int vout = __builtin_amdgcn_ds_bpermute(raddr, prv);
+        const int krow = __builtin_amdgcn_ds_bpermute(raddr, kb);
+        // ------------------------------------------------ update
+        const double fc = act ? -best : 0.0;  // the (sign-normalised) reduced cost of the entering column
+#pragma unroll
+        for (int j = 0; j < NC; ++j) cost[j] = fma(-fc, rho[j], cost[j]);
+        negz = fma(-fc, rhob, negz);
+        double ea[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool other = act & !(is_r & (k == krow));
+            const double f = other ? a[k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) T[k][j] = fma(-f, rho[j], T[k][j]);
+            beta[k] = fma(-f, rhob, beta[k]);
+            ea[k] = -(f * p);
+        }
+        const double ec = -(fc * p);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            if (act & (e == j)) {  // the entering column now holds the leaving variable
+#pragma unroll
+                for (int k = 0; k < R; ++k) T[k][j] = ea[k];
+                cost[j] = ec;
+                rho[j] = p;
+                cv[j] = vout;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (is_r & (k == krow)) {  // the pivot row itself
+#pragma unroll
+                for (int j = 0; j < NC; ++j) T[k][j] = rho[j];
+                beta[k] = rhob;
+                rv[k] = vin;
+                ract &= ~(efree << k);  // a free variable never leaves again
+            }
+        }
+        if (act) {
+            cfree &= ~(1u << e);
+            iters += 1;
+        }
+        // ------------------------------------------------ next entering column = optimality test
+        scan_enter(e, best, chi);
+        if (act & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+    }
+
+    // run to completion from a primal-feasible dictionary in M_P2 (or M_DONE)
+    template <int GS>
+    __device__ __forceinline__ void run_fast(const Grp& g) {
+        static_assert(!INITM && !TRACKX, "fast path: no forced pivot, no x recovery");
+        int e, chi;
+        double best;
+        scan_enter(e, best, chi);
+        if ((mode != M_DONE) & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+        while (__any(mode != M_DONE)) {
+            // rare: Bland's rule lives in step(), kept out of this loop (and of its register budget);
+            // the caller redoes the LP with the general engine
+            if ((mode != M_DONE) & (ndeg >= BLAND_AFTER)) { status = ST_RETRY; mode = M_DONE; }
+            pivot_fast<GS>(g, e, best, chi);
+        }
+    }
+
     // value of structural variable j if one of my rows holds it (found = true)
     __device__ __forceinline__ double x_of(int j, bool& found) const {
+        static_assert(TRACKX, "x_of needs the sign bookkeeping");
         double v = 0.0;
         found = false;
 #pragma unroll

@@ -205,10 +205,53 @@ def test_reduce_vs_oracle_batches(pa, oracle):
         assert nlp_total >= B
 
 
-@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_TPL"])
+def _pyramids(B, m, d, rng):
+    """Polytopes with a highly degenerate vertex: m - d - 1 facets through one apex, a simplex-like base
+    below it and duplicated / nearly parallel facets: the redundancy LPs pivot degenerately at the apex
+    (Bland's rule territory)."""
+    A = np.zeros((B, m, d))
+    b = np.zeros((B, m))
+    for k in range(B):
+        apex = rng.standard_normal(d) * 0.3
+        apex[-1] = 1.0 + rng.random()
+        ns = m - (d + 1)
+        N = rng.standard_normal((ns, d))
+        N[:, -1] = np.abs(N[:, -1]) + 0.2           # side facets face upwards
+        if k % 3 == 0:
+            N[1::2] = N[0::2][: N[1::2].shape[0]] + 1e-5 * rng.standard_normal(N[1::2].shape)  # nearly parallel
+        N /= np.linalg.norm(N, axis=1)[:, None]
+        A[k, :ns] = N
+        b[k, :ns] = N @ apex                          # all through the apex
+        G = rng.standard_normal((d + 1, d))
+        G[:, -1] = -np.abs(G[:, -1]) - 0.5            # base facets face downwards
+        G /= np.linalg.norm(G, axis=1)[:, None]
+        A[k, ns:] = G
+        b[k, ns:] = 1.0 + rng.random(d + 1)
+    return A, b
+
+
+def test_reduce_degenerate_vertices(pa, oracle):
+    """Degenerate vertices (many facets through one point): consecutive zero-length pivots switch
+    the engine to Bland's rule; on the default kernel such a polytope is handed from the fast pivot
+    path to the general engine (second launch).  Masks / flags / LP counts must equal the oracle's."""
+    rng = np.random.default_rng(31)
+    for (m, d, B) in [(16, 3, 300), (14, 2, 120), (24, 4, 100), (40, 5, 40), (64, 6, 12)]:
+        A, b = _pyramids(B, m, d, rng)
+        res = pa.reduce_batch(A, b)
+        masks = pa.keep_to_bool(res["keep"], m)
+        for k in range(B):
+            o = oracle.reduce(A[k], b[k])
+            assert int(res["flags"][k]) == o["flags"], (m, d, k, int(res["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k], o["keep"]), (m, d, k, masks[k], o["keep"])
+            assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
+
+
+@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_TPL", "PLP_REDUCE_RETRY_ALL"])
 def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
     """The three mappings of the fused reduce (4 rows per lane = default, 1 row per lane, 1 polytope
-    per lane) must agree with the oracle; the non-default ones are selected by environment."""
+    per lane) must agree with the oracle; the non-default ones are selected by environment.
+    PLP_REDUCE_RETRY_ALL sends every polytope of the default kernel through its second pass (the
+    hand-over used when the fast pivot path meets a dictionary that needs Bland's rule)."""
     from polytope_amd.synth import random_hpolytopes
     monkeypatch.setenv(variant, "1")
     rng = np.random.default_rng(21)
