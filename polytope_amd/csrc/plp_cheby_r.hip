@@ -1,0 +1,254 @@
+// plp_cheby_r.hip -- Chebyshev-ball LPs (form F1, polytope/polytope.py:1283-1288) with four rows per
+// lane (gfx950):
+//
+//   cheby_r_kernel<D,GS>    : a batch of polytopes (cheby_ball / is_fulldim, :1241-1300, :962-985)
+//   adjacent_r_kernel<D,GS> : all pairs of n cells (is_adjacent(overlap=True), :1843-1866, under the pair
+//                             loop of find_adjacent_regions, prop2partition.py:57-61)
+//
+// A polytope (or a stacked pair) of up to 16 / 32 / 64 rows takes a group of GS = 4 / 8 / 16 lanes, lane l
+// holding rows 4l..4l+3 in VGPRs, so a wavefront carries 16 / 8 / 4 LPs (plp_simplex_r.hpp).  The LP runs
+// on the fast pivot path (forced first pivot "r enters, row argmin b_i/||a_i|| leaves", then Dantzig);
+// when it ends with ST_RETRY (a dictionary that needs Bland's rule) the wavefront rebuilds the LP and
+// solves it with the general engine, behind a wave-uniform branch that is almost never taken.
+#include <stdlib.h>
+
+#include "plp_kernels.hpp"
+#include "plp_simplex_r.hpp"
+
+namespace plp {
+
+namespace {
+
+constexpr int CR = 4;  // rows per lane
+
+// Solve the Chebyshev LP of the rows handed out by `rowA(rr, kk)` / `rowb(rr)` (rr = row index < m).
+// Returns the LP status; x[0..D-1] = centre, x[D] = radius, replicated over the group (valid if status 0).
+template <int D, int GS, bool FAST, class FA, class FB>
+__device__ __forceinline__ int cheby_r_lp(const Grp& g, bool valid, int m, int row0, FA rowA, FB rowb, double* x) {
+    constexpr int R = CR;
+    SimplexR<D + 1, R, !FAST, true> S;
+    S.reset(D + 1, m, row0);
+    double qi[R];
+    unsigned actb = 0u;
+    bool inf0 = false, finite = true;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool h = valid & (row0 + k < m) & (m <= GS * R);
+        double nrm2 = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            const double v = h ? rowA(row0 + k, kk) : 0.0;
+            S.T[k][kk] = v;
+            nrm2 = nrm2 + v * v;
+            finite = finite & isfinite(v);
+        }
+        const double bk = h ? rowb(row0 + k) : 0.0;
+        finite = finite & isfinite(bk);
+        const double nrm = sqrt(nrm2);
+        const bool zero = !(nrm > 0.0);
+        const bool on = h & !zero;
+        S.T[k][D] = on ? nrm : 0.0;
+        S.beta[k] = on ? bk : 0.0;
+        qi[k] = bk / nrm;
+        actb |= on ? (1u << k) : 0u;
+        inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
+    }
+    S.ract = actb;
+    const bool infeasible0 = grp_ballot(inf0, g) != 0;
+    const bool bad = (grp_ballot(!finite, g) != 0) | (m > GS * R);
+    S.cost[D] = -1.0;
+    if constexpr (FAST) {
+        S.mode = M_P2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) S.init_q[k] = qi[k];
+        S.init_elig = actb;
+        S.mode = M_INIT;
+        S.init_col = D;
+        S.mode_after_init = M_P2;
+    }
+    if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
+    else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+    if constexpr (FAST) S.template run_fast<GS, true>(g, qi, actb);
+    else S.run(g);
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+        bool found;
+        const double mine = S.x_of(j, found);
+        const uint64_t ob = grp_ballot(found, g);
+        const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+        x[j] = ob ? v : 0.0;
+    }
+    return S.status;
+}
+
+template <int D, int GS, class FA, class FB>
+__device__ __forceinline__ int cheby_r_solve(const Grp& g, bool valid, int m, int row0, FA rowA, FB rowb, double* x,
+                                             int force_retry) {
+    int st = cheby_r_lp<D, GS, true>(g, valid, m, row0, rowA, rowb, x);
+    if (force_retry) st = ST_RETRY;  // test hook (PLP_CHEBY_RETRY_ALL=1): every LP takes the hand-over below
+    if (__any(st == ST_RETRY)) {  // rare: redo with the general engine (Bland's rule available)
+        double x2[D + 1];
+        const int st2 = cheby_r_lp<D, GS, false>(g, valid & (st == ST_RETRY), m, row0, rowA, rowb, x2);
+        if (st == ST_RETRY) {
+            st = st2;
+#pragma unroll
+            for (int j = 0; j <= D; ++j) x[j] = x2[j];
+        }
+    }
+    return st;
+}
+
+}  // namespace
+
+template <int D, int GS>
+__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long long B, int m_max,
+                                                                          const double* __restrict__ A,
+                                                                          const double* __restrict__ b,
+                                                                          const int* __restrict__ mrows,
+                                                                          double* __restrict__ r,
+                                                                          double* __restrict__ xc,
+                                                                          int* __restrict__ status,
+                                                                          int force_retry) {
+    const Grp g(GS);
+    constexpr int gpb = BLOCK / GS;
+    const int gib = threadIdx.x / GS;
+    const int row0 = g.gl * CR;
+    const long long p = (long long)blockIdx.x * gpb + gib;
+    const bool valid = p < B;
+    const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
+    // lane l loads its 4 consecutive rows straight from HBM (4*D contiguous doubles)
+    double x[D + 1];
+    const int st = cheby_r_solve<D, GS>(
+        g, valid, m, row0, [&](int rr, int kk) { return A[(p * m_max + rr) * D + kk]; },
+        [&](int rr) { return b[p * m_max + rr]; }, x, force_retry);
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    if (valid & (g.gl == 0)) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) xc[p * D + j] = (st == ST_OPT) ? x[j] : qnan;
+        r[p] = (st == ST_OPT) ? x[D] : qnan;
+        status[p] = st;
+    }
+}
+
+// One lane group per pair (i, j < i): the rows of both cells are stacked with b + abs_tol, and the pair is
+// adjacent iff the Chebyshev LP of the stack is optimal with r > abs_tol/10 (`is_fulldim(dummy,
+// abs_tol / 10)`).  The stacked LP is built straight from the resident cells (n cells stay in L2), so
+// nothing is staged by the host.  adj is n x n, symmetric, ones on the diagonal.
+template <int D, int GS>
+__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
+    int n, int m_max, const double* __restrict__ A, const double* __restrict__ b, const int* __restrict__ mrows,
+    double abs_tol, unsigned char* __restrict__ adj, int force_retry) {
+    const Grp g(GS);
+    constexpr int gpb = BLOCK / GS;
+    const int gib = threadIdx.x / GS;
+    const int row0 = g.gl * CR;
+    const long long npairs = (long long)n * (n - 1) / 2;
+    const long long p = (long long)blockIdx.x * gpb + gib;
+    const bool valid = p < npairs;
+    // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
+    long long i = valid ? (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5) : 1;
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const long long j = valid ? p - i * (i - 1) / 2 : 0;
+    const int mi = valid ? (mrows ? mrows[i] : m_max) : 0;
+    const int mj = valid ? (mrows ? mrows[j] : m_max) : 0;
+    double x[D + 1];
+    const int st = cheby_r_solve<D, GS>(
+        g, valid, mi + mj, row0,
+        [&](int rr, int kk) { return A[(((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)) * D + kk]; },
+        [&](int rr) { return b[((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)] + abs_tol; },  // b1 += abs_tol; b2 += abs_tol
+        x, force_retry);
+    const bool yes = (st == ST_OPT) & (x[D] > abs_tol / 10);
+    if (valid & (g.gl == 0)) {
+        adj[i * n + j] = yes ? 1 : 0;
+        adj[j * n + i] = yes ? 1 : 0;
+    }
+    // diagonal
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (t < n) adj[t * n + t] = 1;
+}
+
+static int force_retry_env() {
+    const char* fr = getenv("PLP_CHEBY_RETRY_ALL");
+    return (fr && fr[0] == '1') ? 1 : 0;
+}
+
+template <int D, int GS>
+static int launch_cheby_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
+                             double* xc, int* status, hipStream_t st) {
+    constexpr long long gpb = BLOCK / GS;
+    const long long blocks = (B + gpb - 1) / gpb;
+    if (blocks > 2147483647ll) return 1;
+    hipLaunchKernelGGL((cheby_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max,
+                       A, b, mrows, r, xc, status, force_retry_env());
+    return 0;
+}
+
+template <int D>
+static int launch_cheby_r_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
+                            double* xc, int* status, hipStream_t st) {
+    if (m_max <= 16) return launch_cheby_r_dg<D, 4>(B, m_max, A, b, mrows, r, xc, status, st);
+    if (m_max <= 32) return launch_cheby_r_dg<D, 8>(B, m_max, A, b, mrows, r, xc, status, st);
+    return launch_cheby_r_dg<D, 16>(B, m_max, A, b, mrows, r, xc, status, st);
+}
+
+// returns 0 when launched, 1 when this kernel does not apply (d > 8: one row per lane, plp_lp.hip)
+int launch_cheby_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                   double* xc, int* status, hipStream_t st) {
+    if (m_max < 1 || m_max > MAX_M) return 1;
+    switch (d) {
+        case 1: return launch_cheby_r_d<1>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 2: return launch_cheby_r_d<2>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 3: return launch_cheby_r_d<3>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 4: return launch_cheby_r_d<4>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 5: return launch_cheby_r_d<5>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 6: return launch_cheby_r_d<6>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 7: return launch_cheby_r_d<7>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 8: return launch_cheby_r_d<8>(B, m_max, A, b, mrows, r, xc, status, st);
+        default: return 1;
+    }
+}
+
+template <int D, int GS>
+static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
+                              unsigned char* adj, hipStream_t st) {
+    constexpr long long gpb = BLOCK / GS;
+    const long long npairs = (long long)n * (n - 1) / 2;
+    long long blocks = (npairs + gpb - 1) / gpb;
+    const long long bdiag = ((long long)n + BLOCK - 1) / BLOCK;
+    if (blocks < bdiag) blocks = bdiag;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2147483647ll) return 2;
+    hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, n, m_max, A, b, mrows,
+                       abs_tol, adj, force_retry_env());
+    return 0;
+}
+
+template <int D>
+static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
+                             unsigned char* adj, hipStream_t st) {
+    const int rows = 2 * m_max;
+    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, abs_tol, adj, st);
+    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, abs_tol, adj, st);
+    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, abs_tol, adj, st);
+}
+
+int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                    unsigned char* adj, hipStream_t st) {
+    if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > 8) return 2;
+    if (n == 0) return 0;
+    switch (d) {
+        case 1: return launch_adjacent_d<1>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 2: return launch_adjacent_d<2>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 3: return launch_adjacent_d<3>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 4: return launch_adjacent_d<4>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 5: return launch_adjacent_d<5>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 6: return launch_adjacent_d<6>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 7: return launch_adjacent_d<7>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        case 8: return launch_adjacent_d<8>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        default: return 2;
+    }
+}
+
+}  // namespace plp

@@ -20,6 +20,10 @@ int launch_lp(long long B, int m_max, int n, const double* c, const double* G, c
 int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                  double* xc, int* status, hipStream_t st);
 
+// four rows per lane (d <= 8, plp_cheby_r.hip); returns 1 when it does not apply
+int launch_cheby_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                   double* xc, int* status, hipStream_t st);
+
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8); adj is n x n
 int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
                     unsigned char* adj, hipStream_t st);

@@ -5,12 +5,12 @@
 //                     c = -e_{d+1}, G = [A | sqrt(sum(A*A,1))], h = b
 //
 // One LP per lane group (GS lanes, GS >= rows), 64/GS LPs per wavefront, 256-thread
-// workgroups, grid-stride over the batch.
+// workgroups, grid-stride over the batch.  Chebyshev batches with d <= 8 go to the four-rows-per-lane
+// kernels of plp_cheby_r.hip; cheby_kernel here serves d > 8 (and PLP_CHEBY_1ROW=1).
 #include <stdlib.h>
 
 #include "plp_kernels.hpp"
 #include "plp_simplex.hpp"
-#include "plp_simplex_r.hpp"
 
 namespace plp {
 
@@ -173,203 +173,6 @@ __global__ __launch_bounds__(BLOCK) void cheby_kernel(long long B, int m_max, in
     }
 }
 
-// Chebyshev batch with four rows per lane (SimplexR): a polytope of up to 16 / 32 / 64 rows takes a
-// group of 4 / 8 / 16 lanes, so a wavefront carries 16 / 8 / 4 LPs (see plp_simplex_r.hpp).  Lane l
-// loads its 4 consecutive rows straight from HBM (4*D contiguous doubles).
-template <int D>
-__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long long B, int m_max, int gs,
-                                                                          const double* __restrict__ A,
-                                                                          const double* __restrict__ b,
-                                                                          const int* __restrict__ mrows,
-                                                                          double* __restrict__ r,
-                                                                          double* __restrict__ xc,
-                                                                          int* __restrict__ status) {
-    constexpr int R = 4;
-    const Grp g(gs);
-    const int gpb = BLOCK / gs;
-    const int gib = threadIdx.x / gs;
-    const int row0 = g.gl * R;
-    const long long p = (long long)blockIdx.x * gpb + gib;
-    const bool valid = p < B;
-    const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
-    SimplexR<D + 1, R, true> S;
-    S.reset(D + 1, m, row0);
-    unsigned actb = 0u;
-    bool inf0 = false, finite = true;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const bool h = valid & (row0 + k < m) & (m <= gs * R);
-        double nrm2 = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < D; ++kk) {
-            const double v = h ? A[(p * m_max + row0 + k) * D + kk] : 0.0;
-            S.T[k][kk] = v;
-            nrm2 = nrm2 + v * v;
-            finite = finite & isfinite(v);
-        }
-        const double bk = h ? b[p * m_max + row0 + k] : 0.0;
-        finite = finite & isfinite(bk);
-        const double nrm = sqrt(nrm2);
-        const bool zero = !(nrm > 0.0);
-        const bool on = h & !zero;
-        S.T[k][D] = on ? nrm : 0.0;
-        S.beta[k] = on ? bk : 0.0;
-        S.init_q[k] = bk / nrm;
-        actb |= on ? (1u << k) : 0u;
-        inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
-    }
-    S.ract = actb;
-    S.init_elig = actb;
-    const bool infeasible0 = grp_ballot(inf0, g) != 0;
-    const bool bad = (grp_ballot(!finite, g) != 0) | (m > gs * R);
-    S.cost[D] = -1.0;
-    S.mode = M_INIT;
-    S.init_col = D;
-    S.mode_after_init = M_P2;
-    if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
-    else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
-    S.run(g);
-    const bool ok = S.status == ST_OPT;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-#pragma unroll
-    for (int j = 0; j <= D; ++j) {
-        bool found;
-        const double mine = S.x_of(j, found);
-        const uint64_t ob = grp_ballot(found, g);
-        const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
-        const double xj = ok ? (ob ? v : 0.0) : qnan;
-        if (valid & (g.gl == 0)) {
-            if (j < D) xc[p * D + j] = xj; else r[p] = xj;
-        }
-    }
-    if (valid & (g.gl == 0)) status[p] = S.status;
-}
-
-template <int D>
-static void launch_cheby_r_d(long long B, int m_max, const double* A, const double* b, const int* mrows,
-                             double* r, double* xc, int* status, hipStream_t st) {
-    const int gs = m_max <= 16 ? 4 : (m_max <= 32 ? 8 : 16);
-    const long long gpb = BLOCK / gs;
-    const long long blocks = (B + gpb - 1) / gpb;
-    hipLaunchKernelGGL(cheby_r_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), 0, st, B, m_max, gs, A, b, mrows, r,
-                       xc, status);
-}
-
-// Adjacency of all pairs of n single-polytope cells (polytope.py:1843-1866 `is_adjacent(overlap=True)`
-// under prop2partition.py:57-61 `find_adjacent_regions`): for the pair (i, j < i) the rows of both
-// cells are stacked with b + abs_tol, and the pair is adjacent iff the Chebyshev LP of the stack is
-// optimal with r > abs_tol/10 (`is_fulldim(dummy, abs_tol / 10)`).  One lane group per pair builds
-// the stacked LP straight from the resident cells (n cells stay in L2), so nothing is staged by
-// the host.  adj is n x n, symmetric, ones on the diagonal.
-template <int D>
-__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
-    int n, int m_max, int gs, const double* __restrict__ A, const double* __restrict__ b,
-    const int* __restrict__ mrows, double abs_tol, unsigned char* __restrict__ adj) {
-    constexpr int R = 4;
-    const Grp g(gs);
-    const int gpb = BLOCK / gs;
-    const int gib = threadIdx.x / gs;
-    const int row0 = g.gl * R;
-    const long long npairs = (long long)n * (n - 1) / 2;
-    const long long p = (long long)blockIdx.x * gpb + gib;
-    const bool valid = p < npairs;
-    // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
-    long long i = valid ? (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5) : 1;
-    while (i * (i - 1) / 2 > p) --i;
-    while ((i + 1) * i / 2 <= p) ++i;
-    const long long j = valid ? p - i * (i - 1) / 2 : 0;
-    const int mi = valid ? (mrows ? mrows[i] : m_max) : 0;
-    const int mj = valid ? (mrows ? mrows[j] : m_max) : 0;
-    const int m = mi + mj;
-    SimplexR<D + 1, R, true> S;
-    S.reset(D + 1, m, row0);
-    unsigned actb = 0u;
-    bool inf0 = false, finite = true;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int rr = row0 + k;
-        const bool h = valid & (rr < m) & (m <= gs * R);
-        const long long cell = (rr < mi) ? i : j;
-        const int row = (rr < mi) ? rr : rr - mi;
-        double nrm2 = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < D; ++kk) {
-            const double v = h ? A[(cell * m_max + row) * D + kk] : 0.0;
-            S.T[k][kk] = v;
-            nrm2 = nrm2 + v * v;
-            finite = finite & isfinite(v);
-        }
-        const double bk = h ? b[cell * m_max + row] + abs_tol : 0.0;  // b1 += abs_tol; b2 += abs_tol
-        finite = finite & isfinite(bk);
-        const double nrm = sqrt(nrm2);
-        const bool zero = !(nrm > 0.0);
-        const bool on = h & !zero;
-        S.T[k][D] = on ? nrm : 0.0;
-        S.beta[k] = on ? bk : 0.0;
-        S.init_q[k] = bk / nrm;
-        actb |= on ? (1u << k) : 0u;
-        inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
-    }
-    S.ract = actb;
-    S.init_elig = actb;
-    const bool infeasible0 = grp_ballot(inf0, g) != 0;
-    const bool bad = (grp_ballot(!finite, g) != 0) | (m > gs * R);
-    S.cost[D] = -1.0;
-    S.mode = M_INIT;
-    S.init_col = D;
-    S.mode_after_init = M_P2;
-    if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
-    else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
-    S.run(g);
-    bool found;
-    const double mine = S.x_of(D, found);
-    const uint64_t ob = grp_ballot(found, g);
-    const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
-    const double rad = ob ? v : 0.0;
-    const bool yes = (S.status == ST_OPT) & (rad > abs_tol / 10);
-    if (valid & (g.gl == 0)) {
-        adj[i * n + j] = yes ? 1 : 0;
-        adj[j * n + i] = yes ? 1 : 0;
-    }
-    // diagonal
-    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (t < n) adj[t * n + t] = 1;
-}
-
-template <int D>
-static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
-                             unsigned char* adj, hipStream_t st) {
-    const int rows = 2 * m_max;
-    const int gs = rows <= 16 ? 4 : (rows <= 32 ? 8 : 16);
-    const long long gpb = BLOCK / gs;
-    const long long npairs = (long long)n * (n - 1) / 2;
-    long long blocks = (npairs + gpb - 1) / gpb;
-    const long long bdiag = ((long long)n + BLOCK - 1) / BLOCK;
-    if (blocks < bdiag) blocks = bdiag;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2147483647ll) return 2;
-    hipLaunchKernelGGL(adjacent_r_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), 0, st, n, m_max, gs, A, b, mrows,
-                       abs_tol, adj);
-    return 0;
-}
-
-int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
-                    unsigned char* adj, hipStream_t st) {
-    if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > 8) return 2;
-    if (n == 0) return 0;
-    switch (d) {
-        case 1: return launch_adjacent_d<1>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 2: return launch_adjacent_d<2>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 3: return launch_adjacent_d<3>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 4: return launch_adjacent_d<4>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 5: return launch_adjacent_d<5>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 6: return launch_adjacent_d<6>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 7: return launch_adjacent_d<7>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 8: return launch_adjacent_d<8>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        default: return 2;
-    }
-}
-
 static inline int pick_grid(long long B, int gs) {
     const long long gpb = BLOCK / gs;
     long long blocks = (B + gpb - 1) / gpb;
@@ -415,18 +218,7 @@ int launch_cheby(long long B, int m_max, int d, const double* A, const double* b
     if (gs < 0 || d < 1 || d > MAX_D) return 2;
     // d <= 8: four rows per lane (PLP_CHEBY_1ROW=1 keeps the one-row-per-lane kernel: A/B, tests)
     const char* one = getenv("PLP_CHEBY_1ROW");
-    if (d <= 8 && m_max >= 1 && !(one && one[0] == '1') && (B + 63) / 4 < 2147483647ll) {
-        switch (d) {
-            case 1: launch_cheby_r_d<1>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 2: launch_cheby_r_d<2>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 3: launch_cheby_r_d<3>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 4: launch_cheby_r_d<4>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 5: launch_cheby_r_d<5>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 6: launch_cheby_r_d<6>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 7: launch_cheby_r_d<7>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-            case 8: launch_cheby_r_d<8>(B, m_max, A, b, mrows, r, xc, status, st); return 0;
-        }
-    }
+    if (!(one && one[0] == '1') && launch_cheby_r(B, m_max, d, A, b, mrows, r, xc, status, st) == 0) return 0;
     switch (d) {
         PLP_CASE_D(1) PLP_CASE_D(2) PLP_CASE_D(3) PLP_CASE_D(4) PLP_CASE_D(5) PLP_CASE_D(6)
         PLP_CASE_D(7) PLP_CASE_D(8) PLP_CASE_D(9) PLP_CASE_D(10) PLP_CASE_D(11) PLP_CASE_D(12)

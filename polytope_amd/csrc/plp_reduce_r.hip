@@ -37,9 +37,11 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 }
 
 #ifndef PLP_REDUCE_R_WAVES
-// measured at d=3 (100k polytopes, m=16): 2 waves/SIMD (212 VGPRs, no spill) 0.628 ms,
-// 3 waves (168 VGPRs, 152 B/lane spilled outside the pivot loop) 0.524 ms, 4 waves 0.532 ms
-#define PLP_REDUCE_R_WAVES(D) ((D) <= 4 ? 3 : 1)
+// Waves per SIMD the register allocator must leave room for.  Measured at d=3 (100k polytopes, m=16)
+// with the fast pivot path (no general engine in this kernel: 132 VGPRs unconstrained):
+// 3 waves 0.362 ms, 4 waves (128 VGPRs, 12 B/lane spilled outside the pivot loops) 0.347 ms.
+// d=4 would spill 148 B/lane at 4 waves; d>=5 keeps the whole dictionary of 4 rows x (d+1) only at 1-2.
+#define PLP_REDUCE_R_WAVES(D) ((D) <= 3 ? 4 : ((D) <= 4 ? 3 : 1))
 #endif
 
 #ifndef PLP_R_FAST
@@ -100,7 +102,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
         bool retry = force_retry != 0;
         // ---------------------------------------------------------------- F1: Chebyshev ball
         {
+#if PLP_R_FAST
+            SimplexR<D + 1, R, false, true> S;  // forced first pivot handed to run_fast
+            double qi[R];
+#else
             SimplexR<D + 1, R, true> S;
+#endif
             S.reset(D + 1, m, row0);
             unsigned actb = 0u;
             bool inf0 = false, finite = true;
@@ -124,21 +131,34 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 const bool on = h & !zero;
                 S.T[k][D] = on ? nrm : 0.0;
                 S.beta[k] = on ? bk : 0.0;
+#if PLP_R_FAST
+                qi[k] = bk / nrm;
+#else
                 S.init_q[k] = bk / nrm;
+#endif
                 actb |= on ? (1u << k) : 0u;
                 inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
             }
             S.ract = actb;
-            S.init_elig = actb;
             const bool infeasible0 = grp_ballot(inf0, g) != 0;
             const bool bad = (grp_ballot(!finite, g) != 0) | (m > rows);
             S.cost[D] = -1.0;
+#if PLP_R_FAST
+            S.mode = M_P2;
+#else
+            S.init_elig = actb;
             S.mode = M_INIT;
             S.init_col = D;
             S.mode_after_init = M_P2;
+#endif
             if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
             else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+#if PLP_R_FAST
+            S.template run_fast<GS, true>(g, qi, actb);
+            retry = retry | (valid & (S.status == ST_RETRY));
+#else
             S.run(g);
+#endif
             const bool ok = S.status == ST_OPT;
 #pragma unroll
             for (int j = 0; j <= D; ++j) {

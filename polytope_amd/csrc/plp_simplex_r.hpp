@@ -360,29 +360,50 @@ struct SimplexR {
         }
     }
 
-    template <int GS>
-    __device__ __forceinline__ void pivot_fast(const Grp& g, int& e, double& best, int& chi) {
+    // One pivot.  FORCED = false: Dantzig column (e, best, chi) from the last scan, ratio test on my rows.
+    // FORCED = true: the forced first pivot of the Chebyshev LP (plp_simplex.hpp, M_INIT): the LAST
+    // column enters, the leaving row is the eligible one (bits of ielig) with the smallest caller-supplied
+    // signed ratio qinit[k]; basic values rounded below zero by this pivot are clamped.
+    template <int GS, bool FORCED>
+    __device__ __forceinline__ void pivot_core(const Grp& g, int& e, double& best, int& chi, const double* qinit,
+                                               unsigned ielig) {
         const bool running = mode != M_DONE;
-        const bool over = running & (iters >= maxit);
-        if (over) { status = ST_ITER; mode = M_DONE; }
-        bool act = running & !over;  // e >= 0 here: an optimal dictionary was retired by the last scan
+        bool act = running;
+        if constexpr (!FORCED) {
+            const bool over = running & (iters >= maxit);
+            if (over) { status = ST_ITER; mode = M_DONE; }
+            act = running & !over;  // e >= 0 here: an optimal dictionary was retired by the last scan
+        }
         // ------------------------------------------------ entering column of my rows
         double a[R];
-        int vin = cv[0];
+        int vin;
+        unsigned efree, eneg = 0u;
+        if constexpr (FORCED) {
+            e = NC - 1;
+            vin = cv[NC - 1];
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = T[k][0];
+            for (int k = 0; k < R; ++k) a[k] = T[k][NC - 1];
+            efree = (cfree >> (NC - 1)) & 1u;
+            if constexpr (TRACKX) eneg = (cneg >> (NC - 1)) & 1u;
+        } else {
+            vin = cv[0];
 #pragma unroll
-        for (int j = 1; j < NC; ++j) {
-            if (e == j) {
+            for (int k = 0; k < R; ++k) a[k] = T[k][0];
 #pragma unroll
-                for (int k = 0; k < R; ++k) a[k] = T[k][j];
-                vin = cv[j];
+            for (int j = 1; j < NC; ++j) {
+                if (e == j) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) a[k] = T[k][j];
+                    vin = cv[j];
+                }
             }
-        }
-        const int sgn = (chi >= 0) ? (int)0x80000000 : 0;  // c > 0: the free variable enters downwards, x := -x
+            // c > 0: the free variable enters downwards, x := -x
+            const int sgn = (chi >= 0) ? (int)0x80000000 : 0;
 #pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = __hiloint2double(__double2hiint(a[k]) ^ sgn, __double2loint(a[k]));
-        const unsigned efree = (cfree >> (e & 31)) & 1u;
+            for (int k = 0; k < R; ++k) a[k] = __hiloint2double(__double2hiint(a[k]) ^ sgn, __double2loint(a[k]));
+            efree = (cfree >> (e & 31)) & 1u;
+            if constexpr (TRACKX) eneg = ((cneg >> (e & 31)) & 1u) ^ ((unsigned)sgn >> 31);
+        }
         // ------------------------------------------------ ratio test over my rows, pivot row latched on the way
         int kb = 0, prv = 0;
         double bn = __longlong_as_double(0x7ff0000000000000ll), an = 1.0, pb = 0.0;
@@ -391,14 +412,22 @@ struct SimplexR {
         for (int j = 0; j < NC; ++j) prow[j] = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const bool elig = act & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
-            const double bi = fmax(beta[k], 0.0);
-            if (elig & (bi * an < bn * a[k])) {  // strict: the first (lowest) row keeps a tie
+            bool better;
+            double bi;
+            if constexpr (FORCED) {
+                bi = qinit[k];
+                better = act & (((ielig >> k) & 1u) != 0u) & (bi < bn);
+            } else {
+                const bool elig = act & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
+                bi = fmax(beta[k], 0.0);
+                better = elig & (bi * an < bn * a[k]);
+            }
+            if (better) {  // strict: the first (lowest) row keeps a tie
                 kb = k;
                 bn = bi;
                 an = a[k];
                 pb = beta[k];
-                prv = rv[k];
+                prv = TRACKX ? ((rv[k] << 1) | (int)((rneg >> k) & 1u)) : rv[k];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) prow[j] = T[k][j];
             }
@@ -406,7 +435,7 @@ struct SimplexR {
         const double x0 = __builtin_amdgcn_rcp(an);
         const double x1 = fma(x0, fma(-an, x0, 1.0), x0);
         const double pinv = fma(x1, fma(-an, x1, 1.0), x1);
-        const double q = bn * pinv;  // +inf when no row of mine is eligible
+        const double q = FORCED ? bn : bn * pinv;  // +inf when no row of mine is eligible
         // ------------------------------------------------ group minimum (exact, on a u64 key)
         const int qh = __double2hiint(q), ql = __double2loint(q);
         const int sm = qh >> 31;
@@ -422,7 +451,7 @@ struct SimplexR {
         const unsigned rl = gmin<GS>(((kh == mh) & (kl == ml)) ? (unsigned)g.gl : 0xffu);  // lowest tied lane
         const bool is_r = act & ((unsigned)g.gl == rl);
         const int raddr = (g.gbase + (int)rl) << 2;
-        {
+        if constexpr (!FORCED) {
             const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);  // q >= 0 here
             const int nd = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
             ndeg = act ? nd : ndeg;
@@ -436,7 +465,8 @@ struct SimplexR {
         const int vout = __builtin_amdgcn_ds_bpermute(raddr, prv);
         const int krow = __builtin_amdgcn_ds_bpermute(raddr, kb);
         // ------------------------------------------------ update
-        const double fc = act ? -best : 0.0;  // the (sign-normalised) reduced cost of the entering column
+        // the (sign-normalised) reduced cost of the entering column
+        const double fc = act ? (FORCED ? cost[NC - 1] : -best) : 0.0;
 #pragma unroll
         for (int j = 0; j < NC; ++j) cost[j] = fma(-fc, rho[j], cost[j]);
         negz = fma(-fc, rhob, negz);
@@ -452,13 +482,14 @@ struct SimplexR {
         }
         const double ec = -(fc * p);
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
+        for (int j = FORCED ? NC - 1 : 0; j < NC; ++j) {
             if (act & (e == j)) {  // the entering column now holds the leaving variable
 #pragma unroll
                 for (int k = 0; k < R; ++k) T[k][j] = ea[k];
                 cost[j] = ec;
                 rho[j] = p;
-                cv[j] = vout;
+                cv[j] = TRACKX ? (vout >> 1) : vout;
+                if constexpr (TRACKX) cneg = (cneg & ~(1u << j)) | ((unsigned)(vout & 1) << j);
             }
         }
 #pragma unroll
@@ -468,6 +499,7 @@ struct SimplexR {
                 for (int j = 0; j < NC; ++j) T[k][j] = rho[j];
                 beta[k] = rhob;
                 rv[k] = vin;
+                if constexpr (TRACKX) rneg = (rneg & ~(1u << k)) | (eneg << k);
                 ract &= ~(efree << k);  // a free variable never leaves again
             }
         }
@@ -475,24 +507,36 @@ struct SimplexR {
             cfree &= ~(1u << e);
             iters += 1;
         }
+        if constexpr (FORCED) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {  // rounding of the forced pivot
+                const bool neg = running & (((ract >> k) & 1u) != 0u) & (beta[k] < 0.0);
+                beta[k] = neg ? 0.0 : beta[k];
+            }
+        }
         // ------------------------------------------------ next entering column = optimality test
         scan_enter(e, best, chi);
         if (act & (e < 0)) { status = ST_OPT; mode = M_DONE; }
     }
 
-    // run to completion from a primal-feasible dictionary in M_P2 (or M_DONE)
-    template <int GS>
-    __device__ __forceinline__ void run_fast(const Grp& g) {
-        static_assert(!INITM && !TRACKX, "fast path: no forced pivot, no x recovery");
+    // Run to completion from a primal-feasible dictionary (mode M_P2, or M_DONE for idle lanes).
+    // FORCED: start with the forced pivot (qinit[R] signed ratios of my rows, ielig their eligibility).
+    template <int GS, bool FORCED = false>
+    __device__ __forceinline__ void run_fast(const Grp& g, const double* qinit = nullptr, unsigned ielig = 0u) {
+        static_assert(!INITM, "fast path: the forced pivot is an argument here, not a mode");
         int e, chi;
         double best;
-        scan_enter(e, best, chi);
-        if ((mode != M_DONE) & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+        if constexpr (FORCED) {
+            pivot_core<GS, true>(g, e, best, chi, qinit, ielig);
+        } else {
+            scan_enter(e, best, chi);
+            if ((mode != M_DONE) & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+        }
         while (__any(mode != M_DONE)) {
             // rare: Bland's rule lives in step(), kept out of this loop (and of its register budget);
             // the caller redoes the LP with the general engine
             if ((mode != M_DONE) & (ndeg >= BLAND_AFTER)) { status = ST_RETRY; mode = M_DONE; }
-            pivot_fast<GS>(g, e, best, chi);
+            pivot_core<GS, false>(g, e, best, chi, nullptr, 0u);
         }
     }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction counts of the loops of one kernel (offline, no GPU):
 
-    python scripts/isa_loops.py polytope_amd/csrc/plp_reduce_r.hip 'reduce_r_kernelILi3' [extra hipcc flags]
+    python scripts/isa_loops.py polytope_amd/csrc/plp_reduce_r.hip 'reduce_r_kernelILi3ELi4' [extra hipcc flags]
 
 Compiles the file to gfx950 assembly, cuts out the kernel whose mangled name contains the pattern,
 prints VGPR / scratch / occupancy from the kernel descriptor and, for every backward branch (loop),

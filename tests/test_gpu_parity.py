@@ -156,6 +156,33 @@ def test_cheby_vs_oracle(pa, oracle):
                 assert np.max(Ak @ res["xc"][k] + res["r"][k] - b[k, :mrows[k]]) <= 1e-9
 
 
+@pytest.mark.parametrize("variant", ["PLP_CHEBY_1ROW", "PLP_CHEBY_RETRY_ALL"])
+def test_cheby_kernel_variants(pa, oracle, variant, monkeypatch):
+    """Chebyshev batches: the one-row-per-lane kernel, and the four-rows-per-lane kernel with every LP
+    forced through its hand-over from the fast pivot path to the general engine, against the oracle;
+    the pair-adjacency kernel under the same hand-over against its default path."""
+    from polytope_amd.synth import random_hpolytopes
+    monkeypatch.setenv(variant, "1")
+    for (m, d, B) in [(16, 3, 400), (10, 2, 100), (32, 6, 64), (64, 8, 32), (7, 5, 50)]:
+        A, b = random_hpolytopes(B, m, d, seed=5 * m + d, bounded=False)
+        mrows = np.random.default_rng(m).integers(max(1, m - 4), m + 1, B).astype(np.int32)
+        res = pa.cheby_ball_batch(A, b, m=mrows)
+        for k in range(B):
+            so, ro, xo = oracle.cheby(A[k, :mrows[k]], b[k, :mrows[k]])
+            assert res["status"][k] == so, (variant, m, d, k)
+            if so == 0:
+                assert abs(res["r"][k] - ro) <= TOL, (variant, m, d, k)
+    rng = np.random.default_rng(4)
+    lo = rng.integers(0, 4, (60, 3)).astype(float)
+    A = np.tile(np.vstack([np.eye(3), -np.eye(3)]), (60, 1, 1))
+    b = np.concatenate([lo + 1.0, -lo], axis=1)
+    forced = pa.adjacent_pairs(A, b)
+    monkeypatch.delenv(variant)
+    assert np.array_equal(forced, pa.adjacent_pairs(A, b))
+    touching = np.all(np.abs(lo[:, None, :] - lo[None, :, :]) <= 1.0, axis=2)
+    assert np.array_equal(forced.astype(bool), touching)
+
+
 # ------------------------------------------------------------------------------ reduce
 def test_reduce_golden(pa):
     from polytope_amd import _lib
