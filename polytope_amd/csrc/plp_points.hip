@@ -34,21 +34,25 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
 #pragma unroll
             for (int k = 0; k < D; ++k) x[t][k] = inb[t] ? X[(long long)k * N + q] : 0.0;
         }
-        bool any_in[PPL];
+        // Per-point verdicts are kept as wave-wide lane masks in SGPRs (a v_cmp writes one directly and
+        // the running AND / OR are scalar instructions); as `bool`s they are carried through the row loop
+        // in VGPRs and cost three extra VALU instructions per point and row.
+        unsigned long long any_m[PPL];
 #pragma unroll
-        for (int t = 0; t < PPL; ++t) any_in[t] = false;
+        for (int t = 0; t < PPL; ++t) any_m[t] = 0ull;
         // blockIdx.y selects a contiguous chunk of the polytopes (more waves in flight than one
         // pass over the points alone would give)
         const int pchunk = (P + (int)gridDim.y - 1) / (int)gridDim.y;
         const int p_lo = (int)blockIdx.y * pchunk;
         const int p_hi = (p_lo + pchunk < P) ? p_lo + pchunk : P;
+        const unsigned long long me = 1ull << (threadIdx.x & 63);
         for (int p = p_lo; p < p_hi; ++p) {
             const int m = mrows ? mrows[p] : m_max;
             const double* Ap = A + (size_t)p * m_max * D;
             const double* bp = b + (size_t)p * m_max;
-            bool ok[PPL];
+            unsigned long long ok_m[PPL];
 #pragma unroll
-            for (int t = 0; t < PPL; ++t) ok[t] = true;
+            for (int t = 0; t < PPL; ++t) ok_m[t] = ~0ull;
             for (int i = 0; i < m; ++i) {  // rows are wave-uniform: scalar loads, SGPR operands
                 double ar[D];
 #pragma unroll
@@ -59,18 +63,18 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
                     double s = ar[0] * x[t][0];
 #pragma unroll
                     for (int k = 1; k < D; ++k) s = fma(ar[k], x[t][k], s);
-                    ok[t] = ok[t] && ((s - bi) < tol);
+                    ok_m[t] &= __ballot((s - bi) < tol);
                 }
             }
             if (mode == 1) {
 #pragma unroll
                 for (int t = 0; t < PPL; ++t) {
                     const long long q = q0 + t * stride;
-                    if (inb[t]) out[(size_t)p * N + q] = ok[t] ? 1 : 0;
+                    if (inb[t]) out[(size_t)p * N + q] = (ok_m[t] & me) ? 1 : 0;
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < PPL; ++t) any_in[t] = any_in[t] || ok[t];
+                for (int t = 0; t < PPL; ++t) any_m[t] |= ok_m[t];
             }
         }
         if (mode == 0) {
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
 #pragma unroll
             for (int t = 0; t < PPL; ++t) {
                 const long long q = q0 + t * stride;
-                if (inb[t] && any_in[t]) out[q] = 1;
+                if (inb[t] && (any_m[t] & me)) out[q] = 1;
             }
         }
     }
