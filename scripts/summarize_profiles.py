@@ -27,10 +27,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in mine:
             w.writerow([r["Kernel_Name"].split("(")[0], r["Dispatch_Id"], r["Counter_Name"], r["Counter_Value"],
                         r.get("VGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")])
-    v = [float(r["Counter_Value"]) for r in mine if "plp::reduce" in r["Kernel_Name"]]
+    v = [float(r["Counter_Value"]) for r in mine if "plp::reduce_r_kernel" in r["Kernel_Name"]]
     vals[ctr] = sum(v) / len(v)
 stats = list(csv.DictReader(open(os.path.join(src, "prof", "reduce_kernel_stats.csv"))))
-k = [r for r in stats if "plp::reduce" in r["Name"]][0]
+k = [r for r in stats if "plp::reduce_r_kernel" in r["Name"]][0]
 k_name = k["Name"].split("(")[0].replace("void ", "")
 traffic = {
     "kernel": k_name,
