@@ -177,6 +177,16 @@ int plp_adjacent_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, c
                        const int32_t *m, double abs_tol, uint8_t *adj);
 int plp_adjacent_pairs_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
                            const double *b, const int32_t *m, double abs_tol, uint8_t *adj);
+/*
+ * The same for a slice of the pair space (one rank's shard when the O(n^2) loop is split across
+ * GPUs): pairs pair_lo <= p < pair_hi in the order p = i (i - 1) / 2 + j, j < i; out[p - pair_lo].
+ */
+int plp_adjacent_pairs_range(plp_ctx *ctx, int n, int m_max, int d, const double *A, const double *b,
+                             const int32_t *m, double abs_tol, int64_t pair_lo, int64_t pair_hi,
+                             uint8_t *out);
+int plp_adjacent_pairs_range_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
+                                 const double *b, const int32_t *m, double abs_tol, int64_t pair_lo,
+                                 int64_t pair_hi, uint8_t *out);
 
 /* cross-lane primitive self-test (group size 8/16/32/64); host out_d[128], out_u[128] */
 int plp_selftest(plp_ctx *ctx, int group_size, double *out_d, uint32_t *out_u);

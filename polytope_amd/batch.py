@@ -343,6 +343,32 @@ def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
     return adj
 
 
+def adjacent_pairs_range(A, b, pair_lo, pair_hi, m=None, abs_tol=1e-7):
+    """Adjacency of the cell pairs pair_lo <= p < pair_hi (p = i (i - 1) / 2 + j, j < i) -> uint8[pair_hi - pair_lo];
+    one rank's shard of the O(n^2) loop of find_adjacent_regions (prop2partition.py:57-61)."""
+    lib = _lib.load()
+    lo, hi = int(pair_lo), int(pair_hi)
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        n, m_max, d = A.shape
+        out = torch.empty((max(hi - lo, 0),), dtype=torch.uint8, device=A.device)
+        _lib.check(lib.plp_adjacent_pairs_range_dev(ctx.handle, stream, n, m_max, d, _ptr(A), _ptr(b), _ptr(m),
+                                                    float(abs_tol), lo, hi, _ptr(out)), "plp_adjacent_pairs_range_dev")
+        return out
+    A = _np(A)
+    n, m_max, d = A.shape
+    b = _np(b).reshape(n, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(n)
+    _finite_or_raise("adjacent_pairs_range", A, b)
+    out = np.zeros(max(hi - lo, 0), np.uint8)
+    _lib.check(lib.plp_adjacent_pairs_range(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm),
+                                            float(abs_tol), lo, hi, _ptr(out)), "plp_adjacent_pairs_range")
+    return out
+
+
 def selftest(group_size):
     """Cross-lane primitive self-test -> (out_d[128], out_u[128]) (see plp_points.hip)."""
     lib = _lib.load()

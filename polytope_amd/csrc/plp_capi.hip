@@ -562,9 +562,54 @@ int plp_adjacent_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, 
     if (!A || !b || !adj) return fail(PLP_EINVAL, "NULL pointer");
     if (2 * m_max > plp::MAX_M || d > 8)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
-    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, adj, (hipStream_t)stream))
+    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, adj, 0, 0, nullptr, (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
     return check_launch("adjacent_r_kernel");
+}
+
+int plp_adjacent_pairs_range_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, const double* A,
+                                 const double* b, const int32_t* m, double abs_tol, int64_t pair_lo,
+                                 int64_t pair_hi, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    const int64_t npairs = (int64_t)n * (n - 1) / 2;
+    if (pair_lo < 0 || pair_hi > npairs || pair_lo > pair_hi)
+        return fail(PLP_EINVAL, "pair range [%lld, %lld) outside [0, %lld)", (long long)pair_lo, (long long)pair_hi,
+                    (long long)npairs);
+    if (pair_lo == pair_hi) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    if (2 * m_max > plp::MAX_M || d > 8)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
+    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, nullptr, pair_lo, pair_hi, out, (hipStream_t)stream))
+        return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
+    return check_launch("adjacent_r_kernel");
+}
+
+int plp_adjacent_pairs_range(plp_ctx* ctx, int n, int m_max, int d, const double* A, const double* b,
+                             const int32_t* m, double abs_tol, int64_t pair_lo, int64_t pair_hi, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (pair_lo == pair_hi) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)n * m_max * d, nb = (size_t)n * m_max;
+    const size_t nout = pair_hi > pair_lo ? (size_t)(pair_hi - pair_lo) : 0;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad((size_t)n * 4) + pad(nout) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA);
+    double* db = a.take<double>(nb);
+    int32_t* dm = a.take<int32_t>(n);
+    uint8_t* dout = a.take<uint8_t>(nout ? nout : 1);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    rc = plp_adjacent_pairs_range_dev(ctx, st, n, m_max, d, dA, db, m ? dm : nullptr, abs_tol, pair_lo, pair_hi, dout);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
 }
 
 int plp_adjacent_pairs(plp_ctx* ctx, int n, int m_max, int d, const double* A, const double* b, const int32_t* m,

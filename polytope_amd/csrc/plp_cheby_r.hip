@@ -134,18 +134,20 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
 // One lane group per pair (i, j < i): the rows of both cells are stacked with b + abs_tol, and the pair is
 // adjacent iff the Chebyshev LP of the stack is optimal with r > abs_tol/10 (`is_fulldim(dummy,
 // abs_tol / 10)`).  The stacked LP is built straight from the resident cells (n cells stay in L2), so
-// nothing is staged by the host.  adj is n x n, symmetric, ones on the diagonal.
+// nothing is staged by the host.  adj is n x n, symmetric, ones on the diagonal; with `compact` set the
+// kernel instead solves the pairs p_lo <= p < p_hi (p = i (i - 1) / 2 + j) and writes compact[p - p_lo]
+// (the shard of one rank when the pair space is split across GPUs).
 template <int D, int GS>
 __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     int n, int m_max, const double* __restrict__ A, const double* __restrict__ b, const int* __restrict__ mrows,
-    double abs_tol, unsigned char* __restrict__ adj, int force_retry) {
+    double abs_tol, unsigned char* __restrict__ adj, long long p_lo, long long p_hi,
+    unsigned char* __restrict__ compact, int force_retry) {
     const Grp g(GS);
     constexpr int gpb = BLOCK / GS;
     const int gib = threadIdx.x / GS;
     const int row0 = g.gl * CR;
-    const long long npairs = (long long)n * (n - 1) / 2;
-    const long long p = (long long)blockIdx.x * gpb + gib;
-    const bool valid = p < npairs;
+    const long long p = p_lo + (long long)blockIdx.x * gpb + gib;
+    const bool valid = p < p_hi;
     // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
     long long i = valid ? (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5) : 1;
     while (i * (i - 1) / 2 > p) --i;
@@ -160,6 +162,10 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
         [&](int rr) { return b[((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)] + abs_tol; },  // b1 += abs_tol; b2 += abs_tol
         x, force_retry);
     const bool yes = (st == ST_OPT) & (x[D] > abs_tol / 10);
+    if (compact) {
+        if (valid & (g.gl == 0)) compact[p - p_lo] = yes ? 1 : 0;
+        return;
+    }
     if (valid & (g.gl == 0)) {
         adj[i * n + j] = yes ? 1 : 0;
         adj[j * n + i] = yes ? 1 : 0;
@@ -212,41 +218,43 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 
 template <int D, int GS>
 static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
-                              unsigned char* adj, hipStream_t st) {
+                              unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                              hipStream_t st) {
     constexpr long long gpb = BLOCK / GS;
-    const long long npairs = (long long)n * (n - 1) / 2;
-    long long blocks = (npairs + gpb - 1) / gpb;
-    const long long bdiag = ((long long)n + BLOCK - 1) / BLOCK;
+    long long blocks = (p_hi - p_lo + gpb - 1) / gpb;
+    const long long bdiag = compact ? 0 : ((long long)n + BLOCK - 1) / BLOCK;
     if (blocks < bdiag) blocks = bdiag;
     if (blocks < 1) blocks = 1;
     if (blocks > 2147483647ll) return 2;
     hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, n, m_max, A, b, mrows,
-                       abs_tol, adj, force_retry_env());
+                       abs_tol, adj, p_lo, p_hi, compact, force_retry_env());
     return 0;
 }
 
 template <int D>
 static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
-                             unsigned char* adj, hipStream_t st) {
+                             unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                             hipStream_t st) {
     const int rows = 2 * m_max;
-    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, abs_tol, adj, st);
-    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, abs_tol, adj, st);
-    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, abs_tol, adj, st);
+    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
+    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
+    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
 }
 
+#define PLP_CASE_ADJ(K) \
+    case K: return launch_adjacent_d<K>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
+
+// compact == nullptr: all pairs into the n x n matrix adj; else pairs [p_lo, p_hi) into compact[p - p_lo]
 int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
-                    unsigned char* adj, hipStream_t st) {
+                    unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact, hipStream_t st) {
     if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > 8) return 2;
-    if (n == 0) return 0;
+    const long long npairs = (long long)n * (n - 1) / 2;
+    if (!compact) { p_lo = 0; p_hi = npairs; }
+    if (p_lo < 0 || p_hi > npairs || p_lo > p_hi) return 2;
+    if (n == 0 || (compact && p_lo == p_hi)) return 0;
     switch (d) {
-        case 1: return launch_adjacent_d<1>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 2: return launch_adjacent_d<2>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 3: return launch_adjacent_d<3>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 4: return launch_adjacent_d<4>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 5: return launch_adjacent_d<5>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 6: return launch_adjacent_d<6>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 7: return launch_adjacent_d<7>(n, m_max, A, b, mrows, abs_tol, adj, st);
-        case 8: return launch_adjacent_d<8>(n, m_max, A, b, mrows, abs_tol, adj, st);
+        PLP_CASE_ADJ(1) PLP_CASE_ADJ(2) PLP_CASE_ADJ(3) PLP_CASE_ADJ(4)
+        PLP_CASE_ADJ(5) PLP_CASE_ADJ(6) PLP_CASE_ADJ(7) PLP_CASE_ADJ(8)
         default: return 2;
     }
 }

@@ -132,10 +132,13 @@ def _rank(M, tol):
     return int(np.sum(np.linalg.svd(M, compute_uv=False) > tol))
 
 
-def quickhull(POINTS, abs_tol=1e-7):
+def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
     """Compute the convex hull of a set of points.
 
     @param POINTS: a n*d np array where each row denotes a point
+    @param session_factory: (not in the reference) callable X0 -> outside-set session; default: the
+        device-resident HullSession of the 'hip' backend.  polytope_amd.dist.quickhull_sharded passes
+        the multi-GPU session here.
 
     @return: A,b,vertices: `A` and `b` describing the convex hull polytope as A x <= b
         (H-representation). `vertices` is an array of all the points in the convex hull
@@ -194,7 +197,7 @@ def quickhull(POINTS, abs_tol=1e-7):
             first[ii].neighbors.append(first[jj])
             first[jj].neighbors.append(first[ii])
 
-    session = _open_session(X0)
+    session = (session_factory or _open_session)(X0)
     try:
         pending = OrderedDict()  # the reference's F: facets with outside points, FIFO
 

@@ -147,3 +147,72 @@ def test_shard_bounds_and_packing():
     back = pdist.unpack_results(torch, pdist.pack_results(torch, res))
     for k in res:
         assert torch.equal(back[k], res[k]), k
+
+
+def _grid_cells(shape):
+    """Unit boxes of a grid as stacked H-polytopes A[n, 2d, d], b[n, 2d]."""
+    import itertools
+    d = len(shape)
+    lo = np.array(list(itertools.product(*[range(s) for s in shape])), dtype=float)
+    A = np.tile(np.vstack([np.eye(d), -np.eye(d)]), (lo.shape[0], 1, 1))
+    b = np.concatenate([lo + 1.0, -lo], axis=1)
+    return lo, A, b
+
+
+def _worker_adj_hull(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+    from polytope_amd import dist as pdist
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, A, b = _grid_cells((4, 3, 2))
+
+    def cpu_pairs(A_, b_, p_lo, p_hi, m_, tol):  # oracle stand-in for plp_adjacent_pairs_range
+        ii, jj = np.tril_indices(A_.shape[0], -1)
+        out = np.zeros(p_hi - p_lo, np.uint8)
+        for p in range(p_lo, p_hi):
+            st, r, _ = O.cheby(np.vstack([A_[ii[p]], A_[jj[p]]]), np.r_[b_[ii[p]], b_[jj[p]]] + tol)
+            out[p - p_lo] = 1 if (st == 0 and r > tol / 10) else 0
+        return out
+
+    adj = pdist.adjacent_pairs_sharded(A, b, pairs_fn=cpu_pairs).numpy()
+    P = np.random.default_rng(3).standard_normal((3000, 3))
+    np.random.seed(5)   # every rank draws the same start simplex
+    Ah, bh, Vh = pdist.quickhull_sharded(P, session_factory=O.HullSession)
+    q.put((rank, adj, Ah, bh, Vh))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adjacency_and_quickhull(world):
+    """Pair-space sharding of find_adjacent_regions and point sharding of quickhull's outside sets:
+    every rank ends with the full adjacency matrix / the same hull as the single-process run."""
+    import torch.multiprocessing as mp
+    from scipy.spatial import ConvexHull
+    from polytope_amd.quickhull import quickhull
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_adj_hull, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lo, A, b = _grid_cells((4, 3, 2))
+    touching = np.all(np.abs(lo[:, None, :] - lo[None, :, :]) <= 1.0, axis=2)
+    P = np.random.default_rng(3).standard_normal((3000, 3))
+    np.random.seed(5)
+    A1, b1, V1 = quickhull(P, session_factory=O.HullSession)   # single process, same session type
+    ref = P[np.unique(ConvexHull(P).vertices)]
+    ref = ref[np.lexsort(ref.T[::-1])]
+    assert np.array_equal(V1, ref)
+    for rank, adj, Ah, bh, Vh in outs:
+        assert np.array_equal(adj.astype(bool), touching)
+        assert np.array_equal(Ah, A1) and np.array_equal(bh, b1) and np.array_equal(Vh, V1)

@@ -443,3 +443,35 @@ def test_degenerate_lps(pa, oracle):
             if so == 0:
                 assert abs(res["fun"][j] - sp.fun) <= TOL * max(1.0, abs(sp.fun)), (cases[k][0], m, n)
             assert res["iters"][j] <= 50 * (m + n) + 100
+
+
+def test_adjacent_pairs_range_and_sharded_single(pa):
+    """Slices of the pair space (what one rank computes when the O(n^2) loop is split across GPUs)
+    agree with the full matrix; the sharded wrappers with world size 1 agree with the plain calls."""
+    import itertools
+    from polytope_amd import batch, dist as pdist
+    from polytope_amd.quickhull import quickhull
+    from polytope_amd import solvers
+    lo = np.array(list(itertools.product(range(5), range(4), range(3))), dtype=float)
+    n = lo.shape[0]
+    A = np.tile(np.vstack([np.eye(3), -np.eye(3)]), (n, 1, 1))
+    b = np.concatenate([lo + 1.0, -lo], axis=1)
+    full = pa.adjacent_pairs(A, b)
+    ii, jj = np.tril_indices(n, -1)
+    npairs = n * (n - 1) // 2
+    for (p0, p1) in [(0, npairs), (0, 1), (17, 400), (npairs - 5, npairs), (100, 100)]:
+        part = batch.adjacent_pairs_range(A, b, p0, p1)
+        assert np.array_equal(part, full[ii[p0:p1], jj[p0:p1]])
+    with pytest.raises(ValueError):
+        batch.adjacent_pairs_range(A, b, 0, npairs + 1)
+    assert np.array_equal(pdist.adjacent_pairs_sharded(A, b).cpu().numpy(), full)
+    P = np.random.default_rng(8).standard_normal((20000, 4))
+    old, solvers.default_solver = solvers.default_solver, "hip"
+    try:
+        np.random.seed(4)
+        A1, b1, V1 = quickhull(P)
+        np.random.seed(4)
+        A2, b2, V2 = pdist.quickhull_sharded(P)
+    finally:
+        solvers.default_solver = old
+    assert np.array_equal(A1, A2) and np.array_equal(b1, b2) and np.array_equal(V1, V2)
