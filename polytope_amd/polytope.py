@@ -10,15 +10,14 @@ loop, this module collects them and issues ONE batched call into the HIP engine
     bounding_box                2d LPs (F3) -> one batch                           (ref :1314-1411)
     reduce                      fused kernel: F1 + dedupe + 2d F3 + m F2           (ref :1053-1163)
     Region.intersect            all pair stacks reduced in one batch               (ref :815-830)
-    region_diff                 pre-scan and every level scan = one batch of F1    (ref :2117-2282)
+    region_diff                 pre-scan, level scans, sibling nodes = one F1 batch each (ref :2117-2282)
     envelope                    all (facet, other polytope) F1 LPs in one batch    (ref :1414-1464)
     is_adjacent_pairs           all pair LPs in one batch                          (ref :1827-1866)
     contains                    dense kernel                                       (ref :206-218, :732-746)
+    qhull / extreme             quickhull with device-resident outside sets        (ref :1597-1695, quickhull.py)
 
 With any other backend name the LPs go through `solvers.lpsolve` one by one, as in the
 reference.  There is no silent fallback between backends.
-
-    qhull / extreme             quickhull with device-resident outside sets        (ref :1597-1695, quickhull.py)
 
 Out of scope here: projection, rotation, plotting, grid helpers.
 """
@@ -893,10 +892,52 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
     def poly_of(rows):
         return Polytope(A[rows, :], B[rows])
 
+    # All LPs of the search are Chebyshev LPs on row subsets of (A, B).  On the 'hip' backend they are
+    # packed straight from the row lists -- after the constructor's normalisation (ref :130-138), which
+    # acts row by row and is therefore applied once to all rows -- instead of going through one Polytope
+    # object per candidate.
+    norms = np.sqrt(np.sum(A * A, 1)).flatten()
+    packed = _use_hip() and _fits(1, A.shape[1]) and bool(np.all(norms > 1e-10))
+    if packed:
+        from .batch import cheby_ball_batch
+        scale = 1 / norms
+        An, Bn = A * scale[:, None], B * scale
+
+    def radii_rows(row_lists):
+        """Chebyshev radius (0 when the ball LP fails) of the polytope of each row list, one batch."""
+        lens = [len(r) for r in row_lists]
+        if not packed or max(lens) > _MAX_ROWS:
+            return _radii([poly_of(r) for r in row_lists])
+        m_max = max(lens)
+        A3 = np.zeros((len(row_lists), m_max, A.shape[1]))
+        b3 = np.zeros((len(row_lists), m_max))
+        for k, r in enumerate(row_lists):
+            A3[k, :lens[k]] = An[r]
+            b3[k, :lens[k]] = Bn[r]
+        out = cheby_ball_batch(A3, b3, m=np.asarray(lens, dtype=np.int32))
+        ok = (out["status"] == 0) & (out["r"] >= 0)
+        return [np.double(rr) if o else 0 for rr, o in zip(out["r"], ok)]
+
+    # The children of a node (constraint 1 violated; 1 kept and 2 violated; ...) are all visited, one
+    # after the other, so their LPs are solved together when the first of them is reached.
+    ahead = {}
+
+    def node_radius(rows, lvl):
+        key = tuple(rows)
+        if key not in ahead:
+            ahead.clear()
+            c = counter[lvl]
+            sibs = [list(rows)]
+            for t in range(c + 1, mi[lvl] + 1):
+                sibs.append(rows[:-1] + [rows[-1] - M] + list(range(beg[lvl] + c, beg[lvl] + t - 1))
+                            + [beg[lvl] + t - 1 + M])
+            for sr, rr in zip(sibs, radii_rows(sibs)):
+                ahead[tuple(sr)] = rr
+        return ahead.pop(key)
+
     while level != -1:
         if counter[level] == 0:
-            scan = [poly_of(idx + list(range(beg[j], beg[j] + mi[j]))) for j in range(level, N)]
-            radii = _radii(scan)
+            radii = radii_rows([idx + list(range(beg[j], beg[j] + mi[j])) for j in range(level, N)])
             R = radii[-1]
             for off, Rj in enumerate(radii):
                 if Rj > abs_tol:
@@ -934,11 +975,10 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
                 if level == -1:
                     logger.debug("returning res from 2nd point")
                     return res
-        test_poly = poly_of(idx)
-        rc, _ = cheby_ball(test_poly)
+        rc = node_radius(idx, level)
         if rc > abs_tol:
             if level == N - 1:
-                res = union(res, reduce(test_poly), False)
+                res = union(res, reduce(poly_of(idx)), False)
             else:
                 level = level + 1
     logger.debug("returning res from end")
