@@ -475,3 +475,51 @@ def test_adjacent_pairs_range_and_sharded_single(pa):
     finally:
         solvers.default_solver = old
     assert np.array_equal(A1, A2) and np.array_equal(b1, b2) and np.array_equal(V1, V2)
+
+
+def test_contains_full_config(pa, oracle):
+    """BASELINE config 3 at full size (1M points x 10k polytopes, d=6, m=16), through size-independent
+    properties: the verdict of a point does not depend on which other points share the launch
+    (halves == whole), the OR over polytope subsets equals the whole Region, and a random sample of
+    points agrees with the oracle on all 10k polytopes."""
+    import torch
+    from polytope_amd.synth import containment_workload
+    P, N, d, m = 10000, 1000000, 6, 16
+    A, b, X = containment_workload(P, N, d=d, m=m, seed=0)
+    dev = torch.device("cuda:0")
+    At, bt, Xt = (torch.as_tensor(v).to(dev) for v in (A, b, X))
+    whole = pa.contains_batch(At, bt, Xt, 1e-7).cpu().numpy()
+    assert whole.shape == (N,) and 0 < whole.sum() < N
+    h = N // 2 + 7
+    halves = np.concatenate([pa.contains_batch(At, bt, Xt[:, :h].contiguous(), 1e-7).cpu().numpy(),
+                             pa.contains_batch(At, bt, Xt[:, h:].contiguous(), 1e-7).cpu().numpy()])
+    assert np.array_equal(whole, halves)
+    parts = [pa.contains_batch(At[s], bt[s], Xt, 1e-7).cpu().numpy() for s in (slice(0, 3333), slice(3333, P))]
+    assert np.array_equal(whole, parts[0] | parts[1])
+    idx = np.random.default_rng(0).choice(N, 1500, replace=False)
+    ref = oracle.contains(A, b, np.ascontiguousarray(X[:, idx].T), abs_tol=1e-7, region=True)
+    assert np.array_equal(whole[idx], ref)
+
+
+def test_assign_full_config(pa, oracle):
+    """BASELINE config 5 at full size (1M points, d=8; the 9 facets of a start simplex and 512 synthetic
+    facets): a sample agrees with the oracle; every facet's reported furthest point is one of its own
+    points, attains the maximum of their distances, and is the lowest index doing so."""
+    from polytope_amd.synth import quickhull_workload
+    N, d = 1000000, 8
+    for F in (9, 512):
+        X, nrm, off = quickhull_workload(N, d=d, F=F, seed=0)
+        res = pa.assign_batch(X, nrm, off, 1e-7)
+        fac, dist, am, mx = res["facet"], res["dist"], res["argmax"], res["maxd"]
+        idx = np.random.default_rng(F).choice(N, 20000, replace=False)
+        fo, do_, _, _ = oracle.assign(X[idx], nrm, off, 1e-7)
+        assert np.array_equal(fac[idx], fo) and np.array_equal(dist[idx], do_)
+        assert np.all(dist[fac < 0] == 0.0) and np.all(dist[fac >= 0] > 1e-7)
+        best = np.full(F, -np.inf)
+        np.maximum.at(best, fac[fac >= 0], dist[fac >= 0])
+        for f in range(F):
+            if am[f] < 0:
+                assert not np.any(fac == f)
+                continue
+            assert fac[am[f]] == f and dist[am[f]] == best[f] == mx[f]
+            assert am[f] == np.nonzero((fac == f) & (dist == best[f]))[0][0]
