@@ -405,8 +405,14 @@ struct plp_hull {
     uint8_t* dead;     // one byte per facet id handed out so far (grow-only)
     size_t dead_cap;
     int next_id;       // next facet id to hand out
-    char* io;          // per-call staging: dead ids / facets in, argmax / maxd / count out (grow-only)
+    // Per-call staging, grow-only: one device block and its pinned host mirror with the layout
+    // [dead ids | normals | offsets | argmax | maxd | count] (reassign) or [point indices] (drop), so that a
+    // call is one H2D copy, its kernels and one D2H copy.  (Pageable copies of a few hundred bytes cost
+    // 30-50 us each and made an iteration of quickhull 0.4 ms.)
+    char* io;
+    char* pin;
     size_t io_bytes;
+    bool pending;      // an asynchronous drop still reads `pin`
 };
 
 namespace {
@@ -427,11 +433,16 @@ int hull_ensure(plp_hull* h, size_t ids_needed, size_t io_needed) {
         h->dead_cap = want;
     }
     if (io_needed > h->io_bytes) {
+        HIP_TRY(hipStreamSynchronize(h->ctx->stream));
+        h->pending = false;
         if (h->io) HIP_TRY(hipFree(h->io));
+        if (h->pin) HIP_TRY(hipHostFree(h->pin));
         h->io = nullptr;
+        h->pin = nullptr;
         h->io_bytes = 0;
-        const size_t want = io_needed * 2;
+        const size_t want = io_needed * 2 + 4096;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->io), want));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin), want, hipHostMallocDefault));
         h->io_bytes = want;
     }
     return PLP_OK;
@@ -450,6 +461,7 @@ int plp_hull_destroy(plp_hull* h) {
     if (h->dist) (void)hipFree(h->dist);
     if (h->dead) (void)hipFree(h->dead);
     if (h->io) (void)hipFree(h->io);
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     return PLP_OK;
 }
@@ -483,6 +495,7 @@ int plp_hull_create(plp_ctx* ctx, int64_t N, int d, const double* X, plp_hull** 
     return PLP_OK;
 }
 
+// asynchronous: ordered before the next call of this session on the context's stream
 int plp_hull_drop(plp_hull* h, int64_t n, const int64_t* idx) {
     if (!h) return fail(PLP_EINVAL, "hull is NULL");
     if (n < 0 || (n > 0 && !idx)) return fail(PLP_EINVAL, "bad index list");
@@ -490,14 +503,19 @@ int plp_hull_drop(plp_hull* h, int64_t n, const int64_t* idx) {
     for (int64_t i = 0; i < n; ++i)
         if (idx[i] < 0 || idx[i] >= h->N) return fail(PLP_EINVAL, "point index %lld out of range", (long long)idx[i]);
     HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    if (h->pending) {  // the previous drop may not have consumed the pinned block yet
+        HIP_TRY(hipStreamSynchronize(st));
+        h->pending = false;
+    }
     int rc = hull_ensure(h, 0, (size_t)n * 8);
     if (rc) return rc;
-    hipStream_t st = h->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(h->io, idx, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    memcpy(h->pin, idx, (size_t)n * 8);
+    HIP_TRY(hipMemcpyAsync(h->io, h->pin, (size_t)n * 8, hipMemcpyHostToDevice, st));
     plp::launch_hull_drop(n, reinterpret_cast<const long long*>(h->io), h->owner, st);
     rc = check_launch("hull_drop_kernel");
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    h->pending = true;
     return PLP_OK;
 }
 
@@ -513,31 +531,37 @@ int plp_hull_reassign(plp_hull* h, int n_dead, const int32_t* dead_ids, int n_ne
             return fail(PLP_EINVAL, "dead facet id %d was never handed out", dead_ids[i]);
     if ((long long)h->next_id + n_new > 0x7fffffffll) return fail(PLP_EUNSUPPORTED, "facet ids exhausted");
     HIP_TRY(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    if (h->pending) {
+        HIP_TRY(hipStreamSynchronize(st));
+        h->pending = false;
+    }
     const int id0 = h->next_id;
     const int d = h->d;
     const size_t b_ids = pad((size_t)(n_dead ? n_dead : 1) * 4), b_n = pad((size_t)n_new * d * 8),
                  b_f = pad((size_t)n_new * 8);
-    int rc = hull_ensure(h, (size_t)id0 + n_new, b_ids + b_n + 4 * b_f);
+    const size_t in_bytes = b_ids + b_n + b_f, out_bytes = 3 * b_f;
+    int rc = hull_ensure(h, (size_t)id0 + n_new, in_bytes + out_bytes);
     if (rc) return rc;
-    char* p = h->io;
-    int32_t* d_ids = reinterpret_cast<int32_t*>(p); p += b_ids;
-    double* d_n = reinterpret_cast<double*>(p); p += b_n;
-    double* d_o = reinterpret_cast<double*>(p); p += b_f;
-    int64_t* d_am = reinterpret_cast<int64_t*>(p); p += b_f;
-    double* d_mx = reinterpret_cast<double*>(p); p += b_f;
-    int64_t* d_cn = reinterpret_cast<int64_t*>(p);
-    hipStream_t st = h->ctx->stream;
-    if (n_dead) HIP_TRY(hipMemcpyAsync(d_ids, dead_ids, (size_t)n_dead * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_n, normals, (size_t)n_new * d * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_o, offsets, (size_t)n_new * 8, hipMemcpyHostToDevice, st));
+    memcpy(h->pin, dead_ids, (size_t)n_dead * 4);
+    memcpy(h->pin + b_ids, normals, (size_t)n_new * d * 8);
+    memcpy(h->pin + b_ids + b_n, offsets, (size_t)n_new * 8);
+    HIP_TRY(hipMemcpyAsync(h->io, h->pin, in_bytes, hipMemcpyHostToDevice, st));
+    int32_t* d_ids = reinterpret_cast<int32_t*>(h->io);
+    double* d_n = reinterpret_cast<double*>(h->io + b_ids);
+    double* d_o = reinterpret_cast<double*>(h->io + b_ids + b_n);
+    int64_t* d_am = reinterpret_cast<int64_t*>(h->io + in_bytes);
+    double* d_mx = reinterpret_cast<double*>(h->io + in_bytes + b_f);
+    int64_t* d_cn = reinterpret_cast<int64_t*>(h->io + in_bytes + 2 * b_f);
     plp::launch_hull_mark(n_dead, d_ids, h->dead, st);
     rc = plp_hull_reassign_dev(h->ctx, st, h->N, d, h->X, h->owner, h->dist, h->dead, id0, n_new, d_n, d_o, abs_tol,
                                d_am, d_mx, d_cn);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(argmax, d_am, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(maxd, d_mx, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(count, d_cn, (size_t)n_new * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->pin + in_bytes, h->io + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    memcpy(argmax, h->pin + in_bytes, (size_t)n_new * 8);
+    memcpy(maxd, h->pin + in_bytes + b_f, (size_t)n_new * 8);
+    memcpy(count, h->pin + in_bytes + 2 * b_f, (size_t)n_new * 8);
     h->next_id = id0 + n_new;
     *new_id0 = id0;
     return PLP_OK;
@@ -550,6 +574,7 @@ int plp_hull_read(plp_hull* h, int32_t* owner, double* dist) {
     if (owner && h->N) HIP_TRY(hipMemcpyAsync(owner, h->owner, (size_t)h->N * 4, hipMemcpyDeviceToHost, st));
     if (dist && h->N) HIP_TRY(hipMemcpyAsync(dist, h->dist, (size_t)h->N * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    h->pending = false;
     return PLP_OK;
 }
 

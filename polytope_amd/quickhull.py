@@ -25,7 +25,7 @@ With `solvers.default_solver != 'hip'` the point passes run in numpy with the re
 arithmetic (this is the explicit CPU backend used by the CPU-only tests; nothing falls back to it).
 """
 import logging
-from collections import OrderedDict, deque
+from collections import deque
 
 import numpy as np
 
@@ -95,19 +95,6 @@ def _open_session(X):
     return _NumpySession(X)
 
 
-class _Facet:
-    __slots__ = ("fid", "verts", "normal", "offset", "neighbors", "count", "far")
-
-    def __init__(self, verts, normal, offset):
-        self.fid = -1            # device-side facet id (owner value of the points outside it)
-        self.verts = verts       # d point indices
-        self.normal = normal     # unit outward normal (d,)
-        self.offset = offset     # n.x = offset on the facet (translated coordinates)
-        self.neighbors = []
-        self.count = 0           # points currently outside this facet
-        self.far = -1            # index of the furthest of them
-
-
 def _hyperplanes(V):
     """Unit outward normals and offsets of the facets with vertex coordinates V[k] (d x d each),
     from the linear system of the reference's Facet.__init__ (quickhull.py:66-85)."""
@@ -170,22 +157,38 @@ def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
         xc += startsimplex[ii, :] / (dim + 1)
     X0 = POINTS - xc  # all coordinates below are relative to the simplex centroid (:188-192)
 
-    def make_facets(vert_lists):
+    # ---- facet table, indexed by slot (a facet keeps its slot for life; slots are never reused)
+    FN = np.empty((64, dim))   # unit outward normals
+    FO = np.empty(64)          # offsets: n.x = offset on the facet (translated coordinates)
+    verts, nbrs = [], []       # slot -> d point indices / neighbour slots in the reference's list order
+    cnt, far, fid = [], [], [] # slot -> points outside it, the furthest of them, device-side facet id
+
+    def add_facets(vert_lists):
+        nonlocal FN, FO
         idx = np.asarray(vert_lists, dtype=np.int64).reshape(-1, dim)
         n, off = _hyperplanes(X0[idx])
-        return [_Facet(list(map(int, idx[k])), n[k], float(off[k])) for k in range(idx.shape[0])]
+        s0, k = len(verts), idx.shape[0]
+        while s0 + k > FO.shape[0]:
+            FN = np.concatenate([FN, np.empty_like(FN)])
+            FO = np.concatenate([FO, np.empty_like(FO)])
+        FN[s0:s0 + k] = n
+        FO[s0:s0 + k] = off
+        for row in idx.tolist():
+            verts.append(row)
+            nbrs.append([])
+            cnt.append(0)
+            far.append(-1)
+            fid.append(-1)
+        return s0, k
 
-    order = list(range(dim + 1))
-    first = make_facets([[ind[j] for j in order if j != i] for i in range(dim + 1)])
-    facets = OrderedDict()  # the reference's Forg, insertion ordered; key = id(facet object)
-    for f in first:
-        facets[id(f)] = f
+    s0, k0 = add_facets([[ind[j] for j in range(dim + 1) if j != i] for i in range(dim + 1)])
+    facets = dict.fromkeys(range(s0, s0 + k0))  # the reference's Forg: insertion ordered set of live slots
 
     def result():
-        flist = list(facets.values())
-        A = np.array([f.normal for f in flist]).reshape(len(flist), dim)
-        b = np.array([f.offset for f in flist])
-        vid = np.unique(np.concatenate([np.asarray(f.verts, dtype=np.int64) for f in flist]))
+        slots = list(facets)
+        A = FN[slots].reshape(len(slots), dim)
+        b = FO[slots]
+        vid = np.unique(np.concatenate([np.asarray(verts[f], dtype=np.int64) for f in slots]))
         vert = POINTS[vid]
         vert = vert[np.lexsort(vert.T[::-1])]  # np.unique row order of the reference (:352-354)
         return A, b + np.dot(A, xc), vert
@@ -194,96 +197,98 @@ def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
         return result()
     for ii in range(dim + 1):  # in the starting simplex all facets are neighbours (:215-222)
         for jj in range(ii + 1, dim + 1):
-            first[ii].neighbors.append(first[jj])
-            first[jj].neighbors.append(first[ii])
+            nbrs[ii].append(jj)
+            nbrs[jj].append(ii)
 
     session = (session_factory or _open_session)(X0)
     try:
-        pending = OrderedDict()  # the reference's F: facets with outside points, FIFO
+        pending = {}  # the reference's F: facets with outside points, FIFO (insertion ordered)
 
-        def hand_out(dead_ids, new):
-            id0, count, argmax, _ = session.reassign(dead_ids, np.array([f.normal for f in new]),
-                                                     np.array([f.offset for f in new]), abs_tol)
-            for k, f in enumerate(new):
-                f.fid = id0 + k
-                f.count = int(count[k])
-                f.far = int(argmax[k])
-                if f.count > 0:
-                    pending[id(f)] = f
+        def hand_out(dead_ids, s0, k):
+            id0, count, argmax, _ = session.reassign(dead_ids, FN[s0:s0 + k], FO[s0:s0 + k], abs_tol)
+            count, argmax = count.tolist(), argmax.tolist()
+            for j in range(k):
+                f = s0 + j
+                fid[f] = id0 + j
+                cnt[f] = count[j]
+                far[f] = argmax[j]
+                if count[j] > 0:
+                    pending[f] = None
 
-        session.drop(ind)      # the simplex' own points are not candidates (:186)
-        hand_out([0], first)   # facet id 0 owns every point initially
+        session.drop(ind)           # the simplex' own points are not candidates (:186)
+        hand_out([0], s0, k0)       # facet id 0 owns every point initially
         while pending:
-            facet = next(iter(pending.values()))
-            p = facet.far
+            facet = next(iter(pending))
+            p = far[facet]
             session.drop([p])  # get_furthest() removes it from the facet's outside set (:87-102)
-            facet.count -= 1
-            xp = X0[p]
+            cnt[facet] -= 1
+            # distance of p to every facet made so far, one pass with distance()'s arithmetic (:117-121)
+            nf = len(verts)
+            vis = (np.sum(FN[:nf] * X0[p], axis=1) - FO[:nf]) > abs_tol
             # ---- visible set: breadth-first over neighbours with distance > abs_tol (:254-270)
             visible = [facet]
-            in_visible = {id(facet)}
-            seen = {id(facet)}
-            queue = deque(facet.neighbors)
-            queued = {id(f) for f in facet.neighbors}
+            in_visible = {facet}
+            seen = {facet}
+            queue = deque(nbrs[facet])
+            queued = set(nbrs[facet])
             while queue:
                 nb = queue.popleft()
-                queued.discard(id(nb))
-                seen.add(id(nb))
-                if np.sum(nb.normal * xp) - nb.offset > abs_tol:
+                queued.discard(nb)
+                seen.add(nb)
+                if vis[nb]:
                     visible.append(nb)
-                    in_visible.add(id(nb))
-                    for nn in nb.neighbors:
-                        if id(nn) not in seen and id(nn) not in queued:
+                    in_visible.add(nb)
+                    for nn in nbrs[nb]:
+                        if nn not in seen and nn not in queued:
                             queue.append(nn)
-                            queued.add(id(nn))
+                            queued.add(nn)
             # ---- horizon: one new facet per (visible facet, non-visible neighbour) (:284-304)
             new_verts, outer = [], []
             for f1 in visible:
-                for f2 in f1.neighbors:
-                    if id(f2) in in_visible:
+                v1 = verts[f1]
+                for f2 in nbrs[f1]:
+                    if f2 in in_visible:
                         continue
-                    other = set(f2.verts)
+                    other = set(verts[f2])
                     ridge = None
                     for ii in range(dim):
-                        if f1.verts[ii] not in other:
-                            ridge = [v for jj, v in enumerate(f1.verts) if jj != ii]
+                        if v1[ii] not in other:
+                            ridge = v1[:ii] + v1[ii + 1:]
                             break
                     if ridge is None:  # same vertex set twice: degenerate input
                         raise RuntimeError("quickhull: neighbouring facets with identical vertices")
                     new_verts.append([p] + ridge)
                     outer.append(f2)
-            new = make_facets(new_verts)
-            for f, f2 in zip(new, outer):
-                f.neighbors.append(f2)
-                f2.neighbors.append(f)
+            s0, k = add_facets(new_verts)
+            for j, f2 in enumerate(outer):
+                nbrs[s0 + j].append(f2)
+                nbrs[f2].append(s0 + j)
             # ---- links among the new facets: two of them share p and d-2 ridge vertices (:305-310)
             by_subridge = {}
-            for k, f in enumerate(new):
-                ridge = f.verts[1:]
-                for omit in range(len(ridge)):
-                    key = frozenset(ridge[:omit] + ridge[omit + 1:])
-                    by_subridge.setdefault(key, []).append(k)
-            links = [set() for _ in new]
+            for j in range(k):
+                ridge = verts[s0 + j][1:]
+                for omit in range(dim - 1):
+                    by_subridge.setdefault(frozenset(ridge[:omit] + ridge[omit + 1:]), []).append(j)
+            links = [set() for _ in range(k)]
             for group in by_subridge.values():
-                for a in group:
-                    for c in group:
-                        if a != c:
-                            links[a].add(c)
-            for k, f in enumerate(new):
-                for c in sorted(links[k]):
-                    f.neighbors.append(new[c])
+                if len(group) > 1:
+                    for a in group:
+                        for c in group:
+                            if a != c:
+                                links[a].add(c)
+            for j in range(k):
+                nbrs[s0 + j].extend(s0 + c for c in sorted(links[j]))
             # ---- hand the pooled points to the new facets, retire the visible ones (:311-344)
-            pooled = sum(f.count for f in visible)
-            for f in new:
-                facets[id(f)] = f
-            if pooled > 0:
-                hand_out([f.fid for f in visible if f.count > 0], new)  # facets without points own nothing
+            for j in range(k):
+                facets[s0 + j] = None
+            if sum(cnt[f] for f in visible) > 0:
+                hand_out([fid[f] for f in visible if cnt[f] > 0], s0, k)  # facets without points own nothing
             for f1 in visible:
-                for f2 in f1.neighbors:
-                    f2.neighbors.remove(f1)
-                pending.pop(id(f1), None)
-                del facets[id(f1)]
-                f1.neighbors = []
+                for f2 in nbrs[f1]:
+                    nbrs[f2].remove(f1)
+                pending.pop(f1, None)
+                del facets[f1]
+                nbrs[f1] = []
     finally:
         session.close()
     return result()
