@@ -335,8 +335,9 @@ def test_reduce_properties_full_config(pa):
 def test_fuzz_random_shapes(pa, oracle):
     """Random (rows, dimension) over the whole envelope m <= 64, d <= 16, ragged row counts:
     lpsolve / cheby / reduce against the oracle (status, masks, flags exact; values 1e-9)."""
-    rng = np.random.default_rng(2026)
-    for trial in range(40):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("PLP_FUZZ_SEED", "2026")))
+    for trial in range(int(os.environ.get("PLP_FUZZ_TRIALS", "40"))):   # soak runs: PLP_FUZZ_TRIALS=2000
         d = int(rng.integers(1, 17))
         m = int(rng.integers(1, 65))
         B = int(rng.integers(1, 40))
