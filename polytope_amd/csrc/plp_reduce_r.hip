@@ -65,8 +65,8 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
     double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
     double* sb = sA + (size_t)NG * rows * D;            // [NG][rows]
     double* san = sb + (size_t)NG * rows;               // [NG][rows]
-    const double* myA = sA + (size_t)gib * rows * D;
-    const double* myb = sb + (size_t)gib * rows;
+    double* myA = sA + (size_t)gib * rows * D;
+    double* myb = sb + (size_t)gib * rows;
     double* myan = san + (size_t)gib * rows;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
@@ -217,6 +217,22 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 sk = fma(((has >> k) & 1u) ? myA[(row0 + k) * D + kk] : 0.0, ball ? xc[kk] : 0.0, sk);
             myan[row0 + k] = sk;
         }
+        // Rows that dropped out (never present, or removed by the dedupe) are zeroed in LDS -- A, b and
+        // s -- so that the LP set-ups below load their rows without masking.  Only the owner lane writes
+        // a row's slots and only the owner lane reads them afterwards (live rows, which other lanes read
+        // as F2 objectives, are never written): no cross-lane visibility is relied upon.
+        auto zero_dead = [&](unsigned alive) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (!((alive >> k) & 1u)) {
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) myA[(row0 + k) * D + kk] = 0.0;
+                    myb[row0 + k] = 0.0;
+                    myan[row0 + k] = 0.0;
+                }
+            }
+        };
+        zero_dead((unsigned)((live >> row0) & 0xFull));
         int flags = fulldim ? 0 : RF_EMPTY;
         int nlp = 1;
         uint64_t keep = 0ull;
@@ -248,11 +264,9 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const bool l = (lloc >> k) & 1u;
 #pragma unroll
-                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = l ? myA[(row0 + k) * D + kk] : 0.0;
-                    const double bsh = myb[row0 + k] - myan[row0 + k];
-                    S.beta[k] = (l & (bsh > 0.0)) ? bsh : 0.0;
+                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
+                    S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
                 }
                 S.ract = lloc;
                 S.mode = go ? M_P2 : M_DONE;
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 } else {  // prefilter sums, accumulated in k order (:1131-1134)
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const double aik = ((lloc >> k) & 1u) ? myA[(row0 + k) * D + kx] : 0.0;
+                        const double aik = myA[(row0 + k) * D + kx];
                         const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
                         s1[k] = s1[k] + pa * (val - lbk);
                         s2[k] = s2[k] + aik * lbk;
@@ -287,6 +301,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
             }
             if (go) {
                 live = live & ~outb;
+                zero_dead((unsigned)((live >> row0) & 0xFull));
                 nlp += 2 * D;
                 if (lpfail) flags |= RF_LPFAIL;
                 if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
@@ -296,7 +311,6 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
         // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
         if (__any(stage == 2)) {
             const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
-            // h[k] += 0.1 for LP k; rows k' < k carry the (+0.1, -0.1) round trip (:1149-1151)
             uint64_t todo = (stage == 2) ? live : 0ull;
             if (stage == 2) nlp += __popcll(live);
             while (__any(todo != 0ull)) {
@@ -312,17 +326,15 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                     S.cost[kk] = ck;
                     cxc = fma(ck, xc[kk], cxc);
                 }
+                // h[k] += 0.1 in place, as the reference does (:1149); undone after the LP (:1151), so rows
+                // k' < k carry the (+0.1, -0.1) round trip into the later LPs
+                const bool owner = go & ((kr >> 2) == g.gl);
+                if (owner) myb[kr] = myb[kr] + 0.1;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const bool l = (lloc >> k) & 1u;
-                    const int i = row0 + k;
 #pragma unroll
-                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = l ? myA[(row0 + k) * D + kk] : 0.0;
-                    const double b0 = myb[row0 + k];
-                    const double bup = b0 + 0.1;
-                    const double brt = bup - 0.1;
-                    const double bsh = ((i < kr) ? brt : ((i == kr) ? bup : b0)) - myan[row0 + k];
-                    S.beta[k] = (l & (bsh > 0.0)) ? bsh : 0.0;
+                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
+                    S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
                 }
                 S.ract = lloc;
                 S.mode = go ? M_P2 : M_DONE;
@@ -333,8 +345,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
                 S.run(g);
 #endif
                 const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
-                const double bk = myb[kr];
-                const double hk = (bk + 0.1) - 0.1;
+                // b[k] after the round trip: computed by the lane that owns row k and handed to the others
+                // through registers (an LDS store of one lane followed by loads of other lanes would need a
+                // fence for the compiler, which otherwise keeps an earlier load)
+                double hk_own = 0.0;
+                if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
+                const double hk = bcast(hk_own, g.gbase + (kr >> 2));
                 const double obj = -fun - hk;     // (:1156)
                 const bool keepk = go & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
                 keep |= keepk ? (1ull << kr) : 0ull;
