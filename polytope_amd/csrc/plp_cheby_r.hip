@@ -1,6 +1,7 @@
-// plp_cheby_r.hip -- Chebyshev-ball LPs (form F1, polytope/polytope.py:1283-1288) with four rows per
-// lane (gfx950):
+// plp_cheby_r.hip -- stand-alone LP batches with four rows per lane (gfx950): Chebyshev-ball LPs (form F1,
+// polytope/polytope.py:1283-1288) and generic LPs whose origin is feasible:
 //
+//   lp_r_kernel<N,GS>       : lpsolve() batches (solvers.py:76-106), n <= 8, no phase 1 needed
 //   cheby_r_kernel<D,GS>    : a batch of polytopes (cheby_ball / is_fulldim, :1241-1300, :962-985)
 //   adjacent_r_kernel<D,GS> : all pairs of n cells (is_adjacent(overlap=True), :1843-1866, under the pair
 //                             loop of find_adjacent_regions, prop2partition.py:57-61)
@@ -178,6 +179,119 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
 static int force_retry_env() {
     const char* fr = getenv("PLP_CHEBY_RETRY_ALL");
     return (fr && fr[0] == '1') ? 1 : 0;
+}
+
+// Generic LP  min c'x  s.t.  G x <= h, x free  (solvers.py:76-106) when the origin is feasible (every
+// h_i >= 0): phase 2 starts from the all-slack dictionary, which is what the two-phase kernel of
+// plp_lp.hip does too in that case, so both walk the same path.  LPs that need phase 1 (or, later,
+// Bland's rule) end with ST_RETRY and are redone by that kernel in a second launch.
+template <int N, int GS>
+__global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long B, int m_max,
+                                                                       const double* __restrict__ c,
+                                                                       const double* __restrict__ G,
+                                                                       const double* __restrict__ h,
+                                                                       const int* __restrict__ mrows,
+                                                                       double* __restrict__ x,
+                                                                       double* __restrict__ fun,
+                                                                       int* __restrict__ status,
+                                                                       int* __restrict__ iters) {
+    constexpr int R = CR;
+    const Grp g(GS);
+    constexpr int gpb = BLOCK / GS;
+    const int gib = threadIdx.x / GS;
+    const int row0 = g.gl * R;
+    const long long lp = (long long)blockIdx.x * gpb + gib;
+    const bool valid = lp < B;
+    const int m = valid ? (mrows ? mrows[lp] : m_max) : 0;
+    SimplexR<N, R, false, true> S;
+    S.reset(N, m, row0);
+    double cc[N];
+    bool finite = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        cc[j] = valid ? c[lp * N + j] : 0.0;
+        finite = finite & isfinite(cc[j]);
+        S.cost[j] = cc[j];
+    }
+    unsigned actb = 0u;
+    bool inf0 = false, neg = false;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool hr = valid & (row0 + k < m) & (m <= GS * R);
+        bool zero = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double v = hr ? G[(lp * m_max + row0 + k) * N + j] : 0.0;
+            S.T[k][j] = v;
+            zero = zero & (v == 0.0);
+            finite = finite & isfinite(v);
+        }
+        const double hk = hr ? h[lp * m_max + row0 + k] : 0.0;
+        finite = finite & isfinite(hk);
+        const bool on = hr & !zero;
+        S.beta[k] = on ? hk : 0.0;
+        actb |= on ? (1u << k) : 0u;
+        inf0 = inf0 | (hr & zero & (hk < -TOL_FEAS));  // 0 <= h_i < 0
+        neg = neg | (on & (hk < 0.0));
+    }
+    S.ract = actb;
+    const bool infeasible0 = grp_ballot(inf0, g) != 0;
+    const bool bad = (grp_ballot(!finite, g) != 0) | (m > GS * R);
+    const bool need_p1 = grp_ballot(neg, g) != 0;
+    S.mode = M_P2;
+    if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
+    else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+    else if (need_p1) { S.mode = M_DONE; S.status = ST_RETRY; }
+    S.template run_fast<GS, false>(g);
+    const bool ok = S.status == ST_OPT;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    double f = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        bool found;
+        const double mine = S.x_of(j, found);
+        const uint64_t ob = grp_ballot(found, g);
+        const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+        const double xj = ob ? v : 0.0;
+        f = fma(cc[j], xj, f);
+        if (valid & (g.gl == 0)) x[lp * N + j] = ok ? xj : qnan;
+    }
+    if (valid & (g.gl == 0)) {
+        fun[lp] = ok ? f : qnan;
+        status[lp] = S.status;
+        if (iters) iters[lp] = S.iters;
+    }
+}
+
+template <int N, int GS>
+static int launch_lp_r_ng(long long B, int m_max, const double* c, const double* G, const double* h, const int* mrows,
+                          double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    constexpr long long gpb = BLOCK / GS;
+    const long long blocks = (B + gpb - 1) / gpb;
+    if (blocks > 2147483647ll) return 1;
+    hipLaunchKernelGGL((lp_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max, c,
+                       G, h, mrows, x, fun, status, iters);
+    return 0;
+}
+
+template <int N>
+static int launch_lp_r_n(long long B, int m_max, const double* c, const double* G, const double* h, const int* mrows,
+                         double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    if (m_max <= 16) return launch_lp_r_ng<N, 4>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
+    if (m_max <= 32) return launch_lp_r_ng<N, 8>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
+    return launch_lp_r_ng<N, 16>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
+}
+
+#define PLP_CASE_LPR(K) case K: return launch_lp_r_n<K>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
+
+int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    if (m_max < 1 || m_max > MAX_M || B < 1) return 1;
+    switch (n) {
+        PLP_CASE_LPR(1) PLP_CASE_LPR(2) PLP_CASE_LPR(3) PLP_CASE_LPR(4)
+        PLP_CASE_LPR(5) PLP_CASE_LPR(6) PLP_CASE_LPR(7) PLP_CASE_LPR(8)
+        default: return 1;
+    }
 }
 
 template <int D, int GS>

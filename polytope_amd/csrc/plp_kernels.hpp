@@ -20,6 +20,11 @@ int launch_lp(long long B, int m_max, int n, const double* c, const double* G, c
 int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                  double* xc, int* status, hipStream_t st);
 
+// generic LPs, four rows per lane, origin-feasible ones only (n <= 8, plp_cheby_r.hip): the others get
+// status ST_RETRY for the general kernel; returns 1 when it does not apply
+int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                double* x, double* fun, int* status, int* iters, hipStream_t st);
+
 // four rows per lane (d <= 8, plp_cheby_r.hip); returns 1 when it does not apply
 int launch_cheby_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                    double* xc, int* status, hipStream_t st);

@@ -21,14 +21,20 @@ __global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int g
                                                    const double* __restrict__ h,
                                                    const int* __restrict__ mrows,
                                                    double* __restrict__ x, double* __restrict__ fun,
-                                                   int* __restrict__ status, int* __restrict__ iters) {
+                                                   int* __restrict__ status, int* __restrict__ iters,
+                                                   int retry_only) {
     constexpr int NC = N + 1;  // + phase-1 artificial
     const Grp g(gs);
     const int gpb = BLOCK / gs;
     const int gib = threadIdx.x / gs;
     for (long long base = (long long)blockIdx.x * gpb; base < B; base += (long long)gridDim.x * gpb) {
         const long long lp = base + gib;
-        const bool valid = lp < B;
+        bool valid = lp < B;
+        // second pass after lp_r_kernel: only the LPs it handed over (status ST_RETRY: phase 1 or Bland needed)
+        if (retry_only) {
+            valid = valid && status[lp] == ST_RETRY;
+            if (!__any(valid)) continue;
+        }
         const int m = valid ? (mrows ? mrows[lp] : m_max) : 0;
         const int i = g.gl;
         const bool has_row = valid && i < m;
@@ -184,9 +190,9 @@ static inline int pick_grid(long long B, int gs) {
 
 template <int N>
 static void launch_lp_n(long long B, int m_max, int gs, const double* c, const double* G, const double* h,
-                        const int* mrows, double* x, double* fun, int* status, int* iters, hipStream_t st) {
+                        const int* mrows, double* x, double* fun, int* status, int* iters, int retry, hipStream_t st) {
     hipLaunchKernelGGL(lp_kernel<N>, dim3(pick_grid(B, gs)), dim3(BLOCK), 0, st, B, m_max, gs, c, G, h, mrows, x,
-                       fun, status, iters);
+                       fun, status, iters, retry);
 }
 
 template <int D>
@@ -196,13 +202,19 @@ static void launch_cheby_d(long long B, int m_max, int gs, const double* A, cons
                        xc, status);
 }
 
-#define PLP_CASE_N(K) case K: launch_lp_n<K>(B, m_max, gs, c, G, h, mrows, x, fun, status, iters, st); break;
+#define PLP_CASE_N(K) case K: launch_lp_n<K>(B, m_max, gs, c, G, h, mrows, x, fun, status, iters, retry, st); break;
 #define PLP_CASE_D(K) case K: launch_cheby_d<K>(B, m_max, gs, A, b, mrows, r, xc, status, st); break;
 
 int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
               double* x, double* fun, int* status, int* iters, hipStream_t st) {
     const int gs = group_size_for(m_max);
     if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
+    // n <= 8: LPs whose origin is feasible (no phase 1) are solved by the four-rows-per-lane fast path
+    // (plp_cheby_r.hip); it marks the others ST_RETRY and the launch below redoes exactly those
+    // (PLP_LP_1ROW=1 keeps everything on this file's kernel: A/B, tests).
+    const char* one = getenv("PLP_LP_1ROW");
+    int retry = 0;
+    if (!(one && one[0] == '1') && launch_lp_r(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st) == 0) retry = 1;
     switch (n) {
         PLP_CASE_N(1) PLP_CASE_N(2) PLP_CASE_N(3) PLP_CASE_N(4) PLP_CASE_N(5) PLP_CASE_N(6)
         PLP_CASE_N(7) PLP_CASE_N(8) PLP_CASE_N(9) PLP_CASE_N(10) PLP_CASE_N(11) PLP_CASE_N(12)

@@ -103,6 +103,38 @@ def test_lp_vs_oracle_and_scipy(pa, oracle):
                     assert abs(sp.fun - res["fun"][k]) <= TOL * max(1.0, abs(sp.fun))
 
 
+def test_lp_kernel_variants(pa, oracle, monkeypatch):
+    """lpsolve batches take two kernels: origin-feasible LPs (n <= 8) the four-rows-per-lane fast path,
+    the rest (phase 1 needed, n > 8, Bland cases) the two-phase kernel in a second launch.  A mixed batch
+    must agree LP by LP with the oracle and with the two-phase kernel alone (PLP_LP_1ROW=1)."""
+    rng = np.random.default_rng(12)
+    for (m, n, B) in [(16, 3, 600), (12, 2, 200), (30, 5, 150), (64, 8, 60), (5, 4, 100)]:
+        G = rng.standard_normal((B, m, n))
+        G /= np.linalg.norm(G, axis=2, keepdims=True)
+        h = rng.random((B, m)) + 0.2
+        h[::3] -= 0.6 * rng.random((len(h[::3]), m))        # a third of the LPs: some h_i < 0 -> phase 1
+        if m >= 2 * n:
+            G[:, :2 * n] = np.vstack([np.eye(n), -np.eye(n)])[None]
+            h[:, :2 * n] = 3.0
+        G[1::7, 0] = 0.0                                      # zero rows (kept feasible)
+        c = rng.standard_normal((B, n))
+        mrows = rng.integers(max(1, m - 3), m + 1, B).astype(np.int32)
+        res = pa.lpsolve_batch(c, G, h, m=mrows)
+        monkeypatch.setenv("PLP_LP_1ROW", "1")
+        ref = pa.lpsolve_batch(c, G, h, m=mrows)
+        monkeypatch.delenv("PLP_LP_1ROW")
+        assert np.array_equal(res["status"], ref["status"]) and set(np.unique(res["status"])) <= {0, 2, 3}
+        assert np.array_equal(res["iters"], ref["iters"])     # the same vertex path
+        ok = ref["status"] == 0
+        assert np.allclose(res["fun"][ok], ref["fun"][ok], rtol=0, atol=1e-12)
+        for k in range(0, B, 5):
+            so, xo, fo, _ = oracle.lp_solve(c[k], G[k, :mrows[k]], h[k, :mrows[k]])
+            assert res["status"][k] == so, (m, n, k)
+            if so == 0:
+                assert abs(res["fun"][k] - fo) <= TOL * max(1.0, abs(fo))
+                assert np.max(G[k, :mrows[k]] @ res["x"][k] - h[k, :mrows[k]]) <= 1e-7
+
+
 def test_lp_edge_inputs(pa):
     # known-answer cases of the reference's tests (polytope_test.py:510-548)
     r = pa.lpsolve_batch(np.array([[1.0]]), np.array([[[-1.0]]]), np.array([[1.0]]))
