@@ -178,7 +178,16 @@ int plp_adjacent_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, c
 int plp_adjacent_pairs_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
                            const double *b, const int32_t *m, double abs_tol, uint8_t *adj);
 /*
- * The same for a slice of the pair space (one rank's shard when the O(n^2) loop is split across
+ * Overlap of all pairs of n cells: out[i][j] = 1 iff the stack of cells i and j (nothing inflated) has
+ * Chebyshev radius > abs_tol, i.e. is_fulldim(cell_i.intersect(cell_j)); ones on the diagonal.
+ * Replaces: the O(n^2) pair loop of Partition.are_disjoint (polytope/prop2partition.py:123-192).
+ */
+int plp_overlap_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, const double *b,
+                      const int32_t *m, double abs_tol, uint8_t *out);
+int plp_overlap_pairs_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
+                          const double *b, const int32_t *m, double abs_tol, uint8_t *out);
+/*
+ * plp_adjacent_pairs for a slice of the pair space (one rank's shard when the O(n^2) loop is split across
  * GPUs): pairs pair_lo <= p < pair_hi in the order p = i (i - 1) / 2 + j, j < i; out[p - pair_lo].
  */
 int plp_adjacent_pairs_range(plp_ctx *ctx, int n, int m_max, int d, const double *A, const double *b,

@@ -343,6 +343,32 @@ def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
     return adj
 
 
+def overlap_pairs(A, b, m=None, abs_tol=1e-7):
+    """uint8[n, n]: 1 where the intersection of cells i and j is full-dimensional (Chebyshev radius of the
+    stacked rows > abs_tol) -- the pair test of Partition.are_disjoint (prop2partition.py:146-149); ones
+    on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 8."""
+    lib = _lib.load()
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        n, m_max, d = A.shape
+        out = torch.empty((n, n), dtype=torch.uint8, device=A.device)
+        _lib.check(lib.plp_overlap_pairs_dev(ctx.handle, stream, n, m_max, d, _ptr(A), _ptr(b), _ptr(m),
+                                             float(abs_tol), _ptr(out)), "plp_overlap_pairs_dev")
+        return out
+    A = _np(A)
+    n, m_max, d = A.shape
+    b = _np(b).reshape(n, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(n)
+    _finite_or_raise("overlap_pairs", A, b)
+    out = np.zeros((n, n), np.uint8)
+    _lib.check(lib.plp_overlap_pairs(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
+                                     _ptr(out)), "plp_overlap_pairs")
+    return out
+
+
 def adjacent_pairs_range(A, b, pair_lo, pair_hi, m=None, abs_tol=1e-7):
     """Adjacency of the cell pairs pair_lo <= p < pair_hi (p = i (i - 1) / 2 + j, j < i) -> uint8[pair_hi - pair_lo];
     one rank's shard of the O(n^2) loop of find_adjacent_regions (prop2partition.py:57-61)."""

@@ -587,9 +587,48 @@ int plp_adjacent_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, 
     if (!A || !b || !adj) return fail(PLP_EINVAL, "NULL pointer");
     if (2 * m_max > plp::MAX_M || d > 8)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
-    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, adj, 0, 0, nullptr, (hipStream_t)stream))
+    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, abs_tol / 10, adj, 0, 0, nullptr, (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
     return check_launch("adjacent_r_kernel");
+}
+
+int plp_overlap_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, const double* A, const double* b,
+                          const int32_t* m, double abs_tol, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (n == 0) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    if (2 * m_max > plp::MAX_M || d > 8)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
+    if (plp::launch_adjacent(n, m_max, d, A, b, m, 0.0, abs_tol, out, 0, 0, nullptr, (hipStream_t)stream))
+        return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
+    return check_launch("adjacent_r_kernel");
+}
+
+int plp_overlap_pairs(plp_ctx* ctx, int n, int m_max, int d, const double* A, const double* b, const int32_t* m,
+                      double abs_tol, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (n == 0) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)n * m_max * d, nb = (size_t)n * m_max, nout = (size_t)n * n;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad((size_t)n * 4) + pad(nout) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA);
+    double* db = a.take<double>(nb);
+    int32_t* dm = a.take<int32_t>(n);
+    uint8_t* dout = a.take<uint8_t>(nout);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    rc = plp_overlap_pairs_dev(ctx, st, n, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dout);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
 }
 
 int plp_adjacent_pairs_range_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, const double* A,
@@ -605,7 +644,8 @@ int plp_adjacent_pairs_range_dev(plp_ctx* ctx, void* stream, int n, int m_max, i
     if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
     if (2 * m_max > plp::MAX_M || d > 8)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
-    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, nullptr, pair_lo, pair_hi, out, (hipStream_t)stream))
+    if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, abs_tol / 10, nullptr, pair_lo, pair_hi, out,
+                             (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
     return check_launch("adjacent_r_kernel");
 }

@@ -132,16 +132,18 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
     }
 }
 
-// One lane group per pair (i, j < i): the rows of both cells are stacked with b + abs_tol, and the pair is
-// adjacent iff the Chebyshev LP of the stack is optimal with r > abs_tol/10 (`is_fulldim(dummy,
-// abs_tol / 10)`).  The stacked LP is built straight from the resident cells (n cells stay in L2), so
+// One lane group per pair (i, j < i): the rows of both cells are stacked with b + inflate, and the pair
+// counts iff the Chebyshev LP of the stack is optimal with r > thresh.  Adjacency: inflate = abs_tol,
+// thresh = abs_tol / 10 (`is_fulldim(dummy, abs_tol / 10)`, polytope.py:1860-1866); overlap
+// (Partition.are_disjoint, prop2partition.py:123-192: `is_fulldim(region.intersect(other))`): inflate = 0,
+// thresh = abs_tol.  The stacked LP is built straight from the resident cells (n cells stay in L2), so
 // nothing is staged by the host.  adj is n x n, symmetric, ones on the diagonal; with `compact` set the
 // kernel instead solves the pairs p_lo <= p < p_hi (p = i (i - 1) / 2 + j) and writes compact[p - p_lo]
 // (the shard of one rank when the pair space is split across GPUs).
 template <int D, int GS>
 __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     int n, int m_max, const double* __restrict__ A, const double* __restrict__ b, const int* __restrict__ mrows,
-    double abs_tol, unsigned char* __restrict__ adj, long long p_lo, long long p_hi,
+    double inflate, double thresh, unsigned char* __restrict__ adj, long long p_lo, long long p_hi,
     unsigned char* __restrict__ compact, int force_retry) {
     const Grp g(GS);
     constexpr int gpb = BLOCK / GS;
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     const int st = cheby_r_solve<D, GS>(
         g, valid, mi + mj, row0,
         [&](int rr, int kk) { return A[(((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)) * D + kk]; },
-        [&](int rr) { return b[((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)] + abs_tol; },  // b1 += abs_tol; b2 += abs_tol
+        [&](int rr) { return b[((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)] + inflate; },  // b1 += abs_tol; b2 += abs_tol
         x, force_retry);
-    const bool yes = (st == ST_OPT) & (x[D] > abs_tol / 10);
+    const bool yes = (st == ST_OPT) & (x[D] > thresh);
     if (compact) {
         if (valid & (g.gl == 0)) compact[p - p_lo] = yes ? 1 : 0;
         return;
@@ -331,8 +333,8 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 }
 
 template <int D, int GS>
-static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
-                              unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
+                              double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                               hipStream_t st) {
     constexpr long long gpb = BLOCK / GS;
     long long blocks = (p_hi - p_lo + gpb - 1) / gpb;
@@ -341,26 +343,27 @@ static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b
     if (blocks < 1) blocks = 1;
     if (blocks > 2147483647ll) return 2;
     hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, n, m_max, A, b, mrows,
-                       abs_tol, adj, p_lo, p_hi, compact, force_retry_env());
+                       inflate, thresh, adj, p_lo, p_hi, compact, force_retry_env());
     return 0;
 }
 
 template <int D>
-static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
-                             unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
+                             double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                              hipStream_t st) {
     const int rows = 2 * m_max;
-    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
-    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
-    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
+    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
 }
 
 #define PLP_CASE_ADJ(K) \
-    case K: return launch_adjacent_d<K>(n, m_max, A, b, mrows, abs_tol, adj, p_lo, p_hi, compact, st);
+    case K: return launch_adjacent_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
 
 // compact == nullptr: all pairs into the n x n matrix adj; else pairs [p_lo, p_hi) into compact[p - p_lo]
-int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
-                    unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact, hipStream_t st) {
+int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
+                    double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                    hipStream_t st) {
     if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > 8) return 2;
     const long long npairs = (long long)n * (n - 1) / 2;
     if (!compact) { p_lo = 0; p_hi = npairs; }

@@ -31,8 +31,10 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8) into the n x n matrix adj (compact == nullptr),
 // or of the pairs p_lo <= p < p_hi, p = i (i - 1) / 2 + j, j < i, into compact[p - p_lo]
-int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
-                    unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact, hipStream_t st);
+// a pair counts iff the Chebyshev radius of the two stacked cells, each b inflated by `inflate`, exceeds `thresh`
+int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
+                    double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                    hipStream_t st);
 
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,

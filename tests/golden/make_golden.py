@@ -20,6 +20,8 @@ Sets:
   g6_quickhull.npz Facet normals/offsets, distance(), first-facet assignment,
                    get_furthest, and end-to-end hull facet sets                     (quickhull.py)
   g7_known.npz     the known-answer data of the reference's own tests (tests/polytope_test.py)
+  g9_overlap.npz   the pair test of Partition.are_disjoint (is_fulldim(region.intersect(other))) and
+                   MetricPartition-style adjacency on cell sets with overlaps  (prop2partition.py:123-192,:244-306)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -489,7 +491,39 @@ def gen_g8():
     print("g8: ordered hulls, degenerate cube, extreme() d=1..4, qhull square")
 
 
+# ----------------------------------------------------------------------------- G9
+def gen_g9():
+    import itertools
+    rng = np.random.default_rng(9)
+    out = {}
+    sets = {}
+    # disjoint grid, 2-D and 3-D
+    sets["grid2"] = [pc.box2poly([[i, i + 1], [j, j + 1]]) for i in range(4) for j in range(3)]
+    sets["grid3"] = [pc.box2poly([[i, i + 1], [j, j + 1], [k, k + 1]]) for i, j, k in itertools.product(range(3), range(2), range(2))]
+    # boxes at random offsets: some overlap, some touch, some are apart
+    lo = np.round(rng.random((14, 2)) * 3, 1)
+    sets["rand2"] = [pc.box2poly([[a, a + 1.0], [c, c + 0.7]]) for a, c in lo]
+    lo3 = np.round(rng.random((12, 3)) * 2, 1)
+    sets["rand3"] = [pc.box2poly([[a, a + 0.9], [c, c + 0.9], [e, e + 0.9]]) for a, c, e in lo3]
+    for name, cells in sets.items():
+        n = len(cells)
+        over = np.eye(n, dtype=bool)
+        adj = np.eye(n, dtype=np.int8)
+        for i in range(n):
+            for j in range(i):
+                f = bool(pc.is_fulldim(cells[i].intersect(cells[j])))     # prop2partition.py:149
+                over[i, j] = over[j, i] = f
+                adj[i, j] = adj[j, i] = pc.is_adjacent(cells[i], cells[j])  # :266
+        out[name + "_A"] = np.array([c.A for c in cells])
+        out[name + "_b"] = np.array([c.b for c in cells])
+        out[name + "_over"] = over
+        out[name + "_adj"] = adj
+        print("g9", name, "overlapping pairs", int(over.sum() - n) // 2, "adjacent pairs", int(adj.sum() - n) // 2)
+    out["names"] = np.array(list(sets))
+    np.savez_compressed(os.path.join(HERE, "g9_overlap.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()["gen_" + w]()

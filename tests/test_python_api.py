@@ -304,3 +304,29 @@ def test_find_adjacent_regions(pc, name):
     adj2 = p2p.find_adjacent_regions(mixed).toarray()
     want01 = int(g[name + "_adj"][0, 2] or g[name + "_adj"][1, 2])
     assert adj2[0, 1] == want01 == adj2[1, 0] and adj2[2, 2] == 1
+
+
+# ------------------------------------------------------------------ Partition.are_disjoint / compute_adj
+@pytest.mark.parametrize("name", ["grid2", "grid3", "rand2", "rand3"])
+def test_overlap_and_compute_adj(pc, name):
+    """prop2partition.are_disjoint's pair test (is_fulldim(region.intersect(other)), ref :146-149) and
+    MetricPartition.compute_adj (:244-306) for all pairs at once, against the reference's own loops."""
+    from polytope_amd import prop2partition as p2p
+    g = load_golden("g9_overlap.npz")
+    cells = [pc.Polytope(A, b) for A, b in zip(g[name + "_A"], g[name + "_b"])]
+    over = p2p.overlap_matrix_dense(cells)
+    assert np.array_equal(over, g[name + "_over"])
+    want_disjoint = not (g[name + "_over"] & ~np.eye(len(cells), dtype=bool)).any()
+    assert p2p.are_disjoint(cells) == want_disjoint == p2p.are_disjoint(cells, check_all=True)
+    adj, ok = p2p.compute_adj([pc.Region([c]) for c in cells])
+    assert ok and np.array_equal(adj.toarray() != 0, g[name + "_adj"] != 0)
+    _, ok2 = p2p.compute_adj(cells, previous=adj)
+    assert ok2
+    wrong = adj.copy()
+    wrong[0, len(cells) - 1] = 0 if wrong[0, len(cells) - 1] else 1
+    assert not p2p.compute_adj(cells, previous=wrong)[1]
+    # regions with several member polytopes: overlap if any member pair overlaps
+    regs = [pc.Region(cells[:2]), pc.Region(cells[2:4]), cells[-1]]
+    o3 = p2p.overlap_matrix_dense(regs)
+    go = g[name + "_over"]
+    assert o3[0, 1] == go[:2, 2:4].any() and o3[0, 2] == go[:2, -1].any() and o3[1, 2] == go[2:4, -1].any()
