@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <initializer_list>
+
 #include "../../include/plp.h"
 #include "plp_kernels.hpp"
 
@@ -33,6 +35,7 @@ struct plp_ctx {
     hipStream_t stream;
     char* arena;
     size_t arena_bytes;
+    char* pin;  // pinned host mirror of the first SMALL_XFER bytes of the arena (small calls: one copy each way)
 };
 
 namespace {
@@ -59,6 +62,75 @@ int ensure_arena(plp_ctx* ctx, size_t bytes) {
     size_t want = bytes + bytes / 4;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->arena), want));
     ctx->arena_bytes = want;
+    return PLP_OK;
+}
+
+// Host-pointer calls whose buffers fit SMALL_XFER move them through the pinned mirror: the inputs are
+// gathered into it and cross PCIe as ONE copy, likewise the outputs.  A pageable hipMemcpyAsync of a few
+// hundred bytes costs 10-20 us, and the set operations issue hundreds of small batches (region_diff: one
+// per search level), so six copies per call were most of such a call.  Large calls copy each array directly.
+constexpr size_t SMALL_XFER = 1u << 20;
+
+struct Span {
+    void* dev;
+    const void* host_in;  // copy_in source (or nullptr)
+    void* host_out;       // copy_out destination (or nullptr)
+    size_t bytes;
+};
+
+int ensure_pin(plp_ctx* ctx) {
+    if (ctx->pin) return PLP_OK;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), SMALL_XFER, hipHostMallocDefault));
+    return PLP_OK;
+}
+
+bool fits_small(plp_ctx* ctx, std::initializer_list<Span> spans) {
+    for (const Span& sp : spans) {
+        if (!sp.bytes) continue;
+        const size_t end = (size_t)(static_cast<char*>(sp.dev) - ctx->arena) + sp.bytes;
+        if (end > SMALL_XFER) return false;
+    }
+    return true;
+}
+
+int copy_in(plp_ctx* ctx, hipStream_t st, std::initializer_list<Span> spans) {
+    if (fits_small(ctx, spans) && ensure_pin(ctx) == PLP_OK) {
+        size_t lo = SMALL_XFER, hi = 0;
+        for (const Span& sp : spans) {
+            if (!sp.bytes || !sp.host_in) continue;
+            const size_t off = (size_t)(static_cast<char*>(sp.dev) - ctx->arena);
+            memcpy(ctx->pin + off, sp.host_in, sp.bytes);
+            lo = off < lo ? off : lo;
+            hi = off + sp.bytes > hi ? off + sp.bytes : hi;
+        }
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(ctx->arena + lo, ctx->pin + lo, hi - lo, hipMemcpyHostToDevice, st));
+        return PLP_OK;
+    }
+    for (const Span& sp : spans)
+        if (sp.bytes && sp.host_in) HIP_TRY(hipMemcpyAsync(sp.dev, sp.host_in, sp.bytes, hipMemcpyHostToDevice, st));
+    return PLP_OK;
+}
+
+// copies the outputs to the host and synchronises the stream
+int copy_out(plp_ctx* ctx, hipStream_t st, std::initializer_list<Span> spans) {
+    if (fits_small(ctx, spans) && ensure_pin(ctx) == PLP_OK) {
+        size_t lo = SMALL_XFER, hi = 0;
+        for (const Span& sp : spans) {
+            if (!sp.bytes || !sp.host_out) continue;
+            const size_t off = (size_t)(static_cast<char*>(sp.dev) - ctx->arena);
+            lo = off < lo ? off : lo;
+            hi = off + sp.bytes > hi ? off + sp.bytes : hi;
+        }
+        if (hi > lo) HIP_TRY(hipMemcpyAsync(ctx->pin + lo, ctx->arena + lo, hi - lo, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (const Span& sp : spans)
+            if (sp.bytes && sp.host_out)
+                memcpy(sp.host_out, ctx->pin + (size_t)(static_cast<char*>(sp.dev) - ctx->arena), sp.bytes);
+        return PLP_OK;
+    }
+    for (const Span& sp : spans)
+        if (sp.bytes && sp.host_out) HIP_TRY(hipMemcpyAsync(sp.host_out, sp.dev, sp.bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return PLP_OK;
 }
 
@@ -108,6 +180,7 @@ int plp_ctx_create(int device, plp_ctx** out) {
     ctx->device = device;
     ctx->arena = nullptr;
     ctx->arena_bytes = 0;
+    ctx->pin = nullptr;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -121,6 +194,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (!ctx) return PLP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PLP_OK;
@@ -170,18 +244,13 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
     int32_t* dst = a.take<int32_t>(B);
     int32_t* dit = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(dc, c, nc * 8, hipMemcpyHostToDevice, st));
-    if (nG) HIP_TRY(hipMemcpyAsync(dG, G, nG * 8, hipMemcpyHostToDevice, st));
-    if (nh) HIP_TRY(hipMemcpyAsync(dh, h, nh * 8, hipMemcpyHostToDevice, st));
-    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = copy_in(ctx, st, {{dc, c, nullptr, nc * 8}, {dG, G, nullptr, nG * 8}, {dh, h, nullptr, nh * 8},
+                           {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    if (rc) return rc;
     rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(x, dx, nc * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(fun, dfun, B * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters, dit, B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return PLP_OK;
+    return copy_out(ctx, st, {{dx, nullptr, x, nc * 8}, {dfun, nullptr, fun, (size_t)B * 8},
+                              {dst, nullptr, status, (size_t)B * 4}, {dit, nullptr, iters, iters ? (size_t)B * 4 : 0}});
 }
 
 // ------------------------------------------------------------------------------- cheby
@@ -217,16 +286,12 @@ int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, 
     double* dxc = a.take<double>(nx);
     int32_t* dst = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    if (nA) HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
-    if (nb) HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
-    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    if (rc) return rc;
     rc = plp_cheby_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dr, dxc, dst);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(r, dr, B * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(xc, dxc, nx * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status, dst, B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return PLP_OK;
+    return copy_out(ctx, st, {{dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
+                              {dst, nullptr, status, (size_t)B * 4}});
 }
 
 // ------------------------------------------------------------------------------- reduce
@@ -267,18 +332,13 @@ int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A,
     double* dxc = a.take<double>(nx);
     int32_t* dnlp = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    if (nA) HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
-    if (nb) HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
-    if (m) HIP_TRY(hipMemcpyAsync(dm, m, B * 4, hipMemcpyHostToDevice, st));
+    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    if (rc) return rc;
     rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(keep, dkeep, B * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(flags, dfl, B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(r, dr, B * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(xc, dxc, nx * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(nlp, dnlp, B * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return PLP_OK;
+    return copy_out(ctx, st, {{dkeep, nullptr, keep, (size_t)B * 8}, {dfl, nullptr, flags, (size_t)B * 4},
+                              {dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
+                              {dnlp, nullptr, nlp, (size_t)B * 4}});
 }
 
 // ------------------------------------------------------------------------------- contains
