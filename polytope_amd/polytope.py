@@ -721,6 +721,21 @@ def _members(s):
     return [p for p in s.list_poly if not is_empty(p)]
 
 
+# Region.intersect / mldivide call union(check_convex=True) once per new piece, and every call repeats
+# the greedy merge over ALL pieces gathered so far (ref :815-830, :1214-1224): the same groups are tested
+# for convexity again and again.  The verdict is a pure function of the members' (A, b), so it is kept.
+_convex_memo = {}
+_CONVEX_MEMO_MAX = 50000
+
+
+def _content_key(p):
+    key = getattr(p, "_ckey", None)
+    if key is None or key[0] is not p.A or key[1] is not p.b:
+        key = (p.A, p.b, (p.A.shape, p.A.tobytes(), p.b.tobytes()))  # exact content, no hash collisions
+        p._ckey = key
+    return key[2]
+
+
 def union(polyreg1, polyreg2, check_convex=False):
     """Union as a Region of non-overlapping polytopes; with check_convex the pieces are greedily
     merged whenever their union is convex (ref :1166-1238)."""
@@ -743,12 +758,33 @@ def union(polyreg1, polyreg2, check_convex=False):
         return Region(lst)
     if len(lst) <= 1:
         return Region(lst)
+    # Bounding boxes of all pieces in one batch.  A candidate whose box is separated from the box of every
+    # member of the (convex) group by a clear gap cannot make a convex union with it -- the union would not
+    # even be connected, and is_convex would find the gap in envelope \ union -- so the envelope /
+    # region_diff test is skipped for it; the outcome of the greedy merge (ref :1214-1224) is unchanged.
+    todo = [p for p in lst if p.bbox is None and not is_empty(p)]
+    for p, box in zip(todo, _bbox_raw(todo)):
+        p.bbox = box
+    gap_tol = 1e-4
+
+    def apart(p, q):
+        (pl, pu), (ql, qu) = p.bbox, q.bbox
+        return bool(np.any(pl - qu > gap_tol) or np.any(ql - pu > gap_tol))
+
     final = []
     while lst:
         group = [lst[0]]
         for cand in lst[1:]:
+            if cand.bbox is not None and all(m.bbox is not None and apart(cand, m) for m in group):
+                continue
             group.append(cand)
-            convex, _ = is_convex(Region(group))
+            key = frozenset(_content_key(m) for m in group)
+            convex = _convex_memo.get(key)
+            if convex is None:
+                convex, _ = is_convex(Region(group))
+                if len(_convex_memo) >= _CONVEX_MEMO_MAX:
+                    _convex_memo.clear()
+                _convex_memo[key] = convex
             if not convex:
                 group.pop()
         lst = [p for p in lst if not any(p is q for q in group)]
