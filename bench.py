@@ -204,11 +204,12 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
         # passes (scripts/gpu_check.sh), whose summary is committed by scripts/summarize_profiles.py
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, {}
         try:
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_launch"]
+            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_issue_frac_at_2p4GHz") if k in tj}
             traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
         except Exception:
             pass
@@ -233,9 +234,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_kernel<3, 4>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "FP64-VALU/latency bound: %.3g LP/s inside the kernel"
-                                 % (nlp_local / (kern_ms * 1e-3))},
+                         "note": "FP64-VALU issue bound, not HBM bound: %.3g LP/s inside the kernel" % (
+                             nlp_local / (kern_ms * 1e-3))},
         }
+        if valu:  # PMC SQ_INSTS_VALU of the same kernel: 4 issue cycles per wave64 instruction, 1024 SIMDs
+            line["roofline"]["valu_insts_per_launch"] = valu.get("valu_insts_per_launch")
+            line["roofline"]["valu_issue_frac_at_2p4GHz"] = valu.get("valu_issue_frac_at_2p4GHz")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, b, None)
         print(json.dumps(line), flush=True)

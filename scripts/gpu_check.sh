@@ -21,7 +21,7 @@ if [ "${1:-}" != "quick" ]; then
 fi
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 PMC passes (separate runs, counters only)"
-  for ctr in FETCH_SIZE WRITE_SIZE; do
+  for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_BUSY_CYCLES; do
     (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_$ctr" -o reduce -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$ctr.log" 2>&1)
     f=$(find gpurun_out/pmc_$ctr -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python - "$f" $ctr <<'PY'

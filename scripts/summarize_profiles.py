@@ -18,8 +18,11 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "prof", "reduce_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.log"), os.path.join(dst, tag + "_bench.json"))
 vals = {}
-for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    rows = list(csv.DictReader(open(os.path.join(src, "pmc_" + ctr, "reduce_counter_collection.csv"))))
+for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES"):
+    path = os.path.join(src, "pmc_" + ctr, "reduce_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    rows = list(csv.DictReader(open(path)))
     mine = [r for r in rows if "plp::" in r["Kernel_Name"]]
     with open(os.path.join(dst, "%s_pmc_%s.csv" % (tag, ctr)), "w") as f:
         w = csv.writer(f)
@@ -40,6 +43,11 @@ traffic = {
     "hbm_bytes_per_launch": vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024,
     "rocprof_avg_kernel_ns": float(k["AverageNs"]), "rocprof_calls": int(k["Calls"]),
 }
+if "SQ_INSTS_VALU" in vals:
+    # every VALU instruction of a wave64 occupies its SIMD's issue port for 4 cycles; 256 CUs x 4 SIMDs
+    traffic["valu_insts_per_launch"] = vals["SQ_INSTS_VALU"]
+    traffic["valu_issue_cycles_per_simd"] = vals["SQ_INSTS_VALU"] * 4 / 1024
+    traffic["valu_issue_frac_at_2p4GHz"] = vals["SQ_INSTS_VALU"] * 4 / 1024 / (float(k["AverageNs"]) * 2.4)
 json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
