@@ -100,15 +100,14 @@ def are_disjoint(partition, check_all=False):
     `check_all` only the first offending pair of the first offending region is reported."""
     regions = _regions_of(partition)
     over = overlap_matrix_dense(regions)
-    ok = True
-    for i in range(len(regions)):
-        for j in range(i):
-            if over[i, j]:
-                logger.error("PPP is not a partition, regions: %d and: %d intersect each other.", i, j)
-                ok = False
-                if not check_all:
-                    break
-    return ok
+    ii, jj = np.nonzero(np.tril(over, -1))  # offending pairs, i ascending then j ascending
+    seen = set()
+    for i, j in zip(ii.tolist(), jj.tolist()):
+        if not check_all and i in seen:
+            continue  # the reference breaks out of the inner loop at the first offender of region i
+        seen.add(i)
+        logger.error("PPP is not a partition, regions: %d and: %d intersect each other.", i, j)
+    return ii.size == 0
 
 
 def compute_adj(partition, previous=None):
