@@ -1028,6 +1028,7 @@ def volume(polyreg, nsamples=None, seed=None):
     if not is_fulldim(polyreg):
         return 0.0
     if isinstance(polyreg, Region):
+        bounding_box(polyreg)  # the members' boxes in one batch of 2d LPs each, cached for the calls below
         tot = 0.0
         for p in polyreg.list_poly:
             tot += volume(p)
