@@ -134,7 +134,7 @@ def main():
     import torch
     import polytope_amd as pa
     from polytope_amd import _lib
-    from polytope_amd.dist import pack_results, allgather_packed
+    from polytope_amd.dist import pack_results, GatherPipeline
     from polytope_amd.synth import random_hpolytopes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,28 +158,36 @@ def main():
 
     A, b = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=0, stream=rank)
     At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
-    counts = [B_PER_GPU] * world
+
+    # N > 1: the all-gather of step k overlaps the reduce kernel of step k+1 (RCCL stream vs compute stream);
+    # every step's results are gathered on every rank before the timed region ends (flush below)
+    pipe = GatherPipeline(torch, dist, B_PER_GPU, 3, device=dev) if world > 1 else None
 
     def step():
-        res = pa.reduce_batch(At, bt)  # one fused kernel on torch's current stream
-        if world > 1:
-            return res, allgather_packed(torch, dist, pack_results(torch, res), counts)
-        return res, None
+        res = pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
+        if pipe is not None:
+            pipe.push(pack_results(torch, res))
+        return res
 
     for _ in range(args.warmup):
         step()
+    if pipe is not None:
+        pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gathered = None
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         res = pa.reduce_batch(At, bt)
         ev[k][1].record()  # brackets exactly the reduce kernel on the stream it is launched on
-        if world > 1:
-            gathered = allgather_packed(torch, dist, pack_results(torch, res), counts)
+        if pipe is not None:
+            pipe.push(pack_results(torch, res))
+    if pipe is not None:
+        gathered = pipe.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -229,7 +237,7 @@ def main():
             "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1])"
                                    % (B_PER_GPU, DIM, M_ROWS),
                        "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU,
-                       "parallelism": "batch-sharded x%d + all-gather of packed results" % world},
+                       "parallelism": "batch-sharded x%d + all-gather of packed results (overlapped with the next batch)" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_kernel<3, 4>", "kernel_ms": kern_ms,

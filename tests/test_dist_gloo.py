@@ -161,7 +161,7 @@ def _grid_cells(shape):
 
 def _worker_adj_hull(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    import torch  # noqa: F401
+    import torch
     import torch.distributed as dist
     from polytope_amd import dist as pdist
     from oracle import oracle as O
@@ -178,6 +178,17 @@ def _worker_adj_hull(rank, world, port, q):
             out[p - p_lo] = 1 if (st == 0 and r > tol / 10) else 0
         return out
 
+    # overlapped exchange: push k returns the gathered rows of push k-1
+    pipe = pdist.GatherPipeline(torch, dist, rows=5, cols=3)
+    got = []
+    for k in range(4):
+        prev = pipe.push(torch.full((5, 3), 100 * k + rank, dtype=torch.int64))
+        got.append(None if prev is None else prev.clone())  # the buffer is reused two pushes later
+    got.append(pipe.flush())
+    assert got[0] is None
+    for k in range(4):
+        want = torch.cat([torch.full((5, 3), 100 * k + r, dtype=torch.int64) for r in range(world)])
+        assert torch.equal(got[k + 1], want), (k, rank)
     adj = pdist.adjacent_pairs_sharded(A, b, pairs_fn=cpu_pairs).numpy()
     P = np.random.default_rng(3).standard_normal((3000, 3))
     np.random.seed(5)   # every rank draws the same start simplex
