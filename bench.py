@@ -134,7 +134,7 @@ def main():
     import torch
     import polytope_amd as pa
     from polytope_amd import _lib
-    from polytope_amd.dist import pack_results, GatherPipeline
+    from polytope_amd.dist import GatherPipeline, ResultBuffer
     from polytope_amd.synth import random_hpolytopes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,12 +161,19 @@ def main():
 
     # N > 1: the all-gather of step k overlaps the reduce kernel of step k+1 (RCCL stream vs compute stream);
     # every step's results are gathered on every rank before the timed region ends (flush below)
-    pipe = GatherPipeline(torch, dist, B_PER_GPU, 3, device=dev) if world > 1 else None
+    # The kernel writes its results straight into a flat exchange buffer (no packing kernels); two of them,
+    # because the gather of one batch is still in flight while the next batch is computed.
+    pipe = GatherPipeline(torch, dist, 24 * B_PER_GPU, 1, dtype=torch.uint8, device=dev) if world > 1 else None
+    bufs = [ResultBuffer(torch, B_PER_GPU, DIM, dev) for _ in range(2)] if world > 1 else None
+    nstep = [0]
 
     def step():
-        res = pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
-        if pipe is not None:
-            pipe.push(pack_results(torch, res))
+        if pipe is None:
+            return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
+        rb = bufs[nstep[0] & 1]
+        nstep[0] += 1
+        res = pa.reduce_batch(At, bt, out=rb.views)
+        pipe.push(rb.flat.view(-1, 1))
         return res
 
     for _ in range(args.warmup):
@@ -182,10 +189,15 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        res = pa.reduce_batch(At, bt)
+        if pipe is None:
+            res = pa.reduce_batch(At, bt)
+        else:
+            rb = bufs[nstep[0] & 1]
+            nstep[0] += 1
+            res = pa.reduce_batch(At, bt, out=rb.views)
         ev[k][1].record()  # brackets exactly the reduce kernel on the stream it is launched on
         if pipe is not None:
-            pipe.push(pack_results(torch, res))
+            pipe.push(rb.flat.view(-1, 1))
     if pipe is not None:
         gathered = pipe.flush()
     torch.cuda.synchronize()
@@ -205,7 +217,8 @@ def main():
         t = torch.tensor([nlp_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t)
         nlp_total = int(t.item())
-        assert gathered.shape[0] == world * B_PER_GPU
+        assert gathered.numel() == world * 24 * B_PER_GPU
+        assert int(bufs[0].split(gathered.view(-1))[0]["nlp"].sum().item()) > 0
 
     if rank == 0:
         alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope

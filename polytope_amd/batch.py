@@ -128,11 +128,14 @@ def cheby_ball_batch(A, b, m=None):
     return dict(r=r, xc=xc, status=status)
 
 
-def reduce_batch(A, b, m=None, abs_tol=1e-7):
+def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     """Fused reduce() (polytope.py:1053-1163) of B non-minrep polytopes.
 
     -> dict(keep uint64[B] (bit i = input row i kept), flags int32[B] (RF_*), r[B], xc[B,d],
             nlp int32[B] = LPs the reference would have issued for that polytope)
+    `out` (device path only): a dict of preallocated, contiguous CUDA tensors keep int64[B], flags
+    int32[B], r float64[B], xc float64[B,d], nlp int32[B] to write into (e.g. views of one exchange buffer,
+    polytope_amd.dist.ResultBuffer).
     """
     lib = _lib.load()
     if _is_torch(A):
@@ -141,11 +144,20 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7):
         b = _tprep(torch, b, torch.float64)
         m = _tprep(torch, m, torch.int32)
         B, m_max, d = A.shape
-        keep = torch.empty((B,), dtype=torch.int64, device=A.device)
-        flags = torch.empty((B,), dtype=torch.int32, device=A.device)
-        r = torch.empty((B,), dtype=torch.float64, device=A.device)
-        xc = torch.empty((B, d), dtype=torch.float64, device=A.device)
-        nlp = torch.empty((B,), dtype=torch.int32, device=A.device)
+        if out is not None:
+            keep, flags, r, xc, nlp = out["keep"], out["flags"], out["r"], out["xc"], out["nlp"]
+            want = ((keep, torch.int64, (B,)), (flags, torch.int32, (B,)), (r, torch.float64, (B,)),
+                    (xc, torch.float64, (B, d)), (nlp, torch.int32, (B,)))
+            for t, dt, shp in want:
+                if t.dtype != dt or tuple(t.shape) != shp or not t.is_contiguous() or t.device != A.device:
+                    raise ValueError("reduce_batch: `out` tensors must be contiguous CUDA tensors of the documented "
+                                     "dtype and shape")
+        else:
+            keep = torch.empty((B,), dtype=torch.int64, device=A.device)
+            flags = torch.empty((B,), dtype=torch.int32, device=A.device)
+            r = torch.empty((B,), dtype=torch.float64, device=A.device)
+            xc = torch.empty((B, d), dtype=torch.float64, device=A.device)
+            nlp = torch.empty((B,), dtype=torch.int32, device=A.device)
         _lib.check(lib.plp_reduce_batch_dev(ctx.handle, stream, B, m_max, d, _ptr(A), _ptr(b), _ptr(m), float(abs_tol),
                                             _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)),
                    "plp_reduce_batch_dev")

@@ -63,13 +63,36 @@ def allgather_packed(torch, dist, packed, counts):
     return torch.cat(parts, dim=0)
 
 
+class ResultBuffer:
+    """One flat exchange buffer per batch: [keep int64 | r float64 | flags int32 | nlp int32] x B = 24 B per
+    polytope, with typed views that reduce_batch(..., out=...) writes straight into, so that the all-gather
+    needs no packing kernels.  `split(flat)` gives the same views on a gathered [world * nbytes] buffer."""
+
+    def __init__(self, torch, B, d, device):
+        self.torch, self.B = torch, int(B)
+        self.nbytes = 24 * self.B
+        self.flat = torch.empty((self.nbytes,), dtype=torch.uint8, device=device)
+        self.views = self._views(self.flat)
+        self.views["xc"] = torch.empty((self.B, d), dtype=torch.float64, device=device)  # not exchanged
+
+    def _views(self, flat):
+        t, B = self.torch, self.B
+        return dict(keep=flat[0:8 * B].view(t.int64), r=flat[8 * B:16 * B].view(t.float64),
+                    flags=flat[16 * B:20 * B].view(t.int32), nlp=flat[20 * B:24 * B].view(t.int32))
+
+    def split(self, gathered):
+        """gathered uint8[world * nbytes] -> list (one per rank) of dict(keep, r, flags, nlp)"""
+        world = gathered.numel() // self.nbytes
+        return [self._views(gathered[k * self.nbytes:(k + 1) * self.nbytes]) for k in range(world)]
+
+
 class GatherPipeline:
     """Overlap the exchange step with the next batch: the all-gather of batch k (RCCL's stream) runs while
     the reduce kernel of batch k+1 runs on the compute stream.  xGMI is point-to-point: an 8-rank ring
     all-gather of 8 x 2.4 MB costs a good fraction of the 0.34 ms kernel, so it is taken off the
     critical path instead of being paid after every kernel.
 
-        pipe = GatherPipeline(torch, dist, rows=B, cols=3)
+        pipe = GatherPipeline(torch, dist, rows=B, cols=3)        # or rows=nbytes, cols=1, dtype=torch.uint8
         for batch in batches:
             res = reduce_batch(...)                 # compute stream
             gathered_prev = pipe.push(pack_results(torch, res))   # results of the PREVIOUS batch (or None);
