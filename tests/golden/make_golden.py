@@ -487,6 +487,17 @@ def gen_g8():
     np.random.seed(3)
     q = pc.qhull(sq)
     out["qsq_P"], out["qsq_A"], out["qsq_b"], out["qsq_V"] = sq, q.A, q.b, q.vertices
+    # BASELINE configs[0]: examples/randplot.py with N = 10 -- sample points in the unit square, qhull,
+    # extreme; plus reduce + cheby_ball of the hull (SURVEY 8d, C1 "plumbing")
+    np.random.seed(10)
+    Vr = np.random.rand(10, 2)
+    Pr = pc.qhull(Vr)
+    out["randplot_V"], out["randplot_A"], out["randplot_b"] = Vr, Pr.A, Pr.b
+    out["randplot_extreme"] = pc.extreme(Pr)
+    Pr2 = pc.reduce(pc.Polytope(Pr.A, Pr.b))
+    out["randplot_reduced_Ab"] = np.c_[Pr2.A, Pr2.b]
+    rr, xx = pc.cheby_ball(Pr2)
+    out["randplot_cheb"] = np.r_[rr, xx]
     np.savez_compressed(os.path.join(HERE, "g8_hull.npz"), **out)
     print("g8: ordered hulls, degenerate cube, extreme() d=1..4, qhull square")
 

@@ -254,3 +254,22 @@ def test_hull_abi_errors_without_device():
     from polytope_amd.batch import HullSession
     with pytest.raises(Exception):
         HullSession(np.zeros((10, 3)))
+
+
+def test_config1_randplot_plumbing(backend):
+    """BASELINE configs[0] (examples/randplot.py, N = 10): sample points in the unit square, qhull, extreme,
+    then reduce + cheby_ball of the hull -- the whole plumbing on one small input, against the reference."""
+    import polytope_amd.polytope as pc
+    g = load_golden("g8_hull.npz")
+    np.random.seed(10)
+    V = np.random.rand(10, 2)
+    assert np.array_equal(V, g["randplot_V"])
+    P = pc.qhull(V)
+    assert np.array_equal(P.A, g["randplot_A"]) and np.allclose(P.b, g["randplot_b"], rtol=0, atol=1e-12)
+    ext = pc.extreme(P)
+    assert ext.shape == g["randplot_extreme"].shape and np.allclose(ext, g["randplot_extreme"], rtol=0, atol=1e-9)
+    P2 = pc.reduce(pc.Polytope(P.A, P.b))
+    assert np.allclose(np.c_[P2.A, P2.b], g["randplot_reduced_Ab"], rtol=0, atol=1e-9)
+    r, xc = pc.cheby_ball(P2)
+    assert abs(r - g["randplot_cheb"][0]) <= 1e-9
+    assert np.max(P2.A @ xc + r - P2.b) <= 1e-9   # the centre is feasible (it need not be unique)
