@@ -146,7 +146,10 @@ int plp_assign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const double *X
  *   n.p - offset > abs_tol, else to -1.  The new facets get ids *new_id0 .. *new_id0 + n_new - 1.
  *   Out (per new facet): count[] points received, argmax[] the point furthest from it (-1 if none;
  *   lowest point index among exactly equal distances), maxd[] that distance (0 if none).
- * plp_hull_drop: owner[idx[i]] = -1 (start-simplex members, the apex just taken from its facet).
+ * plp_hull_drop: owner[idx[i]] = -1 (start-simplex members, the apex just taken from its facet).  The
+ *   indices are copied before the call returns; the update itself is enqueued and ordered before the
+ *   session's next call (reassign and read synchronise).
+ * A call moves its small arrays through one pinned block: one H2D copy, the kernels, one D2H copy.
  * plp_hull_read: copy owner[N] / dist[N] to the host (either may be NULL).
  * The "_dev" form is stateless: device pointers X, owner, dist, dead[new_id0] (uint8 per facet id),
  * normals, offsets, argmax, maxd, count; it enqueues on `stream` and returns.
