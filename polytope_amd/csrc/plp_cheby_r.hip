@@ -20,13 +20,17 @@ namespace plp {
 
 namespace {
 
-constexpr int CR = 4;  // rows per lane
+#ifndef PLP_ROWS_BIG_D
+#define PLP_ROWS_BIG_D 2
+#endif
+// rows per lane: 4 for d <= 8; 2 for d = 9..16, where four rows of up to 17 columns would not fit the VGPR file
+template <int D>
+struct RowsPerLane { static constexpr int value = D <= 8 ? 4 : PLP_ROWS_BIG_D; };
 
 // Solve the Chebyshev LP of the rows handed out by `rowA(rr, kk)` / `rowb(rr)` (rr = row index < m).
 // Returns the LP status; x[0..D-1] = centre, x[D] = radius, replicated over the group (valid if status 0).
-template <int D, int GS, bool FAST, class FA, class FB>
+template <int D, int GS, int R, bool FAST, class FA, class FB>
 __device__ __forceinline__ int cheby_r_lp(const Grp& g, bool valid, int m, int row0, FA rowA, FB rowb, double* x) {
-    constexpr int R = CR;
     SimplexR<D + 1, R, !FAST, true> S;
     S.reset(D + 1, m, row0);
     double qi[R];
@@ -83,14 +87,14 @@ __device__ __forceinline__ int cheby_r_lp(const Grp& g, bool valid, int m, int r
     return S.status;
 }
 
-template <int D, int GS, class FA, class FB>
+template <int D, int GS, int R, class FA, class FB>
 __device__ __forceinline__ int cheby_r_solve(const Grp& g, bool valid, int m, int row0, FA rowA, FB rowb, double* x,
                                              int force_retry) {
-    int st = cheby_r_lp<D, GS, true>(g, valid, m, row0, rowA, rowb, x);
+    int st = cheby_r_lp<D, GS, R, true>(g, valid, m, row0, rowA, rowb, x);
     if (force_retry) st = ST_RETRY;  // test hook (PLP_CHEBY_RETRY_ALL=1): every LP takes the hand-over below
     if (__any(st == ST_RETRY)) {  // rare: redo with the general engine (Bland's rule available)
         double x2[D + 1];
-        const int st2 = cheby_r_lp<D, GS, false>(g, valid & (st == ST_RETRY), m, row0, rowA, rowb, x2);
+        const int st2 = cheby_r_lp<D, GS, R, false>(g, valid & (st == ST_RETRY), m, row0, rowA, rowb, x2);
         if (st == ST_RETRY) {
             st = st2;
 #pragma unroll
@@ -114,13 +118,14 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
     const Grp g(GS);
     constexpr int gpb = BLOCK / GS;
     const int gib = threadIdx.x / GS;
-    const int row0 = g.gl * CR;
+    constexpr int R = RowsPerLane<D>::value;
+    const int row0 = g.gl * R;
     const long long p = (long long)blockIdx.x * gpb + gib;
     const bool valid = p < B;
     const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
     // lane l loads its 4 consecutive rows straight from HBM (4*D contiguous doubles)
     double x[D + 1];
-    const int st = cheby_r_solve<D, GS>(
+    const int st = cheby_r_solve<D, GS, R>(
         g, valid, m, row0, [&](int rr, int kk) { return A[(p * m_max + rr) * D + kk]; },
         [&](int rr) { return b[p * m_max + rr]; }, x, force_retry);
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     const Grp g(GS);
     constexpr int gpb = BLOCK / GS;
     const int gib = threadIdx.x / GS;
-    const int row0 = g.gl * CR;
+    constexpr int R = RowsPerLane<D>::value;
+    const int row0 = g.gl * R;
     const long long p = p_lo + (long long)blockIdx.x * gpb + gib;
     const bool valid = p < p_hi;
     // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     const int mi = valid ? (mrows ? mrows[i] : m_max) : 0;
     const int mj = valid ? (mrows ? mrows[j] : m_max) : 0;
     double x[D + 1];
-    const int st = cheby_r_solve<D, GS>(
+    const int st = cheby_r_solve<D, GS, R>(
         g, valid, mi + mj, row0,
         [&](int rr, int kk) { return A[(((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)) * D + kk]; },
         [&](int rr) { return b[((rr < mi) ? i : j) * m_max + ((rr < mi) ? rr : rr - mi)] + inflate; },  // b1 += abs_tol; b2 += abs_tol
@@ -177,6 +183,22 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (t < n) adj[t * n + t] = 1;
 }
+
+// lanes per LP for `rows` rows at R rows per lane: the smallest of 4 / 8 / 16 / 32 that holds them
+#define PLP_DISPATCH_GS(R, rows, CALL)                      \
+    do {                                                    \
+        if ((rows) <= 4 * (R)) { constexpr int GSV = 4; return CALL; }   \
+        if ((rows) <= 8 * (R)) { constexpr int GSV = 8; return CALL; }   \
+        if ((rows) <= 16 * (R)) { constexpr int GSV = 16; return CALL; } \
+        if constexpr ((R) < 4) {                            \
+            if ((rows) <= 32 * (R)) { constexpr int GSV = 32; return CALL; } \
+        }                                                   \
+        if constexpr ((R) < 2) {                            \
+            constexpr int GSV = 64;                         \
+            return CALL;                                    \
+        }                                                   \
+        return 1;                                           \
+    } while (0)
 
 static int force_retry_env() {
     const char* fr = getenv("PLP_CHEBY_RETRY_ALL");
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long
                                                                        double* __restrict__ fun,
                                                                        int* __restrict__ status,
                                                                        int* __restrict__ iters) {
-    constexpr int R = CR;
+    constexpr int R = RowsPerLane<N>::value;
     const Grp g(GS);
     constexpr int gpb = BLOCK / GS;
     const int gib = threadIdx.x / GS;
@@ -279,9 +301,8 @@ static int launch_lp_r_ng(long long B, int m_max, const double* c, const double*
 template <int N>
 static int launch_lp_r_n(long long B, int m_max, const double* c, const double* G, const double* h, const int* mrows,
                          double* x, double* fun, int* status, int* iters, hipStream_t st) {
-    if (m_max <= 16) return launch_lp_r_ng<N, 4>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
-    if (m_max <= 32) return launch_lp_r_ng<N, 8>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
-    return launch_lp_r_ng<N, 16>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
+    PLP_DISPATCH_GS(RowsPerLane<N>::value, m_max,
+                    (launch_lp_r_ng<N, GSV>(B, m_max, c, G, h, mrows, x, fun, status, iters, st)));
 }
 
 #define PLP_CASE_LPR(K) case K: return launch_lp_r_n<K>(B, m_max, c, G, h, mrows, x, fun, status, iters, st);
@@ -310,12 +331,10 @@ static int launch_cheby_r_dg(long long B, int m_max, const double* A, const doub
 template <int D>
 static int launch_cheby_r_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
                             double* xc, int* status, hipStream_t st) {
-    if (m_max <= 16) return launch_cheby_r_dg<D, 4>(B, m_max, A, b, mrows, r, xc, status, st);
-    if (m_max <= 32) return launch_cheby_r_dg<D, 8>(B, m_max, A, b, mrows, r, xc, status, st);
-    return launch_cheby_r_dg<D, 16>(B, m_max, A, b, mrows, r, xc, status, st);
+    PLP_DISPATCH_GS(RowsPerLane<D>::value, m_max, (launch_cheby_r_dg<D, GSV>(B, m_max, A, b, mrows, r, xc, status, st)));
 }
 
-// returns 0 when launched, 1 when this kernel does not apply (d > 8: one row per lane, plp_lp.hip)
+// returns 0 when launched, 1 when this kernel does not apply
 int launch_cheby_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                    double* xc, int* status, hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M) return 1;
@@ -328,6 +347,14 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
         case 6: return launch_cheby_r_d<6>(B, m_max, A, b, mrows, r, xc, status, st);
         case 7: return launch_cheby_r_d<7>(B, m_max, A, b, mrows, r, xc, status, st);
         case 8: return launch_cheby_r_d<8>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 9: return launch_cheby_r_d<9>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 10: return launch_cheby_r_d<10>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 11: return launch_cheby_r_d<11>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 12: return launch_cheby_r_d<12>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 13: return launch_cheby_r_d<13>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 14: return launch_cheby_r_d<14>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 15: return launch_cheby_r_d<15>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 16: return launch_cheby_r_d<16>(B, m_max, A, b, mrows, r, xc, status, st);
         default: return 1;
     }
 }
@@ -352,9 +379,8 @@ static int launch_adjacent_d(int n, int m_max, const double* A, const double* b,
                              double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                              hipStream_t st) {
     const int rows = 2 * m_max;
-    if (rows <= 16) return launch_adjacent_dg<D, 4>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
-    if (rows <= 32) return launch_adjacent_dg<D, 8>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
-    return launch_adjacent_dg<D, 16>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+    PLP_DISPATCH_GS(RowsPerLane<D>::value, rows,
+                    (launch_adjacent_dg<D, GSV>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st)));
 }
 
 #define PLP_CASE_ADJ(K) \
