@@ -729,11 +729,7 @@ _CONVEX_MEMO_MAX = 50000
 
 
 def _content_key(p):
-    key = getattr(p, "_ckey", None)
-    if key is None or key[0] is not p.A or key[1] is not p.b:
-        key = (p.A, p.b, (p.A.shape, p.A.tobytes(), p.b.tobytes()))  # exact content, no hash collisions
-        p._ckey = key
-    return key[2]
+    return (p.A.shape, p.A.tobytes(), p.b.tobytes())  # exact content (recomputed: arrays may be edited in place)
 
 
 def union(polyreg1, polyreg2, check_convex=False):
