@@ -130,7 +130,7 @@ static void launch_hull_d(long long N, const double* X, int* owner, double* dist
     hipLaunchKernelGGL(hull_init_kernel, dim3((n_new + 255) / 256), dim3(256), 0, st, n_new, mb, cn, am);
     if (N == 0) return;
     long long blocks = (N + BLOCK - 1) / BLOCK;
-    if (blocks > 256ll * 8) blocks = 256ll * 8;
+    if (blocks > 256ll * 4) blocks = 256ll * 4;  // more workgroups only add contention on the per-facet global atomics
     const int FS = n_new < HS_CAP ? n_new : HS_CAP;
     const size_t smem = (size_t)HF_CHUNK * (D + 1) * 8 + (size_t)FS * 12 + 16;
     hipLaunchKernelGGL(hull_reassign_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, N, X, owner, dist, dead,
