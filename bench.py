@@ -34,7 +34,6 @@ def cpu_baseline(A, b, nlp_per_poly):
     """Rank 0, N=1 only.  (i) the C oracle ('port') on a bounded sample of the same batch,
     one core; (ii) scipy.optimize.linprog called exactly as polytope/solvers.py:152-154 on
     the redundancy LPs of a smaller sample, 1 process and all cores."""
-    import numpy as np
     from oracle import oracle as O
     O.build()
     n = 40000
@@ -130,7 +129,6 @@ def main():
                     "exercise the N>1 code path with several ranks on one GPU)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import polytope_amd as pa
     from polytope_amd import _lib
