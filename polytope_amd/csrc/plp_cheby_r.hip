@@ -1,7 +1,8 @@
 // plp_cheby_r.hip -- stand-alone LP batches with four rows per lane (gfx950): Chebyshev-ball LPs (form F1,
 // polytope/polytope.py:1283-1288) and generic LPs whose origin is feasible:
 //
-//   lp_r_kernel<N,GS>       : lpsolve() batches (solvers.py:76-106), n <= 8, no phase 1 needed
+//   lp_r_kernel<N,GS>       : lpsolve() batches (solvers.py:76-106), n <= 8, origin feasible (no phase 1)
+//   lp_p1_r_kernel<N,GS>    : the LPs of such a batch that need phase 1 (some h_i < 0)
 //   cheby_r_kernel<D,GS>    : a batch of polytopes (cheby_ball / is_fulldim, :1241-1300, :962-985)
 //   adjacent_r_kernel<D,GS> : all pairs of n cells (is_adjacent(overlap=True), :1843-1866, under the pair
 //                             loop of find_adjacent_regions, prop2partition.py:57-61)
@@ -205,6 +206,12 @@ static int force_retry_env() {
     return (fr && fr[0] == '1') ? 1 : 0;
 }
 
+// Where the two-phase run on the fast path pays: measured on MI355X against the one-row-per-lane two-phase
+// kernel (100k LPs, m=16): n=3 1.35x, n=4 1.22x, n=5 1.0x, n=6 0.88x, n=8 0.7x (the extra column, the carried
+// cost row and the sign bookkeeping push four rows per lane past 250 VGPRs: one wave per SIMD), n=2 0.84x.
+template <int N>
+struct P1_FAST { static constexpr bool value = (N == 3 || N == 4); };
+
 // Generic LP  min c'x  s.t.  G x <= h, x free  (solvers.py:76-106) when the origin is feasible (every
 // h_i >= 0): phase 2 starts from the all-slack dictionary, which is what the two-phase kernel of
 // plp_lp.hip does too in that case, so both walk the same path.  LPs that need phase 1 (or, later,
@@ -265,8 +272,81 @@ __global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long
     S.mode = M_P2;
     if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
     else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
-    else if (need_p1) { S.mode = M_DONE; S.status = ST_RETRY; }
+    else if (need_p1) { S.mode = M_DONE; S.status = P1_FAST<N>::value ? ST_RETRY_P1 : ST_RETRY; }
     S.template run_fast<GS, false>(g);
+    const bool ok = S.status == ST_OPT;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    double f = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        bool found;
+        const double mine = S.x_of(j, found);
+        const uint64_t ob = grp_ballot(found, g);
+        const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+        const double xj = ob ? v : 0.0;
+        f = fma(cc[j], xj, f);
+        if (valid & (g.gl == 0)) x[lp * N + j] = ok ? xj : qnan;
+    }
+    if (valid & (g.gl == 0)) {
+        fun[lp] = ok ? f : qnan;
+        status[lp] = S.status;
+        if (iters) iters[lp] = S.iters;
+    }
+}
+
+// The LPs lp_r_kernel marked ST_RETRY_P1 (some h_i < 0): two-phase run on the fast path with the artificial
+// variable in an extra column and the real objective carried along; Bland cases leave with ST_RETRY for the
+// two-phase kernel of plp_lp.hip (third launch).
+template <int N, int GS>
+__global__ __launch_bounds__(BLOCK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long long B, int m_max,
+                                                                          const double* __restrict__ c,
+                                                                          const double* __restrict__ G,
+                                                                          const double* __restrict__ h,
+                                                                          const int* __restrict__ mrows,
+                                                                          double* __restrict__ x,
+                                                                          double* __restrict__ fun,
+                                                                          int* __restrict__ status,
+                                                                          int* __restrict__ iters) {
+    constexpr int R = RowsPerLane<N>::value;
+    const Grp g(GS);
+    constexpr int gpb = BLOCK / GS;
+    const int gib = threadIdx.x / GS;
+    const int row0 = g.gl * R;
+    const long long lp = (long long)blockIdx.x * gpb + gib;
+    const bool valid = (lp < B) && status[lp] == ST_RETRY_P1;
+    if (!__syncthreads_or(valid)) return;  // no LP of this workgroup needs phase 1
+    const int m = valid ? (mrows ? mrows[lp] : m_max) : 0;
+    SimplexR<N + 1, R, false, true, true> S;
+    S.reset(N, m, row0);
+    S.cv[N] = ID_TR;  // the artificial variable t sits in the last column (not free: reset leaves its cfree bit clear)
+    double cc[N], qi[R];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        cc[j] = valid ? c[lp * N + j] : 0.0;
+        S.cost2[j] = cc[j];
+    }
+    S.cost[N] = 1.0;  // phase 1: minimise t
+    unsigned actb = 0u;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool hr = valid & (row0 + k < m);
+        bool zero = true;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double v = hr ? G[(lp * m_max + row0 + k) * N + j] : 0.0;
+            S.T[k][j] = v;
+            zero = zero & (v == 0.0);
+        }
+        const double hk = hr ? h[lp * m_max + row0 + k] : 0.0;
+        const bool on = hr & !zero;
+        S.T[k][N] = on ? -1.0 : 0.0;
+        S.beta[k] = on ? hk : 0.0;
+        qi[k] = S.beta[k];
+        actb |= on ? (1u << k) : 0u;
+    }
+    S.ract = actb;
+    S.mode = valid ? M_P2 : M_DONE;
+    S.template run_two_phase<GS>(g, qi, actb, valid);
     const bool ok = S.status == ST_OPT;
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     double f = 0.0;
@@ -295,6 +375,9 @@ static int launch_lp_r_ng(long long B, int m_max, const double* c, const double*
     if (blocks > 2147483647ll) return 1;
     hipLaunchKernelGGL((lp_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max, c,
                        G, h, mrows, x, fun, status, iters);
+    if constexpr (P1_FAST<N>::value)
+        hipLaunchKernelGGL((lp_p1_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B,
+                           m_max, c, G, h, mrows, x, fun, status, iters);
     return 0;
 }
 

@@ -10,6 +10,7 @@ enum : int { ST_OPT = 0, ST_ITER = 1, ST_INFEAS = 2, ST_UNBND = 3, ST_NUM = 4 };
 // internal: the fast pivot path met a dictionary that needs Bland's rule; the LP is redone by the
 // general engine (never leaves the library)
 constexpr int ST_RETRY = 5;
+constexpr int ST_RETRY_P1 = 6;  // internal: generic LP that needs phase 1 (second kernel of launch_lp_r)
 
 // flags written by the fused reduce kernel (reference: polytope/polytope.py:1053-1163)
 enum : int {

@@ -22,7 +22,12 @@ namespace plp {
 
 // TRACKX = false drops the sign bookkeeping of the free variables (rneg / cneg): callers that only
 // read the optimal VALUE off the dictionary (F2, F3) never ask for x.
-template <int NC, int R, bool INITM, bool TRACKX = true>
+// CARRY = true (fast path only): a second cost row (cost2 / negz2) is carried through the pivots and columns
+// can be marked dead -- phase 1 of the generic LP, which minimises the artificial variable while the real
+// objective rides along (plp_simplex.hpp does the same with one row per lane).
+constexpr int ID_TR = -1;  // id of the phase-1 artificial variable
+
+template <int NC, int R, bool INITM, bool TRACKX = true, bool CARRY = false>
 struct SimplexR {
     // ---- my R rows
     double T[R][NC];
@@ -32,6 +37,8 @@ struct SimplexR {
     unsigned ract;    // bit k: row k takes part in ratio tests
     // ---- replicated per group
     double cost[NC], negz;
+    double cost2[CARRY ? NC : 1], negz2;  // carried objective (CARRY)
+    unsigned dead;    // bit j: column j never enters (CARRY)
     int cv[NC];       // id of the nonbasic variable of column j
     unsigned cneg;    // bit j: column j holds -x
     unsigned cfree;   // bit j: column j holds a free (structural) variable
@@ -48,6 +55,10 @@ struct SimplexR {
         rneg = 0u;
         ract = 0u;
         negz = 0.0;
+        negz2 = 0.0;
+        dead = 0u;
+#pragma unroll
+        for (int j = 0; j < (CARRY ? NC : 1); ++j) cost2[j] = 0.0;
         cneg = 0u;
         cfree = n_ >= 32 ? 0xffffffffu : ((1u << n_) - 1u);
         ndeg = 0;
@@ -353,22 +364,28 @@ struct SimplexR {
             // free column: clear the sign (|c|); bounded column: flip it (-c)
             const int khi = (hi ^ (int)0x80000000) & ~((int)(cfree << (31 - j)) & (int)0x80000000);
             const double key = __hiloint2double(khi, __double2loint(cost[j]));
-            const bool take = key > best;
+            bool take = key > best;
+            if constexpr (CARRY) take = take & (((dead >> j) & 1u) == 0u);
             e = take ? j : e;
             chi = take ? hi : chi;
-            best = fmax(best, key);
+            if constexpr (CARRY) best = take ? key : best;  // a dead column must not raise the bar
+            else best = fmax(best, key);
         }
     }
 
-    // One pivot.  FORCED = false: Dantzig column (e, best, chi) from the last scan, ratio test on my rows.
-    // FORCED = true: the forced first pivot of the Chebyshev LP (plp_simplex.hpp, M_INIT): the LAST
-    // column enters, the leaving row is the eligible one (bits of ielig) with the smallest caller-supplied
-    // signed ratio qinit[k]; basic values rounded below zero by this pivot are clamped.
-    template <int GS, bool FORCED>
+    // One pivot.  KIND 0: Dantzig column (e, best, chi) from the last scan, ratio test on my rows.
+    // KIND 1: a forced pivot (plp_simplex.hpp, M_INIT): the LAST column enters, the leaving row is the eligible
+    // one (bits of ielig) with the smallest caller-supplied signed ratio qinit[k]; basic values rounded below
+    // zero by this pivot are clamped.  KIND 2: the same with the entering column e given by the caller per
+    // group (M_DRIVE: the artificial variable is pivoted out of the basis after phase 1); neither forced
+    // kind re-chooses the entering column afterwards when KIND is 2.
+    template <int GS, int KIND>
     __device__ __forceinline__ void pivot_core(const Grp& g, int& e, double& best, int& chi, const double* qinit,
                                                unsigned ielig) {
+        constexpr bool FORCED = KIND != 0;
         const bool running = mode != M_DONE;
         bool act = running;
+        if constexpr (KIND == 2) act = running & (e >= 0);
         if constexpr (!FORCED) {
             const bool over = running & (iters >= maxit);
             if (over) { status = ST_ITER; mode = M_DONE; }
@@ -378,8 +395,11 @@ struct SimplexR {
         double a[R];
         int vin;
         unsigned efree, eneg = 0u;
-        if constexpr (FORCED) {
+        double c2e = 0.0, cfe = 0.0;  // cost2[e] (CARRY), cost[e] (forced kinds)
+        if constexpr (KIND == 1) {
             e = NC - 1;
+            cfe = cost[NC - 1];
+            if constexpr (CARRY) c2e = cost2[NC - 1];
             vin = cv[NC - 1];
 #pragma unroll
             for (int k = 0; k < R; ++k) a[k] = T[k][NC - 1];
@@ -387,6 +407,8 @@ struct SimplexR {
             if constexpr (TRACKX) eneg = (cneg >> (NC - 1)) & 1u;
         } else {
             vin = cv[0];
+            if constexpr (CARRY) c2e = cost2[0];
+            if constexpr (KIND == 2) cfe = cost[0];
 #pragma unroll
             for (int k = 0; k < R; ++k) a[k] = T[k][0];
 #pragma unroll
@@ -395,12 +417,15 @@ struct SimplexR {
 #pragma unroll
                     for (int k = 0; k < R; ++k) a[k] = T[k][j];
                     vin = cv[j];
+                    if constexpr (CARRY) c2e = cost2[j];
+                    if constexpr (KIND == 2) cfe = cost[j];
                 }
             }
-            // c > 0: the free variable enters downwards, x := -x
-            const int sgn = (chi >= 0) ? (int)0x80000000 : 0;
+            // c > 0: the free variable enters downwards, x := -x  (never for a forced pivot)
+            const int sgn = (KIND == 0 && chi >= 0) ? (int)0x80000000 : 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) a[k] = __hiloint2double(__double2hiint(a[k]) ^ sgn, __double2loint(a[k]));
+            if constexpr (CARRY) c2e = __hiloint2double(__double2hiint(c2e) ^ sgn, __double2loint(c2e));
             efree = (cfree >> (e & 31)) & 1u;
             if constexpr (TRACKX) eneg = ((cneg >> (e & 31)) & 1u) ^ ((unsigned)sgn >> 31);
         }
@@ -466,10 +491,16 @@ struct SimplexR {
         const int krow = __builtin_amdgcn_ds_bpermute(raddr, kb);
         // ------------------------------------------------ update
         // the (sign-normalised) reduced cost of the entering column
-        const double fc = act ? (FORCED ? cost[NC - 1] : -best) : 0.0;
+        const double fc = act ? (FORCED ? cfe : -best) : 0.0;
 #pragma unroll
         for (int j = 0; j < NC; ++j) cost[j] = fma(-fc, rho[j], cost[j]);
         negz = fma(-fc, rhob, negz);
+        const double fc2 = (CARRY && act) ? c2e : 0.0;
+        if constexpr (CARRY) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cost2[j] = fma(-fc2, rho[j], cost2[j]);
+            negz2 = fma(-fc2, rhob, negz2);
+        }
         double ea[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -481,12 +512,14 @@ struct SimplexR {
             ea[k] = -(f * p);
         }
         const double ec = -(fc * p);
+        const double ec2 = -(fc2 * p);
 #pragma unroll
-        for (int j = FORCED ? NC - 1 : 0; j < NC; ++j) {
+        for (int j = (KIND == 1) ? NC - 1 : 0; j < NC; ++j) {
             if (act & (e == j)) {  // the entering column now holds the leaving variable
 #pragma unroll
                 for (int k = 0; k < R; ++k) T[k][j] = ea[k];
                 cost[j] = ec;
+                if constexpr (CARRY) cost2[j] = ec2;
                 rho[j] = p;
                 cv[j] = TRACKX ? (vout >> 1) : vout;
                 if constexpr (TRACKX) cneg = (cneg & ~(1u << j)) | ((unsigned)(vout & 1) << j);
@@ -515,8 +548,10 @@ struct SimplexR {
             }
         }
         // ------------------------------------------------ next entering column = optimality test
-        scan_enter(e, best, chi);
-        if (act & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+        if constexpr (KIND != 2) {  // (after KIND 2 the caller swaps the cost rows first)
+            scan_enter(e, best, chi);
+            if (act & (e < 0)) { status = ST_OPT; mode = M_DONE; }
+        }
     }
 
     // Run to completion from a primal-feasible dictionary (mode M_P2, or M_DONE for idle lanes).
@@ -527,7 +562,7 @@ struct SimplexR {
         int e, chi;
         double best;
         if constexpr (FORCED) {
-            pivot_core<GS, true>(g, e, best, chi, qinit, ielig);
+            pivot_core<GS, 1>(g, e, best, chi, qinit, ielig);
         } else {
             scan_enter(e, best, chi);
             if ((mode != M_DONE) & (e < 0)) { status = ST_OPT; mode = M_DONE; }
@@ -536,8 +571,84 @@ struct SimplexR {
             // rare: Bland's rule lives in step(), kept out of this loop (and of its register budget);
             // the caller redoes the LP with the general engine
             if ((mode != M_DONE) & (ndeg >= BLAND_AFTER)) { status = ST_RETRY; mode = M_DONE; }
-            pivot_core<GS, false>(g, e, best, chi, nullptr, 0u);
+            pivot_core<GS, 0>(g, e, best, chi, nullptr, 0u);
         }
+    }
+
+    // Generic LP whose origin is infeasible (CARRY): the caller has put the artificial variable t (id ID_TR,
+    // -1 on every active row) in the LAST column, cost = e_t (phase 1: minimise t), cost2 = the real
+    // objective.  `on`: my group takes part.  Phase 1 = forced pivot "t enters on the smallest right-hand
+    // side" + Dantzig; then t is dropped (driven out of the basis first if it stayed basic at ~0) and the
+    // carried row becomes the cost row (plp_simplex.hpp: M_INIT -> M_P1 -> M_DRIVE -> M_P2, same pivots).
+    template <int GS>
+    __device__ __forceinline__ void run_two_phase(const Grp& g, const double* qinit, unsigned ielig, bool on) {
+        static_assert(CARRY && !INITM, "two-phase run: fast path with a carried cost row");
+        run_fast<GS, true>(g, qinit, ielig);
+        // ---- where phase 1 ended
+        const bool p1opt = on & (status == ST_OPT);
+        if (on & !p1opt & (status != ST_RETRY)) status = (status == ST_ITER) ? ST_ITER : ST_NUM;  // never unbounded
+        bool mine = false;   // one of my rows holds t
+        int tk = 0;
+        double tb = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool h = rv[k] == ID_TR;
+            mine = mine | h;
+            tk = h ? k : tk;
+            tb = h ? beta[k] : tb;
+        }
+        const uint64_t tbal = grp_ballot(mine, g);
+        const int rt = g.gbase + (tbal ? __ffsll((long long)tbal) - 1 : 0);
+        const double tval = bcast(tb, rt);
+        const bool basic = tbal != 0;
+        const bool infeas = p1opt & basic & (tval > TOL_FEAS);
+        bool drive = p1opt & basic & !infeas;
+        // t basic at ~0: pivot it out on the largest element of its row (columns still alive)
+        int eo = -1;
+        double big = TOL_PIV;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (mine & (tk == k)) {
+#pragma unroll
+                for (int j = 0; j < NC; ++j) {
+                    const double aj = fabs(T[k][j]);
+                    const bool tkj = (aj > big) & (((dead >> j) & 1u) == 0u);
+                    big = tkj ? aj : big;
+                    eo = tkj ? j : eo;
+                }
+            }
+        }
+        const int ed = bcast(eo, rt);
+        if (drive & (ed < 0)) {  // row "0 = t": redundant, t stays basic in a row that takes no further part
+            if (mine) ract &= ~(1u << tk);
+            drive = false;
+        }
+        if (infeas) status = ST_INFEAS;
+        const bool cont = p1opt & !infeas;
+        if (cont) { mode = M_P2; status = -1; }
+        int e = drive ? ed : -1, chi = 0;
+        double best = 0.0;
+        if (__any(e >= 0)) {
+            double qz[R];
+            unsigned tbits = 0u;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { qz[k] = 0.0; tbits |= (rv[k] == ID_TR) ? (1u << k) : 0u; }
+            pivot_core<GS, 2>(g, e, best, chi, qz, tbits);
+        }
+        if (cont) {  // the column that now holds t is dropped; the carried cost row becomes active
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (cv[j] == ID_TR) dead |= (1u << j);
+                cost[j] = cost2[j];
+            }
+            negz = negz2;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if ((((ract >> k) & 1u) != 0u) & (beta[k] < 0.0)) beta[k] = 0.0;
+            ndeg = 0;
+        }
+        // ---- phase 2
+        run_fast<GS, false>(g);
     }
 
     // value of structural variable j if one of my rows holds it (found = true)
