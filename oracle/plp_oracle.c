@@ -28,6 +28,11 @@
  *   plpo_contains      polytope/polytope.py:206-218, :732-746 (contains)
  *   plpo_assign        polytope/quickhull.py:117-121 (distance), :224-245 / :311-336
  *                      (outside-set assignment), :87-102 (get_furthest)
+ *   plpo_hull_reassign polytope/quickhull.py:273-283, :311-336, :87-102 (one iteration of the
+ *                      main loop: pooling, re-assignment, furthest point) on index arrays
+ *
+ * Pinned: every function is checked against the fixtures tests/golden/g1..g9 (outputs of the
+ * imported reference on seeded inputs, tests/test_oracle_golden.py, tests/test_quickhull.py).
  *
  * The pivot rules, tolerances and operation order of plpo_lp_solve are the ones the HIP
  * kernels use (polytope_amd/csrc/plp_simplex.hpp) so that CPU and GPU walk the same
