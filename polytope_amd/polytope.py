@@ -1159,3 +1159,52 @@ def extreme(poly1):
         raise AssertionError(a)
     poly1.vertices = np.asarray(V, dtype=float).reshape((int(a), nx))
     return poly1.vertices
+
+
+# ====================================================================================== small callers of the path
+def is_interior(r0, r1, abs_tol=ABS_TOL):
+    """The reference's `is_interior` (ref :1888-1909), reproduced as written there: every polytope of r1 is
+    enlarged by abs_tol, and the function returns True as soon as one of the enlarged polytopes is NOT a
+    subset of r0, False otherwise."""
+    if isinstance(r0, Polytope):
+        r0 = Region([r0])
+    if isinstance(r1, Polytope):
+        r1 = Region([r1])
+    for p in r1:
+        dummy = Polytope(p.A.copy(), p.b.copy() + abs_tol)
+        if not dummy <= r0:
+            return True
+    return False
+
+
+def separate(reg1, abs_tol=ABS_TOL):
+    """Divide a region into connected regions (ref :1795-1824).  The reference grows each component with
+    one is_adjacent(component, polytope) call per remaining polytope; a Region is adjacent to a polytope iff
+    one of its members is, so all member pairs are tested in ONE batch up front and the greedy pass of the
+    reference (same order, same result) runs on that matrix."""
+    members = reg1.list_poly
+    n = len(members)
+    ii, jj = np.tril_indices(n, -1)
+    adj = np.eye(n, dtype=bool)
+    if n > 1:
+        flags = is_adjacent_pairs([(members[i], members[j]) for i, j in zip(ii, jj)])
+        adj[ii, jj] = flags
+        adj[jj, ii] = flags
+    final = []
+    left = list(range(n))
+    props = reg1.props
+    while left:
+        comp = [left[0]]
+        for j in left[1:]:
+            if adj[comp, j].any():
+                comp.append(j)
+        reg = Region([members[k] for k in comp], [])
+        reg.props = props.copy()
+        final.append(reg)
+        left = [k for k in left if k not in comp]
+    return final
+
+
+def simplices2polytopes(points, triangles):
+    """Convert a simplicial mesh to polytopes in H-representation (ref :2419-2439): one qhull per simplex."""
+    return [qhull(points[triangle, :]) for triangle in triangles]

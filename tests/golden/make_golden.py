@@ -531,6 +531,24 @@ def gen_g9():
         out[name + "_adj"] = adj
         print("g9", name, "overlapping pairs", int(over.sum() - n) // 2, "adjacent pairs", int(adj.sum() - n) // 2)
     out["names"] = np.array(list(sets))
+    # separate(): two touching squares + one apart + one touching the third -> components (polytope.py:1795-1824)
+    sq = lambda x, y: pc.box2poly([[x, x + 1.0], [y, y + 1.0]])
+    reg = pc.Region([sq(0, 0), sq(3, 0), sq(1, 0), sq(3, 1), sq(6, 6)])
+    comps = alg.separate(reg)
+    out["sep_boxes"] = np.array([[0, 0], [3, 0], [1, 0], [3, 1], [6, 6]], dtype=float)
+    out["sep_sizes"] = np.array([len(c) for c in comps])
+    out["sep_first_b"] = np.array([c.list_poly[0].b for c in comps])
+    # is_interior(): the reference's own semantics (:1888-1909)
+    big, small, edge = pc.box2poly([[0, 4], [0, 4]]), pc.box2poly([[1, 2], [1, 2]]), pc.box2poly([[0, 1], [1, 2]])
+    out["interior"] = np.array([alg.is_interior(big, small), alg.is_interior(big, edge), alg.is_interior(small, big),
+                                alg.is_interior(pc.Region([big]), pc.Region([small, edge]))])
+    # simplices2polytopes(): a 2-triangle mesh of the unit square (:2419-2439)
+    pts = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]])
+    tri = np.array([[0, 1, 2], [0, 2, 3]])
+    np.random.seed(4)
+    polys = alg.simplices2polytopes(pts, tri)
+    out["mesh_pts"], out["mesh_tri"] = pts, tri
+    out["mesh_Ab"] = np.array([np.c_[p.A, p.b][np.lexsort(np.round(np.c_[p.A, p.b], 9).T[::-1])] for p in polys])
     np.savez_compressed(os.path.join(HERE, "g9_overlap.npz"), **out)
 
 

@@ -330,3 +330,23 @@ def test_overlap_and_compute_adj(pc, name):
     o3 = p2p.overlap_matrix_dense(regs)
     go = g[name + "_over"]
     assert o3[0, 1] == go[:2, 2:4].any() and o3[0, 2] == go[:2, -1].any() and o3[1, 2] == go[2:4, -1].any()
+
+
+def test_separate_interior_simplices(pc):
+    """The remaining small callers of the LP path: separate (ref :1795-1824), is_interior (:1888-1909, with the
+    reference's own semantics) and simplices2polytopes (:2419-2439), against the reference's outputs."""
+    g = load_golden("g9_overlap.npz")
+    sq = lambda x, y: pc.box2poly([[x, x + 1.0], [y, y + 1.0]])  # noqa: E731
+    reg = pc.Region([sq(*xy) for xy in g["sep_boxes"]])
+    comps = pc.separate(reg)
+    assert [len(c) for c in comps] == list(g["sep_sizes"])
+    assert np.allclose(np.array([c.list_poly[0].b for c in comps]), g["sep_first_b"])
+    big, small, edge = pc.box2poly([[0, 4], [0, 4]]), pc.box2poly([[1, 2], [1, 2]]), pc.box2poly([[0, 1], [1, 2]])
+    got = [pc.is_interior(big, small), pc.is_interior(big, edge), pc.is_interior(small, big),
+           pc.is_interior(pc.Region([big]), pc.Region([small, edge]))]
+    assert got == [bool(v) for v in g["interior"]]
+    np.random.seed(4)
+    polys = pc.simplices2polytopes(g["mesh_pts"], g["mesh_tri"])
+    for p, want in zip(polys, g["mesh_Ab"]):
+        Ab = np.c_[p.A, p.b]
+        assert np.allclose(Ab[np.lexsort(np.round(Ab, 9).T[::-1])], want, rtol=0, atol=1e-12)
