@@ -16,6 +16,11 @@ namespace plp {
 
 constexpr int RR = 4;  // rows per lane
 
+#ifndef PLP_REDUCE_R_BLOCK
+#define PLP_REDUCE_R_BLOCK 256
+#endif
+constexpr int RBLOCK = PLP_REDUCE_R_BLOCK;  // threads per workgroup
+
 static inline int group_size_r(int m_max) {
     if (m_max <= 16) return 4;
     if (m_max <= 32) return 8;
@@ -23,7 +28,7 @@ static inline int group_size_r(int m_max) {
 }
 
 static inline size_t reduce_r_smem_bytes(int gs, int D) {
-    const int NG = BLOCK / gs;
+    const int NG = RBLOCK / gs;
     return ((size_t)NG * gs * RR * (D + 2) * 8 + 15) & ~(size_t)15;  // A rows, b, 1/||a||
 }
 
@@ -49,7 +54,7 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 #endif
 
 template <int D, int GS>
-__global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int gs = GS;
     const Grp g(gs);
-    constexpr int NG = BLOCK / gs;
+    constexpr int NG = RBLOCK / gs;
     constexpr int rows = gs * R;  // row slots per polytope
     const int gib = threadIdx.x / gs;
     const int row0 = g.gl * R;  // my first row
@@ -78,12 +83,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
         {
             const int rowsz = m_max * D;
             const double* src = Ag + tile * rowsz;
-            for (int idx = threadIdx.x; idx < ntile * rowsz; idx += BLOCK) {
+            for (int idx = threadIdx.x; idx < ntile * rowsz; idx += RBLOCK) {
                 const int p = idx / rowsz, rem = idx - p * rowsz;
                 sA[(size_t)p * rows * D + rem] = src[idx];
             }
             const double* srcb = bg + tile * m_max;
-            for (int idx = threadIdx.x; idx < ntile * m_max; idx += BLOCK) {
+            for (int idx = threadIdx.x; idx < ntile * m_max; idx += RBLOCK) {
                 const int p = idx / m_max, row = idx - p * m_max;
                 sb[p * rows + row] = srcb[idx];
             }
@@ -374,7 +379,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
                              double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                              hipStream_t st) {
     const size_t smem = reduce_r_smem_bytes(GS, D);
-    const long long NG = BLOCK / GS;
+    const long long NG = RBLOCK / GS;
     long long blocks = (B + NG - 1) / NG;
     if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
     if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
@@ -382,7 +387,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    hipLaunchKernelGGL((reduce_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, A, b, mrows,
+    hipLaunchKernelGGL((reduce_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
                        abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
     return 0;
 }
