@@ -840,15 +840,47 @@ def mldivide(a, b, save=False):
         b = Region([b])
     if isinstance(a, Region):
         out = Region()
+        subs = b.list_poly
         for poly in a:
+            # Which subtrahends touch this polytope at all?  One batch of Chebyshev LPs on the stacked rows
+            # instead of one region_diff call per subtrahend: a subtrahend whose intersection with `poly` has
+            # radius < ABS_TOL leaves `poly` -- and every piece cut from it later -- unchanged (region_diff
+            # returns its minuend when nothing intersects, ref :2154-2158), so the chain below skips it.
+            touching = subs
+            if _use_hip() and len(subs) > 1 and not is_empty(poly):
+                live = [c for c in subs if c.A.size]
+                keep = iter(_radii_stacked(poly, live))
+                touching = [c for c in subs if not c.A.size or next(keep) >= ABS_TOL]
             rest = poly
-            for sub in b:
+            for sub in touching:
                 rest = mldivide(rest, sub, save=save)
             out = union(out, rest, check_convex=True)
         return out
     if isinstance(a, Polytope):
         return region_diff(a, b)
     raise Exception("a neither Region nor Polytope")
+
+
+def _radii_stacked(poly, others):
+    """Chebyshev radius (0 when the ball LP fails) of the stack [poly; c] for every c of `others`, as
+    region_diff's own scan computes it (ref :2148-2152) -- including the constructor's row normalisation
+    (ref :130-138) -- but packed straight into one batch instead of one Polytope object per stack."""
+    if not others:
+        return []
+    same = _use_hip() and len({c.A.shape for c in others}) == 1 and \
+        _fits(poly.A.shape[0] + others[0].A.shape[0], poly.A.shape[1])
+    if same:
+        n = len(others)
+        A3 = np.concatenate([np.broadcast_to(poly.A, (n,) + poly.A.shape), np.stack([c.A for c in others])], axis=1)
+        b3 = np.concatenate([np.broadcast_to(poly.b, (n,) + poly.b.shape), np.stack([c.b for c in others])], axis=1)
+        norms = np.sqrt(np.sum(A3 * A3, 2))
+        if np.all(norms > 1e-10):
+            from .batch import cheby_ball_batch
+            scale = 1 / norms
+            out = cheby_ball_batch(A3 * scale[:, :, None], b3 * scale)
+            ok = (out["status"] == 0) & (out["r"] >= 0)
+            return [np.double(rr) if o else 0 for rr, o in zip(out["r"], ok)]
+    return _radii([Polytope(np.vstack([poly.A, c.A]), np.hstack([poly.b, c.b])) for c in others])
 
 
 def _radii(polys):
@@ -888,7 +920,7 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
         return Polytope()
     cells = reg.list_poly
     # which cells meet the polytope at all
-    Rc = np.array(_radii([Polytope(np.vstack([poly.A, c.A]), np.hstack([poly.b, c.b])) for c in cells]), dtype=float)
+    Rc = np.array(_radii_stacked(poly, cells), dtype=float)
     N = int(np.sum(Rc >= intersect_tol))
     if N == 0:
         logger.debug("no Polytope in the Region intersects the given Polytope")
