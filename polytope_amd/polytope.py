@@ -806,24 +806,62 @@ def is_convex(reg, abs_tol=ABS_TOL):
     return True, outer
 
 
+def _envelope_crossed_packed(members, abs_tol):
+    """The (member, facet) pairs of envelope() that some other member reaches beyond, with every test polytope
+    [p2; -row ii of p1] packed straight into ONE batch -- the constructor's row normalisation (ref :130-138)
+    applied to the packed rows -- instead of one Polytope object per test.  None when it does not apply."""
+    if not members:
+        return set()
+    d = members[0].A.shape[1]
+    if not all(p.A.ndim == 2 and p.A.shape[1] == d and _fits(p.A.shape[0] + 1, d) for p in members):
+        return None
+    owner = [(i, ii, j) for i, p1 in enumerate(members) for ii in range(p1.A.shape[0])
+             for j in range(len(members)) if j != i]
+    if not owner:
+        return set()
+    from .batch import cheby_ball_batch
+    m_max = max(p.A.shape[0] for p in members) + 1
+    A3 = np.zeros((len(owner), m_max, d))
+    b3 = np.zeros((len(owner), m_max))
+    lens = np.empty(len(owner), dtype=np.int32)
+    for t, (i, ii, j) in enumerate(owner):
+        p1, p2 = members[i], members[j]
+        m2 = p2.A.shape[0]
+        A3[t, :m2] = p2.A
+        b3[t, :m2] = p2.b
+        A3[t, m2] = -p1.A[ii, :]
+        b3[t, m2] = -p1.b[ii]
+        lens[t] = m2 + 1
+    norms = np.sqrt(np.sum(A3 * A3, 2))
+    used = np.arange(m_max)[None, :] < lens[:, None]
+    if not np.all(norms[used] > 1e-10):
+        return None  # a (near-)zero row: the constructor would drop it
+    scale = np.where(used, 1 / np.where(used, norms, 1.0), 0.0)
+    out = cheby_ball_batch(A3 * scale[:, :, None], b3 * scale, m=lens)
+    hit = (out["status"] == 0) & (out["r"] >= 0) & (out["r"] > abs_tol)
+    return {(owner[t][0], owner[t][1]) for t in np.nonzero(hit)[0]}
+
+
 def envelope(reg, abs_tol=ABS_TOL):
     """Polytope of all 'outer' inequalities of a region: facet ii of member i is outer when no
     other member reaches beyond it (one Chebyshev LP per (facet, other member)); empty Polytope
     when the envelope is not full-dimensional (ref :1414-1464)."""
     members = reg.list_poly
-    tests, owner = [], []
-    for i, p1 in enumerate(members):
-        for ii in range(p1.A.shape[0]):
-            for j, p2 in enumerate(members):
-                if i == j:
-                    continue
-                tests.append(Polytope(np.vstack([p2.A, -p1.A[ii, :]]), np.hstack([p2.b, -p1.b[ii]])))
-                owner.append((i, ii))
-    crossed = set()
-    balls = _cheby_raw(tests) if tests else []
-    for (i, ii), ball in zip(owner, balls):
-        if ball is not None and ball[0] > abs_tol:
-            crossed.add((i, ii))
+    crossed = _envelope_crossed_packed(members, abs_tol) if _use_hip() else None
+    if crossed is None:
+        crossed = set()
+        tests, owner = [], []
+        for i, p1 in enumerate(members):
+            for ii in range(p1.A.shape[0]):
+                for j, p2 in enumerate(members):
+                    if i == j:
+                        continue
+                    tests.append(Polytope(np.vstack([p2.A, -p1.A[ii, :]]), np.hstack([p2.b, -p1.b[ii]])))
+                    owner.append((i, ii))
+        balls = _cheby_raw(tests) if tests else []
+        for (i, ii), ball in zip(owner, balls):
+            if ball is not None and ball[0] > abs_tol:
+                crossed.add((i, ii))
     Ae, be = [], []
     for i, p1 in enumerate(members):
         rows = [ii for ii in range(p1.A.shape[0]) if (i, ii) not in crossed]
