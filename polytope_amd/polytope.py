@@ -641,6 +641,11 @@ def _reduce_many(polys, abs_tol):
             q.minrep = True
         else:
             q = Polytope(p.A[rows], p.b[rows])
+        # q is the same set as p: the ball the kernel found for p is a Chebyshev ball of q too (what a
+        # cheby_ball(q) call would cache, ref :1298-1299), so callers that go on to is_fulldim / cheby_ball
+        # -- intersect, envelope, union -- need no second LP
+        if not np.isnan(res["xc"][k]).any():
+            q._chebR, q._chebXc = np.double(r), res["xc"][k].copy()
         out.append(q)
     return out
 
