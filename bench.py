@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
+                    "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -146,9 +148,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -161,8 +165,8 @@ def main():
     # every step's results are gathered on every rank before the timed region ends (flush below)
     # The kernel writes its results straight into a flat exchange buffer (no packing kernels); two of them,
     # because the gather of one batch is still in flight while the next batch is computed.
-    pipe = GatherPipeline(torch, dist, 24 * B_PER_GPU, 1, dtype=torch.uint8, device=dev) if world > 1 else None
-    bufs = [ResultBuffer(torch, B_PER_GPU, DIM, dev) for _ in range(2)] if world > 1 else None
+    pipe = GatherPipeline(torch, dist, 24 * B_PER_GPU, 1, dtype=torch.uint8, device=dev) if multi else None
+    bufs = [ResultBuffer(torch, B_PER_GPU, DIM, dev) for _ in range(2)] if multi else None
     nstep = [0]
 
     def step():
@@ -179,7 +183,7 @@ def main():
     if pipe is not None:
         pipe.flush()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -199,11 +203,11 @@ def main():
     if pipe is not None:
         gathered = pipe.flush()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         rdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,7 +215,7 @@ def main():
     kern_ms = sum(a.elapsed_time(b_) for a, b_ in ev) / args.steps
     nlp_local = int(res["nlp"].sum().item())
     nlp_total = nlp_local
-    if world > 1:
+    if multi:
         t = torch.tensor([nlp_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t)
         nlp_total = int(t.item())
@@ -259,10 +263,10 @@ def main():
         if valu:  # PMC SQ_INSTS_VALU of the same kernel: 4 issue cycles per wave64 instruction, 1024 SIMDs
             line["roofline"]["valu_insts_per_launch"] = valu.get("valu_insts_per_launch")
             line["roofline"]["valu_issue_frac_at_2p4GHz"] = valu.get("valu_issue_frac_at_2p4GHz")
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, b, None)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
