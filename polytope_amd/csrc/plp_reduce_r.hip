@@ -49,6 +49,10 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 #define PLP_REDUCE_R_WAVES(D) ((D) <= 3 ? 4 : ((D) <= 4 ? 3 : 1))
 #endif
 
+#ifndef PLP_R_ASYNC
+#define PLP_R_ASYNC 1  // F2: every lane group walks its own LP list inside one pivot loop (0: lock-step, for A/B runs)
+#endif
+
 #ifndef PLP_R_FAST
 #define PLP_R_FAST 1  // F2/F3 on SimplexR::run_fast (0: the general step(), for A/B runs)
 #endif
@@ -314,6 +318,75 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
             }
         }
         // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+#if PLP_R_ASYNC && PLP_R_FAST
+        // The 16 polytopes of a wavefront need different numbers of LPs (rows that survived the dedupe and
+        // the prefilter) and their LPs different numbers of pivots; in lock-step every LP costs the wave the
+        // maximum over its polytopes (measured: 3.9 pivots against a mean of 2.3).  Here every group walks its
+        // own list: a group whose LP has ended collects the result and sets up its next row inside the pivot
+        // loop (one exec-masked block per iteration), so an iteration retires one pivot of EVERY busy group.
+        if (__any(stage == 2)) {
+            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            uint64_t todo = (stage == 2) ? live : 0ull;
+            if (stage == 2) nlp += __popcll(live);
+            SimplexR<D, R, false, false> S;
+            S.reset(D, __popcll(live), row0);
+            S.mode = M_DONE;
+            S.status = ST_OPT;
+            bool busy = false;
+            int kr = 0, e = -1, chi = 0;
+            double cxc = 0.0, best = 0.0;
+            for (;;) {
+                const bool fin = busy & (S.mode == M_DONE);
+                const bool start = (fin | !busy) & (todo != 0ull);
+                if (__any(fin | start)) {
+                    if (fin) {
+                        retry = retry | (S.status == ST_RETRY);
+                        const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
+                        // b[k] after the (+0.1, -0.1) round trip (:1149-1151): computed by the lane that owns row k
+                        // and handed to the others through registers (an LDS store of one lane followed by loads of
+                        // other lanes would need a fence for the compiler, which otherwise keeps an earlier load)
+                        const bool owner = (kr >> 2) == g.gl;
+                        double hk_own = 0.0;
+                        if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
+                        const double hk = bcast(hk_own, g.gbase + (kr >> 2));
+                        const double obj = -fun - hk;  // (:1156)
+                        const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
+                        keep |= keepk ? (1ull << kr) : 0ull;
+                        busy = false;
+                    }
+                    if (start) {
+                        kr = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        S.reset(D, __popcll(live), row0);
+                        cxc = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < D; ++kk) {
+                            const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
+                            S.cost[kk] = ck;
+                            cxc = fma(ck, xc[kk], cxc);
+                        }
+                        if ((kr >> 2) == g.gl) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+#pragma unroll
+                            for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
+                            S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
+                        }
+                        S.ract = lloc;
+                        S.mode = M_P2;
+                        S.status = -1;
+                        S.scan_enter(e, best, chi);
+                        if (e < 0) { S.status = ST_OPT; S.mode = M_DONE; }
+                        busy = true;
+                    }
+                }
+                if (!__any(busy)) break;
+                if ((S.mode != M_DONE) & (S.ndeg >= BLAND_AFTER)) { S.status = ST_RETRY; S.mode = M_DONE; }
+                S.template pivot_core<GS, 0>(g, e, best, chi, nullptr, 0u);
+            }
+            if (stage == 2) flags |= RF_MINREP;
+        }
+#else
         if (__any(stage == 2)) {
             const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
             uint64_t todo = (stage == 2) ? live : 0ull;
@@ -362,6 +435,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
             }
             if (stage == 2) flags |= RF_MINREP;
         }
+#endif
         // ---------------------------------------------------------------- results
         if (valid & (g.gl == 0)) {
             keep_out[pg] = keep;

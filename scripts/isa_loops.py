@@ -20,7 +20,7 @@ with tempfile.NamedTemporaryFile(suffix=".s") as f:
                            "-S", "--cuda-device-only", "-o", f.name, src] + flags, stderr=subprocess.DEVNULL)
     text = open(f.name).read().split("\n")
 start = next(i for i, l in enumerate(text) if re.match(r"^_Z\w*%s\w*:" % re.escape(pat), l))
-end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+end = next(i for i in range(start, len(text)) if text[i].startswith(".Lfunc_end"))  # blocks may sit after s_endpgm
 body = text[start:end + 1]
 name = text[start].rstrip(":")
 for key in ("NumVgprs", "NumAgprs", "NumSgprs", "ScratchSize", "Occupancy", "LDSByteSize"):
