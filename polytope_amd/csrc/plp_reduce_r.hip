@@ -5,7 +5,7 @@
 // but built on SimplexR (plp_simplex_r.hpp): a polytope with up to 16 / 32 / 64 rows occupies a
 // group of 4 / 8 / 16 lanes, lane l holding rows 4l..4l+3.  A wavefront therefore advances 16 / 8 / 4
 // polytopes per instruction instead of 4 / 2 / 1, and the per-pivot reductions are DPP quad steps.
-// A 256-thread workgroup takes NG = 256/GS polytopes per tile; their rows are read from HBM once,
+// A workgroup (RBLOCK threads) takes NG = RBLOCK/GS polytopes per tile; their rows are read from HBM once,
 // coalesced, into LDS (rows of F2's objective and the dedupe partners are read back from there).
 #include <stdlib.h>
 
@@ -17,7 +17,10 @@ namespace plp {
 constexpr int RR = 4;  // rows per lane
 
 #ifndef PLP_REDUCE_R_BLOCK
-#define PLP_REDUCE_R_BLOCK 256
+// One wavefront per workgroup: at C2 (100000 polytopes = 6250 wavefronts over 4096 resident slots) the last
+// round is spread over the CUs wave by wave instead of in blocks of four (measured 256: 0.306 ms, 128: 0.305,
+// 64: 0.299), and the workgroup barriers cost nothing.
+#define PLP_REDUCE_R_BLOCK 64
 #endif
 constexpr int RBLOCK = PLP_REDUCE_R_BLOCK;  // threads per workgroup
 
