@@ -14,7 +14,7 @@
 
 namespace plp {
 
-constexpr int RR = 4;  // rows per lane
+constexpr int RR = 4;  // rows per lane (default; R8 variant: 8 rows per lane, groups of 2 lanes for m <= 16)
 
 #ifndef PLP_REDUCE_R_BLOCK
 // One wavefront per workgroup: at C2 (100000 polytopes = 6250 wavefronts over 4096 resident slots) the last
@@ -30,9 +30,9 @@ static inline int group_size_r(int m_max) {
     return 16;
 }
 
-static inline size_t reduce_r_smem_bytes(int gs, int D) {
+static inline size_t reduce_r_smem_bytes(int gs, int D, int R) {
     const int NG = RBLOCK / gs;
-    return ((size_t)NG * gs * RR * (D + 2) * 8 + 15) & ~(size_t)15;  // A rows, b, 1/||a||
+    return ((size_t)NG * gs * R * (D + 2) * 8 + 15) & ~(size_t)15;  // A rows, b, 1/||a||
 }
 
 // bit l of x (l < 16)  ->  bit 4l
@@ -42,6 +42,16 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
     x = (x | (x << 6)) & 0x0303030303030303ull;
     x = (x | (x << 3)) & 0x1111111111111111ull;
     return x;
+}
+
+// bit l of x (l < GS)  ->  bit R*l
+template <int R, int GS>
+__device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
+    if constexpr (R == 4) return spread4(x);
+    uint64_t out = 0ull;
+#pragma unroll
+    for (int l = 0; l < GS; ++l) out |= ((x >> l) & 1ull) << (R * l);
+    return out;
 }
 
 #ifndef PLP_REDUCE_R_WAVES
@@ -60,13 +70,25 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 #define PLP_R_FAST 1  // F2/F3 on SimplexR::run_fast (0: the general step(), for A/B runs)
 #endif
 
-template <int D, int GS>
-__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel(
+#ifndef PLP_REDUCE_R8_MAXD
+// m <= 16 and d <= this: 8 rows per lane, two lanes per polytope (32 polytopes per wavefront).  Measured at C2:
+// 22 % fewer VALU instructions per polytope but 228 VGPRs = 2 waves per SIMD, and the kernel is then bound by the
+// latency of the pivot's dependency chain: 0.344 ms against 0.297 ms (at 3 waves it spills: 0.444 ms).  Off.
+#define PLP_REDUCE_R8_MAXD 0
+#endif
+#ifndef PLP_REDUCE_R8_WAVES
+#define PLP_REDUCE_R8_WAVES 2
+#endif
+
+template <int D, int GS, int R = RR>
+__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
     int* __restrict__ nlp_out) {
-    constexpr int R = RR;
+    constexpr unsigned RMASK = (1u << R) - 1u;
+    constexpr int RSH = R == 8 ? 3 : 2;  // log2(R)
+    static_assert(R == 4 || R == 8, "rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int gs = GS;
     const Grp g(gs);
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
             }
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                live |= spread4(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
+                live |= spread_rows<R, GS>(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
         }
         // dictionary translated to the Chebyshev centre: beta_i = b_i - a_i.xc.  s_i = a_i.xc replaces
         // 1/||a_i|| in LDS (only the owner lane touches its rows' slots from here on).
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
                 }
             }
         };
-        zero_dead((unsigned)((live >> row0) & 0xFull));
+        zero_dead(((unsigned)(live >> row0) & RMASK));
         int flags = fulldim ? 0 : RF_EMPTY;
         int nlp = 1;
         uint64_t keep = 0ull;
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
         // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
         if (__any(stage == 1)) {
             const bool go = stage == 1;
-            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
             double s1[R], s2[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
@@ -309,11 +331,11 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (myb[row0 + k] - s2[k])) < -1e-4);
-                outb |= spread4(grp_ballot(out, g)) << k;
+                outb |= spread_rows<R, GS>(grp_ballot(out, g)) << k;
             }
             if (go) {
                 live = live & ~outb;
-                zero_dead((unsigned)((live >> row0) & 0xFull));
+                zero_dead(((unsigned)(live >> row0) & RMASK));
                 nlp += 2 * D;
                 if (lpfail) flags |= RF_LPFAIL;
                 if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
         // own list: a group whose LP has ended collects the result and sets up its next row inside the pivot
         // loop (one exec-masked block per iteration), so an iteration retires one pivot of EVERY busy group.
         if (__any(stage == 2)) {
-            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
             uint64_t todo = (stage == 2) ? live : 0ull;
             if (stage == 2) nlp += __popcll(live);
             SimplexR<D, R, false, false> S;
@@ -348,10 +370,10 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
                         // b[k] after the (+0.1, -0.1) round trip (:1149-1151): computed by the lane that owns row k
                         // and handed to the others through registers (an LDS store of one lane followed by loads of
                         // other lanes would need a fence for the compiler, which otherwise keeps an earlier load)
-                        const bool owner = (kr >> 2) == g.gl;
+                        const bool owner = (kr >> RSH) == g.gl;
                         double hk_own = 0.0;
                         if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
-                        const double hk = bcast(hk_own, g.gbase + (kr >> 2));
+                        const double hk = bcast(hk_own, g.gbase + (kr >> RSH));
                         const double obj = -fun - hk;  // (:1156)
                         const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
                         keep |= keepk ? (1ull << kr) : 0ull;
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
                             S.cost[kk] = ck;
                             cxc = fma(ck, xc[kk], cxc);
                         }
-                        if ((kr >> 2) == g.gl) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
+                        if ((kr >> RSH) == g.gl) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
 #pragma unroll
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
         }
 #else
         if (__any(stage == 2)) {
-            const unsigned lloc = (unsigned)((live >> row0) & 0xFull);
+            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
             uint64_t todo = (stage == 2) ? live : 0ull;
             if (stage == 2) nlp += __popcll(live);
             while (__any(todo != 0ull)) {
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
                 }
                 // h[k] += 0.1 in place, as the reference does (:1149); undone after the LP (:1151), so rows
                 // k' < k carry the (+0.1, -0.1) round trip into the later LPs
-                const bool owner = go & ((kr >> 2) == g.gl);
+                const bool owner = go & ((kr >> RSH) == g.gl);
                 if (owner) myb[kr] = myb[kr] + 0.1;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -431,7 +453,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
                 // fence for the compiler, which otherwise keeps an earlier load)
                 double hk_own = 0.0;
                 if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
-                const double hk = bcast(hk_own, g.gbase + (kr >> 2));
+                const double hk = bcast(hk_own, g.gbase + (kr >> RSH));
                 const double obj = -fun - hk;     // (:1156)
                 const bool keepk = go & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
                 keep |= keepk ? (1ull << kr) : 0ull;
@@ -451,20 +473,20 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_kernel
     }
 }
 
-template <int D, int GS>
+template <int D, int GS, int R = RR>
 static int launch_reduce_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows,
                              double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                              hipStream_t st) {
-    const size_t smem = reduce_r_smem_bytes(GS, D);
+    const size_t smem = reduce_r_smem_bytes(GS, D, R);
     const long long NG = RBLOCK / GS;
     long long blocks = (B + NG - 1) / NG;
     if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
     if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D, GS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D, GS, R>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    hipLaunchKernelGGL((reduce_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
+    hipLaunchKernelGGL((reduce_r_kernel<D, GS, R>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
                        abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
     return 0;
 }
@@ -473,6 +495,11 @@ template <int D>
 static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
                              double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                              hipStream_t st) {
+    if constexpr (D <= PLP_REDUCE_R8_MAXD) {
+        const char* e8 = getenv("PLP_REDUCE_R8");
+        if (gs == 4 && !(e8 && e8[0] == '0'))
+            return launch_reduce_r_dg<D, 2, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    }
     if (gs == 4) return launch_reduce_r_dg<D, 4>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     if (gs == 8) return launch_reduce_r_dg<D, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     return launch_reduce_r_dg<D, 16>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);

@@ -344,7 +344,7 @@ struct SimplexR {
     template <int GS>
     static __device__ __forceinline__ unsigned gmin(unsigned v) {
         PLP_MIN_U32_DPP(v, "quad_perm:[1,0,3,2]");
-        PLP_MIN_U32_DPP(v, "quad_perm:[2,3,0,1]");
+        if constexpr (GS > 2) PLP_MIN_U32_DPP(v, "quad_perm:[2,3,0,1]");
         if constexpr (GS > 4) PLP_MIN_U32_DPP(v, "row_half_mirror");
         if constexpr (GS > 8) PLP_MIN_U32_DPP(v, "row_mirror");
         if constexpr (GS > 16) v = min_u(v, (unsigned)__shfl_xor((int)v, 16, 64));
