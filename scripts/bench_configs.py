@@ -118,6 +118,23 @@ def lp():
                                        "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
 
 
+def red():
+    """Fused reduce() over the supported envelope: shapes other than the headline (16,3), up to (64,16)."""
+    for (B, m, d) in [(100000, 16, 3), (50000, 16, 4), (20000, 32, 6), (20000, 32, 8), (5000, 64, 8), (5000, 64, 12),
+                      (5000, 64, 16)]:
+        A, b = synth.random_hpolytopes(B, m, d, seed=2)
+        At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+        res = pa.reduce_batch(At, bt)
+        nlp = int(res["nlp"].sum().item())
+        ms = timeit(lambda: pa.reduce_batch(At, bt), reps=5, warm=1)
+        by = B * (8 * m * (d + 1) + 12)
+        print(json.dumps({"config": "fused reduce B=%d m=%d d=%d" % (B, m, d), "ms": ms, "lps": nlp,
+                          "lp_per_s": nlp / (ms * 1e-3), "kept_rows_mean": float(
+                              sum(bin(int(k) & (2 ** 64 - 1)).count("1") for k in res["keep"].cpu().numpy()[:2000]) / 2000.0),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
+                                       "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
+
+
 def c4():
     """Config 4: 1000-cell Region in d=4 (10x10x5x2 grid of boxes on [0,1]^4): adjacency of all
     499 500 cell pairs (one batch of (16,5) Chebyshev LPs) and region_diff of a polytope against
@@ -194,6 +211,6 @@ def hull():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c3", "c5", "lp"]
+    which = sys.argv[1:] or ["c3", "c5", "lp", "red"]
     for w in which:
         globals()[w]()
