@@ -11,10 +11,10 @@ timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee gpurun_out
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 echo "== bench"
-timeout 600 python bench.py --steps 10 --warmup 2 2>&1 | tail -3 | tee gpurun_out/bench.log
+timeout 600 python bench.py 2>&1 | tail -3 | tee gpurun_out/bench.log
 if [ "${1:-}" != "quick" ]; then
   echo "== rocprofv3 kernel trace"
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o reduce -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o reduce -- python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.log" 2>&1)
   tail -2 gpurun_out/prof_bench.log
   find gpurun_out/prof -name "*kernel_stats*" | head -3
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
