@@ -27,6 +27,12 @@ __global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int g
     const Grp g(gs);
     const int gpb = BLOCK / gs;
     const int gib = threadIdx.x / gs;
+    if (retry_only) {  // normally nothing was handed over: one round trip of status loads, then leave
+        bool any = false;
+        for (long long base = (long long)blockIdx.x * gpb; base < B; base += (long long)gridDim.x * gpb)
+            any = any | ((base + gib < B) && status[base + gib] == ST_RETRY);
+        if (!__syncthreads_or(any)) return;
+    }
     for (long long base = (long long)blockIdx.x * gpb; base < B; base += (long long)gridDim.x * gpb) {
         const long long lp = base + gib;
         bool valid = lp < B;
@@ -191,7 +197,9 @@ static inline int pick_grid(long long B, int gs) {
 template <int N>
 static void launch_lp_n(long long B, int m_max, int gs, const double* c, const double* G, const double* h,
                         const int* mrows, double* x, double* fun, int* status, int* iters, int retry, hipStream_t st) {
-    hipLaunchKernelGGL(lp_kernel<N>, dim3(pick_grid(B, gs)), dim3(BLOCK), 0, st, B, m_max, gs, c, G, h, mrows, x,
+    int blocks = pick_grid(B, gs);
+    if (retry && blocks > 256 * 8) blocks = 256 * 8;  // second pass: mostly status reads, a grid-stride sweep
+    hipLaunchKernelGGL(lp_kernel<N>, dim3(blocks), dim3(BLOCK), 0, st, B, m_max, gs, c, G, h, mrows, x,
                        fun, status, iters, retry);
 }
 

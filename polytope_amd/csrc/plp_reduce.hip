@@ -68,6 +68,14 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
+    if (retry_only) {
+        // normally nothing was handed back: all flag loads of this workgroup's tiles are issued at once (one
+        // memory round trip instead of one per tile of the sweep below) and the workgroup leaves
+        bool any = false;
+        for (long long tile = (long long)blockIdx.x * NG; tile < B; tile += (long long)gridDim.x * NG)
+            any = any | ((tile + gib < B) && (flags_out[tile + gib] & RF_RETRY) != 0);
+        if (!__syncthreads_or(any)) return;
+    }
     for (long long tile = (long long)blockIdx.x * NG; tile < B; tile += (long long)gridDim.x * NG) {
         const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
         // second pass after reduce_r_kernel: only polytopes it flagged RF_RETRY (tiles without one are skipped)
