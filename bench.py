@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
+    ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -161,27 +162,40 @@ def main():
     A, b = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=0, stream=rank)
     At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
 
-    # N > 1: the all-gather of step k overlaps the reduce kernel of step k+1 (RCCL stream vs compute stream);
-    # every step's results are gathered on every rank before the timed region ends (flush below)
-    # The kernel writes its results straight into a flat exchange buffer (no packing kernels); two of them,
-    # because the gather of one batch is still in flight while the next batch is computed.
-    pipe = GatherPipeline(torch, dist, 24 * B_PER_GPU, 1, dtype=torch.uint8, device=dev) if multi else None
-    bufs = [ResultBuffer(torch, B_PER_GPU, DIM, dev) for _ in range(2)] if multi else None
+    # N > 1: the kernel writes its results straight into a slot of a flat exchange buffer (24 B per polytope, no
+    # packing kernels); every G batches the buffer goes out as ONE all-gather (xGMI is point-to-point: fewer,
+    # larger collectives -- G x 2.4 MB per rank), on RCCL's stream while the next group of batches is computed in
+    # the other buffer.  Every batch's results are on every rank before the timed region ends (flush below).
+    G = max(1, args.gather_every)
+    nb = 24 * B_PER_GPU
+    pipe = GatherPipeline(torch, dist, G * nb, 1, dtype=torch.uint8, device=dev) if multi else None
+    big = [torch.zeros((G * nb,), dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
+    bufs = [[ResultBuffer(torch, B_PER_GPU, DIM, dev, flat=big[g][s * nb:(s + 1) * nb]) for s in range(G)]
+            for g in range(2)] if multi else None
     nstep = [0]
 
     def step():
         if pipe is None:
             return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
-        rb = bufs[nstep[0] & 1]
+        k = nstep[0]
         nstep[0] += 1
-        res = pa.reduce_batch(At, bt, out=rb.views)
-        pipe.push(rb.flat.view(-1, 1))
+        g, slot = (k // G) & 1, k % G
+        res = pa.reduce_batch(At, bt, out=bufs[g][slot].views)
+        if slot == G - 1:
+            pipe.push(big[g].view(-1, 1))
         return res
+
+    def drain():
+        """exchange a partly filled group, then wait for the last collective"""
+        if nstep[0] % G:
+            pipe.push(big[(nstep[0] // G) & 1].view(-1, 1))
+            nstep[0] += G - nstep[0] % G
+        return pipe.flush()
 
     for _ in range(args.warmup):
         step()
     if pipe is not None:
-        pipe.flush()
+        drain()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -196,16 +210,10 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for k in range(args.steps):
-        if pipe is None:
-            res = pa.reduce_batch(At, bt)
-        else:
-            rb = bufs[nstep[0] & 1]
-            nstep[0] += 1
-            res = pa.reduce_batch(At, bt, out=rb.views)
-            pipe.push(rb.flat.view(-1, 1))
+        res = step()
     ev1.record()
     if pipe is not None:
-        gathered = pipe.flush()
+        gathered = drain()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -223,8 +231,9 @@ def main():
         t = torch.tensor([nlp_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t)
         nlp_total = int(t.item())
-        assert gathered.numel() == world * 24 * B_PER_GPU
-        assert int(bufs[0].split(gathered.view(-1))[0]["nlp"].sum().item()) > 0
+        assert gathered.numel() == world * G * nb
+        mine = gathered.view(-1)[rank * G * nb: rank * G * nb + nb]  # my slot 0 of the last exchanged group
+        assert int(bufs[0][0].split(mine)[0]["nlp"].sum().item()) == nlp_local
 
     if rank == 0:
         alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
@@ -256,7 +265,7 @@ def main():
             "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1])"
                                    % (B_PER_GPU, DIM, M_ROWS),
                        "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU,
-                       "parallelism": "batch-sharded x%d + all-gather of packed results (overlapped with the next batch)" % world},
+                       "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_kernel<3, 4, 4>", "kernel_ms": kern_ms,

@@ -68,10 +68,13 @@ class ResultBuffer:
     polytope, with typed views that reduce_batch(..., out=...) writes straight into, so that the all-gather
     needs no packing kernels.  `split(flat)` gives the same views on a gathered [world * nbytes] buffer."""
 
-    def __init__(self, torch, B, d, device):
+    def __init__(self, torch, B, d, device, flat=None):
+        """`flat`: use this uint8[24 B] slice as storage (one slot of a larger buffer that is exchanged as a whole:
+        fewer, larger collectives)."""
         self.torch, self.B = torch, int(B)
         self.nbytes = 24 * self.B
-        self.flat = torch.empty((self.nbytes,), dtype=torch.uint8, device=device)
+        self.flat = torch.empty((self.nbytes,), dtype=torch.uint8, device=device) if flat is None else flat
+        assert self.flat.numel() == self.nbytes and self.flat.dtype == torch.uint8
         self.views = self._views(self.flat)
         self.views["xc"] = torch.empty((self.B, d), dtype=torch.float64, device=device)  # not exchanged
 
