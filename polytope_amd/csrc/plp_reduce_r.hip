@@ -1,495 +1,17 @@
-// plp_reduce_r.hip -- fused reduce() (polytope/polytope.py:1053-1163) with R = 4 rows per lane.
-//
-// Same pipeline and the same reference steps as plp_reduce.hip (F1 -> dedupe -> 2d F3 -> prefilter
-// -> one F2 per surviving row, all LPs of a polytope solved by one lane group out of registers),
-// but built on SimplexR (plp_simplex_r.hpp): a polytope with up to 16 / 32 / 64 rows occupies a
-// group of 4 / 8 / 16 lanes, lane l holding rows 4l..4l+3.  A wavefront therefore advances 16 / 8 / 4
-// polytopes per instruction instead of 4 / 2 / 1, and the per-pivot reductions are DPP quad steps.
-// A workgroup (RBLOCK threads) takes NG = RBLOCK/GS polytopes per tile; their rows are read from HBM once,
-// coalesced, into LDS (rows of F2's objective and the dedupe partners are read back from there).
-#include <stdlib.h>
-
-#include "plp_kernels.hpp"
-#include "plp_simplex_r.hpp"
+// plp_reduce_r.hip -- dispatch of the fused reduce() on R rows per lane (kernel: plp_reduce_r_impl.hpp).
+//   d <= 8 : four rows per lane, groups of 4 / 8 / 16 lanes (this file)
+//   d >= 9 : two rows per lane, groups of 16 / 32 lanes (plp_reduce_r2a.hip d = 9..12, plp_reduce_r2b.hip d = 13..16;
+//            separate translation units only to keep the build parallel)
+#include "plp_reduce_r_impl.hpp"
 
 namespace plp {
 
-constexpr int RR = 4;  // rows per lane (default; R8 variant: 8 rows per lane, groups of 2 lanes for m <= 16)
-
-#ifndef PLP_REDUCE_R_BLOCK
-// One wavefront per workgroup: at C2 (100000 polytopes = 6250 wavefronts over 4096 resident slots) the last
-// round is spread over the CUs wave by wave instead of in blocks of four (measured 256: 0.306 ms, 128: 0.305,
-// 64: 0.299), and the workgroup barriers cost nothing.
-#define PLP_REDUCE_R_BLOCK 64
-#endif
-constexpr int RBLOCK = PLP_REDUCE_R_BLOCK;  // threads per workgroup
-
-static inline int group_size_r(int m_max) {
-    if (m_max <= 16) return 4;
-    if (m_max <= 32) return 8;
-    return 16;
-}
-
-static inline size_t reduce_r_smem_bytes(int gs, int D, int R) {
-    const int NG = RBLOCK / gs;
-    return ((size_t)NG * gs * R * (D + 2) * 8 + 15) & ~(size_t)15;  // A rows, b, 1/||a||
-}
-
-// bit l of x (l < 16)  ->  bit 4l
-__device__ __forceinline__ uint64_t spread4(uint64_t x) {
-    x = (x | (x << 24)) & 0x000000ff000000ffull;
-    x = (x | (x << 12)) & 0x000f000f000f000full;
-    x = (x | (x << 6)) & 0x0303030303030303ull;
-    x = (x | (x << 3)) & 0x1111111111111111ull;
-    return x;
-}
-
-// bit l of x (l < GS)  ->  bit R*l
-template <int R, int GS>
-__device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
-    if constexpr (R == 4) return spread4(x);
-    uint64_t out = 0ull;
-#pragma unroll
-    for (int l = 0; l < GS; ++l) out |= ((x >> l) & 1ull) << (R * l);
-    return out;
-}
-
-#ifndef PLP_REDUCE_R_WAVES
-// Waves per SIMD the register allocator must leave room for.  Measured at d=3 (100k polytopes, m=16)
-// with the fast pivot path (no general engine in this kernel: 132 VGPRs unconstrained):
-// 3 waves 0.362 ms, 4 waves (128 VGPRs, 12 B/lane spilled outside the pivot loops) 0.347 ms.
-// d=4 would spill 148 B/lane at 4 waves; d>=5 keeps the whole dictionary of 4 rows x (d+1) only at 1-2.
-#define PLP_REDUCE_R_WAVES(D) ((D) <= 3 ? 4 : ((D) <= 4 ? 3 : 1))
-#endif
-
-#ifndef PLP_R_ASYNC
-#define PLP_R_ASYNC 1  // F2: every lane group walks its own LP list inside one pivot loop (0: lock-step, for A/B runs)
-#endif
-
-#ifndef PLP_R_FAST
-#define PLP_R_FAST 1  // F2/F3 on SimplexR::run_fast (0: the general step(), for A/B runs)
-#endif
-
-#ifndef PLP_REDUCE_R8_MAXD
-// m <= 16 and d <= this: 8 rows per lane, two lanes per polytope (32 polytopes per wavefront).  Measured at C2:
-// 22 % fewer VALU instructions per polytope but 228 VGPRs = 2 waves per SIMD, and the kernel is then bound by the
-// latency of the pivot's dependency chain: 0.344 ms against 0.297 ms (at 3 waves it spills: 0.444 ms).  Off.
-#define PLP_REDUCE_R8_MAXD 0
-#endif
-#ifndef PLP_REDUCE_R8_WAVES
-#define PLP_REDUCE_R8_WAVES 2
-#endif
-
-template <int D, int GS, int R = RR>
-__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
-    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
-    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
-    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
-    constexpr unsigned RMASK = (1u << R) - 1u;
-    constexpr int RSH = R == 8 ? 3 : 2;  // log2(R)
-    static_assert(R == 4 || R == 8, "rows per lane");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int gs = GS;
-    const Grp g(gs);
-    constexpr int NG = RBLOCK / gs;
-    constexpr int rows = gs * R;  // row slots per polytope
-    const int gib = threadIdx.x / gs;
-    const int row0 = g.gl * R;  // my first row
-    double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
-    double* sb = sA + (size_t)NG * rows * D;            // [NG][rows]
-    double* san = sb + (size_t)NG * rows;               // [NG][rows]
-    double* myA = sA + (size_t)gib * rows * D;
-    double* myb = sb + (size_t)gib * rows;
-    double* myan = san + (size_t)gib * rows;
-    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
-
-    {  // one tile per workgroup (grid.x = number of tiles: no values kept live across a tile loop)
-        const long long tile = (long long)blockIdx.x * NG;
-        const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
-        __syncthreads();
-        {
-            const int rowsz = m_max * D;
-            const double* src = Ag + tile * rowsz;
-            for (int idx = threadIdx.x; idx < ntile * rowsz; idx += RBLOCK) {
-                const int p = idx / rowsz, rem = idx - p * rowsz;
-                sA[(size_t)p * rows * D + rem] = src[idx];
-            }
-            const double* srcb = bg + tile * m_max;
-            for (int idx = threadIdx.x; idx < ntile * m_max; idx += RBLOCK) {
-                const int p = idx / m_max, row = idx - p * m_max;
-                sb[p * rows + row] = srcb[idx];
-            }
-        }
-        __syncthreads();
-        const long long pg = tile + gib;
-        const bool valid = gib < ntile;
-        const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
-        double xc[D];
-        double rr = 0.0;
-        bool ball, fulldim;
-        uint64_t live = 0ull;
-        unsigned has = 0u;
-        // an F2/F3 LP needed Bland's rule: the whole polytope goes to the general kernel
-        // (force_retry: test hook, PLP_REDUCE_RETRY_ALL=1 sends every polytope through that second pass)
-        bool retry = force_retry != 0;
-        // ---------------------------------------------------------------- F1: Chebyshev ball
-        {
-#if PLP_R_FAST
-            SimplexR<D + 1, R, false, true> S;  // forced first pivot handed to run_fast
-            double qi[R];
-#else
-            SimplexR<D + 1, R, true> S;
-#endif
-            S.reset(D + 1, m, row0);
-            unsigned actb = 0u;
-            bool inf0 = false, finite = true;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const bool h = valid & (row0 + k < m) & (m <= rows);
-                has |= h ? (1u << k) : 0u;
-                double nrm2 = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < D; ++kk) {
-                    const double v = h ? myA[(row0 + k) * D + kk] : 0.0;
-                    S.T[k][kk] = v;
-                    nrm2 = nrm2 + v * v;
-                    finite = finite & isfinite(v);
-                }
-                const double bk = h ? myb[row0 + k] : 0.0;
-                finite = finite & isfinite(bk);
-                const double nrm = sqrt(nrm2);
-                myan[row0 + k] = 1.0 / nrm;
-                const bool zero = !(nrm > 0.0);
-                const bool on = h & !zero;
-                S.T[k][D] = on ? nrm : 0.0;
-                S.beta[k] = on ? bk : 0.0;
-#if PLP_R_FAST
-                qi[k] = bk / nrm;
-#else
-                S.init_q[k] = bk / nrm;
-#endif
-                actb |= on ? (1u << k) : 0u;
-                inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
-            }
-            S.ract = actb;
-            const bool infeasible0 = grp_ballot(inf0, g) != 0;
-            const bool bad = (grp_ballot(!finite, g) != 0) | (m > rows);
-            S.cost[D] = -1.0;
-#if PLP_R_FAST
-            S.mode = M_P2;
-#else
-            S.init_elig = actb;
-            S.mode = M_INIT;
-            S.init_col = D;
-            S.mode_after_init = M_P2;
-#endif
-            if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
-            else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
-#if PLP_R_FAST
-            S.template run_fast<GS, true>(g, qi, actb);
-            retry = retry | (valid & (S.status == ST_RETRY));
-#else
-            S.run(g);
-#endif
-            const bool ok = S.status == ST_OPT;
-#pragma unroll
-            for (int j = 0; j <= D; ++j) {
-                bool found;
-                const double mine = S.x_of(j, found);
-                const uint64_t ob = grp_ballot(found, g);
-                const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
-                const double xj = ob ? v : 0.0;
-                if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
-            }
-            ball = ok & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
-            fulldim = ball & (rr > abs_tol);
-        }
-        __syncthreads();  // 1/||a|| of every row is in LDS
-        // ---------------------------------------------------------------- dedupe (:1094-1110)
-        // (rows are re-read from LDS: the register file limits the occupancy of this kernel, LDS is idle)
-        {
-            unsigned removed = 0u;
-            double ni[R][D], bin_[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double an_i = myan[row0 + k];
-#pragma unroll
-                for (int kk = 0; kk < D; ++kk) ni[k][kk] = myA[(row0 + k) * D + kk] * an_i;
-                bin_[k] = myb[row0 + k] * an_i;
-            }
-            for (int j = 0; j < m_max; ++j) {
-                const bool jrow = valid & (j < m);
-                const double an_j = myan[j];
-                double nj[D];
-#pragma unroll
-                for (int kk = 0; kk < D; ++kk) nj[kk] = myA[j * D + kk] * an_j;
-                const double bjn = myb[j] * an_j;
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    double dot = 0.0;
-#pragma unroll
-                    for (int kk = 0; kk < D; ++kk) dot = dot + ni[k][kk] * nj[kk];
-                    const int i = row0 + k;
-                    const bool par = (((has >> k) & 1u) != 0u) & jrow & (j != i) & (dot > 1.0 - abs_tol);
-                    const bool rem = par & ((i < j) ? !(bin_[k] < bjn) : (bjn < bin_[k]));
-                    removed |= rem ? (1u << k) : 0u;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-                live |= spread_rows<R, GS>(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
-        }
-        // dictionary translated to the Chebyshev centre: beta_i = b_i - a_i.xc.  s_i = a_i.xc replaces
-        // 1/||a_i|| in LDS (only the owner lane touches its rows' slots from here on).
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            double sk = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < D; ++kk)
-                sk = fma(((has >> k) & 1u) ? myA[(row0 + k) * D + kk] : 0.0, ball ? xc[kk] : 0.0, sk);
-            myan[row0 + k] = sk;
-        }
-        // Rows that dropped out (never present, or removed by the dedupe) are zeroed in LDS -- A, b and
-        // s -- so that the LP set-ups below load their rows without masking.  Only the owner lane writes
-        // a row's slots and only the owner lane reads them afterwards (live rows, which other lanes read
-        // as F2 objectives, are never written): no cross-lane visibility is relied upon.
-        auto zero_dead = [&](unsigned alive) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                if (!((alive >> k) & 1u)) {
-#pragma unroll
-                    for (int kk = 0; kk < D; ++kk) myA[(row0 + k) * D + kk] = 0.0;
-                    myb[row0 + k] = 0.0;
-                    myan[row0 + k] = 0.0;
-                }
-            }
-        };
-        zero_dead(((unsigned)(live >> row0) & RMASK));
-        int flags = fulldim ? 0 : RF_EMPTY;
-        int nlp = 1;
-        uint64_t keep = 0ull;
-        int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
-        if (fulldim) {
-            const int neq = __popcll(live);
-            if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
-            else stage = (neq > 3 * D) ? 1 : 2;
-        }
-        // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
-        if (__any(stage == 1)) {
-            const bool go = stage == 1;
-            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
-            double s1[R], s2[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-            bool lpfail = false;
-            double lbk = 0.0;
-            for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
-                const int kx = it >> 1;
-                const bool up = it & 1;
-                double xck = 0.0;
-                SimplexR<D, R, false, false> S;
-                S.reset(D, __popcll(live), row0);
-#pragma unroll
-                for (int kk = 0; kk < D; ++kk) {
-                    xck = (kk == kx) ? xc[kk] : xck;
-                    S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-#pragma unroll
-                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
-                    S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
-                }
-                S.ract = lloc;
-                S.mode = go ? M_P2 : M_DONE;
-#if PLP_R_FAST
-                S.template run_fast<GS>(g);
-                retry = retry | (go & (S.status == ST_RETRY));
-#else
-                S.run(g);
-#endif
-                // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
-                double val;
-                if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
-                else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
-                else { val = qnan; lpfail = lpfail | go; }
-                if (!up) {
-                    lbk = val;
-                } else {  // prefilter sums, accumulated in k order (:1131-1134)
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const double aik = myA[(row0 + k) * D + kx];
-                        const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
-                        s1[k] = s1[k] + pa * (val - lbk);
-                        s2[k] = s2[k] + aik * lbk;
-                    }
-                }
-            }
-            uint64_t outb = 0ull;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (myb[row0 + k] - s2[k])) < -1e-4);
-                outb |= spread_rows<R, GS>(grp_ballot(out, g)) << k;
-            }
-            if (go) {
-                live = live & ~outb;
-                zero_dead(((unsigned)(live >> row0) & RMASK));
-                nlp += 2 * D;
-                if (lpfail) flags |= RF_LPFAIL;
-                if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
-                else stage = 2;
-            }
-        }
-        // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
-#if PLP_R_ASYNC && PLP_R_FAST
-        // The 16 polytopes of a wavefront need different numbers of LPs (rows that survived the dedupe and
-        // the prefilter) and their LPs different numbers of pivots; in lock-step every LP costs the wave the
-        // maximum over its polytopes (measured: 3.9 pivots against a mean of 2.3).  Here every group walks its
-        // own list: a group whose LP has ended collects the result and sets up its next row inside the pivot
-        // loop (one exec-masked block per iteration), so an iteration retires one pivot of EVERY busy group.
-        if (__any(stage == 2)) {
-            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
-            uint64_t todo = (stage == 2) ? live : 0ull;
-            if (stage == 2) nlp += __popcll(live);
-            SimplexR<D, R, false, false> S;
-            S.reset(D, __popcll(live), row0);
-            S.mode = M_DONE;
-            S.status = ST_OPT;
-            bool busy = false;
-            int kr = 0, e = -1, chi = 0;
-            double cxc = 0.0, best = 0.0;
-            for (;;) {
-                const bool fin = busy & (S.mode == M_DONE);
-                const bool start = (fin | !busy) & (todo != 0ull);
-                if (__any(fin | start)) {
-                    if (fin) {
-                        retry = retry | (S.status == ST_RETRY);
-                        const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
-                        // b[k] after the (+0.1, -0.1) round trip (:1149-1151): computed by the lane that owns row k
-                        // and handed to the others through registers (an LDS store of one lane followed by loads of
-                        // other lanes would need a fence for the compiler, which otherwise keeps an earlier load)
-                        const bool owner = (kr >> RSH) == g.gl;
-                        double hk_own = 0.0;
-                        if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
-                        const double hk = bcast(hk_own, g.gbase + (kr >> RSH));
-                        const double obj = -fun - hk;  // (:1156)
-                        const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
-                        keep |= keepk ? (1ull << kr) : 0ull;
-                        busy = false;
-                    }
-                    if (start) {
-                        kr = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1ull;
-                        S.reset(D, __popcll(live), row0);
-                        cxc = 0.0;
-#pragma unroll
-                        for (int kk = 0; kk < D; ++kk) {
-                            const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
-                            S.cost[kk] = ck;
-                            cxc = fma(ck, xc[kk], cxc);
-                        }
-                        if ((kr >> RSH) == g.gl) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
-#pragma unroll
-                        for (int k = 0; k < R; ++k) {
-#pragma unroll
-                            for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
-                            S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
-                        }
-                        S.ract = lloc;
-                        S.mode = M_P2;
-                        S.status = -1;
-                        S.scan_enter(e, best, chi);
-                        if (e < 0) { S.status = ST_OPT; S.mode = M_DONE; }
-                        busy = true;
-                    }
-                }
-                if (!__any(busy)) break;
-                if ((S.mode != M_DONE) & (S.ndeg >= BLAND_AFTER)) { S.status = ST_RETRY; S.mode = M_DONE; }
-                S.template pivot_core<GS, 0>(g, e, best, chi, nullptr, 0u);
-            }
-            if (stage == 2) flags |= RF_MINREP;
-        }
-#else
-        if (__any(stage == 2)) {
-            const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
-            uint64_t todo = (stage == 2) ? live : 0ull;
-            if (stage == 2) nlp += __popcll(live);
-            while (__any(todo != 0ull)) {
-                const bool go = todo != 0ull;
-                const int kr = go ? __ffsll((long long)todo) - 1 : 0;
-                todo &= todo - 1ull;
-                SimplexR<D, R, false, false> S;
-                S.reset(D, __popcll(live), row0);
-                double cxc = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < D; ++kk) {
-                    const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
-                    S.cost[kk] = ck;
-                    cxc = fma(ck, xc[kk], cxc);
-                }
-                // h[k] += 0.1 in place, as the reference does (:1149); undone after the LP (:1151), so rows
-                // k' < k carry the (+0.1, -0.1) round trip into the later LPs
-                const bool owner = go & ((kr >> RSH) == g.gl);
-                if (owner) myb[kr] = myb[kr] + 0.1;
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-#pragma unroll
-                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
-                    S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
-                }
-                S.ract = lloc;
-                S.mode = go ? M_P2 : M_DONE;
-#if PLP_R_FAST
-                S.template run_fast<GS>(g);
-                retry = retry | (go & (S.status == ST_RETRY));
-#else
-                S.run(g);
-#endif
-                const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
-                // b[k] after the round trip: computed by the lane that owns row k and handed to the others
-                // through registers (an LDS store of one lane followed by loads of other lanes would need a
-                // fence for the compiler, which otherwise keeps an earlier load)
-                double hk_own = 0.0;
-                if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
-                const double hk = bcast(hk_own, g.gbase + (kr >> RSH));
-                const double obj = -fun - hk;     // (:1156)
-                const bool keepk = go & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
-                keep |= keepk ? (1ull << kr) : 0ull;
-            }
-            if (stage == 2) flags |= RF_MINREP;
-        }
-#endif
-        // ---------------------------------------------------------------- results
-        if (valid & (g.gl == 0)) {
-            keep_out[pg] = keep;
-            flags_out[pg] = retry ? (int)RF_RETRY : flags;
-            nlp_out[pg] = nlp;
-            r_out[pg] = ball ? rr : 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
-        }
-    }
-}
-
-template <int D, int GS, int R = RR>
-static int launch_reduce_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows,
-                             double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
-                             hipStream_t st) {
-    const size_t smem = reduce_r_smem_bytes(GS, D, R);
-    const long long NG = RBLOCK / GS;
-    long long blocks = (B + NG - 1) / NG;
-    if (blocks > 2147483647ll) return 2;  // grid.x limit (never reached for realistic batches)
-    if (smem > 48 * 1024)  // 64 rows x d>=5: up to 82 KB of the CU's 160 KB
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_r_kernel<D, GS, R>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (blocks < 1) blocks = 1;
-    const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    hipLaunchKernelGGL((reduce_r_kernel<D, GS, R>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
-                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
-    return 0;
-}
+int launch_reduce_r2a(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                      hipStream_t st);
+int launch_reduce_r2b(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                      hipStream_t st);
 
 template <int D>
 static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, const double* b, const int* mrows,
@@ -512,7 +34,13 @@ static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, co
 int launch_reduce_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st) {
-    if (m_max < 1 || m_max > MAX_M || d < 1 || d > 8) return 1;
+    if (m_max < 1 || m_max > MAX_M || d < 1 || d > MAX_D) return 1;
+    if (d > 8) {
+        const char* e2 = getenv("PLP_REDUCE_R2");  // PLP_REDUCE_R2=0: d > 8 stays on the one-row-per-lane kernel (A/B)
+        if (e2 && e2[0] == '0') return 1;
+        return d <= 12 ? launch_reduce_r2a(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st)
+                       : launch_reduce_r2b(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    }
     const int gs = group_size_r(m_max);
     switch (d) {
         PLP_CASE_RR(1) PLP_CASE_RR(2) PLP_CASE_RR(3) PLP_CASE_RR(4)

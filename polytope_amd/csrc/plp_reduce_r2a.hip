@@ -1,0 +1,25 @@
+// plp_reduce_r2a.hip -- fused reduce() for d = 9..12: two rows per lane (four rows of up to 17 columns do not fit the
+// VGPR file), groups of 16 / 32 lanes for up to 32 / 64 rows.  Same kernel template as d <= 8.
+#include "plp_reduce_r_impl.hpp"
+
+namespace plp {
+
+template <int D>
+static int launch_r2_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
+                       unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    if (m_max <= 32) return launch_reduce_r_dg<D, 16, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    return launch_reduce_r_dg<D, 32, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+}
+
+#define PLP_CASE_R2(K) case K: return launch_r2_d<K>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+
+int launch_reduce_r2a(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                      hipStream_t st) {
+    switch (d) {
+        PLP_CASE_R2(9) PLP_CASE_R2(10) PLP_CASE_R2(11) PLP_CASE_R2(12)
+        default: return 1;
+    }
+}
+
+}  // namespace plp

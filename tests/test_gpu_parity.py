@@ -305,6 +305,40 @@ def test_reduce_degenerate_vertices(pa, oracle):
             assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
+@pytest.mark.parametrize("variant", [None, "PLP_REDUCE_RETRY_ALL", "PLP_REDUCE_R2=0"])
+def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
+    """d = 9..16: the fused reduce on two rows per lane (groups of 16 / 32 lanes), its hand-over to the general
+    engine, and the one-row-per-lane kernel it replaced -- random, degenerate and ragged polytopes vs the oracle."""
+    from polytope_amd.synth import random_hpolytopes
+    if variant:
+        name, _, val = variant.partition("=")
+        monkeypatch.setenv(name, val or "1")
+    rng = np.random.default_rng(77)
+    for (m, d, B) in [(30, 9, 24), (32, 12, 20), (64, 13, 10), (50, 16, 10), (18, 10, 30), (64, 16, 8)]:
+        A, b = random_hpolytopes(B, m, d, seed=3 * m + d, bounded=True)
+        for k in range(0, B, 4):
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.05])
+        for k in range(2, B, 7):
+            b[k, 0] = -4.0
+        mrows = rng.integers(max(2, m - 6), m + 1, B).astype(np.int32)
+        res = pa.reduce_batch(A, b, m=mrows)
+        masks = pa.keep_to_bool(res["keep"], m)
+        for k in range(B):
+            o = oracle.reduce(A[k, :mrows[k]], b[k, :mrows[k]])
+            assert int(res["flags"][k]) == o["flags"], (variant, m, d, k, int(res["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k, :mrows[k]], o["keep"]), (variant, m, d, k)
+            assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
+    A, b = _pyramids(20, 40, 9, rng)   # degenerate vertices at d = 9
+    res = pa.reduce_batch(A, b)
+    masks = pa.keep_to_bool(res["keep"], 40)
+    for k in range(20):
+        o = oracle.reduce(A[k], b[k])
+        assert int(res["flags"][k]) == o["flags"] and np.array_equal(masks[k], o["keep"]), (variant, k)
+        assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
+
+
 @pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_TPL", "PLP_REDUCE_RETRY_ALL"])
 def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
     """The three mappings of the fused reduce (4 rows per lane = default, 1 row per lane, 1 polytope
