@@ -396,6 +396,8 @@ int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G,
     switch (n) {
         PLP_CASE_LPR(1) PLP_CASE_LPR(2) PLP_CASE_LPR(3) PLP_CASE_LPR(4)
         PLP_CASE_LPR(5) PLP_CASE_LPR(6) PLP_CASE_LPR(7) PLP_CASE_LPR(8)
+        PLP_CASE_LPR(9) PLP_CASE_LPR(10) PLP_CASE_LPR(11) PLP_CASE_LPR(12) PLP_CASE_LPR(13)  // two rows per lane
+        PLP_CASE_LPR(14) PLP_CASE_LPR(15) PLP_CASE_LPR(16) PLP_CASE_LPR(17)
         default: return 1;
     }
 }

@@ -104,11 +104,12 @@ def test_lp_vs_oracle_and_scipy(pa, oracle):
 
 
 def test_lp_kernel_variants(pa, oracle, monkeypatch):
-    """lpsolve batches take two kernels: origin-feasible LPs (n <= 8) the four-rows-per-lane fast path,
-    the rest (phase 1 needed, n > 8, Bland cases) the two-phase kernel in a second launch.  A mixed batch
+    """lpsolve batches take two kernels: origin-feasible LPs the fast path (four rows per lane for n <= 8, two
+    for n = 9..17), the rest (phase 1 needed beyond n = 4, Bland cases) the two-phase kernel in a second launch.  A mixed batch
     must agree LP by LP with the oracle and with the two-phase kernel alone (PLP_LP_1ROW=1)."""
     rng = np.random.default_rng(12)
-    for (m, n, B) in [(16, 3, 600), (12, 2, 200), (30, 5, 150), (64, 8, 60), (5, 4, 100)]:
+    for (m, n, B) in [(16, 3, 600), (12, 2, 200), (30, 5, 150), (64, 8, 60), (5, 4, 100), (30, 9, 80), (64, 12, 40),
+                      (64, 17, 30), (24, 11, 60)]:
         G = rng.standard_normal((B, m, n))
         G /= np.linalg.norm(G, axis=2, keepdims=True)
         h = rng.random((B, m)) + 0.2
