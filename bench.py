@@ -276,6 +276,9 @@ def main():
         if valu:  # PMC SQ_INSTS_VALU of the same kernel: 4 issue cycles per wave64 instruction, 1024 SIMDs
             line["roofline"]["valu_insts_per_launch"] = valu.get("valu_insts_per_launch")
             line["roofline"]["valu_issue_frac_at_2p4GHz"] = valu.get("valu_issue_frac_at_2p4GHz")
+            if valu.get("valu_issue_frac_of_busy_cycles"):  # against SQ_BUSY_CYCLES: the clock actually held
+                line["roofline"]["valu_issue_frac_of_busy_cycles"] = valu.get("valu_issue_frac_of_busy_cycles")
+                line["roofline"]["shader_clock_GHz_estimate"] = valu.get("shader_clock_GHz_estimate")
         if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, b, None)
         print(json.dumps(line), flush=True)

@@ -48,6 +48,16 @@ if "SQ_INSTS_VALU" in vals:
     traffic["valu_insts_per_launch"] = vals["SQ_INSTS_VALU"]
     traffic["valu_issue_cycles_per_simd"] = vals["SQ_INSTS_VALU"] * 4 / 1024
     traffic["valu_issue_frac_at_2p4GHz"] = vals["SQ_INSTS_VALU"] * 4 / 1024 / (float(k["AverageNs"]) * 2.4)
+if "SQ_BUSY_CYCLES" in vals and "SQ_INSTS_VALU" in vals:
+    # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4); per engine it is the kernel's duration in
+    # shader clocks, which gives the clock the chip held (kernel-trace timestamps of the same PMC pass) and the
+    # VALU issue fraction without assuming 2.4 GHz
+    tr = list(csv.DictReader(open(os.path.join(src, "pmc_SQ_BUSY_CYCLES", "reduce_kernel_trace.csv"))))
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "plp::reduce_r_kernel" in r["Kernel_Name"]]
+    per_se = vals["SQ_BUSY_CYCLES"] / 32
+    traffic["sq_busy_cycles_per_shader_engine"] = per_se
+    traffic["shader_clock_GHz_estimate"] = per_se / (sum(dur) / len(dur))
+    traffic["valu_issue_frac_of_busy_cycles"] = vals["SQ_INSTS_VALU"] * 4 / 1024 / per_se
 json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic))
