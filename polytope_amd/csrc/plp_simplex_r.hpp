@@ -27,6 +27,31 @@ namespace plp {
 // objective rides along (plp_simplex.hpp does the same with one row per lane).
 constexpr int ID_TR = -1;  // id of the phase-1 artificial variable
 
+// max(a, b) as ONE v_max_f64.  fmax() makes the compiler canonicalise operands it cannot prove to be the result
+// of an arithmetic instruction (values that went through selects or bit operations) with an extra v_max_f64 x, x;
+// the operands here are never signalling NaNs, and v_max_f64 itself returns the non-NaN operand like fmax().
+#ifndef PLP_RAW_MAX
+#define PLP_RAW_MAX 1
+#endif
+__device__ __forceinline__ double max_raw(double a, double b) {
+#if PLP_RAW_MAX
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(a, b);
+#endif
+}
+__device__ __forceinline__ double max0_raw(double a) {  // max(a, 0) with the inline constant
+#if PLP_RAW_MAX
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+    return r;
+#else
+    return fmax(a, 0.0);
+#endif
+}
+
 template <int NC, int R, bool INITM, bool TRACKX = true, bool CARRY = false>
 struct SimplexR {
     // ---- my R rows
@@ -369,7 +394,7 @@ struct SimplexR {
             e = take ? j : e;
             chi = take ? hi : chi;
             if constexpr (CARRY) best = take ? key : best;  // a dead column must not raise the bar
-            else best = fmax(best, key);
+            else best = max_raw(best, key);
         }
     }
 
@@ -444,7 +469,7 @@ struct SimplexR {
                 better = act & (((ielig >> k) & 1u) != 0u) & (bi < bn);
             } else {
                 const bool elig = act & (((ract >> k) & 1u) != 0u) & (a[k] > TOL_PIV);
-                bi = fmax(beta[k], 0.0);
+                bi = max0_raw(beta[k]);
                 better = elig & (bi * an < bn * a[k]);
             }
             if (better) {  // strict: the first (lowest) row keeps a tie

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 for lib in build_variants/*.so; do
   echo "== $lib"
-  PLP_LIB=$PWD/$lib timeout 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+  PLP_LIB=$PWD/$lib timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('   LP/s %.4g  ms/step %.4f  kernel_ms %.4f' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))"
 done
