@@ -30,11 +30,22 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_BUSY_CYCLES"):
         for r in mine:
             w.writerow([r["Kernel_Name"].split("(")[0], r["Dispatch_Id"], r["Counter_Name"], r["Counter_Value"],
                         r.get("VGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size")])
-    v = [float(r["Counter_Value"]) for r in mine if "plp::reduce_r_kernel" in r["Kernel_Name"]]
+    # full-size dispatches only (bench.py primes the code object with a 64-polytope call)
+    rk = [r for r in mine if "plp::reduce_r_kernel" in r["Kernel_Name"]]
+    gmax = max(int(r["Grid_Size"]) for r in rk)
+    v = [float(r["Counter_Value"]) for r in rk if int(r["Grid_Size"]) == gmax]
     vals[ctr] = sum(v) / len(v)
 stats = list(csv.DictReader(open(os.path.join(src, "prof", "reduce_kernel_stats.csv"))))
-k = [r for r in stats if "plp::reduce_r_kernel" in r["Name"]][0]
+k = dict([r for r in stats if "plp::reduce_r_kernel" in r["Name"]][0])
 k_name = k["Name"].split("(")[0].replace("void ", "")
+# the stats line averages over every dispatch, including the 64-polytope priming call: redo the average over the
+# full-size dispatches from the kernel trace of the same run
+ktr = [r for r in csv.DictReader(open(os.path.join(src, "prof", "reduce_kernel_trace.csv")))
+       if "plp::reduce_r_kernel" in r["Kernel_Name"]]
+gfull = max(int(r["Grid_Size_X"]) for r in ktr)
+dfull = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ktr if int(r["Grid_Size_X"]) == gfull]
+k["AverageNs"], k["Calls"] = sum(dfull) / len(dfull), len(dfull)
+shutil.copy(os.path.join(src, "prof", "reduce_kernel_trace.csv"), os.path.join(dst, tag + "_kernel_trace.csv"))
 traffic = {
     "kernel": k_name,
     "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one rocprofv3 --pmc run per counter)",
@@ -53,7 +64,9 @@ if "SQ_BUSY_CYCLES" in vals and "SQ_INSTS_VALU" in vals:
     # shader clocks, which gives the clock the chip held (kernel-trace timestamps of the same PMC pass) and the
     # VALU issue fraction without assuming 2.4 GHz
     tr = list(csv.DictReader(open(os.path.join(src, "pmc_SQ_BUSY_CYCLES", "reduce_kernel_trace.csv"))))
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "plp::reduce_r_kernel" in r["Kernel_Name"]]
+    gm = max(int(r["Grid_Size_X"]) for r in tr if "plp::reduce_r_kernel" in r["Kernel_Name"])
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr
+           if "plp::reduce_r_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == gm]
     per_se = vals["SQ_BUSY_CYCLES"] / 32
     traffic["sq_busy_cycles_per_shader_engine"] = per_se
     traffic["shader_clock_GHz_estimate"] = per_se / (sum(dur) / len(dur))
