@@ -135,7 +135,7 @@ def main():
     import torch
     import polytope_amd as pa
     from polytope_amd import _lib
-    from polytope_amd.dist import GatherPipeline, ResultBuffer
+    from polytope_amd.dist import GroupedExchange
     from polytope_amd.synth import random_hpolytopes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,35 +168,20 @@ def main():
     # the other buffer.  Every batch's results are on every rank before the timed region ends (flush below).
     G = max(1, args.gather_every)
     nb = 24 * B_PER_GPU
-    pipe = GatherPipeline(torch, dist, G * nb, 1, dtype=torch.uint8, device=dev) if multi else None
-    big = [torch.zeros((G * nb,), dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
-    bufs = [[ResultBuffer(torch, B_PER_GPU, DIM, dev, flat=big[g][s * nb:(s + 1) * nb]) for s in range(G)]
-            for g in range(2)] if multi else None
-    nstep = [0]
+    ex = GroupedExchange(torch, dist, B_PER_GPU, DIM, G, dev) if multi else None
 
     def step():
-        if pipe is None:
+        if ex is None:
             return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
-        k = nstep[0]
-        nstep[0] += 1
-        g, slot = (k // G) & 1, k % G
-        res = pa.reduce_batch(At, bt, out=bufs[g][slot].views)
-        if slot == G - 1:
-            pipe.push(big[g].view(-1, 1))
+        res = pa.reduce_batch(At, bt, out=ex.slot().views)
+        ex.commit()
         return res
-
-    def drain():
-        """exchange a partly filled group, then wait for the last collective"""
-        if nstep[0] % G:
-            pipe.push(big[(nstep[0] // G) & 1].view(-1, 1))
-            nstep[0] += G - nstep[0] % G
-        return pipe.flush()
 
     pa.reduce_batch(At[:64], bt[:64])  # loads the code object (hipModule load is lazy): not a step, not timed
     for _ in range(args.warmup):
         step()
-    if pipe is not None:
-        drain()
+    if ex is not None:
+        ex.drain()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -213,8 +198,8 @@ def main():
     for k in range(args.steps):
         res = step()
     ev1.record()
-    if pipe is not None:
-        gathered = drain()
+    if ex is not None:
+        gathered = ex.drain()[-1]
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -233,8 +218,7 @@ def main():
         dist.all_reduce(t)
         nlp_total = int(t.item())
         assert gathered.numel() == world * G * nb
-        mine = gathered.view(-1)[rank * G * nb: rank * G * nb + nb]  # my slot 0 of the last exchanged group
-        assert int(bufs[0][0].split(mine)[0]["nlp"].sum().item()) == nlp_local
+        assert int(ex.slot_views(gathered, rank, 0)["nlp"].sum().item()) == nlp_local  # my slot 0 of the last group
 
     if rank == 0:
         alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope

@@ -135,6 +135,62 @@ class GatherPipeline:
         return self._wait()
 
 
+class GroupedExchange:
+    """The exchange step of a stream of batches, coalesced: the reduce kernel of batch k writes its results
+    straight into slot k mod G of a flat buffer (ResultBuffer views, 24 B per polytope, no packing kernels) and
+    every G batches the whole buffer goes out as ONE all-gather (xGMI is point-to-point: fewer, larger
+    collectives) on RCCL's stream, while the next G batches are computed into the second buffer
+    (GatherPipeline).  Every batch's results reach every rank; a partly filled group is exchanged by drain().
+
+        ex = GroupedExchange(torch, dist, B, d, G, device)
+        for batch in batches:
+            res = reduce_batch(A, b, out=ex.slot().views)   # compute stream
+            gathered = ex.commit()      # None, or the uint8[world * G * 24 B] buffer of an EARLIER group
+        rest = ex.drain()               # the groups not handed out yet, oldest first (the last may be partly filled)
+        ex.slot_views(gathered, rank, s)  # dict(keep, r, flags, nlp) of rank `rank`, slot s
+    """
+
+    def __init__(self, torch, dist, B, d, G, device):
+        self.torch, self.G, self.nb = torch, int(G), 24 * int(B)
+        host = dist.get_backend() == "gloo"
+        dev = torch.device("cpu") if host and device is None else device
+        self.big = [torch.zeros((self.G * self.nb,), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.bufs = [[ResultBuffer(torch, B, d, dev, flat=self.big[g][s * self.nb:(s + 1) * self.nb])
+                      for s in range(self.G)] for g in range(2)]
+        self.pipe = GatherPipeline(torch, dist, self.G * self.nb, 1, dtype=torch.uint8, device=dev)
+        self.k = 0
+
+    def slot(self):
+        """ResultBuffer the next batch writes into"""
+        return self.bufs[(self.k // self.G) & 1][self.k % self.G]
+
+    def commit(self):
+        """the batch written into slot() is complete (enqueued on the compute stream)"""
+        k = self.k
+        self.k += 1
+        if k % self.G == self.G - 1:
+            return self.pipe.push(self.big[(k // self.G) & 1].view(-1, 1))
+        return None
+
+    def drain(self):
+        """Exchange a partly filled group and wait for what is in flight: the list of gathered groups that
+        commit() has not handed out yet, oldest first (at most two; they live in different buffers)."""
+        outs = []
+        if self.k % self.G:
+            prev = self.pipe.push(self.big[(self.k // self.G) & 1].view(-1, 1))
+            if prev is not None:
+                outs.append(prev.view(-1))
+            self.k += self.G - self.k % self.G
+        last = self.pipe.flush()
+        if last is not None:
+            outs.append(last.view(-1))
+        return outs
+
+    def slot_views(self, gathered, rank, s):
+        lo = rank * self.G * self.nb + s * self.nb
+        return self.bufs[0][0].split(gathered.view(-1)[lo:lo + self.nb])[0]
+
+
 def reduce_batch_sharded(A, b, m=None, abs_tol=1e-7, reduce_fn=None, device=None):
     """Every rank holds (or can regenerate) the full batch A[B,m,d], b[B,m]; each rank reduces
     its contiguous shard and all ranks end up with the results of the whole batch.

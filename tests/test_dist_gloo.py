@@ -189,6 +189,30 @@ def _worker_adj_hull(rank, world, port, q):
     for k in range(4):
         want = torch.cat([torch.full((5, 3), 100 * k + r, dtype=torch.int64) for r in range(world)])
         assert torch.equal(got[k + 1], want), (k, rank)
+    # coalesced exchange (what bench.py --gpus N runs): G batches per all-gather, results written into slot views
+    Bq, G = 7, 3
+    ex = pdist.GroupedExchange(torch, dist, Bq, 3, G, None)
+    groups = []
+    for k in range(8):                                   # 2 full groups + a partly filled one
+        v = ex.slot().views
+        v["keep"][:] = 1000 * k + rank
+        v["r"][:] = k + 0.25 * rank
+        v["flags"][:] = k
+        v["nlp"][:] = 10 * k + rank
+        out = ex.commit()
+        if out is not None:
+            groups.append(out.clone())                   # an EARLIER group (buffers are reused two pushes later)
+    groups += [g.clone() for g in ex.drain()]
+    assert len(groups) == 3 and all(g.numel() == world * G * 24 * Bq for g in groups)
+    for gi, g in enumerate(groups):
+        for r in range(world):
+            for sl in range(G):
+                k = gi * G + sl
+                if k >= 8:
+                    continue                             # slots of the last group that were not filled
+                w = ex.slot_views(g, r, sl)
+                assert int(w["keep"][0]) == 1000 * k + r and int(w["keep"][-1]) == 1000 * k + r, (gi, r, sl)
+                assert float(w["r"][3]) == k + 0.25 * r and int(w["flags"][2]) == k and int(w["nlp"][6]) == 10 * k + r
     adj = pdist.adjacent_pairs_sharded(A, b, pairs_fn=cpu_pairs).numpy()
     P = np.random.default_rng(3).standard_normal((3000, 3))
     np.random.seed(5)   # every rank draws the same start simplex
