@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
+    ap.add_argument("--streams", type=int, default=1, help="N = 1 only: issue the steps round-robin on this many HIP "
+                    "streams (independent batches in flight: the half-empty last round of one launch overlaps the "
+                    "next launch).  Default 1: one launch at a time, which is what roofline.kernel_ms describes")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
@@ -170,7 +173,15 @@ def main():
     nb = 24 * B_PER_GPU
     ex = GroupedExchange(torch, dist, B_PER_GPU, DIM, G, dev) if multi else None
 
+    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if (args.streams > 1 and not multi) else None
+    nissued = [0]
+
     def step():
+        if side is not None:  # independent batches on several streams (results of each stay in its own tensors)
+            st = side[nissued[0] % len(side)]
+            nissued[0] += 1
+            with torch.cuda.stream(st):
+                return pa.reduce_batch(At, bt)
         if ex is None:
             return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
         res = pa.reduce_batch(At, bt, out=ex.slot().views)
@@ -195,8 +206,14 @@ def main():
     gathered = None
     t0 = time.perf_counter()
     ev0.record()
+    if side is not None:
+        for st in side:
+            st.wait_stream(torch.cuda.current_stream())
     for k in range(args.steps):
         res = step()
+    if side is not None:
+        for st in side:
+            torch.cuda.current_stream().wait_stream(st)
     ev1.record()
     if ex is not None:
         gathered = ex.drain()[-1]
@@ -249,7 +266,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1])"
                                    % (B_PER_GPU, DIM, M_ROWS),
-                       "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU,
+                       "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU, "streams": args.streams,
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -264,6 +281,27 @@ def main():
             if valu.get("valu_issue_frac_of_busy_cycles"):  # against SQ_BUSY_CYCLES: the clock actually held
                 line["roofline"]["valu_issue_frac_of_busy_cycles"] = valu.get("valu_issue_frac_of_busy_cycles")
                 line["roofline"]["shader_clock_GHz_estimate"] = valu.get("shader_clock_GHz_estimate")
+        if not multi and args.streams == 1:
+            # Not `value`: the same K steps again with two independent batches in flight (two HIP streams).  100 000
+            # polytopes are 6250 wavefronts for 4096 resident slots, so the last round of a launch runs half empty;
+            # with a second launch in flight that hole is filled -- what a caller with a stream of batches should do.
+            two = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            for k in range(2 * max(1, args.warmup)):  # untimed: the streams' queues are created on first use
+                with torch.cuda.stream(two[k & 1]):
+                    pa.reduce_batch(At, bt)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for st in two:
+                st.wait_stream(torch.cuda.current_stream())
+            for k in range(args.steps):
+                with torch.cuda.stream(two[k & 1]):
+                    res2 = pa.reduce_batch(At, bt)
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp
+            assert int(res2["nlp"].sum().item()) == nlp_local
+            line["pipelined"] = {"streams": 2, "value": nlp_local * args.steps / tp, "unit": "LP/s",
+                                 "ms_per_step": tp / args.steps * 1e3,
+                                 "note": "two batches in flight; not the headline, see DESIGN.md section 6"}
         if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, b, None)
         print(json.dumps(line), flush=True)
