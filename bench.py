@@ -247,7 +247,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_launch"]
-            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_issue_frac_at_2p4GHz") if k in tj}
+            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_issue_frac_at_2p4GHz", "valu_issue_frac_of_busy_cycles",
+                                         "shader_clock_GHz_estimate") if k in tj}
             traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
         except Exception:
             pass
@@ -272,7 +273,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_kernel<3, 4, 4>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "FP64-VALU issue bound, not HBM bound: %.3g LP/s inside the kernel" % (
+                         "note": "FP64-VALU issue bound (see valu_issue_frac_*), not HBM bound: %.3g LP/s inside the kernel" % (
                              nlp_local / (kern_ms * 1e-3))},
         }
         if valu:  # PMC SQ_INSTS_VALU of the same kernel: 4 issue cycles per wave64 instruction, 1024 SIMDs
