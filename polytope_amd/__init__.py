@@ -9,7 +9,7 @@ library or without a gfx950 device the 'hip' backend raises.
 """
 from . import _lib  # noqa: F401
 from .batch import (  # noqa: F401
-    lpsolve_batch, cheby_ball_batch, reduce_batch, contains_batch, assign_batch, adjacent_pairs, keep_to_bool,
+    lpsolve_batch, cheby_ball_batch, bbox_batch, reduce_batch, contains_batch, assign_batch, adjacent_pairs, keep_to_bool,
 )
 
 __version__ = "0.1.0"

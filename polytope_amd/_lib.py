@@ -33,6 +33,8 @@ SIGNATURES = {
     "plp_lp_solve_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plp_cheby_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plp_cheby_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plp_bbox_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plp_bbox_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "plp_reduce_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_reduce_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_contains": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_double, C.c_int, _vp]),

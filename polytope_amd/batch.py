@@ -128,6 +128,41 @@ def cheby_ball_batch(A, b, m=None):
     return dict(r=r, xc=xc, status=status)
 
 
+def bbox_batch(A, b, m=None):
+    """Bounding boxes of B polytopes with 1 <= d <= 8 (bounding_box's LP loops, polytope.py:1367-1409): the
+    Chebyshev LP and 2d LPs from its centre per polytope, one launch.
+
+    -> dict(lb[B,d], ub[B,d], status[B]): status 0 = box valid (+-inf where unbounded), 1 = polytope not handled
+    here (no centre with r >= 1e-6, or a Bland case): the caller solves the 2d generic LPs for it.
+    """
+    lib = _lib.load()
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        B, m_max, d = A.shape
+        lb = torch.empty((B, d), dtype=torch.float64, device=A.device)
+        ub = torch.empty((B, d), dtype=torch.float64, device=A.device)
+        status = torch.empty((B,), dtype=torch.int32, device=A.device)
+        _lib.check(lib.plp_bbox_batch_dev(ctx.handle, stream, B, m_max, d, _ptr(A), _ptr(b), _ptr(m), _ptr(lb),
+                                          _ptr(ub), _ptr(status)), "plp_bbox_batch_dev")
+        return dict(lb=lb, ub=ub, status=status)
+    A = _np(A)
+    if A.ndim != 3:
+        raise ValueError("A must be [B, m_max, d]")
+    B, m_max, d = A.shape
+    b = _np(b).reshape(B, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(B)
+    _finite_or_raise("bbox_batch", A, b)
+    lb = np.empty((B, d))
+    ub = np.empty((B, d))
+    status = np.empty(B, np.int32)
+    _lib.check(lib.plp_bbox_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), _ptr(lb),
+                                  _ptr(ub), _ptr(status)), "plp_bbox_batch")
+    return dict(lb=lb, ub=ub, status=status)
+
+
 def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     """Fused reduce() (polytope.py:1053-1163) of B non-minrep polytopes.
 

@@ -1,0 +1,36 @@
+// plp_bbox_r.hip -- launcher of the fused bounding-box batches (kernel: plp_cheby_r_impl.hpp, bbox_r_kernel).
+#include "plp_cheby_r_impl.hpp"
+
+namespace plp {
+
+template <int D, int GS>
+static int launch_bbox_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
+                            double* ub, int* status, hipStream_t st) {
+    constexpr long long gpb = BLOCK / GS;
+    const long long blocks = (B + gpb - 1) / gpb;
+    if (blocks > 2147483647ll) return 1;
+    hipLaunchKernelGGL((bbox_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max,
+                       A, b, mrows, lb, ub, status, force_retry_env());
+    return 0;
+}
+
+template <int D>
+static int launch_bbox_r_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
+                           double* ub, int* status, hipStream_t st) {
+    PLP_DISPATCH_GS(RowsPerLane<D>::value, m_max, (launch_bbox_r_dg<D, GSV>(B, m_max, A, b, mrows, lb, ub, status, st)));
+}
+
+#define PLP_CASE_BB(K) case K: return launch_bbox_r_d<K>(B, m_max, A, b, mrows, lb, ub, status, st);
+
+// returns 0 when launched, 1 when this kernel does not apply (d > 8: the caller uses the generic LPs)
+int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
+                double* ub, int* status, hipStream_t st) {
+    if (m_max < 1 || m_max > MAX_M || B < 1) return 1;
+    switch (d) {
+        PLP_CASE_BB(1) PLP_CASE_BB(2) PLP_CASE_BB(3) PLP_CASE_BB(4)
+        PLP_CASE_BB(5) PLP_CASE_BB(6) PLP_CASE_BB(7) PLP_CASE_BB(8)
+        default: return 1;
+    }
+}
+
+}  // namespace plp

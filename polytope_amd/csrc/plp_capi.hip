@@ -294,6 +294,47 @@ int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, 
                               {dst, nullptr, status, (size_t)B * 4}});
 }
 
+// ------------------------------------------------------------------------------- bounding box
+int plp_bbox_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, const double* A, const double* b,
+                       const int32_t* m, double* lb, double* ub, int32_t* status) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!lb || !ub || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
+    if (m_max < 1 || d > 8) return fail(PLP_EUNSUPPORTED, "bbox kernel: d=%d m_max=%d (needs 1 <= d <= 8, m_max >= 1)", d, m_max);
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
+    if (plp::launch_bbox(B, m_max, d, A, b, m, lb, ub, status, st))
+        return fail(PLP_EUNSUPPORTED, "bbox kernel: unsupported size");
+    return check_launch("bbox_r_kernel");
+}
+
+int plp_bbox_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b, const int32_t* m,
+                   double* lb, double* ub, int32_t* status) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!lb || !ub || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nA = (size_t)B * m_max * d, nb = (size_t)B * m_max, nx = (size_t)B * d;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nx * 8) * 2 + pad(B * 4) * 2 + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA ? nA : 1);
+    double* db = a.take<double>(nb ? nb : 1);
+    int32_t* dm = a.take<int32_t>(B);
+    double* dlb = a.take<double>(nx);
+    double* dub = a.take<double>(nx);
+    int32_t* dst = a.take<int32_t>(B);
+    hipStream_t st = ctx->stream;
+    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    if (rc) return rc;
+    rc = plp_bbox_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dlb, dub, dst);
+    if (rc) return rc;
+    return copy_out(ctx, st, {{dlb, nullptr, lb, nx * 8}, {dub, nullptr, ub, nx * 8}, {dst, nullptr, status, (size_t)B * 4}});
+}
+
 // ------------------------------------------------------------------------------- reduce
 int plp_reduce_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, const double* A,
                          const double* b, const int32_t* m, double abs_tol, uint64_t* keep, int32_t* flags,

@@ -140,6 +140,83 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
     }
 }
 
+// Bounding box (polytope/polytope.py:1314-1411): the reference solves 2d generic LPs per polytope (F3:
+// min +-e_i.x over {Ax <= b}), each from scratch.  Here one lane group solves the Chebyshev LP of its polytope first
+// and, when that yields a centre with r >= BBOX_MIN_R, starts all 2d LPs from the dictionary translated to that
+// centre (primal feasible, no phase 1; the fused reduce does the same for its box), reading x_i off the optimal
+// value.  status: 0 = lb/ub hold the box (+-inf where an LP is unbounded, :1376/:1398), 1 = not handled here
+// (empty / flat / unbounded-ball polytopes and Bland cases): the caller solves the generic LPs for those.
+constexpr double BBOX_MIN_R = 1e-6;
+
+template <int D, int GS>
+__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long long B, int m_max,
+                                                                         const double* __restrict__ A,
+                                                                         const double* __restrict__ b,
+                                                                         const int* __restrict__ mrows,
+                                                                         double* __restrict__ lb,
+                                                                         double* __restrict__ ub,
+                                                                         int* __restrict__ status, int force_retry) {
+    const Grp g(GS);
+    constexpr int gpb = BLOCK / GS;
+    const int gib = threadIdx.x / GS;
+    constexpr int R = RowsPerLane<D>::value;
+    const int row0 = g.gl * R;
+    const long long p = (long long)blockIdx.x * gpb + gib;
+    const bool valid = p < B;
+    const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
+    double x[D + 1];
+    const int st = cheby_r_solve<D, GS, R>(
+        g, valid, m, row0, [&](int rr, int kk) { return A[(p * m_max + rr) * D + kk]; },
+        [&](int rr) { return b[p * m_max + rr]; }, x, force_retry);
+    const bool ok = valid & (st == ST_OPT) & (x[D] >= BBOX_MIN_R);
+    bool handed = !ok;
+    // my rows and their slacks at the centre
+    double T0[R][D], be0[R];
+    unsigned has = 0u;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool h = ok & (row0 + k < m);
+        has |= h ? (1u << k) : 0u;
+        double s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            T0[k][kk] = h ? A[(p * m_max + row0 + k) * D + kk] : 0.0;
+            s = fma(T0[k][kk], ok ? x[kk] : 0.0, s);
+        }
+        be0[k] = h ? fmax(b[p * m_max + row0 + k] - s, 0.0) : 0.0;
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
+        const int kx = it >> 1;
+        const bool up = it & 1;
+        double xck = 0.0;
+        SimplexR<D, R, false, false> S;
+        S.reset(D, m, row0);
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            xck = (kk == kx) ? x[kk] : xck;
+            S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) S.T[k][kk] = T0[k][kk];
+            S.beta[k] = be0[k];
+        }
+        S.ract = has;
+        S.mode = ok ? M_P2 : M_DONE;
+        S.template run_fast<GS>(g);
+        // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
+        double val;
+        if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+        else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+        else { val = qnan; handed = true; }
+        if (valid & (g.gl == 0)) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
+    }
+    if (valid & (g.gl == 0)) status[p] = handed ? 1 : 0;
+}
+
 // One lane group per pair (i, j < i): the rows of both cells are stacked with b + inflate, and the pair
 // counts iff the Chebyshev LP of the stack is optimal with r > thresh.  Adjacency: inflate = abs_tol,
 // thresh = abs_tol / 10 (`is_fulldim(dummy, abs_tol / 10)`, polytope.py:1860-1866); overlap

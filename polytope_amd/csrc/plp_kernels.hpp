@@ -29,6 +29,11 @@ int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G,
 int launch_cheby_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                    double* xc, int* status, hipStream_t st);
 
+// bounding boxes, Chebyshev LP + 2d LPs from its centre per polytope (d <= 8, plp_bbox_r.hip): status 0 = lb/ub
+// valid, 1 = polytope left to the generic LPs; returns 1 when the kernel does not apply
+int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
+                double* ub, int* status, hipStream_t st);
+
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8) into the n x n matrix adj (compact == nullptr),
 // or of the pairs p_lo <= p < p_hi, p = i (i - 1) / 2 + j, j < i, into compact[p - p_lo]
 // a pair counts iff the Chebyshev radius of the two stacked cells, each b inflated by `inflate`, exceeds `thresh`

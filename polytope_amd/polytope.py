@@ -497,10 +497,11 @@ def is_subset(small, big, abs_tol=ABS_TOL):
 
 # ====================================================================================== bounding box
 def _bbox_packed(polys):
-    """_bbox_raw for polytopes of one dimension on the 'hip' backend: the 2d LPs of every polytope packed into
-    one (B*2d, m_max, d) batch with array operations and the corners read off the batch result -- no per-LP
-    Python objects.  Same status handling as the loop below (ref :1372-1409)."""
-    from .batch import lpsolve_batch
+    """_bbox_raw for polytopes of one dimension on the 'hip' backend, with array operations only (no per-LP
+    Python objects).  d <= 8: the fused kernel (Chebyshev LP + 2d LPs from its centre per polytope, one launch);
+    polytopes it hands back (empty, flat, unbounded ball) and d > 8 go down as ONE batch of 2d generic LPs each.
+    Same status handling as the reference (:1372-1409)."""
+    from .batch import bbox_batch, lpsolve_batch
     d = polys[0].A.shape[1]
     ms = np.array([p.A.shape[0] for p in polys], dtype=np.int32)
     m_max = max(int(ms.max()), 1)
@@ -510,19 +511,29 @@ def _bbox_packed(polys):
     for k, p in enumerate(polys):
         A3[k, :ms[k]] = p.A
         b3[k, :ms[k]] = p.b
-    cost = np.vstack([np.eye(d), -np.eye(d)])                      # lower_0..lower_{d-1}, upper_0..upper_{d-1}
-    res = lpsolve_batch(np.tile(cost, (B, 1)), np.repeat(A3, 2 * d, axis=0), np.repeat(b3, 2 * d, axis=0),
-                        m=np.repeat(ms, 2 * d))
-    st = res["status"].reshape(B, 2, d)
-    xi = res["x"].reshape(B, 2, d, d)[:, :, np.arange(d), np.arange(d)]   # x[i] of LP i
-    bad = ~np.isin(st, (0, 2, 3))
-    if bad.any():
-        k, side, i = np.argwhere(bad)[0]
-        raise RuntimeError("bounding_box (%s corner): `polytope.solvers.lpsolve` returned:  {'status': %d, 'x': None, "
-                           "'fun': None}\nits docstring describes return values"
-                           % ("lower" if side == 0 else "upper", int(st[k, side, i])))
-    lo = np.where(st[:, 0] == 0, xi[:, 0], np.where(st[:, 0] == 3, -np.inf, 0.0))
-    hi = np.where(st[:, 1] == 0, xi[:, 1], np.where(st[:, 1] == 3, np.inf, lo))
+    lo = np.empty((B, d))
+    hi = np.empty((B, d))
+    rest = np.arange(B)
+    if d <= 8 and int(ms.min()) >= 1:
+        res = bbox_batch(A3, b3, m=ms)
+        done = res["status"] == 0
+        lo[done], hi[done] = res["lb"][done], res["ub"][done]
+        rest = np.nonzero(~done)[0]
+    if rest.size:
+        nr = rest.size
+        cost = np.vstack([np.eye(d), -np.eye(d)])                  # lower_0..lower_{d-1}, upper_0..upper_{d-1}
+        res = lpsolve_batch(np.tile(cost, (nr, 1)), np.repeat(A3[rest], 2 * d, axis=0),
+                            np.repeat(b3[rest], 2 * d, axis=0), m=np.repeat(ms[rest], 2 * d))
+        st = res["status"].reshape(nr, 2, d)
+        xi = res["x"].reshape(nr, 2, d, d)[:, :, np.arange(d), np.arange(d)]   # x[i] of LP i
+        bad = ~np.isin(st, (0, 2, 3))
+        if bad.any():
+            k, side, i = np.argwhere(bad)[0]
+            raise RuntimeError("bounding_box (%s corner): `polytope.solvers.lpsolve` returned:  {'status': %d, "
+                               "'x': None, 'fun': None}\nits docstring describes return values"
+                               % ("lower" if side == 0 else "upper", int(st[k, side, i])))
+        lo[rest] = np.where(st[:, 0] == 0, xi[:, 0], np.where(st[:, 0] == 3, -np.inf, 0.0))
+        hi[rest] = np.where(st[:, 1] == 0, xi[:, 1], np.where(st[:, 1] == 3, np.inf, lo[rest]))
     return [(lo[k].reshape(d, 1).copy(), hi[k].reshape(d, 1).copy()) for k in range(B)]
 
 

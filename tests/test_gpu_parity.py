@@ -159,6 +159,58 @@ def test_lp_edge_inputs(pa):
         pa.lpsolve_batch(np.zeros((1, 2)), np.zeros((1, 65, 2)), np.zeros((1, 65)))
 
 
+# ------------------------------------------------------------------------------ bounding box
+@pytest.mark.parametrize("variant", [None, "PLP_CHEBY_RETRY_ALL"])
+def test_bbox_vs_oracle(pa, oracle, variant, monkeypatch):
+    """Fused bounding-box kernel (Chebyshev LP, then 2d LPs from its centre) against the oracle's 2d generic LPs
+    (bounding_box, polytope.py:1367-1409): boxes within 1e-9, +-inf in the same places; polytopes the kernel hands
+    back (status 1) are exactly those without a usable centre."""
+    from polytope_amd.synth import random_hpolytopes
+    if variant:
+        monkeypatch.setenv(variant, "1")
+    rng = np.random.default_rng(41)
+    for (m, d, B) in [(16, 3, 300), (10, 2, 200), (32, 6, 60), (64, 8, 24), (6, 4, 80), (12, 1, 50), (20, 5, 60)]:
+        A, b = random_hpolytopes(B, m, d, seed=5 * m + d, bounded=(m >= 2 * d))
+        cen = rng.standard_normal((B, d))                     # move them off the origin (generic LPs: phase 1)
+        b = b + np.einsum("bij,bj->bi", A, cen)
+        for k in range(3, B, 9):
+            b[k, 0] = b[k, 0] - 6.0                            # empty or nearly so
+        for k in range(5, B, 13):
+            A[k, : min(2 * d, m)] = A[k, -1]                   # drop the box: some become unbounded
+            b[k, : min(2 * d, m)] = b[k, -1]
+        mrows = rng.integers(max(1, m - 4), m + 1, B).astype(np.int32)
+        res = pa.bbox_batch(A, b, m=mrows)
+        n_done = 0
+        for k in range(B):
+            mk = mrows[k]
+            lb, ub, bad = oracle.bounding_box(A[k, :mk], b[k, :mk])
+            r, xc = oracle.cheby_ball(A[k, :mk], b[k, :mk])
+            if res["status"][k] == 0:
+                n_done += 1
+                assert bad == 0 and r >= 1e-6 - 1e-12, (m, d, k, r)
+                assert np.allclose(res["lb"][k], lb.ravel(), rtol=0, atol=TOL, equal_nan=False), (m, d, k, res["lb"][k], lb.ravel())
+                assert np.allclose(res["ub"][k], ub.ravel(), rtol=0, atol=TOL, equal_nan=False), (m, d, k, res["ub"][k], ub.ravel())
+            else:
+                assert res["status"][k] == 1 and (r < 1e-6 + 1e-12), (m, d, k, r)
+        assert n_done > B // 3 or m < 2 * d, (m, d, n_done)   # (m < 2d: mostly unbounded, handed back)
+    # the golden edge cases through the Python layer (kernel + generic LPs for what it hands back)
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    g = load_golden("g3_edge.npz")
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    try:
+        for name in g["names"]:
+            P = pc.Polytope(g[f"{name}_A"], g[f"{name}_b"], normalize=False)
+            if P.A.size == 0 or not np.all(np.isfinite(P.b)):
+                continue
+            lo, hi = pc.bounding_box(P)
+            assert np.allclose(lo.ravel(), g[f"{name}_lb"].ravel(), rtol=0, atol=TOL), (name, lo.ravel(), g[f"{name}_lb"])
+            assert np.allclose(hi.ravel(), g[f"{name}_ub"].ravel(), rtol=0, atol=TOL), (name, hi.ravel(), g[f"{name}_ub"])
+    finally:
+        solvers.default_solver = old
+
+
 # ------------------------------------------------------------------------------ Chebyshev
 def test_cheby_golden_edges(pa, oracle):
     g = load_golden("g3_edge.npz")
