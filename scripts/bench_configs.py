@@ -135,6 +135,22 @@ def red():
                                        "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
 
 
+def bbox():
+    """bounding_box batches: the fused kernel (Chebyshev LP + 2d LPs from its centre) against the 2d generic LPs."""
+    import numpy as np
+    for (B, m, d) in [(100000, 16, 3), (20000, 32, 6), (5000, 64, 8)]:
+        A, b = synth.random_hpolytopes(B, m, d, seed=3)
+        b = b + np.einsum("bij,bj->bi", A, np.random.default_rng(1).standard_normal((B, d)))  # origin outside
+        At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+        ms = timeit(lambda: pa.bbox_batch(At, bt))
+        cost = torch.as_tensor(np.tile(np.vstack([np.eye(d), -np.eye(d)]), (B, 1))).to(dev)
+        A2, b2 = At.repeat_interleave(2 * d, dim=0), bt.repeat_interleave(2 * d, dim=0)
+        ms_gen = timeit(lambda: pa.lpsolve_batch(cost, A2, b2), reps=5, warm=1)
+        print(json.dumps({"config": "bounding boxes B=%d m=%d d=%d" % (B, m, d), "ms": ms,
+                          "lp_per_s": B * (2 * d + 1) / (ms * 1e-3), "generic_2d_lps_ms": ms_gen,
+                          "speedup": ms_gen / ms}), flush=True)
+
+
 def c4():
     """Config 4: 1000-cell Region in d=4 (10x10x5x2 grid of boxes on [0,1]^4): adjacency of all
     499 500 cell pairs (one batch of (16,5) Chebyshev LPs) and region_diff of a polytope against
@@ -211,6 +227,6 @@ def hull():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c3", "c5", "lp", "red"]
+    which = sys.argv[1:] or ["c3", "c5", "lp", "red", "bbox"]
     for w in which:
         globals()[w]()
