@@ -127,9 +127,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
-    ap.add_argument("--streams", type=int, default=1, help="N = 1 only: issue the steps round-robin on this many HIP "
-                    "streams (independent batches in flight: the half-empty last round of one launch overlaps the "
-                    "next launch).  Default 1: one launch at a time, which is what roofline.kernel_ms describes")
+    ap.add_argument("--streams", type=int, default=1, help="issue the steps round-robin on this many HIP streams "
+                    "(independent batches in flight: the half-empty last round of one launch overlaps the next "
+                    "launch; with N > 1 the exchange is ordered against them at group boundaries).  Default 1: one "
+                    "launch at a time, the regime roofline.kernel_ms and the rocprofv3 per-kernel durations describe; "
+                    "the two-stream throughput is reported beside it as `pipelined`")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
@@ -173,26 +175,51 @@ def main():
     nb = 24 * B_PER_GPU
     ex = GroupedExchange(torch, dist, B_PER_GPU, DIM, G, dev) if multi else None
 
-    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if (args.streams > 1 and not multi) else None
+    # --streams S > 1: the steps are issued round-robin on S HIP streams, i.e. S independent batches are in flight.
+    # 100 000 polytopes are 6 250 wavefronts for 4 096 resident slots, so the last round of a launch runs half
+    # empty; with a second launch in flight that hole is filled.  The exchange (N > 1) is ordered against the side
+    # streams at group boundaries only.
+    main = torch.cuda.current_stream()
+    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
     nissued = [0]
 
+    def join():  # the main stream waits for everything issued on the side streams
+        if side is not None:
+            for st in side:
+                main.wait_stream(st)
+
     def step():
-        if side is not None:  # independent batches on several streams (results of each stay in its own tensors)
-            st = side[nissued[0] % len(side)]
-            nissued[0] += 1
+        k = nissued[0]
+        nissued[0] += 1
+        if side is None:
+            if ex is None:
+                return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
+            res = pa.reduce_batch(At, bt, out=ex.slot().views)
+            ex.commit()
+            return res
+        st = side[k % len(side)]
+        if ex is None:
             with torch.cuda.stream(st):
                 return pa.reduce_batch(At, bt)
-        if ex is None:
-            return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
-        res = pa.reduce_batch(At, bt, out=ex.slot().views)
+        if ex.k % G == 0:  # a new group starts in the other buffer: its last all-gather was waited for on `main`
+            for s_ in side:
+                s_.wait_stream(main)
+        with torch.cuda.stream(st):
+            res = pa.reduce_batch(At, bt, out=ex.slot().views)
+        if ex.k % G == G - 1:  # the group is complete: its kernels must have run before the all-gather reads it
+            join()
         ex.commit()
         return res
+
+    def drain():
+        join()
+        return ex.drain()
 
     pa.reduce_batch(At[:64], bt[:64])  # loads the code object (hipModule load is lazy): not a step, not timed
     for _ in range(args.warmup):
         step()
     if ex is not None:
-        ex.drain()
+        drain()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -203,20 +230,20 @@ def main():
     # reports; event pairs around every single launch were dropped because their marker packets cost 8 % of the
     # throughput they were there to explain.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = side[0] if side is not None else main  # with S streams: the launches of stream 0 (every S-th step)
+    n_on_evs = (args.steps + len(side) - 1) // len(side) if side is not None else args.steps
     gathered = None
     t0 = time.perf_counter()
-    ev0.record()
     if side is not None:
         for st in side:
-            st.wait_stream(torch.cuda.current_stream())
+            st.wait_stream(main)
+    ev0.record(evs)
     for k in range(args.steps):
         res = step()
-    if side is not None:
-        for st in side:
-            torch.cuda.current_stream().wait_stream(st)
-    ev1.record()
+    ev1.record(evs)
+    join()
     if ex is not None:
-        gathered = ex.drain()[-1]
+        gathered = drain()[-1]
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -227,7 +254,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    kern_ms = ev0.elapsed_time(ev1) / n_on_evs  # average launch duration on the stream the events sit on
     nlp_local = int(res["nlp"].sum().item())
     nlp_total = nlp_local
     if multi:
