@@ -38,6 +38,11 @@ int main(void)
       uint8_t out[4];
       CHECK(plp_contains(ctx, 1, 4, 2, A, b, NULL, 4, X, 1e-7, 0, out));
       printf("contains %d %d %d %d\n", out[0], out[1], out[2], out[3]); }
+    /* bounding boxes: the rectangle [2,5]x[-1,3] (origin outside) and an infeasible strip (handed back: status 1) */
+    { double A[16] = {1, 0, 0, 1, -1, 0, 0, -1,   1, 0, -1, 0, 0, 1, 0, -1}, b[8] = {5, 3, -2, 1,   1, -2, 1, 1};
+      double lb[4], ub[4]; int32_t st[2];
+      CHECK(plp_bbox_batch(ctx, 2, 4, 2, A, b, NULL, lb, ub, st));
+      printf("bbox status %d lb %.9f %.9f ub %.9f %.9f | status %d\n", st[0], lb[0], lb[1], ub[0], ub[1], st[1]); }
     /* misuse is reported, not crashed on */
     { double c[1] = {1.0}; int rc = plp_lp_solve_batch(ctx, 1, 65, 1, c, c, c, NULL, c, c, (int32_t *)c, NULL);
       printf("envelope rc %d (%s)\n", rc, rc == PLP_EUNSUPPORTED ? "PLP_EUNSUPPORTED" : "?"); }

@@ -40,5 +40,6 @@ def test_c_client_results(tmp_path):
     assert "lp1 status 0 x -1 fun -1" in out
     assert "lp2 status 0 x -1 -1 | status 3" in out
     assert any(l.startswith("reduce keep 0x1d flags 4 nlp ") for l in out), out   # rows 0,2,3,4 kept, minrep
+    assert "bbox status 0 lb 2.000000000 -1.000000000 ub 5.000000000 3.000000000 | status 1" in out, out
     assert "contains 1 0 1 0" in out      # the corner (1,1): A x - b = 0 < abs_tol counts as inside
     assert "envelope rc 2 (PLP_EUNSUPPORTED)" in out and out[-1] == "done"
