@@ -92,7 +92,7 @@ class ResultBuffer:
 class GatherPipeline:
     """Overlap the exchange step with the next batch: the all-gather of batch k (RCCL's stream) runs while
     the reduce kernel of batch k+1 runs on the compute stream.  xGMI is point-to-point: an 8-rank ring
-    all-gather of 8 x 2.4 MB costs a good fraction of the 0.34 ms kernel, so it is taken off the
+    all-gather of 8 x 2.4 MB costs a good fraction of the 0.28 ms kernel, so it is taken off the
     critical path instead of being paid after every kernel.
 
         pipe = GatherPipeline(torch, dist, rows=B, cols=3)        # or rows=nbytes, cols=1, dtype=torch.uint8
