@@ -22,6 +22,8 @@ Sets:
   g7_known.npz     the known-answer data of the reference's own tests (tests/polytope_test.py)
   g9_overlap.npz   the pair test of Partition.are_disjoint (is_fulldim(region.intersect(other))) and
                    MetricPartition-style adjacency on cell sets with overlaps  (prop2partition.py:123-192,:244-306)
+  g10_bbox.npz     bounding_box() of random polytopes that do not contain the origin, incl. unbounded and
+                   empty ones                                                       (polytope.py:1314-1411)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -552,7 +554,35 @@ def gen_g9():
     np.savez_compressed(os.path.join(HERE, "g9_overlap.npz"), **out)
 
 
+def gen_g10():
+    """bounding_box (polytope.py:1314-1411) on polytopes away from the origin (the generic LPs need a phase 1
+    there): bounded, unbounded (-inf / +inf corners) and empty (the status-2 branch: l = 0, u = l)."""
+    rng = np.random.default_rng(10)
+    recs = []
+    for (m, d, cnt) in [(8, 2, 16), (16, 3, 24), (20, 4, 12), (24, 6, 10), (40, 8, 6)]:
+        for k in range(cnt):
+            A, b = rand_hpoly(rng, m, d, bounded=(k % 5 != 3))
+            if k % 5 == 3:
+                A, b = A[:d], b[:d]                       # d half-spaces: an unbounded cone
+            cen = 3.0 * rng.standard_normal(d)
+            b = b + A @ cen
+            if k % 7 == 5:
+                b[0] -= 8.0                               # empty
+            P = pc.Polytope(A.copy(), b.copy(), normalize=False)
+            lo, hi = pc.bounding_box(P)
+            recs.append((A, b, np.asarray(lo).ravel(), np.asarray(hi).ravel()))
+    mmax = max(r[0].shape[0] for r in recs)
+    dmax = max(r[0].shape[1] for r in recs)
+    out = dict(m=np.array([r[0].shape[0] for r in recs]), d=np.array([r[0].shape[1] for r in recs]),
+               A=pad([r[0].ravel() for r in recs], mmax * dmax), b=pad([r[1] for r in recs], mmax),
+               lb=pad([r[2] for r in recs], dmax), ub=pad([r[3] for r in recs], dmax))
+    np.savez_compressed(os.path.join(HERE, "g10_bbox.npz"), **out)
+    n_inf = int(sum(np.isinf(r[2]).any() or np.isinf(r[3]).any() for r in recs))
+    n_empty = int(sum((r[2] == 0).all() and (r[3] == 0).all() for r in recs))
+    print("g10: %d polytopes, %d with infinite corners, %d empty" % (len(recs), n_inf, n_empty))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()["gen_" + w]()

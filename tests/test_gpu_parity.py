@@ -211,6 +211,32 @@ def test_bbox_vs_oracle(pa, oracle, variant, monkeypatch):
         solvers.default_solver = old
 
 
+def test_bbox_golden(pa):
+    """The reference's own bounding_box outputs (g10: origin outside, unbounded, empty): the fused kernel where it
+    answers, and the Python layer (kernel + generic LPs for what it hands back) for every case."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    g = load_golden("g10_bbox.npz")
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    n_kernel = 0
+    try:
+        for i in range(len(g["m"])):
+            m, d = int(g["m"][i]), int(g["d"][i])
+            A, b = g["A"][i, :m * d].reshape(m, d).copy(), g["b"][i, :m].copy()
+            lb, ub = g["lb"][i, :d], g["ub"][i, :d]
+            res = pa.bbox_batch(A[None], b[None])
+            if res["status"][0] == 0:
+                n_kernel += 1
+                assert np.array_equal(np.isinf(res["lb"][0]), np.isinf(lb)) and np.array_equal(np.isinf(res["ub"][0]), np.isinf(ub)), i
+                assert np.allclose(res["lb"][0], lb, rtol=0, atol=TOL) and np.allclose(res["ub"][0], ub, rtol=0, atol=TOL), i
+            lo, hi = pc.bounding_box(pc.Polytope(A, b, normalize=False))
+            assert np.allclose(lo.ravel(), lb, rtol=0, atol=TOL) and np.allclose(hi.ravel(), ub, rtol=0, atol=TOL), (i, lo.ravel(), lb)
+    finally:
+        solvers.default_solver = old
+    assert n_kernel >= 40
+
+
 # ------------------------------------------------------------------------------ Chebyshev
 def test_cheby_golden_edges(pa, oracle):
     g = load_golden("g3_edge.npz")
