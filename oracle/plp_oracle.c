@@ -31,7 +31,7 @@
  *   plpo_hull_reassign polytope/quickhull.py:273-283, :311-336, :87-102 (one iteration of the
  *                      main loop: pooling, re-assignment, furthest point) on index arrays
  *
- * Pinned: every function is checked against the fixtures tests/golden/g1..g10 (outputs of the
+ * Pinned: every function is checked against the fixtures tests/golden/g1..g11 (outputs of the
  * imported reference on seeded inputs, tests/test_oracle_golden.py, tests/test_quickhull.py).
  *
  * The pivot rules, tolerances and operation order of plpo_lp_solve are the ones the HIP

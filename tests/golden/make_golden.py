@@ -24,6 +24,9 @@ Sets:
                    MetricPartition-style adjacency on cell sets with overlaps  (prop2partition.py:123-192,:244-306)
   g10_bbox.npz     bounding_box() of random polytopes that do not contain the origin, incl. unbounded and
                    empty ones                                                       (polytope.py:1314-1411)
+  g11_convex.npz   envelope / is_convex / union(check_convex=True) / mldivide / is_adjacent / intersect on random
+                   overlapping, touching and separated polytope pairs (d = 2, 3) and on splits of one polytope
+                   by a hyperplane (convex unions)            (polytope.py:1414-1464, 988-1014, 1166-1238, 1470-1505)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -582,7 +585,56 @@ def gen_g10():
     print("g10: %d polytopes, %d with infinite corners, %d empty" % (len(recs), n_inf, n_empty))
 
 
+def gen_g11():
+    rng = np.random.default_rng(11)
+    out = {}
+    names = []
+
+    def store(tag, P, Q):
+        R = pc.Region([P.copy(), Q.copy()])
+        env = alg.envelope(pc.Region([P.copy(), Q.copy()]))
+        convex = bool(alg.is_convex(pc.Region([P.copy(), Q.copy()]))[0])
+        U = alg.union(P.copy(), Q.copy(), check_convex=True)
+        D = alg.mldivide(P.copy(), Q.copy())
+        I = P.copy().intersect(Q.copy())
+        out[tag + "_PA"], out[tag + "_Pb"], out[tag + "_QA"], out[tag + "_Qb"] = P.A, P.b, Q.A, Q.b
+        out[tag + "_convex"] = np.int8(convex)
+        out[tag + "_adjacent"] = np.int8(bool(pc.is_adjacent(P.copy(), Q.copy())))
+        for key, X in (("env", env), ("union", U), ("diff", D), ("isect", I)):
+            ps = pieces_of(X)
+            out[f"{tag}_{key}_n"] = np.int32(len(ps))
+            out[f"{tag}_{key}_m"] = np.array([q.A.shape[0] for q in ps], np.int32)
+            out[f"{tag}_{key}_Ab"] = pad([np.c_[q.A, q.b].ravel() for q in ps], 64 * (P.A.shape[1] + 1)) if ps \
+                else np.zeros((0, 64 * (P.A.shape[1] + 1)))
+            out[f"{tag}_{key}_r"] = np.array([float(pc.cheby_ball(q)[0]) for q in ps])
+        names.append(tag)
+        print("g11", tag, "convex", convex, "union", len(pieces_of(U)), "diff", len(pieces_of(D)), "env rows",
+              0 if env.A.size == 0 else env.A.shape[0])
+
+    k = 0
+    for d in (2, 3):
+        for trial in range(5):
+            A1, b1 = rand_hpoly(rng, 4 * d + 2, d, bounded=True)
+            A2, b2 = rand_hpoly(rng, 3 * d + 2, d, bounded=True)
+            shift = [0.4, 1.5, 2.9, 4.5, 9.0][trial] * np.eye(d)[0] + 0.2 * rng.standard_normal(d)
+            P = pc.Polytope(A1, 0.6 * b1)
+            Q = pc.Polytope(A2, 0.5 * b2 + A2 @ shift)
+            store("pair%d" % k, P, Q)
+            k += 1
+        for trial in range(3):   # one polytope cut in two by a hyperplane through its interior: the union is convex
+            A, b = rand_hpoly(rng, 4 * d + 1, d, bounded=True)
+            n = rng.standard_normal(d)
+            n /= np.linalg.norm(n)
+            c = 0.3 * rng.standard_normal()
+            P = pc.reduce(pc.Polytope(np.vstack([A, n]), np.r_[0.7 * b, c]))
+            Q = pc.reduce(pc.Polytope(np.vstack([A, -n]), np.r_[0.7 * b, -c]))
+            store("split%d" % k, P, Q)
+            k += 1
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "g11_convex.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()["gen_" + w]()

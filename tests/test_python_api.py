@@ -269,6 +269,38 @@ def test_region_intersect_merges_convex(pc, name):
     assert np.array_equal(I.contains(X, abs_tol=0), P.contains(X, abs_tol=0) & pc.Region(cells).contains(X, abs_tol=0))
 
 
+def _g11_names():
+    return [str(n) for n in load_golden("g11_convex.npz")["names"]]
+
+
+@pytest.mark.parametrize("name", _g11_names())
+def test_envelope_convexity_union_vs_reference(pc, name):
+    """g11: envelope / is_convex / union(check_convex=True) / mldivide / intersect / is_adjacent of polytope pairs as
+    the reference computes them (polytope.py:1414-1464, 988-1014, 1166-1238, 1470-1505): overlapping, touching,
+    separated pairs and hyperplane splits (convex unions).  Same pieces in the same order, rows within 1e-9."""
+    g = load_golden("g11_convex.npz")
+    P = pc.Polytope(g[name + "_PA"], g[name + "_Pb"], normalize=False)
+    Q = pc.Polytope(g[name + "_QA"], g[name + "_Qb"], normalize=False)
+    d = P.dim
+    got = {
+        "env": pc.envelope(pc.Region([P.copy(), Q.copy()])),
+        "union": pc.union(P.copy(), Q.copy(), check_convex=True),
+        "diff": pc.mldivide(P.copy(), Q.copy()),
+        "isect": P.copy().intersect(Q.copy()),
+    }
+    assert bool(pc.is_convex(pc.Region([P.copy(), Q.copy()]))[0]) == bool(g[name + "_convex"])
+    assert bool(pc.is_adjacent(P.copy(), Q.copy())) == bool(g[name + "_adjacent"])
+    for key, X in got.items():
+        ps = _pieces(pc, X)
+        assert len(ps) == int(g[f"{name}_{key}_n"]), (name, key, len(ps), int(g[f"{name}_{key}_n"]))
+        for k, q in enumerate(ps):
+            m = int(g[f"{name}_{key}_m"][k])
+            Ab = g[f"{name}_{key}_Ab"][k][:m * (d + 1)].reshape(m, d + 1)
+            assert q.A.shape[0] == m, (name, key, k, q.A.shape[0], m)
+            assert np.allclose(np.c_[q.A, q.b], Ab, rtol=0, atol=1e-9), (name, key, k)
+            assert abs(float(pc.cheby_ball(q)[0]) - g[f"{name}_{key}_r"][k]) <= TOL, (name, key, k)
+
+
 def test_mldivide_and_subset(pc):
     a = pc.box2poly([[0.0, 2.0], [0.0, 1.0]])
     b = pc.box2poly([[1.0, 3.0], [0.0, 1.0]])
