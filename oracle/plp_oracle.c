@@ -31,8 +31,9 @@
  *   plpo_hull_reassign polytope/quickhull.py:273-283, :311-336, :87-102 (one iteration of the
  *                      main loop: pooling, re-assignment, furthest point) on index arrays
  *
- * Pinned: every function is checked against the fixtures tests/golden/g1..g11 (outputs of the
- * imported reference on seeded inputs, tests/test_oracle_golden.py, tests/test_quickhull.py).
+ * Pinned: every function is checked against the fixtures tests/golden/g1..g10 (outputs of the
+ * imported reference on seeded inputs, tests/test_oracle_golden.py, tests/test_quickhull.py); g5, g9 and
+ * g11 pin the Python layer above it (tests/test_python_api.py).
  *
  * The pivot rules, tolerances and operation order of plpo_lp_solve are the ones the HIP
  * kernels use (polytope_amd/csrc/plp_simplex.hpp) so that CPU and GPU walk the same
