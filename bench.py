@@ -64,7 +64,7 @@ def cpu_baseline(A, b, nlp_per_poly):
         out["port_allcores_error"] = repr(e)
     try:
         from scipy.optimize import linprog
-        ns = 40
+        ns = 128  # x 16 rows = 2048 LPs on one process (a >= 2000-LP sample)
         t0 = time.perf_counter()
         cnt = 0
         for k in range(ns):
@@ -91,6 +91,13 @@ def cpu_baseline(A, b, nlp_per_poly):
             ns, len(chunks), ncpu)
     except Exception as e:  # scipy is the reference's own backend; report, never fail the bench on it
         out["scipy_error"] = repr(e)
+    try:
+        with open("/proc/cpuinfo") as f:
+            models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        out["cpu_model"] = models[0] if models else "?"
+        out["os_cpu_count"] = os.cpu_count()
+    except Exception:
+        pass
     return out
 
 
