@@ -134,11 +134,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
+    ap.add_argument("--pipelined", action="store_true", help="N = 1: after the timed region run the same K steps again "
+                    "with two batches in flight (two HIP streams) and report them as the extra object `pipelined`. "
+                    "Off by default so that a rocprofv3 run of the default command sees single-launch dispatches only")
     ap.add_argument("--streams", type=int, default=1, help="issue the steps round-robin on this many HIP streams "
                     "(independent batches in flight: the half-empty last round of one launch overlaps the next "
                     "launch; with N > 1 the exchange is ordered against them at group boundaries).  Default 1: one "
                     "launch at a time, the regime roofline.kernel_ms and the rocprofv3 per-kernel durations describe; "
-                    "the two-stream throughput is reported beside it as `pipelined`")
+                    "`--pipelined` reports the two-stream throughput beside it")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
@@ -316,7 +319,7 @@ def main():
             if valu.get("valu_issue_frac_of_busy_cycles"):  # against SQ_BUSY_CYCLES: the clock actually held
                 line["roofline"]["valu_issue_frac_of_busy_cycles"] = valu.get("valu_issue_frac_of_busy_cycles")
                 line["roofline"]["shader_clock_GHz_estimate"] = valu.get("shader_clock_GHz_estimate")
-        if not multi and args.streams == 1:
+        if args.pipelined and not multi and args.streams == 1:
             # Not `value`: the same K steps again with two independent batches in flight (two HIP streams).  100 000
             # polytopes are 6250 wavefronts for 4096 resident slots, so the last round of a launch runs half empty;
             # with a second launch in flight that hole is filled -- what a caller with a stream of batches should do.
