@@ -479,7 +479,7 @@ def test_reduce_properties_full_config(pa):
 
 def test_fuzz_random_shapes(pa, oracle):
     """Random (rows, dimension) over the whole envelope m <= 64, d <= 16, ragged row counts:
-    lpsolve / cheby / reduce against the oracle (status, masks, flags exact; values 1e-9)."""
+    lpsolve / cheby / reduce / bounding boxes against the oracle (status, masks, flags exact; values 1e-9)."""
     import os
     rng = np.random.default_rng(int(os.environ.get("PLP_FUZZ_SEED", "2026")))
     for trial in range(int(os.environ.get("PLP_FUZZ_TRIALS", "40"))):   # soak runs: PLP_FUZZ_TRIALS=2000
@@ -498,8 +498,13 @@ def test_fuzz_random_shapes(pa, oracle):
         masks = pa.keep_to_bool(rd["keep"], m)
         c = rng.standard_normal((B, d))
         lp = pa.lpsolve_batch(c, A, b, m=mrows)
+        bb = pa.bbox_batch(A, b, m=mrows) if d <= 8 else None
         for k in range(B):
             Ak, bk = A[k, :mrows[k]], b[k, :mrows[k]]
+            if bb is not None and bb["status"][k] == 0:   # fused boxes vs the generic LPs of the oracle
+                lo, hi, bad = oracle.bounding_box(Ak, bk)
+                assert bad == 0 and np.allclose(bb["lb"][k], lo, rtol=0, atol=TOL) and np.allclose(
+                    bb["ub"][k], hi, rtol=0, atol=TOL), (trial, m, d, k, bb["lb"][k], lo, bb["ub"][k], hi)
             so, ro, _ = oracle.cheby(Ak, bk)
             assert ch["status"][k] == so, (trial, m, d, k)
             if so == 0:
