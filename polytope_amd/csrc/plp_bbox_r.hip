@@ -6,10 +6,10 @@ namespace plp {
 template <int D, int GS>
 static int launch_bbox_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
                             double* ub, int* status, hipStream_t st) {
-    constexpr long long gpb = BLOCK / GS;
+    constexpr long long gpb = RBLK / GS;
     const long long blocks = (B + gpb - 1) / gpb;
     if (blocks > 2147483647ll) return 1;
-    hipLaunchKernelGGL((bbox_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max,
+    hipLaunchKernelGGL((bbox_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B, m_max,
                        A, b, mrows, lb, ub, status, force_retry_env());
     return 0;
 }

@@ -7,10 +7,10 @@ namespace plp {
 template <int D, int GS>
 static int launch_cheby_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
                              double* xc, int* status, hipStream_t st) {
-    constexpr long long gpb = BLOCK / GS;
+    constexpr long long gpb = RBLK / GS;
     const long long blocks = (B + gpb - 1) / gpb;
     if (blocks > 2147483647ll) return 1;
-    hipLaunchKernelGGL((cheby_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max,
+    hipLaunchKernelGGL((cheby_r_kernel<D, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B, m_max,
                        A, b, mrows, r, xc, status, force_retry_env());
     return 0;
 }
@@ -50,13 +50,13 @@ template <int D, int GS>
 static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
                               double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                               hipStream_t st) {
-    constexpr long long gpb = BLOCK / GS;
+    constexpr long long gpb = RBLK / GS;
     long long blocks = (p_hi - p_lo + gpb - 1) / gpb;
-    const long long bdiag = compact ? 0 : ((long long)n + BLOCK - 1) / BLOCK;
+    const long long bdiag = compact ? 0 : ((long long)n + RBLK - 1) / RBLK;
     if (blocks < bdiag) blocks = bdiag;
     if (blocks < 1) blocks = 1;
     if (blocks > 2147483647ll) return 2;
-    hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, n, m_max, A, b, mrows,
+    hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(RBLK), 0, st, n, m_max, A, b, mrows,
                        inflate, thresh, adj, p_lo, p_hi, compact, force_retry_env());
     return 0;
 }

@@ -20,6 +20,14 @@
 #include "plp_simplex_r.hpp"
 
 namespace plp {
+// One wavefront per workgroup for the batch kernels of this file (they use no LDS and no barrier): the tail of a
+// launch is balanced wave by wave.  Against 256 threads (rocprofv3 kernel durations): lp_r_kernel<6,8> 271 -> 172 us,
+// <16,32> 103 -> 81, <8,16> 186 -> 142, cheby_r_kernel<16,32> 692 -> 590, adjacent_r_kernel<4,4> 188 -> 181,
+// lp_p1_r_kernel<3,4> 250 -> 199; cheby_r_kernel<3,4> and lp_r_kernel<3,4> at 100 k LPs unchanged.
+#ifndef PLP_R_BLOCK
+#define PLP_R_BLOCK 64
+#endif
+constexpr int RBLK = PLP_R_BLOCK;  // threads per workgroup
 
 namespace {
 
@@ -110,7 +118,7 @@ __device__ __forceinline__ int cheby_r_solve(const Grp& g, bool valid, int m, in
 }  // namespace
 
 template <int D, int GS>
-__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long long B, int m_max,
+__global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long long B, int m_max,
                                                                           const double* __restrict__ A,
                                                                           const double* __restrict__ b,
                                                                           const int* __restrict__ mrows,
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
                                                                           int* __restrict__ status,
                                                                           int force_retry) {
     const Grp g(GS);
-    constexpr int gpb = BLOCK / GS;
+    constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
     constexpr int R = RowsPerLane<D>::value;
     const int row0 = g.gl * R;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void cheby_r_kernel(long l
 constexpr double BBOX_MIN_R = 1e-6;
 
 template <int D, int GS>
-__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long long B, int m_max,
+__global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long long B, int m_max,
                                                                          const double* __restrict__ A,
                                                                          const double* __restrict__ b,
                                                                          const int* __restrict__ mrows,
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lo
                                                                          double* __restrict__ ub,
                                                                          int* __restrict__ status, int force_retry) {
     const Grp g(GS);
-    constexpr int gpb = BLOCK / GS;
+    constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
     constexpr int R = RowsPerLane<D>::value;
     const int row0 = g.gl * R;
@@ -226,12 +234,12 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lo
 // kernel instead solves the pairs p_lo <= p < p_hi (p = i (i - 1) / 2 + j) and writes compact[p - p_lo]
 // (the shard of one rank when the pair space is split across GPUs).
 template <int D, int GS>
-__global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
+__global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     int n, int m_max, const double* __restrict__ A, const double* __restrict__ b, const int* __restrict__ mrows,
     double inflate, double thresh, unsigned char* __restrict__ adj, long long p_lo, long long p_hi,
     unsigned char* __restrict__ compact, int force_retry) {
     const Grp g(GS);
-    constexpr int gpb = BLOCK / GS;
+    constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
     constexpr int R = RowsPerLane<D>::value;
     const int row0 = g.gl * R;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(BLOCK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
         adj[j * n + i] = yes ? 1 : 0;
     }
     // diagonal
-    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const long long t = (long long)blockIdx.x * RBLK + threadIdx.x;
     if (t < n) adj[t * n + t] = 1;
 }
 
@@ -296,7 +304,7 @@ struct P1_FAST { static constexpr bool value = (N == 3 || N == 4); };
 // plp_lp.hip does too in that case, so both walk the same path.  LPs that need phase 1 (or, later,
 // Bland's rule) end with ST_RETRY and are redone by that kernel in a second launch.
 template <int N, int GS>
-__global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long B, int m_max,
+__global__ __launch_bounds__(RBLK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long B, int m_max,
                                                                        const double* __restrict__ c,
                                                                        const double* __restrict__ G,
                                                                        const double* __restrict__ h,
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long
                                                                        int* __restrict__ iters) {
     constexpr int R = RowsPerLane<N>::value;
     const Grp g(GS);
-    constexpr int gpb = BLOCK / GS;
+    constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
     const int row0 = g.gl * R;
     const long long lp = (long long)blockIdx.x * gpb + gib;
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long
 // variable in an extra column and the real objective carried along; Bland cases leave with ST_RETRY for the
 // two-phase kernel of plp_lp.hip (third launch).
 template <int N, int GS>
-__global__ __launch_bounds__(BLOCK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long long B, int m_max,
+__global__ __launch_bounds__(RBLK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long long B, int m_max,
                                                                           const double* __restrict__ c,
                                                                           const double* __restrict__ G,
                                                                           const double* __restrict__ h,
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(BLOCK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long l
                                                                           int* __restrict__ iters) {
     constexpr int R = RowsPerLane<N>::value;
     const Grp g(GS);
-    constexpr int gpb = BLOCK / GS;
+    constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
     const int row0 = g.gl * R;
     const long long lp = (long long)blockIdx.x * gpb + gib;

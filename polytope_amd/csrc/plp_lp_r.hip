@@ -6,13 +6,13 @@ namespace plp {
 template <int N, int GS>
 static int launch_lp_r_ng(long long B, int m_max, const double* c, const double* G, const double* h, const int* mrows,
                           double* x, double* fun, int* status, int* iters, hipStream_t st) {
-    constexpr long long gpb = BLOCK / GS;
+    constexpr long long gpb = RBLK / GS;
     const long long blocks = (B + gpb - 1) / gpb;
     if (blocks > 2147483647ll) return 1;
-    hipLaunchKernelGGL((lp_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B, m_max, c,
+    hipLaunchKernelGGL((lp_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B, m_max, c,
                        G, h, mrows, x, fun, status, iters);
     if constexpr (P1_FAST<N>::value)
-        hipLaunchKernelGGL((lp_p1_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(BLOCK), 0, st, B,
+        hipLaunchKernelGGL((lp_p1_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B,
                            m_max, c, G, h, mrows, x, fun, status, iters);
     return 0;
 }
