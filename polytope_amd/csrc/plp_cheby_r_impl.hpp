@@ -296,8 +296,17 @@ static int force_retry_env() {
 // Where the two-phase run on the fast path pays: measured on MI355X against the one-row-per-lane two-phase
 // kernel (100k LPs, m=16): n=3 1.35x, n=4 1.22x, n=5 1.0x, n=6 0.88x, n=8 0.7x (the extra column, the carried
 // cost row and the sign bookkeeping push four rows per lane past 250 VGPRs: one wave per SIMD), n=2 0.84x.
+// Two rows per lane for n = 5..8 (groups twice as wide, two waves per SIMD) was measured too: 0.84x / 0.82x / 0.66x
+// of the one-row kernel at (16,5) / (16,6) / (32,8) -- bitwise the same results, so the cut-off stays at n = 4.
+#ifndef PLP_P1_FAST_MAXN
+#define PLP_P1_FAST_MAXN 4
+#endif
 template <int N>
-struct P1_FAST { static constexpr bool value = (N == 3 || N == 4); };
+struct P1_FAST { static constexpr bool value = (N >= 3 && N <= PLP_P1_FAST_MAXN); };
+// rows per lane of the phase-1 kernel: 4 for n <= 4; 2 beyond (groups twice as wide), which keeps the extra column
+// and the carried cost row within two waves per SIMD
+template <int N>
+struct P1Rows { static constexpr int value = N <= 4 ? 4 : 2; };
 
 // Generic LP  min c'x  s.t.  G x <= h, x free  (solvers.py:76-106) when the origin is feasible (every
 // h_i >= 0): phase 2 starts from the all-slack dictionary, which is what the two-phase kernel of
@@ -384,8 +393,8 @@ __global__ __launch_bounds__(RBLK, (N <= 4 ? 3 : 1)) void lp_r_kernel(long long 
 // The LPs lp_r_kernel marked ST_RETRY_P1 (some h_i < 0): two-phase run on the fast path with the artificial
 // variable in an extra column and the real objective carried along; Bland cases leave with ST_RETRY for the
 // two-phase kernel of plp_lp.hip (third launch).
-template <int N, int GS>
-__global__ __launch_bounds__(RBLK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long long B, int m_max,
+template <int N, int GS, int R>
+__global__ __launch_bounds__(RBLK, (R == 2 ? 2 : (N <= 3 ? 2 : 1))) void lp_p1_r_kernel(long long B, int m_max,
                                                                           const double* __restrict__ c,
                                                                           const double* __restrict__ G,
                                                                           const double* __restrict__ h,
@@ -394,7 +403,6 @@ __global__ __launch_bounds__(RBLK, (N <= 3 ? 2 : 1)) void lp_p1_r_kernel(long lo
                                                                           double* __restrict__ fun,
                                                                           int* __restrict__ status,
                                                                           int* __restrict__ iters) {
-    constexpr int R = RowsPerLane<N>::value;
     const Grp g(GS);
     constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;

@@ -11,9 +11,14 @@ static int launch_lp_r_ng(long long B, int m_max, const double* c, const double*
     if (blocks > 2147483647ll) return 1;
     hipLaunchKernelGGL((lp_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B, m_max, c,
                        G, h, mrows, x, fun, status, iters);
-    if constexpr (P1_FAST<N>::value)
-        hipLaunchKernelGGL((lp_p1_r_kernel<N, GS>), dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(RBLK), 0, st, B,
-                           m_max, c, G, h, mrows, x, fun, status, iters);
+    if constexpr (P1_FAST<N>::value) {
+        constexpr int RP = P1Rows<N>::value;
+        constexpr int GSP = GS * RowsPerLane<N>::value / RP;  // same row slots, RP rows per lane
+        constexpr long long gpbp = RBLK / GSP;
+        const long long blocksp = (B + gpbp - 1) / gpbp;
+        hipLaunchKernelGGL((lp_p1_r_kernel<N, GSP, RP>), dim3((unsigned)(blocksp < 1 ? 1 : blocksp)), dim3(RBLK), 0, st,
+                           B, m_max, c, G, h, mrows, x, fun, status, iters);
+    }
     return 0;
 }
 
