@@ -9,6 +9,12 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     count is the number of lpsolve() calls the reference would issue on the same input
     (returned by the kernel as nlp[] and checked against the oracle in tests/).
 
+The timed region rotates over NB = 6 distinct 100k-polytope batches (6 x 52.4 MB = 314 MB, more than the 256 MiB
+Infinity Cache), all resident in HBM before the clock starts, so a step never re-reads what the previous step left
+in cache.  Extra objects of the line (N = 1): `end_to_end` = the same pass for a caller that holds numpy arrays
+(host buffers in, host-visible results out; pageable and pinned, H2D / kernel / D2H split) and `cpu_baseline` =
+scipy.optimize.linprog called as polytope/solvers.py:152-154 calls it, on the host cores (count stated).
+
 Launch:  python bench.py [--gpus N --steps K --warmup W]; for N>1 under
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU; every rank reduces its own 100k-polytope shard (weak scaling) and the
@@ -30,40 +36,19 @@ B_PER_GPU, M_ROWS, DIM = 100000, 16, 3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(A, b, nlp_per_poly):
-    """Rank 0, N=1 only.  (i) the C oracle ('port') on a bounded sample of the same batch,
-    one core; (ii) scipy.optimize.linprog called exactly as polytope/solvers.py:152-154 on
-    the redundancy LPs of a smaller sample, 1 process and all cores."""
+def cpu_baseline(A, b, nlp_gpu):
+    """Rank 0, N=1 only, bounded samples of batch 0.  `value` = the reference's own LP path on this host:
+    scipy.optimize.linprog called exactly as polytope/solvers.py:152-154 calls it (the only backend the reference
+    finds installed here), on the redundancy LPs (F2) of a sample, one process per host core; the one-process
+    figure and the C restatement (oracle/plp_oracle.c, 'port') on one core / all cores ride along as side keys.
+    The oracle leg doubles as a check: the LP count the GPU reported for the sample must equal the oracle's."""
     from oracle import oracle as O
     O.build()
-    n = 40000
-    t0 = time.perf_counter()
-    lps = 0
-    for k in range(n):
-        lps += O.reduce(A[k], b[k])["nlp"]
-    t_or = time.perf_counter() - t0
-    out = {"value": lps / t_or, "unit": "LP/s", "cores": 1, "kind": "port",
-           "sample": "oracle/plp_oracle.c reduce() on the first %d polytopes of the same batch (%d LPs, %.1f s)"
-                     % (n, lps, t_or)}
-    try:  # the same C port on every host core: what a competent CPU code does with the box
-        import multiprocessing as mp
-        global _ORACLE_AB
-        _ORACLE_AB = (A, b)
-        ncpu = os.cpu_count() or 1
-        per = 2000
-        tasks = [((t * per) % A.shape[0], per) for t in range(4 * ncpu)]
-        with mp.get_context("fork").Pool(ncpu) as pool:
-            pool.map(_oracle_chunk, tasks[:ncpu], chunksize=1)  # start the workers, load the library
-            t0 = time.perf_counter()
-            res = pool.map(_oracle_chunk, tasks, chunksize=1)
-            t_all = time.perf_counter() - t0
-        out["port_allcores_lp_per_s"] = sum(res) / t_all
-        out["port_allcores_cores"] = ncpu
-        out["sample"] += "; the same on %d processes x %d polytopes each (%.2f s)" % (ncpu, 4 * per, t_all)
-    except Exception as e:
-        out["port_allcores_error"] = repr(e)
+    out = {"value": None, "unit": "LP/s", "cores": None, "kind": "reference", "sample": ""}
+    ncpu = os.cpu_count() or 1
     try:
         from scipy.optimize import linprog
+        import multiprocessing as mp
         ns = 128  # x 16 rows = 2048 LPs on one process (BASELINE.md section 4: a >= 2000-LP sample)
         t0 = time.perf_counter()
         cnt = 0
@@ -76,21 +61,47 @@ def cpu_baseline(A, b, nlp_per_poly):
                 cnt += 1
         t1 = time.perf_counter() - t0
         out["scipy_linprog_1proc_lp_per_s"] = cnt / t1
-        import multiprocessing as mp
-        ncpu = os.cpu_count() or 1
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
         chunks = [(A[k], b[k]) for k in range(ns, ns + 8 * ncpu)]
         with mp.get_context("fork").Pool(ncpu) as pool:
+            pool.map(_scipy_chunk, chunks[:ncpu], chunksize=1)  # start the workers, import scipy
             t0 = time.perf_counter()
             res = pool.map(_scipy_chunk, chunks, chunksize=1)
             t2 = time.perf_counter() - t0
-        out["scipy_linprog_allcores_lp_per_s"] = sum(res) / t2
-        out["scipy_cores"] = ncpu
-        out["sample"] += "; scipy.optimize.linprog (HiGHS) on the F2 LPs of %d (1 proc) / %d (%d procs) polytopes" % (
-            ns, len(chunks), ncpu)
-    except Exception as e:  # scipy is the reference's own backend; report, never fail the bench on it
+        out["value"] = sum(res) / t2
+        out["cores"] = ncpu
+        out["sample"] = ("scipy.optimize.linprog (HiGHS), called as polytope/solvers.py:152-154, on the F2 LPs of %d "
+                         "polytopes of batch 0 over %d processes (%d LPs, %.1f s); 1 process: %d LPs, %.1f s"
+                         % (len(chunks), ncpu, sum(res), t2, cnt, t1))
+    except Exception as e:  # report, never fail the bench on the baseline
         out["scipy_error"] = repr(e)
+    n = 40000
+    t0 = time.perf_counter()
+    lps = 0
+    for k in range(n):
+        lps += O.reduce(A[k], b[k])["nlp"]
+    t_or = time.perf_counter() - t0
+    gpu_lps = int(nlp_gpu[:n].sum())
+    assert gpu_lps == lps, "LP count of the GPU (%d) != oracle (%d) on the first %d polytopes" % (gpu_lps, lps, n)
+    out["port_1core_lp_per_s"] = lps / t_or
+    out["nlp_checked"] = "GPU nlp[:%d].sum() == oracle count == %d" % (n, lps)
+    out["sample"] += "; port: oracle/plp_oracle.c reduce() on the first %d polytopes (%d LPs, %.1f s)" % (n, lps, t_or)
+    try:  # the same C port on every host core: what a competent CPU code does with the box
+        import multiprocessing as mp
+        global _ORACLE_AB
+        _ORACLE_AB = (A, b)
+        per = 2000
+        tasks = [((t * per) % A.shape[0], per) for t in range(4 * ncpu)]
+        with mp.get_context("fork").Pool(ncpu) as pool:
+            pool.map(_oracle_chunk, tasks[:ncpu], chunksize=1)  # start the workers, load the library
+            t0 = time.perf_counter()
+            res = pool.map(_oracle_chunk, tasks, chunksize=1)
+            t_all = time.perf_counter() - t0
+        out["port_allcores_lp_per_s"] = sum(res) / t_all
+        out["port_allcores_cores"] = ncpu
+    except Exception as e:
+        out["port_allcores_error"] = repr(e)
     try:
         with open("/proc/cpuinfo") as f:
             models = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
@@ -98,6 +109,51 @@ def cpu_baseline(A, b, nlp_per_poly):
         out["os_cpu_count"] = os.cpu_count()
     except Exception:
         pass
+    return out
+
+
+def end_to_end(torch, pa, A, b, dev, reps=10):
+    """The same pass for a caller whose polytopes live in host memory (wall time = host-visible results).
+    (i) pageable numpy arrays through the C ABI's host entry point (copies in, kernel, copies out, blocks);
+    (ii) pinned host tensors: async H2D, kernel, D2H of keep / flags / r / nlp, one synchronisation; the three
+    legs timed with HIP events on the stream.  PCIe-inclusive figures, never `value`."""
+    out = {"unit": "LP/s", "note": "numpy in -> host-visible keep/flags/r/xc/nlp out; never the headline value"}
+    res = pa.reduce_batch(A, b)
+    nlp = int(res["nlp"].sum())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = pa.reduce_batch(A, b)
+    t = (time.perf_counter() - t0) / reps
+    out["pageable"] = {"ms_per_pass": t * 1e3, "value": nlp / t, "h2d_bytes": A.nbytes + b.nbytes,
+                       "d2h_bytes": int(sum(v.nbytes for v in res.values()))}
+    Ap, bp = torch.as_tensor(A).pin_memory(), torch.as_tensor(b).pin_memory()
+    Ad, bd = torch.empty_like(Ap, device=dev), torch.empty_like(bp, device=dev)
+    B = A.shape[0]
+    outs = dict(keep=torch.empty(B, dtype=torch.int64, device=dev), flags=torch.empty(B, dtype=torch.int32, device=dev),
+                r=torch.empty(B, dtype=torch.float64, device=dev), xc=torch.empty((B, A.shape[2]), dtype=torch.float64, device=dev),
+                nlp=torch.empty(B, dtype=torch.int32, device=dev))
+    host = {k: torch.empty_like(v, device="cpu").pin_memory() for k, v in outs.items() if k != "xc"}
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps + 1)]
+    walls = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        evs[i][0].record()
+        Ad.copy_(Ap, non_blocking=True)
+        bd.copy_(bp, non_blocking=True)
+        evs[i][1].record()
+        pa.reduce_batch(Ad, bd, out=outs)
+        evs[i][2].record()
+        for k, v in host.items():
+            v.copy_(outs[k], non_blocking=True)
+        evs[i][3].record()
+        torch.cuda.synchronize()
+        walls.append(time.perf_counter() - t0)
+    assert int(host["nlp"].sum().item()) == nlp
+    w = sum(walls[1:]) / reps
+    leg = lambda a, c: sum(evs[i][a].elapsed_time(evs[i][c]) for i in range(1, reps + 1)) / reps  # noqa: E731
+    out["pinned"] = {"ms_per_pass": w * 1e3, "value": nlp / w, "h2d_ms": leg(0, 1), "kernel_ms": leg(1, 2),
+                     "d2h_ms": leg(2, 3), "h2d_GBs": (A.nbytes + b.nbytes) / leg(0, 1) / 1e6,
+                     "d2h_bytes": int(sum(v.numel() * v.element_size() for v in host.values()))}
     return out
 
 
@@ -132,6 +188,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)  # 0.3 ms each: the timed region is ~60 ms
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--batches", type=int, default=6, help="distinct 100k-polytope batches the steps rotate over "
+                    "(6 x 52.4 MB > 256 MiB Infinity Cache: every step reads its input from HBM)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
     ap.add_argument("--pipelined", action="store_true", help="N = 1: after the timed region run the same K steps again "
@@ -174,8 +233,12 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    A, b = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=0, stream=rank)
-    At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+    # NB distinct batches, all resident in HBM before the timed region; step k reduces batch k mod NB.  6 x 52.4 MB
+    # is more than the 256 MiB Infinity Cache, so a step never finds its input cached from the previous pass.
+    NB = max(1, args.batches)
+    host_batches = [random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=rank) for i in range(NB)]
+    dev_batches = [(torch.as_tensor(A_).to(dev), torch.as_tensor(b_).to(dev)) for A_, b_ in host_batches]
+    A, b = host_batches[0]
 
     # N > 1: the kernel writes its results straight into a slot of a flat exchange buffer (24 B per polytope, no
     # packing kernels); every G batches the buffer goes out as ONE all-gather (xGMI is point-to-point: fewer,
@@ -201,6 +264,7 @@ def main():
     def step():
         k = nissued[0]
         nissued[0] += 1
+        At, bt = dev_batches[k % NB]
         if side is None:
             if ex is None:
                 return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
@@ -225,9 +289,14 @@ def main():
         join()
         return ex.drain()
 
-    pa.reduce_batch(At[:64], bt[:64])  # loads the code object (hipModule load is lazy): not a step, not timed
+    # every batch once, untimed: loads the code object (hipModule load is lazy) and yields the LP count of each batch
+    # (the number of lpsolve() calls the reference would issue on it: kernel output nlp[], checked against the
+    # oracle in tests/ and, for batch 0, in the cpu_baseline leg below)
+    nlp_batches = [pa.reduce_batch(At_, bt_)["nlp"] for At_, bt_ in dev_batches]
+    nlp_of = [int(v.sum().item()) for v in nlp_batches]
     for _ in range(args.warmup):
         step()
+    nissued[0] = 0
     if ex is not None:
         drain()
     torch.cuda.synchronize()
@@ -265,14 +334,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = ev0.elapsed_time(ev1) / n_on_evs  # average launch duration on the stream the events sit on
-    nlp_local = int(res["nlp"].sum().item())
-    nlp_total = nlp_local
+    assert int(res["nlp"].sum().item()) == nlp_of[(args.steps - 1) % NB]  # the last step's own output
+    lps_timed_local = sum(nlp_of[k % NB] for k in range(args.steps))  # LPs of the K timed steps on this rank
+    nlp_local = lps_timed_local / args.steps                           # mean per step
+    lps_timed = lps_timed_local
     if multi:
-        t = torch.tensor([nlp_local], dtype=torch.int64, device=rdev)
+        t = torch.tensor([lps_timed_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t)
-        nlp_total = int(t.item())
+        lps_timed = int(t.item())
         assert gathered.numel() == world * G * nb
-        assert int(ex.slot_views(gathered, rank, 0)["nlp"].sum().item()) == nlp_local  # my slot 0 of the last group
+    nlp_total = lps_timed / args.steps
 
     if rank == 0:
         alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
@@ -284,14 +355,14 @@ def main():
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_launch"]
-            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_issue_frac_at_2p4GHz", "valu_issue_frac_of_busy_cycles",
-                                         "shader_clock_GHz_estimate") if k in tj}
+            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_busy_frac_measured", "effective_clock_GHz", "source")
+                    if k in tj}
             traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
         except Exception:
             pass
         line = {
             "metric": "LP solves/sec (batched Chebyshev + redundancy)",
-            "value": nlp_total * args.steps / elapsed,
+            "value": lps_timed / elapsed,
             "unit": "LP/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -302,23 +373,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1])"
-                                   % (B_PER_GPU, DIM, M_ROWS),
-                       "lps_per_step": nlp_total, "polytopes_per_gpu": B_PER_GPU, "streams": args.streams,
+            "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1]); %d distinct "
+                                   "batches resident in HBM, one per step in rotation (%.0f MB > 256 MiB Infinity Cache)"
+                                   % (B_PER_GPU, DIM, M_ROWS, NB, NB * B_PER_GPU * 8 * M_ROWS * (DIM + 1) / 1e6),
+                       "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_PER_GPU, "streams": args.streams,
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_kernel<3, 4, 4>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "FP64-VALU issue bound (see valu_issue_frac_*), not HBM bound: %.3g LP/s inside the kernel" % (
+                         "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
                              nlp_local / (kern_ms * 1e-3))},
         }
-        if valu:  # PMC SQ_INSTS_VALU of the same kernel: 4 issue cycles per wave64 instruction, 1024 SIMDs
-            line["roofline"]["valu_insts_per_launch"] = valu.get("valu_insts_per_launch")
-            line["roofline"]["valu_issue_frac_at_2p4GHz"] = valu.get("valu_issue_frac_at_2p4GHz")
-            if valu.get("valu_issue_frac_of_busy_cycles"):  # against SQ_BUSY_CYCLES: the clock actually held
-                line["roofline"]["valu_issue_frac_of_busy_cycles"] = valu.get("valu_issue_frac_of_busy_cycles")
-                line["roofline"]["shader_clock_GHz_estimate"] = valu.get("shader_clock_GHz_estimate")
+        if valu:  # measured PMC counters of the same kernel (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE)
+            line["roofline"].update({k: v for k, v in valu.items() if k != "source"})
+            line["roofline"]["counters_source"] = valu.get("source")
         if args.pipelined and not multi and args.streams == 1:
             # Not `value`: the same K steps again with two independent batches in flight (two HIP streams).  100 000
             # polytopes are 6250 wavefronts for 4096 resident slots, so the last round of a launch runs half empty;
@@ -326,22 +395,24 @@ def main():
             two = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for k in range(2 * max(1, args.warmup)):  # untimed: the streams' queues are created on first use
                 with torch.cuda.stream(two[k & 1]):
-                    pa.reduce_batch(At, bt)
+                    pa.reduce_batch(*dev_batches[k % NB])
             torch.cuda.synchronize()
             tp = time.perf_counter()
             for st in two:
                 st.wait_stream(torch.cuda.current_stream())
             for k in range(args.steps):
                 with torch.cuda.stream(two[k & 1]):
-                    res2 = pa.reduce_batch(At, bt)
+                    res2 = pa.reduce_batch(*dev_batches[k % NB])
             torch.cuda.synchronize()
             tp = time.perf_counter() - tp
-            assert int(res2["nlp"].sum().item()) == nlp_local
-            line["pipelined"] = {"streams": 2, "value": nlp_local * args.steps / tp, "unit": "LP/s",
+            assert int(res2["nlp"].sum().item()) == nlp_of[(args.steps - 1) % NB]
+            line["pipelined"] = {"streams": 2, "value": lps_timed_local / tp, "unit": "LP/s",
                                  "ms_per_step": tp / args.steps * 1e3,
                                  "note": "two batches in flight; not the headline, see DESIGN.md section 6"}
+        if not multi and not args.no_end_to_end:
+            line["end_to_end"] = end_to_end(torch, pa, A, b, dev)
         if not multi and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(A, b, None)
+            line["cpu_baseline"] = cpu_baseline(A, b, nlp_batches[0].cpu().numpy())
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()

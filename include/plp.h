@@ -11,7 +11,11 @@
  *     nothing is retained after a call returns (reduce() passes aliases of arrays it
  *     mutates around the call: polytope/polytope.py:1146-1151).
  *   - a batch of polytopes is packed as A[B][m_max][d], b[B][m_max] with an optional
- *     int32 m[B] (rows actually used, <= m_max; NULL = all m_max).  m_max <= 64, d <= 16.
+ *     int32 m[B] (rows actually used, <= m_max; NULL = all m_max).  d <= 16.  m_max <= 64 for the fused
+ *     kernels (reduce, bounding boxes, pair LPs: register-resident dictionaries); plp_lp_solve_batch and
+ *     plp_cheby_batch also take m_max > 64 -- region_diff stacks m_poly + sum(active rows) without a limit
+ *     (polytope/polytope.py:2212-2224) -- as long as one dictionary fits the CU's 160 KB of LDS
+ *     (about 890 rows at n = 17, 3000 at n = 4); beyond that PLP_EUNSUPPORTED.
  *   - per-LP status codes are scipy.optimize.linprog's, as returned by
  *     polytope.solvers.lpsolve (polytope/solvers.py:76-106, 155-158):
  *        0 optimal, 1 iteration limit, 2 infeasible, 3 unbounded, 4 numerical trouble.
@@ -36,7 +40,7 @@ extern "C" {
 
 #define PLP_OK 0
 #define PLP_EINVAL 1       /* bad argument (NULL pointer, negative size, ...)            */
-#define PLP_EUNSUPPORTED 2 /* size outside the engine's envelope (m_max > 64, d > 16)    */
+#define PLP_EUNSUPPORTED 2 /* size outside the engine's envelope (d > 16, too many rows)  */
 #define PLP_EHIP 3         /* HIP runtime error                                          */
 #define PLP_ENODEVICE 4    /* no gfx950 device visible                                   */
 
@@ -63,7 +67,7 @@ int plp_ctx_synchronize(plp_ctx *ctx, void *stream);
  * Replaces: polytope.solvers.lpsolve / _solve_lp_using_scipy
  *           (polytope/solvers.py:76-106, :149-158) called in Python loops at
  *           polytope/polytope.py:1150, :1288, :1371, :1393.
- * c[B][n], G[B][m_max][n], h[B][m_max], m[B] or NULL;  n <= 17.
+ * c[B][n], G[B][m_max][n], h[B][m_max], m[B] or NULL;  n <= 17.  m_max > 64: LDS-resident engine.
  * Out: x[B][n], fun[B] (NaN unless status 0), status[B], iters[B] (may be NULL).
  */
 int plp_lp_solve_batch(plp_ctx *ctx, int64_t B, int m_max, int n, const double *c, const double *G,

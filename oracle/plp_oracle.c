@@ -46,7 +46,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define PLPO_MAXM 64
+#define PLPO_MAXM 256 /* rows of one LP (the HIP engine goes past 64 rows with its LDS-resident dictionary) */
+#define PLPO_MAXM_RED 64 /* rows of a polytope handed to plpo_reduce: the keep mask is one 64-bit word */
 #define PLPO_MAXN 18 /* d+1 structural columns (<=17) + phase-1 artificial */
 
 #define TOL_D 1e-9     /* reduced-cost (dual feasibility) tolerance            */
@@ -168,7 +169,12 @@ static int run(dict_t *D)
 
 static void dict_init(dict_t *D, int m, int n)
 {
-    memset(D, 0, sizeof(*D));
+    /* clear the scalars, the cost rows and the first m rows only (the struct is sized for PLPO_MAXM rows) */
+    memset(D->T, 0, (size_t)m * sizeof(D->T[0]));
+    memset(D->beta, 0, (size_t)m * sizeof(double));
+    memset(D->cost, 0, sizeof(D->cost)); memset(D->cost2, 0, sizeof(D->cost2));
+    memset(D->coldead, 0, sizeof(D->coldead));
+    D->negz = D->negz2 = 0.0; D->carry = 0; D->iters = 0;
     D->m = m; D->n = n; D->nc = n;
     for (int i = 0; i < m; ++i) { D->rowvar[i] = n + i; D->rowsgn[i] = 1; D->rowact[i] = 1; }
     for (int j = 0; j < PLPO_MAXN; ++j) { D->colvar[j] = j; D->colsgn[j] = 1; }
@@ -327,6 +333,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     double Aw[PLPO_MAXM * 16], bw[PLPO_MAXM];
     *keep = 0; *nlp = 0;
     for (int i = 0; i < m; ++i) bout[i] = b[i];
+    if (m > PLPO_MAXM_RED) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; return RF_EMPTY; } /* one-word mask */
     /* :1081 is_fulldim -> cheby_ball -> F1 */
     int st = plpo_cheby(m, d, A, b, r, xc, NULL);
     ++*nlp;

@@ -214,8 +214,8 @@ int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int
     if (B < 0 || m_max < 0 || n < 1) return fail(PLP_EINVAL, "bad sizes B=%lld m_max=%d n=%d", (long long)B, m_max, n);
     if (B == 0) return PLP_OK;
     if (!c || !h || !x || !fun || !status || (!G && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
-    if (m_max > plp::MAX_M || n > plp::MAX_D + 1)
-        return fail(PLP_EUNSUPPORTED, "m_max=%d n=%d outside envelope (m<=64, n<=17)", m_max, n);
+    if (n > plp::MAX_D + 1 || (m_max > plp::MAX_M && !plp::lds_lp_bytes(m_max, n + 1)))
+        return fail(PLP_EUNSUPPORTED, "m_max=%d n=%d outside envelope (n<=17; rows: the dictionary must fit 160 KB of LDS)", m_max, n);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_lp(B, m_max, n, c, G, h, m, x, fun, status, iters, st))
         return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
@@ -229,6 +229,8 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
     if (B < 0 || m_max < 0 || n < 1) return fail(PLP_EINVAL, "bad sizes");
     if (B == 0) return PLP_OK;
     if (!c || !h || !x || !fun || !status || (!G && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (n > plp::MAX_D + 1 || (m_max > plp::MAX_M && !plp::lds_lp_bytes(m_max, n + 1)))  // before any buffer is read
+        return fail(PLP_EUNSUPPORTED, "m_max=%d n=%d outside envelope (n<=17; rows: the dictionary must fit 160 KB of LDS)", m_max, n);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t nc = (size_t)B * n, nG = (size_t)B * m_max * n, nh = (size_t)B * m_max;
     size_t need = pad(nc * 8) * 2 + pad(nG * 8) + pad(nh * 8) + pad(B * 8) + pad(B * 4) * 3 + 4096;
@@ -260,8 +262,8 @@ int plp_cheby_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d,
     if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
     if (B == 0) return PLP_OK;
     if (!r || !xc || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
-    if (m_max > plp::MAX_M || d > plp::MAX_D)
-        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
+    if (d > plp::MAX_D || (m_max > plp::MAX_M && !plp::lds_lp_bytes(m_max, d + 1)))
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (d<=16; rows: the dictionary must fit 160 KB of LDS)", m_max, d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_cheby(B, m_max, d, A, b, m, r, xc, status, st))
         return fail(PLP_EUNSUPPORTED, "cheby kernel: unsupported size");
@@ -274,6 +276,8 @@ int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, 
     if (B < 0 || m_max < 0 || d < 1) return fail(PLP_EINVAL, "bad sizes");
     if (B == 0) return PLP_OK;
     if (!r || !xc || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
+    if (d > plp::MAX_D || (m_max > plp::MAX_M && !plp::lds_lp_bytes(m_max, d + 1)))
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (d<=16; rows: the dictionary must fit 160 KB of LDS)", m_max, d);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t nA = (size_t)B * m_max * d, nb = (size_t)B * m_max, nx = (size_t)B * d;
     int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nx * 8) + pad(B * 8) + pad(B * 4) * 2 + 4096);

@@ -20,6 +20,13 @@ int launch_lp(long long B, int m_max, int n, const double* c, const double* G, c
 int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                  double* xc, int* status, hipStream_t st);
 
+// dictionary in LDS, one LP per wavefront, any row count that fits 160 KB (plp_lds.hip): the engine for m_max > 64
+int launch_lp_lds(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                  double* x, double* fun, int* status, int* iters, hipStream_t st);
+int launch_cheby_lds(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                     double* xc, int* status, hipStream_t st);
+size_t lds_lp_bytes(int m_max, int nc);  // 0: does not fit
+
 // generic LPs, four rows per lane, origin-feasible ones only (n <= 8, plp_cheby_r.hip): the others get
 // status ST_RETRY for the general kernel; returns 1 when it does not apply
 int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,

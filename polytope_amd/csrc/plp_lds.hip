@@ -1,0 +1,494 @@
+// plp_lds.hip -- LP engine with the dictionary in LDS (gfx950): one LP per wavefront, rows striped over the lanes.
+//
+//   lp_lds_kernel    : lpsolve() batches (solvers.py:76-106, 149-158) of ANY row count that fits the CU's LDS
+//   cheby_lds_kernel : Chebyshev-ball LPs (form F1, polytope.py:1283-1288) likewise
+//
+// The register-resident engines (plp_simplex.hpp, plp_simplex_r.hpp) give every dictionary row a lane (or a
+// quarter of one) and stop at 64 rows.  region_diff (polytope.py:2117-2282) stacks m_poly + sum(active rows) and
+// passes that limit on a 1000-cell Region (BASELINE config 4: up to 73 rows; the reference has no limit), and its
+// leaf pieces go through reduce() with as many rows.  Here the dictionary T[m][nc], beta[m] and the cost rows
+// live in LDS, where a dynamic column index is an address instead of a chain of selects; lane l owns rows
+// l, l+64, l+128, ...  The pivot rules, tolerances and the arithmetic of every dictionary entry are those of
+// plp_simplex.hpp's step() (two-phase, Dantzig pricing, Bland's rule after BLAND_AFTER degenerate pivots, free
+// variables enter in either direction and never leave, 1/a = v_rcp_f64 + 2 Newton steps), so an LP that fits
+// both engines walks the same vertex path and ends with bitwise the same numbers (tests: PLP_LDS=1).
+#include <stdlib.h>
+
+#include "plp_kernels.hpp"
+#include "plp_wave.hpp"
+#include "plp_simplex.hpp"  // mode names
+
+namespace plp {
+
+namespace {
+
+constexpr int LDS_MAXC = 32;  // column slots (n <= 17 structural + artificial)
+
+struct LdsDict {
+    double* T;      // [m][ld]
+    double* beta;   // [m]
+    double* qk;     // [m]   ratio of row i in the current pivot / forced-pivot ratios (INIT)
+    int* rowvar;    // [m]   id of the basic variable
+    int* rowfl;     // [m]   bit 0: stored negated, bit 1: takes part in ratio tests
+    double* cost;   // [LDS_MAXC]
+    double* cost2;  // [LDS_MAXC]
+    double* rho;    // [LDS_MAXC]
+    int* cv;        // [LDS_MAXC] packed (id+1)<<1 | negated
+    int ld;
+};
+
+__device__ __forceinline__ size_t lds_dict_bytes(int m, int ld) {
+    return (size_t)m * ld * 8 + (size_t)m * 16 + (size_t)m * 8 + 3 * LDS_MAXC * 8 + LDS_MAXC * 4;
+}
+
+__device__ __forceinline__ LdsDict lds_carve(unsigned char* base, int m, int ld) {
+    LdsDict D;
+    D.ld = ld;
+    D.T = reinterpret_cast<double*>(base);
+    D.beta = D.T + (size_t)m * ld;
+    D.qk = D.beta + m;
+    D.cost = D.qk + m;
+    D.cost2 = D.cost + LDS_MAXC;
+    D.rho = D.cost2 + LDS_MAXC;
+    D.rowvar = reinterpret_cast<int*>(D.rho + LDS_MAXC);
+    D.rowfl = D.rowvar + m;
+    D.cv = D.rowfl + m;
+    return D;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, o, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o, 64);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// order-preserving u64 key of a double (plp_simplex.hpp: the exact f64 minimum is the minimum of the keys)
+__device__ __forceinline__ unsigned long long key_of(double q) {
+    const int qh = __double2hiint(q), ql = __double2loint(q);
+    const int sm = qh >> 31;
+    const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
+    const unsigned kl = (unsigned)(ql ^ sm);
+    return ((unsigned long long)kh << 32) | kl;
+}
+__device__ __forceinline__ double unkey(unsigned long long k) {  // for keys of non-negative doubles
+    return __hiloint2double((int)((unsigned)(k >> 32) ^ 0x80000000u), (int)(unsigned)k);
+}
+
+__device__ __forceinline__ double rcp_newton(double a) {
+    const double x0 = __builtin_amdgcn_rcp(a);
+    const double x1 = fma(x0, fma(-a, x0, 1.0), x0);
+    return fma(x1, fma(-a, x1, 1.0), x1);
+}
+
+// Wave-uniform solver state (one LP per wavefront).
+struct LdsState {
+    int m, n, nc;
+    unsigned cfree, dead;
+    int ndeg, iters, maxit, mode, status;
+    int init_col, mode_after_init;
+    double negz, negz2;
+    bool carry;
+};
+
+__device__ __forceinline__ bool col_eligible(const LdsState& S, int j, double c) {
+    return (fabs(c) > TOL_D) & ((((S.cfree >> j) & 1u) != 0u) | (c < 0.0)) & (((S.dead >> j) & 1u) == 0u);
+}
+
+// One iteration (plp_simplex.hpp Simplex::step, same order of decisions).  All lanes take every branch together.
+__device__ void lds_step(LdsState& S, const LdsDict& D, int lane) {
+    const bool bland = S.ndeg >= BLAND_AFTER;
+    const int m = S.m, nc = S.nc, ld = D.ld;
+    // ---- entering column: lane j looks at column j
+    int e = -1;
+    double best = 0.0;
+    bool epos = false;
+    {
+        const double c = lane < nc ? D.cost[lane] : 0.0;
+        const bool elig = (lane < nc) && col_eligible(S, lane, c);
+        const uint64_t eb = __ballot(elig);
+        if (eb) {
+            if (!bland) {  // largest |c|, first column among equals
+                const unsigned long long k = elig ? key_of(-fabs(c)) : ~0ull;
+                const unsigned long long kmin = wave_min_u64(k);
+                const uint64_t tb = __ballot(elig && k == kmin);
+                e = __ffsll((long long)tb) - 1;
+            } else {  // lowest variable id
+                const unsigned long long k = elig ? (unsigned long long)(unsigned)D.cv[lane] : ~0ull;
+                const unsigned long long kmin = wave_min_u64(k);
+                const uint64_t tb = __ballot(elig && k == kmin);
+                e = __ffsll((long long)tb) - 1;
+            }
+            const double ce_ = D.cost[e];
+            best = fabs(ce_);
+            epos = ce_ > 0.0;
+        }
+    }
+    int fin = -1;
+    bool normal = (S.mode == M_P1) | (S.mode == M_P2);
+    if (normal && e < 0) { fin = ST_OPT; normal = false; }
+    if (normal && S.iters >= S.maxit) { fin = ST_ITER; normal = false; }
+    const bool init = S.mode == M_INIT;
+    bool drive = S.carry && S.mode == M_DRIVE;
+    int rt = -1;
+    if (drive) {  // t is basic at ~0 after phase 1: pivot it out on the largest element of its row
+        int cand = 0x7fffffff;
+        for (int i = lane; i < m; i += 64) cand = (D.rowvar[i] == ID_T && i < cand) ? i : cand;
+        rt = (int)wave_min_u64((unsigned long long)(unsigned)cand);
+        if (rt == 0x7fffffff) rt = 0;
+        const double aj = lane < nc ? fabs(D.T[(size_t)rt * ld + lane]) : 0.0;
+        const bool ok = (lane < nc) && (aj > TOL_PIV) && !((S.dead >> lane) & 1u);
+        int eo = -1;
+        if (__ballot(ok)) {
+            const unsigned long long k = ok ? key_of(-aj) : ~0ull;
+            const unsigned long long kmin = wave_min_u64(k);
+            eo = __ffsll((long long)__ballot(ok && k == kmin)) - 1;
+        }
+        e = eo;
+        if (eo < 0) {  // row "0 = t": redundant
+            if (lane == 0) D.rowfl[rt] &= ~2;
+            drive = false;
+            fin = -2;  // -> phase 2 without a pivot
+        }
+    }
+    if (init) e = S.init_col;
+    bool act = normal | init | drive;
+    if (act) {
+        const bool flip = normal & epos;  // free variable entering downwards: x := -x
+        double ce = -best;
+        if (init | drive) ce = D.cost[e];
+        double ce2 = S.carry ? D.cost2[e] : 0.0;
+        if (flip) ce2 = -ce2;
+        const int vin = D.cv[e];
+        const bool efree = (S.cfree >> e) & 1u;
+        // ---- ratio test over my rows
+        unsigned long long kbest = ~0ull;
+        for (int i = lane; i < m; i += 64) {
+            double a = D.T[(size_t)i * ld + e];
+            a = flip ? -a : a;
+            const double b = D.beta[i];
+            bool erow = normal & ((D.rowfl[i] & 2) != 0) & (a > TOL_PIV);
+            double q = (b > 0.0 ? b : 0.0) * rcp_newton(a);
+            if (init) { erow = (D.rowfl[i] & 2) != 0; q = D.qk[i]; }  // forced pivot: caller-supplied ratios
+            if (drive) { erow = i == rt; q = 0.0; }
+            q = erow ? q : __longlong_as_double(0x7ff0000000000000ll);
+            const unsigned long long k = key_of(q);
+            if (!init) D.qk[i] = __longlong_as_double((long long)k);
+            kbest = k < kbest ? k : kbest;
+        }
+        const unsigned long long kmin = wave_min_u64(kbest);
+        const unsigned mh = (unsigned)(kmin >> 32), ml = (unsigned)kmin;
+        if (mh >= 0xfff00000u) {  // +inf: no eligible row (or NaN): unbounded / numerical
+            fin = (mh == 0xfff00000u && ml == 0u) ? ST_UNBND : ST_NUM;
+            act = false;
+        }
+        if (act) {
+            // lowest row among the ties (Dantzig), lowest basic-variable id among them (Bland)
+            unsigned long long pick = ~0ull;
+            for (int i = lane; i < m; i += 64) {
+                const unsigned long long k = init ? key_of(((D.rowfl[i] & 2) != 0) ? D.qk[i] : __longlong_as_double(0x7ff0000000000000ll))
+                                                  : (unsigned long long)__double_as_longlong(D.qk[i]);
+                if (k == kmin) {
+                    const unsigned long long c =
+                        (bland & normal) ? (((unsigned long long)(unsigned)(D.rowvar[i] + 1) << 32) | (unsigned)i)
+                                         : (unsigned long long)(unsigned)i;
+                    pick = c < pick ? c : pick;
+                }
+            }
+            const int r = (int)(unsigned)wave_min_u64(pick);
+            if (normal) S.ndeg = (unkey(kmin) <= DEGEN_EPS) ? S.ndeg + 1 : 0;
+            // ---- pivot row scaled: rho_j = T[r][j] * p, rho_e = p
+            double ar = D.T[(size_t)r * ld + e];
+            ar = flip ? -ar : ar;
+            const double p = rcp_newton(ar);
+            const double rhob = D.beta[r] * p;
+            if (lane < nc) D.rho[lane] = D.T[(size_t)r * ld + lane] * p;
+            const int rpack = ((D.rowvar[r] + 1) << 1) | (D.rowfl[r] & 1);
+            __syncthreads();
+            // ---- update my rows
+            for (int i = lane; i < m; i += 64) {
+                double* Ti = D.T + (size_t)i * ld;
+                if (i == r) continue;
+                double f = Ti[e];
+                f = flip ? -f : f;
+                for (int j = 0; j < nc; ++j) Ti[j] = fma(-f, D.rho[j], Ti[j]);
+                Ti[e] = -(f * p);
+                D.beta[i] = fma(-f, rhob, D.beta[i]);
+            }
+            __syncthreads();
+            if (lane < nc) {
+                const double rj = D.rho[lane];
+                D.T[(size_t)r * ld + lane] = lane == e ? p : rj;
+                D.cost[lane] = lane == e ? -(ce * p) : fma(-ce, rj, D.cost[lane]);
+                if (S.carry) D.cost2[lane] = lane == e ? -(ce2 * p) : fma(-ce2, rj, D.cost2[lane]);
+            }
+            S.negz = fma(-ce, rhob, S.negz);
+            if (S.carry) S.negz2 = fma(-ce2, rhob, S.negz2);
+            if (lane == 0) {
+                D.beta[r] = rhob;
+                D.cv[e] = rpack;
+                D.rowvar[r] = (vin >> 1) - 1;
+                D.rowfl[r] = ((vin & 1) ^ (flip ? 1 : 0)) | (efree ? 0 : 2);  // a free variable never leaves again
+            }
+            S.cfree &= ~(1u << e);
+            S.iters += 1;
+            __syncthreads();
+            // optimal right after this pivot?
+            if (normal) {
+                const double c = lane < nc ? D.cost[lane] : 0.0;
+                if (!__ballot((lane < nc) && col_eligible(S, lane, c))) fin = ST_OPT;
+            }
+        }
+    }
+    // ---- mode transitions
+    if (init) {
+        S.mode = (fin >= 0) ? M_DONE : S.mode_after_init;
+        if (fin >= 0) S.status = fin;
+        for (int i = lane; i < m; i += 64)
+            if ((D.rowfl[i] & 2) && D.beta[i] < 0.0) D.beta[i] = 0.0;  // rounding of the forced pivot
+        __syncthreads();
+    } else if (S.carry && (S.mode == M_P1 || S.mode == M_DRIVE)) {
+        bool to_p2 = false;
+        if (S.mode == M_DRIVE) {
+            to_p2 = true;
+        } else if (fin == ST_OPT) {
+            int cand = 0x7fffffff;
+            for (int i = lane; i < m; i += 64) cand = (D.rowvar[i] == ID_T && i < cand) ? i : cand;
+            const int rtt = (int)wave_min_u64((unsigned long long)(unsigned)cand);
+            if (rtt != 0x7fffffff) {
+                const double tval = D.beta[rtt];
+                if (tval > TOL_FEAS) { S.mode = M_DONE; S.status = ST_INFEAS; }
+                else S.mode = M_DRIVE;
+            } else {
+                to_p2 = true;
+            }
+        } else if (fin >= 0) {
+            S.mode = M_DONE;
+            S.status = (fin == ST_ITER) ? ST_ITER : ST_NUM;
+        }
+        if (to_p2) {  // the column that now holds t is dropped; the carried cost row becomes active
+            unsigned dd = 0u;
+            if (lane < nc) {
+                dd = ((D.cv[lane] >> 1) == 0) ? (1u << lane) : 0u;
+                D.cost[lane] = D.cost2[lane];
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) dd |= (unsigned)__shfl_xor((int)dd, o, 64);
+            S.dead |= dd;
+            S.negz = S.negz2;
+            for (int i = lane; i < m; i += 64)
+                if ((D.rowfl[i] & 2) && D.beta[i] < 0.0) D.beta[i] = 0.0;
+            S.ndeg = 0;
+            S.mode = M_P2;
+            __syncthreads();
+        }
+    } else if (fin >= 0) {
+        S.mode = M_DONE;
+        S.status = fin;
+    }
+}
+
+// x_j of the final dictionary (0 when nonbasic), every lane gets the value
+__device__ __forceinline__ double lds_x_of(const LdsDict& D, int m, int j, int lane) {
+    double v = 0.0;
+    bool found = false;
+    for (int i = lane; i < m; i += 64) {
+        if (D.rowvar[i] == j) { v = (D.rowfl[i] & 1) ? -D.beta[i] : D.beta[i]; found = true; }
+    }
+    const uint64_t ob = __ballot(found);
+    const double w = __shfl(v, ob ? __ffsll((long long)ob) - 1 : 0, 64);
+    return ob ? w : 0.0;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void lp_lds_kernel(long long B, int m_max, int n, const double* __restrict__ c,
+                                                    const double* __restrict__ G, const double* __restrict__ h,
+                                                    const int* __restrict__ mrows, double* __restrict__ x,
+                                                    double* __restrict__ fun, int* __restrict__ status,
+                                                    int* __restrict__ iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int nc = n + 1;  // + phase-1 artificial
+    const int ld = nc | 1;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (long long lp = blockIdx.x; lp < B; lp += gridDim.x) {
+        const int m = mrows ? mrows[lp] : m_max;
+        const LdsDict D = lds_carve(smem_raw, m_max, ld);
+        __syncthreads();
+        LdsState S;
+        S.m = m; S.n = n; S.nc = nc;
+        S.cfree = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+        S.dead = 0u; S.ndeg = 0; S.iters = 0; S.maxit = 50 * (m + n) + 100;
+        S.mode = M_P2; S.status = -1; S.init_col = -1; S.mode_after_init = M_P2;
+        S.negz = 0.0; S.negz2 = 0.0; S.carry = true;
+        bool finite = true, inf0 = false, neg = false;
+        for (int i = lane; i < m; i += 64) {
+            const double* Gr = G + (lp * m_max + i) * n;
+            double* Ti = D.T + (size_t)i * ld;
+            bool zero = true;
+            for (int j = 0; j < n; ++j) {
+                const double v = Gr[j];
+                Ti[j] = v;
+                zero = zero & (v == 0.0);
+                finite = finite & isfinite(v);
+            }
+            Ti[n] = 0.0;
+            const double hi = h[lp * m_max + i];
+            finite = finite & isfinite(hi);
+            D.beta[i] = zero ? 0.0 : hi;
+            D.rowvar[i] = n + i;
+            D.rowfl[i] = zero ? 0 : 2;
+            inf0 = inf0 | (zero & (hi < -TOL_FEAS));  // 0 <= h_i < 0
+            neg = neg | (!zero & (hi < 0.0));
+        }
+        double cj = 0.0;
+        if (lane < nc) {
+            cj = lane < n ? c[lp * n + lane] : 0.0;
+            finite = finite & isfinite(cj);
+            D.cv[lane] = lane < n ? ((lane + 1) << 1) : 0;  // last column: the artificial variable t (id -1)
+        }
+        const bool bad = __ballot(!finite) != 0;
+        const bool infeasible0 = __ballot(inf0) != 0;
+        const bool need_p1 = __ballot(neg) != 0;
+        if (need_p1) {
+            for (int i = lane; i < m; i += 64) {
+                if (D.rowfl[i] & 2) D.T[(size_t)i * ld + n] = -1.0;
+                D.qk[i] = D.beta[i];
+            }
+            if (lane < nc) { D.cost[lane] = lane == n ? 1.0 : 0.0; D.cost2[lane] = cj; }
+            S.mode = M_INIT; S.init_col = n; S.mode_after_init = M_P1;
+        } else {
+            if (lane < nc) { D.cost[lane] = cj; D.cost2[lane] = 0.0; }
+            S.dead = 1u << n;
+        }
+        if (bad) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+        __syncthreads();
+        while (S.mode != M_DONE) lds_step(S, D, lane);
+        const bool ok = S.status == ST_OPT;
+        double f = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double xj = lds_x_of(D, m, j, lane);
+            f = fma(c[lp * n + j], xj, f);
+            if (lane == 0) x[lp * n + j] = ok ? xj : qnan;
+        }
+        if (lane == 0) {
+            fun[lp] = ok ? f : qnan;
+            status[lp] = S.status;
+            if (iters) iters[lp] = S.iters;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void cheby_lds_kernel(long long B, int m_max, int d, const double* __restrict__ A,
+                                                       const double* __restrict__ b, const int* __restrict__ mrows,
+                                                       double* __restrict__ r, double* __restrict__ xc,
+                                                       int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int nc = d + 1;
+    const int ld = nc | 1;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (long long p = blockIdx.x; p < B; p += gridDim.x) {
+        const int m = mrows ? mrows[p] : m_max;
+        const LdsDict D = lds_carve(smem_raw, m_max, ld);
+        __syncthreads();
+        LdsState S;
+        S.m = m; S.n = nc; S.nc = nc;
+        S.cfree = (1u << nc) - 1u;
+        S.dead = 0u; S.ndeg = 0; S.iters = 0; S.maxit = 50 * (m + nc) + 100;
+        S.mode = M_INIT; S.status = -1; S.init_col = d; S.mode_after_init = M_P2;
+        S.negz = 0.0; S.negz2 = 0.0; S.carry = false;
+        bool finite = true, inf0 = false;
+        for (int i = lane; i < m; i += 64) {
+            const double* Ar = A + (p * m_max + i) * d;
+            double* Ti = D.T + (size_t)i * ld;
+            double nrm2 = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double v = Ar[k];
+                Ti[k] = v;
+                nrm2 = nrm2 + v * v;
+                finite = finite & isfinite(v);
+            }
+            const double bi = b[p * m_max + i];
+            finite = finite & isfinite(bi);
+            const double nrm = sqrt(nrm2);
+            const bool zero = !(nrm > 0.0);
+            Ti[d] = zero ? 0.0 : nrm;
+            D.beta[i] = zero ? 0.0 : bi;
+            D.qk[i] = bi / nrm;
+            D.rowvar[i] = nc + i;
+            D.rowfl[i] = zero ? 0 : 2;
+            inf0 = inf0 | (zero & (bi < -TOL_FEAS));
+        }
+        if (lane < nc) {
+            D.cost[lane] = lane == d ? -1.0 : 0.0;
+            D.cost2[lane] = 0.0;
+            D.cv[lane] = (lane + 1) << 1;
+        }
+        const bool bad = __ballot(!finite) != 0;
+        const bool infeasible0 = __ballot(inf0) != 0;
+        if (bad) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+        __syncthreads();
+        while (S.mode != M_DONE) lds_step(S, D, lane);
+        const bool ok = S.status == ST_OPT;
+        for (int j = 0; j < nc; ++j) {
+            const double xj = lds_x_of(D, m, j, lane);
+            if (lane == 0) {
+                if (j < d) xc[p * d + j] = ok ? xj : qnan; else r[p] = ok ? xj : qnan;
+            }
+        }
+        if (lane == 0) status[p] = S.status;
+    }
+}
+
+// LDS bytes one LP of (m_max, columns nc) needs; 0 when it does not fit a workgroup (160 KB per CU on gfx950)
+size_t lds_lp_bytes(int m_max, int nc) {
+    const int ld = nc | 1;
+    const size_t need = (size_t)m_max * ld * 8 + (size_t)m_max * 24 + 3 * LDS_MAXC * 8 + LDS_MAXC * 4 + 64;
+    return need <= 160 * 1024 ? ((need + 15) & ~(size_t)15) : 0;
+}
+
+static int lds_grid(long long B, size_t smem) {
+    // resident wavefronts: limited by LDS per CU and 8 single-wave workgroups per SIMD-set; the loop strides the rest
+    long long per_cu = (long long)(160 * 1024 / smem);
+    if (per_cu > 32) per_cu = 32;
+    if (per_cu < 1) per_cu = 1;
+    long long blocks = 256 * per_cu * 4;
+    if (blocks > B) blocks = B;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+int launch_lp_lds(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                  double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    if (n < 1 || n > MAX_D + 1 || m_max < 0) return 2;
+    const size_t smem = lds_lp_bytes(m_max < 1 ? 1 : m_max, n + 1);
+    if (!smem) return 2;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lp_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+    hipLaunchKernelGGL(lp_lds_kernel, dim3(lds_grid(B, smem)), dim3(64), smem, st, B, m_max, n, c, G, h, mrows, x, fun,
+                       status, iters);
+    return 0;
+}
+
+int launch_cheby_lds(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                     double* xc, int* status, hipStream_t st) {
+    if (d < 1 || d > MAX_D || m_max < 0) return 2;
+    const size_t smem = lds_lp_bytes(m_max < 1 ? 1 : m_max, d + 1);
+    if (!smem) return 2;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cheby_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(cheby_lds_kernel, dim3(lds_grid(B, smem)), dim3(64), smem, st, B, m_max, d, A, b, mrows, r, xc,
+                       status);
+    return 0;
+}
+
+}  // namespace plp

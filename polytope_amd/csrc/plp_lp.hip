@@ -215,6 +215,9 @@ static void launch_cheby_d(long long B, int m_max, int gs, const double* A, cons
 
 int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
               double* x, double* fun, int* status, int* iters, hipStream_t st) {
+    // more than 64 rows (or PLP_LDS=1: A/B, tests): the LDS-resident engine, one LP per wavefront (plp_lds.hip)
+    const char* lds = getenv("PLP_LDS");
+    if (m_max > MAX_M || (lds && lds[0] == '1')) return launch_lp_lds(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st);
     const int gs = group_size_for(m_max);
     if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
     // n <= 8: LPs whose origin is feasible (no phase 1) are solved by the four-rows-per-lane fast path
@@ -234,6 +237,8 @@ int launch_lp(long long B, int m_max, int n, const double* c, const double* G, c
 
 int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                  double* xc, int* status, hipStream_t st) {
+    const char* lds = getenv("PLP_LDS");
+    if (m_max > MAX_M || (lds && lds[0] == '1')) return launch_cheby_lds(B, m_max, d, A, b, mrows, r, xc, status, st);
     const int gs = group_size_for(m_max);
     if (gs < 0 || d < 1 || d > MAX_D) return 2;
     // d <= 8: four rows per lane (PLP_CHEBY_1ROW=1 keeps the one-row-per-lane kernel: A/B, tests)

@@ -43,7 +43,19 @@ def _use_hip():
 
 
 def _fits(m, d):
+    """Fused reduce / bounding-box / containment kernels: register-resident dictionaries, m <= 64."""
     return 1 <= d <= _MAX_DIM and m <= _MAX_ROWS
+
+
+def _max_rows_lp(d):
+    """Rows a stand-alone LP may have: beyond 64 the engine keeps the dictionary in LDS (csrc/plp_lds.hip), one LP
+    per wavefront, and the limit is what fits the CU's 160 KB (d + 1 structural columns + the artificial one)."""
+    return (160 * 1024 - 1024) // ((((d + 2) | 1) * 8) + 24)
+
+
+def _fits_lp(m, d):
+    """Chebyshev / generic LP batches (region_diff stacks m_poly + sum(active rows): ref :2212-2224 has no limit)."""
+    return 1 <= d <= _MAX_DIM and m <= _max_rows_lp(d)
 
 
 # ======================================================================================
@@ -406,11 +418,20 @@ def _cheby_raw(polys):
     if not polys:
         return []
     d = polys[0].A.shape[1]
-    if _use_hip() and all(_fits(p.A.shape[0], p.A.shape[1]) and p.A.shape[1] == d for p in polys):
+    if _use_hip() and all(_fits_lp(p.A.shape[0], p.A.shape[1]) and p.A.shape[1] == d for p in polys):
         from .batch import cheby_ball_batch
-        A, b, ms = _pack(polys)
-        res = cheby_ball_batch(A, b, m=ms)
-        return [_ball_from_lp(int(res["status"][k]), float(res["r"][k]), res["xc"][k]) for k in range(len(polys))]
+        out = [None] * len(polys)
+        # stacks of more than 64 rows take the LDS-resident engine: keep them out of the batch of the small ones
+        big = [k for k, p in enumerate(polys) if p.A.shape[0] > _MAX_ROWS]
+        small = [k for k, p in enumerate(polys) if p.A.shape[0] <= _MAX_ROWS]
+        for idx in (small, big):
+            if not idx:
+                continue
+            A, b, ms = _pack([polys[k] for k in idx])
+            res = cheby_ball_batch(A, b, m=ms)
+            for t, k in enumerate(idx):
+                out[k] = _ball_from_lp(int(res["status"][t]), float(res["r"][t]), res["xc"][t])
+        return out
     out = []
     for p in polys:
         n = p.A.shape[1]
@@ -955,7 +976,7 @@ def _radii_stacked(poly, others):
     if not others:
         return []
     same = _use_hip() and len({c.A.shape for c in others}) == 1 and \
-        _fits(poly.A.shape[0] + others[0].A.shape[0], poly.A.shape[1])
+        _fits_lp(poly.A.shape[0] + others[0].A.shape[0], poly.A.shape[1])
     if same:
         n = len(others)
         A3 = np.concatenate([np.broadcast_to(poly.A, (n,) + poly.A.shape), np.stack([c.A for c in others])], axis=1)
@@ -982,8 +1003,14 @@ def _radii(polys):
     return out
 
 
-def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
+def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _order=None):
     """poly minus the union of the polytopes of reg, as non-overlapping pieces.
+
+    The cells of `reg` are visited in the order argsort(-Rc) of the Chebyshev radii of their stacks with `poly`
+    (ref :2153-2157).  Cells whose radii are mathematically equal -- on a grid every cell whose ball is limited by
+    its own facets -- are ordered by the last-bit rounding of whichever LP code computed Rc, and the decomposition
+    (a valid one either way) depends on that order.  `_order` (a permutation of range(len(reg)), test hook) replaces
+    the argsort, so that the search can be compared with the reference's on such inputs (tests/golden g12 c4_order).
 
     Depth-first enumeration of the sign patterns of the subtrahends' new constraints, one
     Chebyshev LP per node (the algorithm of ref :2117-2282, same visiting order and the same
@@ -1012,7 +1039,7 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
     if N == 0:
         logger.debug("no Polytope in the Region intersects the given Polytope")
         return poly
-    order = np.argsort(-Rc)
+    order = np.argsort(-Rc) if _order is None else np.asarray(_order, dtype=int)
     m = poly.A.shape[0]
     A = poly.A.copy()
     B = poly.b.copy()
@@ -1057,17 +1084,24 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False):
     def radii_rows(row_lists):
         """Chebyshev radius (0 when the ball LP fails) of the polytope of each row list, one batch."""
         lens = [len(r) for r in row_lists]
-        if not packed or max(lens) > _MAX_ROWS:
+        if not packed or max(lens) > _max_rows_lp(A.shape[1]):
             return _radii([poly_of(r) for r in row_lists])
-        m_max = max(lens)
-        A3 = np.zeros((len(row_lists), m_max, A.shape[1]))
-        b3 = np.zeros((len(row_lists), m_max))
-        for k, r in enumerate(row_lists):
-            A3[k, :lens[k]] = An[r]
-            b3[k, :lens[k]] = Bn[r]
-        out = cheby_ball_batch(A3, b3, m=np.asarray(lens, dtype=np.int32))
-        ok = (out["status"] == 0) & (out["r"] >= 0)
-        return [np.double(rr) if o else 0 for rr, o in zip(out["r"], ok)]
+        res = [0] * len(row_lists)
+        # stacks of more than 64 rows go to the LDS-resident engine in a batch of their own
+        for sel in ([k for k, n_ in enumerate(lens) if n_ <= _MAX_ROWS], [k for k, n_ in enumerate(lens) if n_ > _MAX_ROWS]):
+            if not sel:
+                continue
+            m_max = max(lens[k] for k in sel)
+            A3 = np.zeros((len(sel), m_max, A.shape[1]))
+            b3 = np.zeros((len(sel), m_max))
+            for t, k in enumerate(sel):
+                A3[t, :lens[k]] = An[row_lists[k]]
+                b3[t, :lens[k]] = Bn[row_lists[k]]
+            out = cheby_ball_batch(A3, b3, m=np.asarray([lens[k] for k in sel], dtype=np.int32))
+            ok = (out["status"] == 0) & (out["r"] >= 0)
+            for t, k in enumerate(sel):
+                res[k] = np.double(out["r"][t]) if ok[t] else 0
+        return res
 
     # The children of a node (constraint 1 violated; 1 kept and 2 violated; ...) are all visited, one
     # after the other, so their LPs are solved together when the first of them is reached.

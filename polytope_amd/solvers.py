@@ -34,7 +34,11 @@ except ImportError:  # pragma: no cover
     _optimize = None
 
 _KNOWN = ("hip", "scipy", "glpk", "mosek", "gurobi")
-default_solver = "hip"
+# The default is chosen from the installed choices by the reference's own rule (solvers.py:66-73: glpk, else
+# scipy); 'hip' is never made the default behind the user's back -- select it like any other backend:
+#     from polytope_amd import solvers;  solvers.default_solver = 'hip'
+# Selecting it on a machine without the library or a gfx950 device raises RuntimeError (no CPU fallback).
+default_solver = "scipy"
 
 
 def _probe_hip():

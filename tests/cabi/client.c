@@ -44,7 +44,7 @@ int main(void)
       CHECK(plp_bbox_batch(ctx, 2, 4, 2, A, b, NULL, lb, ub, st));
       printf("bbox status %d lb %.9f %.9f ub %.9f %.9f | status %d\n", st[0], lb[0], lb[1], ub[0], ub[1], st[1]); }
     /* misuse is reported, not crashed on */
-    { double c[1] = {1.0}; int rc = plp_lp_solve_batch(ctx, 1, 65, 1, c, c, c, NULL, c, c, (int32_t *)c, NULL);
+    { double c[1] = {1.0}; int rc = plp_lp_solve_batch(ctx, 1, 100000, 1, c, c, c, NULL, c, c, (int32_t *)c, NULL);  /* no LDS for 100000 rows */
       printf("envelope rc %d (%s)\n", rc, rc == PLP_EUNSUPPORTED ? "PLP_EUNSUPPORTED" : "?"); }
     CHECK(plp_ctx_destroy(ctx));
     printf("done\n");

@@ -27,6 +27,9 @@ Sets:
   g11_convex.npz   envelope / is_convex / union(check_convex=True) / mldivide / is_adjacent / intersect on random
                    overlapping, touching and separated polytope pairs (d = 2, 3) and on splits of one polytope
                    by a hyperplane (convex unions)            (polytope.py:1414-1464, 988-1014, 1166-1238, 1470-1505)
+  g12_config4.npz  BASELINE config 4: region_diff / Region.intersect / adjacency on the 81-cell 3x3x3x3 grid and
+                   region_diff + an adjacency sample on the full 1000-cell 10x10x5x2 grid  (polytope.py:2117-2282)
+  g13_volume_subset.npz  seeded volume(), is_subset, == / <= / >= on polytopes and Regions (polytope.py:1529-1594, :1032-1050)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -634,7 +637,198 @@ def gen_g11():
     np.savez_compressed(os.path.join(HERE, "g11_convex.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G12
+def _store_pieces(out, key, ps, d):
+    """Pieces of a Region in the reference's order: row counts, [A|b] rows (NaN padded), Chebyshev radii."""
+    width = max([q.A.shape[0] for q in ps] + [1])
+    out[key + "_n"] = np.int32(len(ps))
+    out[key + "_m"] = np.array([q.A.shape[0] for q in ps], np.int32)
+    out[key + "_Ab"] = pad([np.c_[q.A, q.b].ravel() for q in ps], width * (d + 1)) if ps else np.zeros((0, d + 1))
+    out[key + "_r"] = np.array([float(pc.cheby_ball(q)[0]) for q in ps])
+
+
+def gen_g12():
+    """BASELINE config 4 (region_diff / find_adjacent_regions on box grids in d = 4, polytope.py:2117-2282,
+    prop2partition.py:46-63) at the sizes SURVEY 8c asks for: the 3x3x3x3 grid (81 cells) completely, and the
+    full 10x10x5x2 grid (1000 cells): region_diff of a polytope against the 500 cells with x0 < 0.5 (the
+    reference needs ~150 s and 88 000 LPs, stacks of up to 73 rows) plus is_adjacent on a 3000-pair sample."""
+    import time
+    rng = np.random.default_rng(1212)
+    out = {}
+    # ---- 81 cells
+    shape = (3, 3, 3, 3)
+    d = 4
+    cells = grid_cells(shape)
+    A, b = rand_hpoly(rng, 16, d, bounded=False)
+    P = pc.Polytope(A, 0.3 * b + A @ (0.5 * np.ones(d)))
+    sub = pc.Region(cells[:40])
+    calls = []
+    orig = alg.lpsolve
+    alg.lpsolve = lambda c, G, h, solver=None: (calls.append(G.shape[0]), orig(c, G, h, solver))[1]
+    t0 = time.time()
+    D = alg.region_diff(P.copy(), sub)
+    out["g81_diff_nlp"], out["g81_diff_maxrows"] = np.int32(len(calls)), np.int32(max(calls))
+    print("g12 81 cells: region_diff %d pieces, %d LPs, max rows %d, %.1f s" % (len(pieces_of(D)), len(calls), max(calls), time.time() - t0))
+    alg.lpsolve = orig
+    t0 = time.time()
+    I = pc.Region(cells).intersect(P.copy())
+    print("g12 81 cells: Region.intersect %d pieces, %.1f s" % (len(pieces_of(I)), time.time() - t0))
+    adj = np.eye(len(cells), dtype=np.int8)
+    for i, a in enumerate(cells):
+        for j, bb in enumerate(cells[:i]):
+            adj[i, j] = adj[j, i] = pc.is_adjacent(a, bb)
+    out["g81_cellsA"] = np.array([c.A for c in cells])
+    out["g81_cellsb"] = np.array([c.b for c in cells])
+    out["g81_PA"], out["g81_Pb"], out["g81_nsub"] = P.A, P.b, np.int32(40)
+    _store_pieces(out, "g81_diff", pieces_of(D), d)
+    _store_pieces(out, "g81_isect", pieces_of(I), d)
+    out["g81_adj"] = adj
+    # the reference's volume of the difference with explicit seeds per piece (volume(piece, nsamples, seed))
+    out["g81_diff_vol"] = np.array([alg.volume(q.copy(), nsamples=4000, seed=100 + k) for k, q in enumerate(pieces_of(D))])
+    # ---- 256 cells (4x4x4x4), seeds tried until no two intersecting cells have radii closer than 1e-9 (see the
+    # note on ties below): the largest grid on which the reference's visiting order is well defined
+    shape = (4, 4, 4, 4)
+    cells = grid_cells(shape)
+    for seed in range(100):
+        r2 = np.random.default_rng(5000 + seed)
+        A, b = rand_hpoly(r2, 16, d, bounded=False)
+        P = pc.Polytope(A, 0.22 * b + A @ (0.5 * np.ones(d) + 0.05 * r2.standard_normal(d)))
+        Rc = np.array([alg.cheby_ball(pc.Polytope(np.vstack([P.A, c.A]), np.hstack([P.b, c.b])))[0] for c in cells[:128]])
+        srt = -np.sort(-Rc[Rc >= 1e-7])
+        if len(srt) > 20 and (-np.diff(srt)).min() > 1e-9:
+            break
+    else:
+        raise RuntimeError("no tie-free instance found")
+    calls = []
+    alg.lpsolve = lambda c, G, h, solver=None: (calls.append(G.shape[0]), orig(c, G, h, solver))[1]
+    t0 = time.time()
+    D = alg.region_diff(P.copy(), pc.Region(cells[:128]))
+    alg.lpsolve = orig
+    print("g12 256 cells (seed %d, %d intersecting, min radius gap %.2e): region_diff %d pieces, %d LPs, max rows %d, %.1f s"
+          % (seed, len(srt), (-np.diff(srt)).min(), len(pieces_of(D)), len(calls), max(calls), time.time() - t0))
+    out["g256_PA"], out["g256_Pb"], out["g256_nsub"] = P.A, P.b, np.int32(128)
+    out["g256_diff_nlp"], out["g256_diff_maxrows"] = np.int32(len(calls)), np.int32(max(calls))
+    _store_pieces(out, "g256_diff", pieces_of(D), d)
+    # ---- 1000 cells (C4)
+    shape = (10, 10, 5, 2)
+    cells = grid_cells(shape)
+    A, b = rand_hpoly(rng, 16, d, bounded=False)
+    P = pc.Polytope(A, 0.3 * b + A @ (0.5 * np.ones(d)))
+    calls = []
+    alg.lpsolve = lambda c, G, h, solver=None: (calls.append(G.shape[0]), orig(c, G, h, solver))[1]
+    t0 = time.time()
+    D = alg.region_diff(P.copy(), pc.Region(cells[:500]))
+    alg.lpsolve = orig
+    print("g12 1000 cells: region_diff %d pieces, %d LPs, max rows %d, %.1f s" % (len(pieces_of(D)), len(calls), max(calls), time.time() - t0))
+    out["c4_diff_nlp"], out["c4_diff_maxrows"] = np.int32(len(calls)), np.int32(max(calls))
+    # region_diff visits the cells in the order argsort(-Rc) of their stacked Chebyshev radii (polytope.py:2145-2157).
+    # On a grid hundreds of cells have mathematically EQUAL radii (every cell whose ball is limited by its own
+    # facets: 301 of 444 here), so the reference's order among them -- and with it the decomposition -- is decided
+    # by the last-bit rounding of its LP solver.  The order it used is recorded so that the search itself can be
+    # pinned at this size; Rc is recomputed exactly as :2148-2152 does.
+    Rc = np.zeros(500)
+    for i, c in enumerate(cells[:500]):
+        Rc[i], _ = alg.cheby_ball(pc.Polytope(np.vstack([P.A, c.A]), np.hstack([P.b, c.b])))
+    out["c4_Rc"] = Rc
+    out["c4_order"] = np.argsort(-Rc).astype(np.int32)
+    srt = -np.sort(-Rc[Rc >= 1e-7])
+    out["c4_ties_1e12"] = np.int32(int((-np.diff(srt) < 1e-12).sum()))
+    print("g12 1000 cells: %d intersecting cells, %d neighbouring radii closer than 1e-12" % (len(srt), int(out["c4_ties_1e12"])))
+    out["c4_shape"] = np.array(shape, np.int32)
+    out["c4_PA"], out["c4_Pb"], out["c4_nsub"] = P.A, P.b, np.int32(500)
+    _store_pieces(out, "c4_diff", pieces_of(D), d)
+    # pair sample: every pair among the first 40 cells + 2220 random pairs
+    n = len(cells)
+    pairs = [(i, j) for i in range(40) for j in range(i)]
+    while len(pairs) < 3000:
+        i, j = (int(v) for v in rng.integers(0, n, 2))
+        if i != j:
+            pairs.append((max(i, j), min(i, j)))
+    out["c4_pairs"] = np.array(pairs, np.int32)
+    out["c4_pairs_adj"] = np.array([pc.is_adjacent(cells[i], cells[j]) for i, j in pairs], np.int8)
+    print("g12 1000 cells: %d sampled pairs, %d adjacent" % (len(pairs), int(out["c4_pairs_adj"].sum())))
+    np.savez_compressed(os.path.join(HERE, "g12_config4.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G13
+def gen_g13():
+    """volume (polytope.py:1529-1594: seeded via numpy.random.default_rng(seed)), is_subset (:1032-1050),
+    == / <= / >= (:220-230, :748-758) on polytopes and Regions."""
+    rng = np.random.default_rng(1313)
+    out = {}
+    vols = []
+    k = 0
+    for d in (1, 2, 3, 4, 5):
+        for trial in range(3):
+            A, b = rand_hpoly(rng, max(2 * d, 3 * d + trial), d, bounded=True)
+            shift = 0.5 * rng.standard_normal(d)
+            P = pc.Polytope(A, (0.4 + 0.3 * trial) * b + A @ shift)
+            out["v%d_A" % k], out["v%d_b" % k] = P.A, P.b
+            ns = [None, 777, 20000][trial]
+            seed = 5 + k
+            v = alg.volume(P.copy(), nsamples=ns, seed=seed)
+            l, u = P.copy().bounding_box
+            # number of samples and of hits, so that a mismatch can be told from a rounding difference of the box
+            N = {1: 50, 2: 500, 3: 3000}.get(d, 10000) if ns is None else ns
+            out["v%d_nsamples" % k] = np.int64(-1 if ns is None else ns)
+            out["v%d_seed" % k] = np.int64(seed)
+            out["v%d_vol" % k] = np.float64(v)
+            out["v%d_hits" % k] = np.int64(round(v / np.prod(u - l) * N))
+            out["v%d_lb" % k], out["v%d_ub" % k] = l.ravel(), u.ravel()
+            vols.append(v)
+            k += 1
+    out["nvol"] = np.int32(k)
+    print("g13: %d seeded volumes" % k, np.round(vols, 4))
+    # subset / equality tests
+    rel = []
+
+    def store(tag, X, Y):
+        def pack(Z, key):
+            ps = pieces_of(Z)
+            dd = ps[0].A.shape[1]
+            out[f"{tag}_{key}_n"] = np.int32(len(ps))
+            out[f"{tag}_{key}_isreg"] = np.int8(isinstance(Z, pc.Region))
+            out[f"{tag}_{key}_m"] = np.array([q.A.shape[0] for q in ps], np.int32)
+            out[f"{tag}_{key}_Ab"] = pad([np.c_[q.A, q.b].ravel() for q in ps], max(q.A.shape[0] for q in ps) * (dd + 1))
+        pack(X, "X")
+        pack(Y, "Y")
+        res = [bool(pc.is_subset(X.copy(), Y.copy())), bool(pc.is_subset(Y.copy(), X.copy())),
+               bool(X.copy() == Y.copy()), bool(X.copy() <= Y.copy()), bool(X.copy() >= Y.copy()),
+               bool(X.copy() != Y.copy())]
+        out[tag + "_res"] = np.array(res, np.int8)
+        rel.append(tag)
+        print("g13", tag, res)
+
+    t = 0
+    for d in (2, 3):
+        for trial in range(4):
+            A1, b1 = rand_hpoly(rng, 4 * d, d, bounded=True)
+            P = pc.Polytope(A1, 0.5 * b1)
+            if trial == 0:      # shrunk copy: strict subset
+                Q = pc.Polytope(A1, 0.4 * b1)
+            elif trial == 1:    # the same set with redundant rows added: equal
+                A2, b2 = rand_hpoly(rng, 3, d, bounded=False)
+                Q = pc.Polytope(np.vstack([A1, A2]), np.r_[0.5 * b1, 5.0 * b2])
+            elif trial == 2:    # overlapping, neither contains the other
+                Q = pc.Polytope(A1, 0.5 * b1 + A1 @ (0.8 * np.eye(d)[0]))
+            else:               # disjoint
+                Q = pc.Polytope(A1, 0.5 * b1 + A1 @ (9.0 * np.eye(d)[0]))
+            store("rel%d" % t, Q, P)
+            t += 1
+    # Regions: a box against its own grid cells, a sub-grid, a grid with one cell missing, and polytope vs Region
+    for shape in ((2, 2), (3, 2), (2, 2, 2)):
+        d = len(shape)
+        cells = grid_cells(shape)
+        box = pc.box2poly([[0.0, 1.0]] * d)
+        store("rel%d" % t, box, pc.Region(cells)); t += 1
+        store("rel%d" % t, pc.Region(cells[:-1]), pc.Region(cells)); t += 1
+        store("rel%d" % t, pc.Region(cells[:-1]), box); t += 1
+        store("rel%d" % t, pc.Region(cells[: len(cells) // 2]), pc.Region(cells[len(cells) // 2:])); t += 1
+    out["rel_names"] = np.array(rel)
+    np.savez_compressed(os.path.join(HERE, "g13_volume_subset.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()["gen_" + w]()

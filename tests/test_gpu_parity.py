@@ -43,6 +43,97 @@ def test_group_primitives(pa, gs):
         assert ou[64 + l] == bal, (gs, l)
 
 
+# ------------------------------------------------------------------------------ LDS-resident engine (m > 64)
+def test_lds_engine_equals_register_engines(pa, monkeypatch):
+    """csrc/plp_lds.hip keeps the dictionary in LDS (one LP per wavefront) and applies the pivot rules and the
+    arithmetic of the one-row-per-lane engine entry by entry: on LPs both can hold it must return bitwise the same
+    numbers and iteration counts (PLP_LDS=1 sends every batch to it)."""
+    from degenerate_cases import degenerate_lps
+    rng = np.random.default_rng(21)
+    for (m, n, B) in [(16, 3, 300), (33, 5, 100), (64, 8, 60), (64, 17, 30), (7, 4, 50)]:
+        G = rng.standard_normal((B, m, n))
+        G /= np.linalg.norm(G, axis=2, keepdims=True)
+        h = rng.random((B, m)) + 0.2
+        h[::3] -= 0.6 * rng.random((len(h[::3]), m))   # phase 1
+        h[5::11] -= 3.0                                 # infeasible ones
+        if m >= 2 * n:
+            G[::2, :2 * n] = np.vstack([np.eye(n), -np.eye(n)])[None]
+            h[::2, :2 * n] = 3.0
+        G[1::7, 0] = 0.0
+        c = rng.standard_normal((B, n))
+        mrows = rng.integers(max(1, m - 3), m + 1, B).astype(np.int32)
+        monkeypatch.setenv("PLP_LP_1ROW", "1")
+        ref = pa.lpsolve_batch(c, G, h, m=mrows)
+        monkeypatch.delenv("PLP_LP_1ROW")
+        monkeypatch.setenv("PLP_LDS", "1")
+        got = pa.lpsolve_batch(c, G, h, m=mrows)
+        monkeypatch.delenv("PLP_LDS")
+        assert np.array_equal(got["status"], ref["status"]) and {0, 2, 3} >= set(np.unique(got["status"]))
+        assert np.array_equal(got["iters"], ref["iters"])
+        assert np.array_equal(got["fun"], ref["fun"], equal_nan=True) and np.array_equal(got["x"], ref["x"], equal_nan=True)
+        # Chebyshev LPs (forced first pivot)
+        A = G[:, :, : n - 1] if n > 1 else G
+        monkeypatch.setenv("PLP_CHEBY_1ROW", "1")
+        ref = pa.cheby_ball_batch(A, h, m=mrows)
+        monkeypatch.delenv("PLP_CHEBY_1ROW")
+        monkeypatch.setenv("PLP_LDS", "1")
+        got = pa.cheby_ball_batch(A, h, m=mrows)
+        monkeypatch.delenv("PLP_LDS")
+        assert np.array_equal(got["status"], ref["status"])
+        assert np.array_equal(got["r"], ref["r"], equal_nan=True) and np.array_equal(got["xc"], ref["xc"], equal_nan=True)
+    # degenerate dictionaries (Bland's rule, phase 1 ending with t basic at 0)
+    for kind, c, G, h in degenerate_lps():
+        monkeypatch.setenv("PLP_LP_1ROW", "1")
+        ref = pa.lpsolve_batch(c[None], G[None], h[None])
+        monkeypatch.delenv("PLP_LP_1ROW")
+        monkeypatch.setenv("PLP_LDS", "1")
+        got = pa.lpsolve_batch(c[None], G[None], h[None])
+        monkeypatch.delenv("PLP_LDS")
+        assert got["status"][0] == ref["status"][0] and got["iters"][0] == ref["iters"][0], kind
+        assert np.array_equal(got["fun"], ref["fun"], equal_nan=True), kind
+
+
+def test_lps_beyond_64_rows(pa, oracle):
+    """region_diff stacks m_poly + sum(active rows) (polytope.py:2212-2224; 73 rows at BASELINE config 4): LPs and
+    Chebyshev balls with 65..250 rows against the oracle -- random, stacked duplicates, infeasible, unbounded."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(65)
+    for (m, n, B) in [(65, 5, 40), (73, 5, 60), (100, 3, 30), (130, 9, 16), (250, 17, 6), (200, 2, 20)]:
+        G = rng.standard_normal((B, m, n))
+        G /= np.linalg.norm(G, axis=2, keepdims=True)
+        x0 = rng.standard_normal((B, n))
+        h = np.einsum("bij,bj->bi", G, x0) + rng.random((B, m)) * rng.choice([1.0, 1.0, -0.02], (B, 1))
+        G[::2, :2 * n] = np.vstack([np.eye(n), -np.eye(n)])[None]
+        h[::2, :2 * n] = 4.0
+        G[3::4, m // 2:] = G[3::4, : m - m // 2]          # every fourth LP: the second half repeats the first
+        h[3::4, m // 2:] = h[3::4, : m - m // 2]
+        c = rng.standard_normal((B, n))
+        mrows = rng.integers(65, m + 1, B).astype(np.int32)
+        res = pa.lpsolve_batch(c, G, h, m=mrows)
+        assert set(np.unique(res["status"])) <= {0, 2, 3}
+        for k in range(B):
+            mk = mrows[k]
+            so, xo, fo, ito = oracle.lp_solve(c[k], G[k, :mk], h[k, :mk])
+            assert res["status"][k] == so, (m, n, k, res["status"][k], so)
+            if so == 0:
+                assert abs(res["fun"][k] - fo) <= TOL * max(1.0, abs(fo)), (m, n, k)
+                assert np.max(G[k, :mk] @ res["x"][k] - h[k, :mk]) <= 1e-7
+            if k < 6:
+                sp = linprog(c[k], G[k, :mk], h[k, :mk], None, None, bounds=(None, None), options={"presolve": False})
+                assert sp.status == res["status"][k], (m, n, k)
+                if sp.status == 0:
+                    assert abs(sp.fun - res["fun"][k]) <= TOL * max(1.0, abs(sp.fun))
+        if n <= 16:
+            ch = pa.cheby_ball_batch(G, h, m=mrows)
+            for k in range(B):
+                so, ro, _ = oracle.cheby(G[k, :mrows[k]], h[k, :mrows[k]])
+                assert ch["status"][k] == so, (m, n, k)
+                if so == 0:
+                    assert abs(ch["r"][k] - ro) <= TOL * max(1.0, abs(ro))
+                    nrm = np.linalg.norm(G[k, :mrows[k]], axis=1)
+                    assert np.max(G[k, :mrows[k]] @ ch["xc"][k] + nrm * ch["r"][k] - h[k, :mrows[k]]) <= 1e-8
+
+
 # ------------------------------------------------------------------------------ raw LPs
 def _g1_groups():
     g = load_golden("g1_lp.npz")
@@ -155,8 +246,12 @@ def test_lp_edge_inputs(pa):
     assert r["status"][0] == 2
     with pytest.raises(ValueError):
         pa.lpsolve_batch(np.array([[1.0]]), np.array([[[1.0], [-1.0]]]), np.array([[np.inf, 1.0]]))
+    # more than 64 rows: the LDS-resident engine (csrc/plp_lds.hip); beyond what 160 KB of LDS hold: ValueError
+    r = pa.lpsolve_batch(np.array([[1.0, 1.0]]), np.tile(np.array([[-1.0, 0], [0, -1.0], [1.0, 1.0]]), (30, 1))[None],
+                         np.tile(np.array([1.0, 1.0, 5.0]), 30)[None])
+    assert r["status"][0] == 0 and np.array_equal(r["x"][0], [-1.0, -1.0])
     with pytest.raises(ValueError):
-        pa.lpsolve_batch(np.zeros((1, 2)), np.zeros((1, 65, 2)), np.zeros((1, 65)))
+        pa.lpsolve_batch(np.zeros((1, 2)), np.zeros((1, 6000, 2)), np.zeros((1, 6000)))
 
 
 # ------------------------------------------------------------------------------ bounding box
