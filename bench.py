@@ -201,6 +201,9 @@ def main():
                     "launch; with N > 1 the exchange is ordered against them at group boundaries).  Default 1: one "
                     "launch at a time, the regime roofline.kernel_ms and the rocprofv3 per-kernel durations describe; "
                     "`--pipelined` reports the two-stream throughput beside it")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): every GPU reduces its "
+                    "own 100k-polytope batches; strong: ONE 100k-polytope batch per step is partitioned across the GPUs "
+                    "(contiguous shards, north_star) and reassembled on every rank by the all-gather")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
@@ -236,7 +239,18 @@ def main():
     # NB distinct batches, all resident in HBM before the timed region; step k reduces batch k mod NB.  6 x 52.4 MB
     # is more than the 256 MiB Infinity Cache, so a step never finds its input cached from the previous pass.
     NB = max(1, args.batches)
-    host_batches = [random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=rank) for i in range(NB)]
+    strong = args.scaling == "strong"
+    B_LOCAL = B_PER_GPU
+    if strong:  # every rank regenerates the same global batch (counter-based RNG) and keeps its contiguous shard
+        from polytope_amd.dist import shard_bounds
+        if B_PER_GPU % world:
+            raise SystemExit("--scaling strong: %d polytopes do not split evenly over %d ranks" % (B_PER_GPU, world))
+        lo, hi = shard_bounds(B_PER_GPU, rank, world)
+        B_LOCAL = hi - lo
+        host_batches = [tuple(v[lo:hi].copy() for v in random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=0))
+                        for i in range(NB)]
+    else:
+        host_batches = [random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=rank) for i in range(NB)]
     dev_batches = [(torch.as_tensor(A_).to(dev), torch.as_tensor(b_).to(dev)) for A_, b_ in host_batches]
     A, b = host_batches[0]
 
@@ -245,8 +259,8 @@ def main():
     # larger collectives -- G x 2.4 MB per rank), on RCCL's stream while the next group of batches is computed in
     # the other buffer.  Every batch's results are on every rank before the timed region ends (flush below).
     G = max(1, args.gather_every)
-    nb = 24 * B_PER_GPU
-    ex = GroupedExchange(torch, dist, B_PER_GPU, DIM, G, dev) if multi else None
+    nb = 24 * B_LOCAL
+    ex = GroupedExchange(torch, dist, B_LOCAL, DIM, G, dev) if multi else None
 
     # --streams S > 1: the steps are issued round-robin on S HIP streams, i.e. S independent batches are in flight.
     # 100 000 polytopes are 6 250 wavefronts for 4 096 resident slots, so the last round of a launch runs half
@@ -346,7 +360,7 @@ def main():
     nlp_total = lps_timed / args.steps
 
     if rank == 0:
-        alg_bytes = B_PER_GPU * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
+        alg_bytes = B_LOCAL * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
         # passes (scripts/gpu_check.sh), whose summary is committed by scripts/summarize_profiles.py
@@ -369,14 +383,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1]); %d distinct "
                                    "batches resident in HBM, one per step in rotation (%.0f MB > 256 MiB Infinity Cache)"
                                    % (B_PER_GPU, DIM, M_ROWS, NB, NB * B_PER_GPU * 8 * M_ROWS * (DIM + 1) / 1e6),
-                       "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_PER_GPU, "streams": args.streams,
+                       "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_LOCAL, "streams": args.streams,
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

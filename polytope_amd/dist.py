@@ -190,6 +190,13 @@ class GroupedExchange:
         lo = rank * self.G * self.nb + s * self.nb
         return self.bufs[0][0].split(gathered.view(-1)[lo:lo + self.nb])[0]
 
+    def global_views(self, gathered, s):
+        """Strong scaling (ONE batch partitioned into equal contiguous shards, rank r holding shard r): the results
+        of the whole batch of slot s, reassembled in batch order from a gathered group -- dict(keep, r, flags, nlp)."""
+        world = gathered.numel() // (self.G * self.nb)
+        parts = [self.slot_views(gathered, r, s) for r in range(world)]
+        return {k: self.torch.cat([p[k] for p in parts]) for k in parts[0]}
+
 
 def reduce_batch_sharded(A, b, m=None, abs_tol=1e-7, reduce_fn=None, device=None):
     """Every rank holds (or can regenerate) the full batch A[B,m,d], b[B,m]; each rank reduces

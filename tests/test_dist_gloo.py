@@ -251,3 +251,65 @@ def test_sharded_adjacency_and_quickhull(world):
     for rank, adj, Ah, bh, Vh in outs:
         assert np.array_equal(adj.astype(bool), touching)
         assert np.array_equal(Ah, A1) and np.array_equal(bh, b1) and np.array_equal(Vh, V1)
+
+
+def _worker_strong(rank, world, port, q):
+    """bench.py --scaling strong: ONE batch per step, partitioned into equal contiguous shards; every rank reduces its
+    shard straight into its slot of the exchange buffer and the coalesced all-gather reassembles the batch."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from polytope_amd import dist as pdist
+    from polytope_amd.synth import random_hpolytopes
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, G, steps = 12 * world, 2, 5
+    lo, hi = pdist.shard_bounds(B, rank, world)
+    ex = pdist.GroupedExchange(torch, dist, hi - lo, 2, G, None)
+    groups = []
+    for k in range(steps):
+        A, b = random_hpolytopes(B, 10, 2, seed=100 + k)   # the same global batch on every rank (Philox)
+        v = ex.slot().views
+        for t, p in enumerate(range(lo, hi)):
+            o = O.reduce(A[p], b[p])
+            v["keep"][t] = int(np.uint64(o["mask"]).astype(np.int64))
+            v["flags"][t], v["nlp"][t], v["r"][t] = o["flags"], o["nlp"], o["r"]
+        out = ex.commit()
+        if out is not None:
+            groups.append(out.clone())
+    groups += [g.clone() for g in ex.drain()]
+    res = []
+    for k in range(steps):
+        gv = ex.global_views(groups[k // G], k % G)
+        res.append((gv["keep"].numpy().copy(), gv["flags"].numpy().copy(), gv["nlp"].numpy().copy(), gv["r"].numpy().copy()))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strong_scaling_exchange(world):
+    import torch.multiprocessing as mp
+    from polytope_amd.synth import random_hpolytopes
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B = 12 * world
+    for k in range(5):
+        A, b = random_hpolytopes(B, 10, 2, seed=100 + k)
+        want = [O.reduce(A[p], b[p]) for p in range(B)]
+        for rank, res in outs:   # every rank ends up with the whole batch of every step, in batch order
+            keep, flags, nlp, r = res[k]
+            assert [int(x) for x in keep.astype(np.uint64)] == [w["mask"] for w in want], (k, rank)
+            assert list(flags) == [w["flags"] for w in want] and list(nlp) == [w["nlp"] for w in want]
+            assert np.array_equal(r, np.array([w["r"] for w in want]))

@@ -769,3 +769,36 @@ def test_assign_full_config(pa, oracle):
                 continue
             assert fac[am[f]] == f and dist[am[f]] == best[f] == mx[f]
             assert am[f] == np.nonzero((fac == f) & (dist == best[f]))[0][0]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_force_dist_rccl_path(pa, scaling):
+    """bench.py's N > 1 code path (process group on RCCL, exchange buffers, coalesced overlapped all-gather) driven
+    at world size 1 with --force-dist, in both scaling modes: the line must carry the contract's fields and the
+    LP count of the unsharded run."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "9", "--warmup", "2", "--no-cpu-baseline",
+           "--no-end-to-end", "--force-dist", "--scaling", scaling, "--batches", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == scaling and line["n_gpus"] == 1 and line["steps"] == 9 and line["unit"] == "LP/s"
+    assert line["value"] > 1e9 and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # LP count per step: the mean over the two batches in the rotation 0,1,0,1,... of 9 steps
+    from polytope_amd.synth import random_hpolytopes
+    import torch
+    n = []
+    for i in range(2):
+        A, b = random_hpolytopes(100000, 16, 3, seed=i, stream=0)
+        n.append(int(pa.reduce_batch(torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda())["nlp"].sum().item()))
+    assert abs(line["config"]["lps_per_step"] - (5 * n[0] + 4 * n[1]) / 9) < 1e-6
