@@ -219,6 +219,29 @@ int plp_adjacent_pairs_range_dev(plp_ctx *ctx, void *stream, int n, int m_max, i
                                  const double *b, const int32_t *m, double abs_tol, int64_t pair_lo,
                                  int64_t pair_hi, uint8_t *out);
 
+/*
+ * The search of region_diff: poly minus the union of N cells (polytope/polytope.py:2201-2281), run by the library.
+ * The caller has done the reference's preparation (:2144-2199): cells sorted by the Chebyshev radius of their stack
+ * with poly, mi[j] >= 1 new constraints per cell, and the table  A[m + 2M][d], b[m + 2M]  (M = sum mi) = poly's m rows,
+ * the cells' new rows in that order, and the negations of those M rows -- each row already scaled to unit length as
+ * Polytope.__init__ does (:130-138), because every LP of the search is the Chebyshev ball (:1283-1288) of
+ * Polytope(A[rows], b[rows]) for some row list.  The table is uploaded once; the library walks the reference's search
+ * (same visiting order, same tests "R > abs_tol", including its index arithmetic on INDICES / counter) and solves the
+ * LPs in batches that are described by row-index lists only and gathered on the device; each batch holds what the
+ * search needs now plus what it will need next if the current node is not empty (its scan and the first child of
+ * every cell), so there is one launch and one synchronisation per visited node instead of one per LP.
+ * Result: the pieces in the reference's order, as row lists: kind[k] = 0 -> Polytope(A[rows], b[rows]) as is (:2229),
+ * 1 -> reduce() of it (:2276).  PLP_EINVAL with "row index out of range" where the reference raises IndexError.
+ */
+typedef struct plp_rdiff_result plp_rdiff_result;
+int plp_region_diff_search(plp_ctx *ctx, int d, int m, int N, const int32_t *mi, const double *A, const double *b,
+                           double abs_tol, plp_rdiff_result **out);
+int plp_rdiff_result_sizes(const plp_rdiff_result *r, int64_t *n_leaves, int64_t *n_rows, int64_t *n_lps,
+                           int64_t *n_batches);
+/* kind[n_leaves], off[n_leaves + 1], rows[n_rows]: piece k holds rows[off[k] .. off[k+1]) */
+int plp_rdiff_result_copy(const plp_rdiff_result *r, int32_t *kind, int32_t *off, int32_t *rows);
+int plp_rdiff_result_free(plp_rdiff_result *r);
+
 /* cross-lane primitive self-test (group size 8/16/32/64); host out_d[128], out_u[128] */
 int plp_selftest(plp_ctx *ctx, int group_size, double *out_d, uint32_t *out_u);
 

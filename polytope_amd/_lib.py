@@ -56,6 +56,10 @@ SIGNATURES = {
                                            C.c_int64, _vp]),
     "plp_adjacent_pairs_range_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double,
                                                C.c_int64, C.c_int64, _vp]),
+    "plp_region_diff_search": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.POINTER(_vp)]),
+    "plp_rdiff_result_sizes": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "plp_rdiff_result_copy": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "plp_rdiff_result_free": (C.c_int, [_vp]),
     "plp_selftest": (C.c_int, [_vp, C.c_int, _vp, _vp]),
 }
 

@@ -449,3 +449,34 @@ def selftest(group_size):
     ou = np.empty(128, np.uint32)
     _lib.check(lib.plp_selftest(_lib.context().handle, int(group_size), _ptr(od), _ptr(ou)), "plp_selftest")
     return od, ou
+
+
+def region_diff_search(A, b, m, mi, abs_tol=1e-7):
+    """The search of region_diff (polytope.py:2201-2281) run by the library on the table A[m + 2M, d], b[m + 2M]
+    (poly's m rows, the cells' new rows, their negations; rows already unit length) with mi[j] new rows per cell.
+
+    -> (pieces, stats): pieces = list of (kind, rows) in the reference's order, kind 0 = Polytope(A[rows], b[rows]) as
+    is, 1 = reduce() of it; stats = dict(lps, batches).  One launch + one synchronisation per visited node; the LPs
+    are gathered on the device from the resident table by row index (include/plp.h: plp_region_diff_search)."""
+    lib = _lib.load()
+    A = _np(A)
+    b = _np(b).ravel()
+    mi = _np(mi, np.int32).ravel()
+    nrows, d = A.shape
+    if nrows != m + 2 * int(mi.sum()) or b.size != nrows:
+        raise ValueError("region_diff_search: table must have m + 2 * sum(mi) rows")
+    _finite_or_raise("region_diff_search", A, b)
+    h = C.c_void_p()
+    _lib.check(lib.plp_region_diff_search(_lib.context().handle, d, int(m), int(mi.size), _ptr(mi), _ptr(A), _ptr(b),
+                                          float(abs_tol), C.byref(h)), "plp_region_diff_search")
+    try:
+        nl, nr, nlp, nb = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.plp_rdiff_result_sizes(h, C.byref(nl), C.byref(nr), C.byref(nlp), C.byref(nb)), "plp_rdiff_result_sizes")
+        kind = np.empty(max(nl.value, 1), np.int32)
+        off = np.empty(nl.value + 1, np.int32)
+        rows = np.empty(max(nr.value, 1), np.int32)
+        _lib.check(lib.plp_rdiff_result_copy(h, _ptr(kind), _ptr(off), _ptr(rows)), "plp_rdiff_result_copy")
+    finally:
+        lib.plp_rdiff_result_free(h)
+    pieces = [(int(kind[k]), rows[off[k]:off[k + 1]].copy()) for k in range(nl.value)]
+    return pieces, dict(lps=int(nlp.value), batches=int(nb.value))

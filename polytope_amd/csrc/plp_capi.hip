@@ -3,9 +3,15 @@
 // context, call the *_dev entry point on the context's stream and synchronise.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <algorithm>
 #include <initializer_list>
+#include <string>
+#include <unordered_map>
+#include <vector>
 
 #include "../../include/plp.h"
 #include "plp_kernels.hpp"
@@ -36,6 +42,13 @@ struct plp_ctx {
     char* arena;
     size_t arena_bytes;
     char* pin;  // pinned host mirror of the first SMALL_XFER bytes of the arena (small calls: one copy each way)
+    // region_diff search (kept across calls: a pinned allocation costs more than a small search)
+    char* rd_pin = nullptr;      // host-mapped block [index block | radii | sequence word]
+    char* rd_pin_dev = nullptr;
+    double* rd_out = nullptr;    // radii of a batch (device)
+    double* rd_tab = nullptr;    // the constraint table A | b (device)
+    size_t rd_tab_bytes = 0;
+    unsigned long long rd_seq = 0;
 };
 
 namespace {
@@ -195,6 +208,9 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->rd_pin) (void)hipHostFree(ctx->rd_pin);
+    if (ctx->rd_out) (void)hipFree(ctx->rd_out);
+    if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PLP_OK;
@@ -822,6 +838,489 @@ int plp_selftest(plp_ctx* ctx, int group_size, double* out_d, uint32_t* out_u) {
     HIP_TRY(hipMemcpyAsync(out_d, dd, 128 * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out_u, du, 128 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLP_OK;
+}
+
+// ------------------------------------------------------------------------------- region_diff search
+}  // extern "C"
+
+struct plp_rdiff_result {
+    std::vector<int32_t> kind;   // per leaf: 0 = piece as is (ref :2229), 1 = piece to be reduce()d (ref :2276)
+    std::vector<int32_t> off;    // leaf k holds rows[off[k] .. off[k+1])
+    std::vector<int32_t> rows;
+    long long n_lps = 0, n_batches = 0, n_requests = 0;
+};
+
+namespace {
+
+// 128-bit order-dependent hash of a row list, extendable by a suffix (lists are "current rows + a few more")
+struct Key {
+    uint64_t a, b;
+    bool operator==(const Key& o) const { return a == o.a && b == o.b; }
+};
+inline Key key_push(Key k, int32_t r) {
+    k.a = (k.a ^ (uint64_t)(uint32_t)(r + 1)) * 0x9E3779B97F4A7C15ull;
+    k.a ^= k.a >> 29;
+    k.b = (k.b + (uint64_t)(uint32_t)(r + 1)) * 0xC2B2AE3D27D4EB4Full;
+    k.b ^= k.b >> 31;
+    return k;
+}
+inline Key key_of_list(const int32_t* r, size_t n) {
+    Key k{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+    for (size_t i = 0; i < n; ++i) k = key_push(k, r[i]);
+    return k;
+}
+
+// open-addressing table Key -> radius; grows by rehashing, clear() touches only the occupied slots
+struct RadiusTable {
+    std::vector<Key> keys;
+    std::vector<double> vals;
+    std::vector<unsigned char> used;
+    std::vector<uint32_t> slots;   // occupied positions, in insertion order
+    size_t count = 0, mask = 0;
+    void reset(size_t cap_pow2) {
+        keys.assign(cap_pow2, Key{0, 0});
+        vals.assign(cap_pow2, 0.0);
+        used.assign(cap_pow2, 0);
+        slots.clear();
+        count = 0;
+        mask = cap_pow2 - 1;
+    }
+    void clear() {
+        for (uint32_t i : slots) used[i] = 0;
+        slots.clear();
+        count = 0;
+    }
+    const double* find(const Key& k) const {
+        for (size_t i = (size_t)k.a & mask;; i = (i + 1) & mask) {
+            if (!used[i]) return nullptr;
+            if (keys[i] == k) return &vals[i];
+        }
+    }
+    void put(const Key& k, double v) {
+        if ((count + 1) * 2 > mask) grow();
+        for (size_t i = (size_t)k.a & mask;; i = (i + 1) & mask) {
+            if (!used[i]) { used[i] = 1; keys[i] = k; vals[i] = v; ++count; slots.push_back((uint32_t)i); return; }
+            if (keys[i] == k) { vals[i] = v; return; }
+        }
+    }
+    void grow() {
+        std::vector<Key> ok;
+        std::vector<double> ov;
+        ok.reserve(count);
+        ov.reserve(count);
+        for (uint32_t i : slots) { ok.push_back(keys[i]); ov.push_back(vals[i]); }
+        reset((mask + 1) * 2);
+        for (size_t t = 0; t < ok.size(); ++t) put(ok[t], ov[t]);
+    }
+};
+
+// The Chebyshev radii the search asks for, keyed by the row list, filled by batches of LPs that are solved on the
+// device straight from the resident table (plp_rdiff.hip).  A miss triggers ONE batch holding the missing list
+// plus whatever the search will need next if the current node is not empty (speculation), so the search pays one
+// launch + one synchronisation per visited node instead of one per LP (the reference) or per scan.
+struct RadiusOracle {
+    plp_ctx* ctx;
+    int d;
+    long long nrows;
+    double *dA = nullptr, *dB = nullptr, *dOut = nullptr;
+    char* pin = nullptr;          // host-mapped block: [index block | radii | sequence word]
+    char* pin_dev = nullptr;      // the same block as the device sees it
+    volatile unsigned long long* flag = nullptr;
+    unsigned long long seq = 0;
+    size_t cap_lp = 0, cap_rows = 0;
+    RadiusTable memo, pending;    // pending: key -> position in the batch being assembled
+    std::vector<int32_t> prow, poff;
+    std::vector<Key> pkey;
+    long long n_lps = 0, n_batches = 0;
+    double t_launch = 0.0, t_wait = 0.0;  // seconds spent enqueueing / waiting for the device (PLP_RDIFF_STATS=1 prints them)
+
+    int init(plp_ctx* c, int d_, long long nrows_, const double* A, const double* b) {
+        ctx = c; d = d_; nrows = nrows_;
+        cap_lp = 1 << 15;
+        cap_rows = (size_t)cap_lp * 64;
+        memo.reset(1 << 14);
+        pending.reset(1 << 12);
+        poff.assign(1, 0);
+        const size_t blk = (2 * cap_lp + 1 + cap_rows) * 4;
+        if (!ctx->rd_pin) {
+            // host-mapped, coherent: the kernels read the index block and publish the radii through it (no copies, no
+            // stream synchronisation per batch: the host spins on a sequence word the last kernel of the batch raises)
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->rd_pin), blk + cap_lp * 8 + 64,
+                                  hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->rd_pin_dev), ctx->rd_pin, 0));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->rd_out), cap_lp * 8));
+            *reinterpret_cast<volatile unsigned long long*>(ctx->rd_pin + blk + cap_lp * 8) = 0ull;
+            ctx->rd_seq = 0;
+        }
+        const size_t need = (size_t)nrows * (d + 1) * 8 + 64;
+        if (need > ctx->rd_tab_bytes) {
+            if (ctx->rd_tab) HIP_TRY(hipFree(ctx->rd_tab));
+            ctx->rd_tab = nullptr;
+            ctx->rd_tab_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->rd_tab), need + need / 2));
+            ctx->rd_tab_bytes = need + need / 2;
+        }
+        pin = ctx->rd_pin;
+        pin_dev = ctx->rd_pin_dev;
+        dOut = ctx->rd_out;
+        dA = ctx->rd_tab;
+        dB = ctx->rd_tab + (size_t)nrows * d;
+        flag = reinterpret_cast<volatile unsigned long long*>(pin + blk + cap_lp * 8);
+        seq = ctx->rd_seq;
+        HIP_TRY(hipMemcpyAsync(dA, A, (size_t)nrows * d * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dB, b, (size_t)nrows * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return PLP_OK;
+    }
+    void release() {
+        if (ctx) { (void)hipStreamSynchronize(ctx->stream); ctx->rd_seq = seq; }
+    }
+    // queue the list base[0..nb) + suf[0..ns) (key given) for the next batch unless known or queued already
+    void want(const Key& k, const int32_t* base, size_t nb, const int32_t* suf, size_t ns) {
+        if (memo.find(k) || pending.find(k)) return;
+        if (pkey.size() >= (1u << 16)) return;  // bound on one batch (speculation only: the lists the search needs come first)
+        pending.put(k, (double)pkey.size());
+        pkey.push_back(k);
+        prow.insert(prow.end(), base, base + nb);
+        prow.insert(prow.end(), suf, suf + ns);
+        poff.push_back((int32_t)prow.size());
+    }
+    // solve everything queued; results go to the memo
+    int flush() {
+        const size_t total = pkey.size();
+        size_t done = 0;
+        while (done < total) {
+            size_t n = 0, nr = 0;
+            while (done + n < total && n < cap_lp && nr + (size_t)(poff[done + n + 1] - poff[done + n]) <= cap_rows) {
+                nr += (size_t)(poff[done + n + 1] - poff[done + n]);
+                ++n;
+            }
+            if (n == 0) return fail(PLP_EUNSUPPORTED, "region_diff: a row list of %d rows exceeds the staging buffer", poff[done + 1] - poff[done]);
+            // one contiguous block per batch: [off (n + 1) | sel (n) | rows (nr)] -> ONE copy across PCIe
+            int32_t* off = reinterpret_cast<int32_t*>(pin);
+            int32_t* sel = off + n + 1;
+            int32_t* rows = sel + n;
+            const int32_t base0 = poff[done];
+            memcpy(rows, prow.data() + base0, nr * 4);
+            int cnt[4] = {0, 0, 0, 0};
+            int max_len = 0;
+            for (size_t k = 0; k <= n; ++k) off[k] = poff[done + k] - base0;
+            auto cls_of = [&](int len) { return (d > 8 || len > 64) ? 3 : (len > 32 ? 2 : (len > 16 ? 1 : 0)); };
+            for (size_t k = 0; k < n; ++k) {
+                const int len = off[k + 1] - off[k];
+                max_len = len > max_len ? len : max_len;
+                cnt[cls_of(len)]++;
+            }
+            size_t start[4], fill[4];
+            start[0] = 0;
+            for (int c = 1; c < 4; ++c) start[c] = start[c - 1] + cnt[c - 1];
+            for (int c = 0; c < 4; ++c) fill[c] = start[c];
+            for (size_t k = 0; k < n; ++k) sel[fill[cls_of(off[k + 1] - off[k])]++] = (int32_t)k;
+            hipStream_t st = ctx->stream;
+            const auto tp0 = std::chrono::steady_clock::now();
+            const int32_t* d_off = reinterpret_cast<const int32_t*>(pin_dev);
+            const int32_t* d_sel = d_off + n + 1;
+            const int32_t* d_rows = d_sel + n;
+            if ((cnt[0] | cnt[1] | cnt[2]) &&
+                plp::launch_cheby_gather_r(d, cnt[0], cnt[1], cnt[2], d_off, d_rows, d_sel, dA, dB, dOut, st))
+                return fail(PLP_EUNSUPPORTED, "region_diff: gather kernel does not apply (d=%d)", d);
+            if (cnt[3] && plp::launch_cheby_gather_lds(d, max_len, cnt[3], d_off, d_rows, d_sel + start[3], dA, dB, dOut, st))
+                return fail(PLP_EUNSUPPORTED, "region_diff: a stack of %d rows does not fit the LDS engine", max_len);
+            double* out = reinterpret_cast<double*>(pin + (2 * cap_lp + 1 + cap_rows) * 4);
+            double* out_dev = reinterpret_cast<double*>(pin_dev + (2 * cap_lp + 1 + cap_rows) * 4);
+            ++seq;
+            plp::launch_rdiff_publish((long long)n, dOut, out_dev,
+                                      reinterpret_cast<unsigned long long*>(pin_dev + (2 * cap_lp + 1 + cap_rows) * 4 + cap_lp * 8),
+                                      seq, st);
+            int rc = check_launch("cheby_gather");
+            if (rc) return rc;
+            const auto tp1 = std::chrono::steady_clock::now();
+            // spin on the sequence word (bounded: fall back to a stream synchronisation, which also reports errors)
+            {
+                unsigned long long spins = 0;
+                while (__atomic_load_n(const_cast<const unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+                    if (++spins > 400000000ull) { HIP_TRY(hipStreamSynchronize(st)); break; }
+                }
+                if (__atomic_load_n(const_cast<const unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (*flag != seq) return fail(PLP_EHIP, "region_diff: batch %llu did not complete", seq);
+                }
+            }
+            const auto tp2 = std::chrono::steady_clock::now();
+            t_launch += std::chrono::duration<double>(tp1 - tp0).count();
+            t_wait += std::chrono::duration<double>(tp2 - tp1).count();
+            if (memo.count + n > (1u << 20)) memo.clear();  // radii are consumed soon after they are computed
+            for (size_t k = 0; k < n; ++k) memo.put(pkey[done + k], out[k]);
+            n_lps += (long long)n;
+            n_batches += 1;
+            done += n;
+        }
+        pkey.clear();
+        prow.clear();
+        poff.assign(1, 0);
+        pending.clear();
+        return PLP_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi, const double* A, const double* b,
+                           double abs_tol, plp_rdiff_result** out) {
+    if (!ctx || !mi || !A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    if (d < 1 || d > plp::MAX_D || m < 0 || N < 1) return fail(PLP_EINVAL, "bad sizes d=%d m=%d N=%d", d, m, N);
+    *out = nullptr;
+    long long M = 0;
+    std::vector<long long> beg(N);
+    for (int j = 0; j < N; ++j) {
+        if (mi[j] < 1) return fail(PLP_EINVAL, "mi[%d] = %d (a cell without a new constraint covers the polytope)", j, mi[j]);
+        beg[j] = m + M;
+        M += mi[j];
+    }
+    const long long nrows = m + 2 * M;
+    HIP_TRY(hipSetDevice(ctx->device));
+    RadiusOracle R;
+    int rc = R.init(ctx, d, nrows, A, b);
+    if (rc) { R.release(); return rc; }
+    plp_rdiff_result* res = new plp_rdiff_result();
+    res->off.push_back(0);
+    // Python's negative indexing of counter / mi / beg_mi (level == -1 reads the LAST cell, ref :2231) and of the
+    // table rows (an index that went below zero after "- M" wraps to the end of A, ref :2233)
+    auto at = [&](long long level) { return (int)(level < 0 ? level + N : level); };
+    std::vector<int> counter(N, 0);
+    std::vector<long long> idx(m);       // the reference's INDICES (may hold wrapped / out-of-range values)
+    for (int i = 0; i < m; ++i) idx[i] = i;
+    long long level = 0;
+    std::vector<int32_t> cur, suf;        // cur = idx resolved to table rows
+    bool cur_ok = true;
+    auto resolve = [&]() {
+        cur.resize(idx.size());
+        cur_ok = true;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            long long r = idx[k] < 0 ? idx[k] + nrows : idx[k];
+            if (r < 0 || r >= nrows) { cur_ok = false; r = 0; }
+            cur[k] = (int32_t)r;
+        }
+    };
+    auto emit = [&](int kind) {
+        res->kind.push_back(kind);
+        res->rows.insert(res->rows.end(), cur.begin(), cur.end());
+        res->off.push_back((int32_t)res->rows.size());
+    };
+    // open cells (counter != 0) in ascending order and the sum of the counters, kept incrementally
+    std::vector<int> open_cells;
+    long long sumc = 0;
+    auto set_counter = [&](int L, int v) {
+        const int old = counter[L];
+        sumc += v - old;
+        counter[L] = v;
+        if (old == 0 && v != 0) open_cells.insert(std::lower_bound(open_cells.begin(), open_cells.end(), L), L);
+        else if (old != 0 && v == 0) open_cells.erase(std::lower_bound(open_cells.begin(), open_cells.end(), L));
+    };
+    auto sum_counter = [&]() { return sumc; };
+    // ---- what earlier scans already decided.  A cell whose stack with the rows of an ANCESTOR node had radius
+    // <= abs_tol / 2 cannot reach abs_tol with more rows added (the set only shrinks; LP values are exact to ~1e-12),
+    // so its LP is not issued again below that node: it counts as "no hit", which is what the reference would find.
+    // A frame = the rows a scan was made with + the cells that stayed alive; it is used only while the current rows
+    // contain all of its rows (checked, because the reference's INDICES arithmetic does not always nest).
+    struct Frame { std::vector<int32_t> rows; std::vector<int> alive; };
+    std::vector<Frame> frames;
+    std::vector<int> mult(nrows, 0);
+    std::vector<int> all_cells(N);
+    for (int j = 0; j < N; ++j) all_cells[j] = j;
+    auto alive_now = [&]() -> const std::vector<int>& {  // needs `cur` resolved
+        for (int32_t r : cur) mult[r]++;
+        while (!frames.empty()) {
+            bool sub = true;
+            for (int32_t r : frames.back().rows) if (!mult[r]) { sub = false; break; }
+            if (sub) break;
+            frames.pop_back();
+        }
+        for (int32_t r : cur) mult[r]--;
+        return frames.empty() ? all_cells : frames.back().alive;
+    };
+    // queue, for every alive cell j >= from: the stack of the current rows with ALL its new rows (the scan, ref
+    // :2212-2224) and with its first new row negated (the node the search enters when j is the first hit)
+    std::vector<int32_t> child;
+    auto queue_scan1 = [&](const std::vector<int>& alive, long long from, const Key& kbase, const std::vector<int32_t>& base) {
+        for (int j : alive) {
+            if (j < from) continue;
+            suf.resize(mi[j]);
+            Key k = kbase;
+            for (int t = 0; t < mi[j]; ++t) { suf[t] = (int32_t)(beg[j] + t); k = key_push(k, suf[t]); }
+            R.want(k, base.data(), base.size(), suf.data(), suf.size());
+            const int32_t neg = (int32_t)(beg[j] + M);
+            R.want(key_push(kbase, neg), base.data(), base.size(), &neg, 1);
+        }
+    };
+    // ... and the same one level further down for the cell the scan will most likely stop at (the first one still
+    // alive): when that guess is right the search descends two levels on one batch
+    auto queue_scan = [&](const std::vector<int>& alive, long long from, const Key& kbase) {
+        queue_scan1(alive, from, kbase, cur);
+        for (int j : alive) {
+            if (j < from) continue;
+            if (j < N - 1) {
+                child = cur;
+                child.push_back((int32_t)(beg[j] + M));
+                queue_scan1(alive, (long long)j + 1, key_push(kbase, (int32_t)(beg[j] + M)), child);
+            }
+            break;
+        }
+    };
+    rc = PLP_OK;
+    bool bad_index = false;
+    while (level != -1 && rc == PLP_OK) {
+        if (counter[at(level)] == 0) {
+            // ---- scan: first cell j >= level whose stack with the current rows is full-dimensional
+            resolve();
+            if (!cur_ok) { bad_index = true; break; }
+            const Key kbase = key_of_list(cur.data(), cur.size());
+            const std::vector<int>& alive = alive_now();
+            for (int attempt = 0; attempt < 3; ++attempt) {  // (a full memo is emptied by flush(): ask again then)
+                bool miss = false;
+                for (int j : alive) {
+                    if (j < level) continue;
+                    Key k = kbase;
+                    for (int t = 0; t < mi[j]; ++t) k = key_push(k, (int32_t)(beg[j] + t));
+                    if (!R.memo.find(k)) { miss = true; break; }
+                }
+                if (!miss) break;
+                queue_scan(alive, level, kbase);
+                rc = R.flush();
+                if (rc) break;
+            }
+            if (rc) break;
+            double Rl = 0.0;  // the reference's R after the loop: the radius of the LAST cell looked at
+            Frame fr;
+            fr.rows = cur;
+            long long hit = -1;
+            for (int j : alive) {
+                if (j < level) continue;
+                Key k = kbase;
+                for (int t = 0; t < mi[j]; ++t) k = key_push(k, (int32_t)(beg[j] + t));
+                const double Rj = *R.memo.find(k);
+                if (Rj > 0.5 * abs_tol) fr.alive.push_back(j);
+                if (hit < 0) {
+                    res->n_requests++;
+                    if (Rj > abs_tol) { hit = j; Rl = Rj; }
+                    else if (j == N - 1) Rl = Rj;
+                }
+            }
+            frames.push_back(std::move(fr));
+            if (hit >= 0) {
+                level = hit;
+                set_counter((int)level, 1);
+                idx.push_back(beg[level] + M);
+            }
+            if (Rl < abs_tol) {  // nothing left to subtract: the current rows are a piece (ref :2226-2245)
+                level = level - 1;
+                emit(0);
+                const int nz = (int)open_cells.size();
+                bool returned = false;
+                for (int t = 0; t < nz; ++t) {
+                    const int L = at(level);
+                    if (counter[L] <= mi[L]) {
+                        idx.back() -= M;
+                        idx.push_back(beg[L] + counter[L] + M);
+                        break;
+                    }
+                    set_counter(L, 0);
+                    const long long keep_n = m + sum_counter();
+                    if ((long long)idx.size() > keep_n) idx.resize(keep_n < 0 ? 0 : keep_n);
+                    if (level == -1) { returned = true; break; }
+                }
+                if (returned) break;
+            }
+        } else {
+            // ---- next sibling of the deepest open cell, closing exhausted cells on the way (ref :2246-2271)
+            bool returned = false;
+            while (!open_cells.empty()) {   // deepest open cell first (the reference walks nzcount backwards)
+                level = open_cells.back();
+                set_counter((int)level, counter[level] + 1);
+                if (counter[level] <= mi[level]) {
+                    idx.back() -= M;
+                    idx.push_back(beg[level] + counter[level] + M - 1);
+                    break;
+                }
+                set_counter((int)level, 0);
+                const long long keep_n = m + sum_counter();
+                if ((long long)idx.size() > keep_n) idx.resize(keep_n < 0 ? 0 : keep_n);
+                level = level - 1;
+                if (level == -1) { returned = true; break; }
+            }
+            if (returned) break;
+        }
+        // ---- the node itself
+        resolve();
+        if (!cur_ok) { bad_index = true; break; }
+        const Key knode = key_of_list(cur.data(), cur.size());
+        if (!R.memo.find(knode)) {
+            R.want(knode, cur.data(), cur.size(), nullptr, 0);
+            const int L = at(level);
+            const int c = counter[L];
+            // the siblings that follow when this node is empty, with the rows the search will form for them
+            if (c >= 1 && !idx.empty()) {
+                std::vector<int32_t> sib(cur.begin(), cur.end() - 1);
+                long long flipped = idx.back() - M;
+                flipped = flipped < 0 ? flipped + nrows : flipped;
+                bool ok = flipped >= 0 && flipped < nrows;
+                if (ok) sib.push_back((int32_t)flipped);
+                for (int t = c + 1; ok && t <= mi[L]; ++t) {
+                    // rows beg+c .. beg+t-2 kept, row beg+t-1 negated
+                    if (t > c + 1) sib.push_back((int32_t)(beg[L] + t - 2));
+                    const long long neg = beg[L] + t - 1 + M;
+                    if (neg >= nrows) break;
+                    const int32_t n32 = (int32_t)neg;
+                    Key k = key_push(key_of_list(sib.data(), sib.size()), n32);
+                    R.want(k, sib.data(), sib.size(), &n32, 1);
+                }
+            }
+            // what it needs next when it is NOT empty: its scan and the first child of every cell still alive
+            if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode);
+            rc = R.flush();
+            if (rc) break;
+        }
+        const double rcv = *R.memo.find(knode);
+        res->n_requests++;
+        if (rcv > abs_tol) {
+            if (level == N - 1) emit(1);
+            else level = level + 1;
+        }
+    }
+    res->n_lps = R.n_lps;
+    res->n_batches = R.n_batches;
+    if (getenv("PLP_RDIFF_STATS"))
+        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches, %lld requests, launch %.1f ms, device wait %.1f ms\n",
+                R.n_lps, R.n_batches, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3);
+    R.release();
+    if (rc == PLP_OK && bad_index) rc = fail(PLP_EINVAL, "region_diff: row index out of range (the reference raises IndexError here)");
+    if (rc) { delete res; return rc; }
+    *out = res;
+    return PLP_OK;
+}
+
+int plp_rdiff_result_sizes(const plp_rdiff_result* r, int64_t* n_leaves, int64_t* n_rows, int64_t* n_lps, int64_t* n_batches) {
+    if (!r) return fail(PLP_EINVAL, "NULL result");
+    if (n_leaves) *n_leaves = (int64_t)r->kind.size();
+    if (n_rows) *n_rows = (int64_t)r->rows.size();
+    if (n_lps) *n_lps = r->n_lps;
+    if (n_batches) *n_batches = r->n_batches;
+    return PLP_OK;
+}
+
+int plp_rdiff_result_copy(const plp_rdiff_result* r, int32_t* kind, int32_t* off, int32_t* rows) {
+    if (!r || !kind || !off || !rows) return fail(PLP_EINVAL, "NULL pointer");
+    if (!r->kind.empty()) memcpy(kind, r->kind.data(), r->kind.size() * 4);
+    memcpy(off, r->off.data(), r->off.size() * 4);
+    if (!r->rows.empty()) memcpy(rows, r->rows.data(), r->rows.size() * 4);
+    return PLP_OK;
+}
+
+int plp_rdiff_result_free(plp_rdiff_result* r) {
+    delete r;
     return PLP_OK;
 }
 

@@ -27,6 +27,15 @@ int launch_cheby_lds(long long B, int m_max, int d, const double* A, const doubl
                      double* xc, int* status, hipStream_t st);
 size_t lds_lp_bytes(int m_max, int nc);  // 0: does not fit
 
+// Chebyshev LPs on row subsets rows[off[p] .. off[p+1]) of one resident table (region_diff's search): LPs sel[0..nlp)
+// of the batch; out[p] = radius as cheby_ball reads it (0 unless optimal with r >= 0).  plp_rdiff.hip / plp_lds.hip
+int launch_cheby_gather_r(int d, long long n0, long long n1, long long n2, const int* off, const int* rows, const int* sel,
+                          const double* A, const double* b, double* out, hipStream_t st);
+void launch_rdiff_publish(long long n, const double* src, double* host_out, unsigned long long* host_flag,
+                          unsigned long long seq, hipStream_t st);
+int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, const int* rows, const int* sel,
+                            const double* A, const double* b, double* out, hipStream_t st);
+
 // generic LPs, four rows per lane, origin-feasible ones only (n <= 8, plp_cheby_r.hip): the others get
 // status ST_RETRY for the general kernel; returns 1 when it does not apply
 int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,

@@ -448,6 +448,65 @@ __global__ __launch_bounds__(64) void cheby_lds_kernel(long long B, int m_max, i
     }
 }
 
+// Chebyshev LPs on row subsets of one resident table (region_diff's search, see plp_rdiff.hip): index lists of any
+// length that fits LDS.  out[p] = x[-1] if optimal with r >= 0, else 0 (cheby_ball's reading, polytope.py:1289-1297).
+__global__ __launch_bounds__(64) void cheby_gather_lds_kernel(long long nlp, int m_cap, int d, const int* __restrict__ off,
+                                                              const int* __restrict__ rows, const int* __restrict__ sel,
+                                                              const double* __restrict__ A, const double* __restrict__ b,
+                                                              double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int nc = d + 1;
+    const int ld = nc | 1;
+    for (long long q = blockIdx.x; q < nlp; q += gridDim.x) {
+        const int p = sel[q];
+        const int o = off[p];
+        const int m = off[p + 1] - o;
+        const LdsDict D = lds_carve(smem_raw, m_cap, ld);
+        __syncthreads();
+        LdsState S;
+        S.m = m; S.n = nc; S.nc = nc;
+        S.cfree = (1u << nc) - 1u;
+        S.dead = 0u; S.ndeg = 0; S.iters = 0; S.maxit = 50 * (m + nc) + 100;
+        S.mode = M_INIT; S.status = -1; S.init_col = d; S.mode_after_init = M_P2;
+        S.negz = 0.0; S.negz2 = 0.0; S.carry = false;
+        bool finite = true, inf0 = false;
+        for (int i = lane; i < m; i += 64) {
+            const long long src = rows[o + i];
+            const double* Ar = A + src * d;
+            double* Ti = D.T + (size_t)i * ld;
+            double nrm2 = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double v = Ar[k];
+                Ti[k] = v;
+                nrm2 = nrm2 + v * v;
+                finite = finite & isfinite(v);
+            }
+            const double bi = b[src];
+            finite = finite & isfinite(bi);
+            const double nrm = sqrt(nrm2);
+            const bool zero = !(nrm > 0.0);
+            Ti[d] = zero ? 0.0 : nrm;
+            D.beta[i] = zero ? 0.0 : bi;
+            D.qk[i] = bi / nrm;
+            D.rowvar[i] = nc + i;
+            D.rowfl[i] = zero ? 0 : 2;
+            inf0 = inf0 | (zero & (bi < -TOL_FEAS));
+        }
+        if (lane < nc) {
+            D.cost[lane] = lane == d ? -1.0 : 0.0;
+            D.cost2[lane] = 0.0;
+            D.cv[lane] = (lane + 1) << 1;
+        }
+        if (__ballot(!finite) != 0) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (__ballot(inf0) != 0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+        __syncthreads();
+        while (S.mode != M_DONE) lds_step(S, D, lane);
+        const double rr = lds_x_of(D, m, d, lane);
+        if (lane == 0) out[p] = ((S.status == ST_OPT) & (rr >= 0.0)) ? rr : 0.0;
+    }
+}
+
 // LDS bytes one LP of (m_max, columns nc) needs; 0 when it does not fit a workgroup (160 KB per CU on gfx950)
 size_t lds_lp_bytes(int m_max, int nc) {
     const int ld = nc | 1;
@@ -488,6 +547,22 @@ int launch_cheby_lds(long long B, int m_max, int d, const double* A, const doubl
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(cheby_lds_kernel, dim3(lds_grid(B, smem)), dim3(64), smem, st, B, m_max, d, A, b, mrows, r, xc,
                        status);
+    return 0;
+}
+
+int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, const int* rows, const int* sel,
+                            const double* A, const double* b, double* out, hipStream_t st) {
+    if (d < 1 || d > MAX_D || nlp < 1) return nlp < 1 ? 0 : 2;
+    const size_t smem = lds_lp_bytes(m_cap < 1 ? 1 : m_cap, d + 1);
+    if (!smem) return 2;
+    static size_t attr = 0;
+    if (smem > 48 * 1024 && smem > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cheby_gather_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = smem;
+    }
+    hipLaunchKernelGGL(cheby_gather_lds_kernel, dim3(lds_grid(nlp, smem)), dim3(64), smem, st, nlp, m_cap, d, off, rows, sel,
+                       A, b, out);
     return 0;
 }
 

@@ -36,6 +36,7 @@ ABS_TOL = 1e-7
 
 _RF_EMPTY, _RF_EARLY, _RF_MINREP, _RF_LPFAIL = 1, 2, 4, 8
 _MAX_ROWS, _MAX_DIM = 64, 16
+_RDIFF_NATIVE = True   # region_diff's search in the library (False: the host loop over batched calls, for A/B runs)
 
 
 def _use_hip():
@@ -1046,16 +1047,16 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
     base = np.hstack([poly.A, poly.b[:, None]])
     _cheby_fill([cells[order[ii]] for ii in range(N) if cells[order[ii]].fulldim is None])
     mi = np.zeros(N, dtype=int)
-    for ii in range(N):
-        cell = cells[order[ii]]
-        if not is_fulldim(cell):
-            continue
-        for j in range(cell.A.shape[0]):
-            row = np.hstack([cell.A[j, :], cell.b[j]])
-            if np.all(np.sum(np.abs(base - row), axis=1) >= abs_tol):  # constraint not already in poly
-                mi[ii] += 1
-                A = np.vstack([A, cell.A[j, :]])
-                B = np.hstack([B, cell.b[j]])
+    # constraints of the cells that are not already rows of poly (ref :2166-2183), all cells at once
+    picked = [cells[order[ii]] for ii in range(N)]
+    full = np.array([bool(is_fulldim(c)) for c in picked])
+    if full.any():
+        rows_all = np.vstack([np.hstack([c.A, c.b[:, None]]) for c, f in zip(picked, full) if f])
+        owner = np.concatenate([np.full(c.A.shape[0], ii) for ii, (c, f) in enumerate(zip(picked, full)) if f])
+        new = np.all(np.sum(np.abs(rows_all[:, None, :] - base[None, :, :]), axis=2) >= abs_tol, axis=1)
+        mi = np.bincount(owner[new], minlength=N).astype(int)
+        A = np.vstack([A, rows_all[new, :-1]])
+        B = np.hstack([B, rows_all[new, -1]])
     if np.any(mi == 0):
         return Polytope()  # some cell covers the polytope
     M = int(np.sum(mi))
@@ -1080,6 +1081,27 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
         from .batch import cheby_ball_batch
         scale = 1 / norms
         An, Bn = A * scale[:, None], B * scale
+    if packed and abs_tol > 0 and not save and _RDIFF_NATIVE:
+        # The search itself runs in the library (csrc/plp_capi.hip: plp_region_diff_search): the reference's
+        # visiting order and tests, LPs gathered on the device from the resident table by row index, one launch and
+        # one synchronisation per visited node.  What comes back are the pieces as row lists, in order.
+        from .batch import region_diff_search
+        try:
+            leaves, _stats = region_diff_search(An, Bn, m, mi, abs_tol)
+        except ValueError as e:
+            if "out of range" in str(e):
+                raise IndexError("index out of bounds in region_diff (the reference's INDICES arithmetic, ref :2233)")
+            raise
+        todo = [poly_of(list(rows)) for kind, rows in leaves if kind == 1]   # leaves the reference reduces (:2276)
+        done = [None] * len(todo)
+        small = [k for k, p in enumerate(todo) if p.A.size > 0 and _fits(p.A.shape[0], p.A.shape[1])]
+        if small:   # one fused reduce launch for all of them
+            for k, q in zip(small, _reduce_many([todo[k] for k in small], ABS_TOL)):
+                done[k] = q
+        red = iter([q if q is not None else reduce(p) for p, q in zip(todo, done)])
+        for kind, rows in leaves:
+            res = union(res, next(red) if kind == 1 else poly_of(list(rows)), False)
+        return res
 
     def radii_rows(row_lists):
         """Chebyshev radius (0 when the ball LP fails) of the polytope of each row list, one batch."""
