@@ -36,6 +36,10 @@ void launch_rdiff_publish(long long n, const double* src, double* host_out, unsi
 int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, const int* rows, const int* sel,
                             const double* A, const double* b, double* out, hipStream_t st);
 
+// one LP per wavefront, one row per lane, wave-uniform pivot column (plp_wide.hip): the engine for d >= 9
+int launch_cheby_w(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                   double* xc, int* status, hipStream_t st);
+
 // generic LPs, four rows per lane, origin-feasible ones only (n <= 8, plp_cheby_r.hip): the others get
 // status ST_RETRY for the general kernel; returns 1 when it does not apply
 int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,

@@ -14,6 +14,13 @@
 
 namespace plp {
 
+#ifndef PLP_WIDE_MIN_D
+#define PLP_WIDE_MIN_D 9    // Chebyshev batches with d >= this and more than PLP_WIDE_MIN_M rows: one LP per wavefront
+#endif
+#ifndef PLP_WIDE_MIN_M
+#define PLP_WIDE_MIN_M 32
+#endif
+
 template <int N>
 __global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int gs,
                                                    const double* __restrict__ c,
@@ -241,6 +248,11 @@ int launch_cheby(long long B, int m_max, int d, const double* A, const double* b
     if (m_max > MAX_M || (lds && lds[0] == '1')) return launch_cheby_lds(B, m_max, d, A, b, mrows, r, xc, status, st);
     const int gs = group_size_for(m_max);
     if (gs < 0 || d < 1 || d > MAX_D) return 2;
+    // large shapes: one LP per wavefront with a wave-uniform pivot column (plp_wide.hip); PLP_CHEBY_WIDE=0 keeps the
+    // lane-group kernels, PLP_CHEBY_WIDE=1 sends every shape it supports (d >= 5) there: A/B, tests
+    const char* wide = getenv("PLP_CHEBY_WIDE");
+    const bool wide_on = wide ? wide[0] == '1' : (d >= PLP_WIDE_MIN_D && m_max > PLP_WIDE_MIN_M);
+    if (wide_on && !(wide && wide[0] == '0') && launch_cheby_w(B, m_max, d, A, b, mrows, r, xc, status, st) == 0) return 0;
     // d <= 8: four rows per lane (PLP_CHEBY_1ROW=1 keeps the one-row-per-lane kernel: A/B, tests)
     const char* one = getenv("PLP_CHEBY_1ROW");
     if (!(one && one[0] == '1') && launch_cheby_r(B, m_max, d, A, b, mrows, r, xc, status, st) == 0) return 0;

@@ -1,0 +1,349 @@
+// plp_wide.hip -- one LP per WAVEFRONT, one dictionary row per lane, for the large shapes (d = 9..16, m <= 64).
+//
+//   cheby_w_kernel<D> : Chebyshev-ball LPs (form F1, polytope/polytope.py:1283-1288) of a batch of polytopes
+//
+// The lane-group engines (plp_simplex.hpp, plp_simplex_r.hpp) let several LPs share a wavefront, so the entering
+// column differs from lane to lane and every access T[e] is a chain of selects over the columns: at 17 columns that
+// chain (and its twin for the column fix-up) is most of the ~500 VALU instructions a (64,17) pivot costs there.  Here a
+// wavefront owns ONE LP: the entering column e and the pivot row r are wave-uniform (SGPRs), so
+//   * T[e] is one indexed register move (the row is a register vector), not 17 selects;
+//   * the reduced costs live ONCE, in LDS, lane j looking after column j: pricing is one load, one compare and a
+//     DPP wave reduction instead of a 17-step scan of replicated values, and the cost row's update is one FMA;
+//   * the pivot row is scaled in place by its own lane (exec = that lane), stored to LDS, and read back by all lanes
+//     as broadcast ds_reads -- no ds_bpermute pairs, no VALU slots spent on moving it;
+//   * the ratio test's exact f64 minimum is a DPP reduction over the 64 lanes (row_bcast15/31 for the upper levels).
+// About 110 VALU instructions per pivot.  Pivot rules as everywhere (oracle/plp_oracle.c restates them): free
+// variables enter in either direction and never leave, Dantzig pricing (largest |c_j|, lowest column on ties), ratio
+// test ties to the lowest row, Bland's rule after BLAND_AFTER consecutive degenerate pivots, forced first pivot
+// "r enters, row argmin b_i/||a_i|| leaves" for F1.
+#include <stdlib.h>
+
+#include "plp_kernels.hpp"
+#include "plp_wave.hpp"
+
+namespace plp {
+
+namespace {
+
+#define PLP_DPP_BCAST15 0x142
+#define PLP_DPP_BCAST31 0x143
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_d_rm(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double min_raw(double a, double b) {  // one v_min_f64 (fmin() canonicalises its operands first)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_raw2(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// wave-wide max / min of a double; the result is returned wave-uniform (read from lane 63)
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = max_raw2(v, dpp_d<PLP_DPP_XOR1>(v));
+    v = max_raw2(v, dpp_d<PLP_DPP_XOR2>(v));
+    v = max_raw2(v, dpp_d<PLP_DPP_HMIRROR>(v));
+    v = max_raw2(v, dpp_d<PLP_DPP_MIRROR>(v));
+    v = max_raw2(v, dpp_d_rm<PLP_DPP_BCAST15, 0xA>(v));
+    v = max_raw2(v, dpp_d_rm<PLP_DPP_BCAST31, 0xC>(v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = min_raw(v, dpp_d<PLP_DPP_XOR1>(v));
+    v = min_raw(v, dpp_d<PLP_DPP_XOR2>(v));
+    v = min_raw(v, dpp_d<PLP_DPP_HMIRROR>(v));
+    v = min_raw(v, dpp_d<PLP_DPP_MIRROR>(v));
+    v = min_raw(v, dpp_d_rm<PLP_DPP_BCAST15, 0xA>(v));
+    v = min_raw(v, dpp_d_rm<PLP_DPP_BCAST31, 0xC>(v));
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR1, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR2, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_HMIRROR, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_MIRROR, 0xF, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_BCAST15, 0xA, 0xF, false); v = t < v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_BCAST31, 0xC, 0xF, false); v = t < v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double uniform_lane(double v, int lane) {  // value of `lane` (wave-uniform index)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// wave-wide min / max of a u32 with the DPP operand folded into the VALU op (one instruction per level; hipcc does
+// not fold v_mov_dpp into the consumer by itself); result wave-uniform (lane 63 holds it after the row_bcast levels)
+#define PLP_W_DPP(OP, v, CTRL, RM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:" RM " bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
+    PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1]", "0xf");
+    PLP_W_DPP("v_min_u32_dpp", v, "row_half_mirror", "0xf");
+    PLP_W_DPP("v_min_u32_dpp", v, "row_mirror", "0xf");
+    PLP_W_DPP("v_min_u32_dpp", v, "row_bcast:15", "0xa");
+    PLP_W_DPP("v_min_u32_dpp", v, "row_bcast:31", "0xc");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    PLP_W_DPP("v_max_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
+    PLP_W_DPP("v_max_u32_dpp", v, "quad_perm:[2,3,0,1]", "0xf");
+    PLP_W_DPP("v_max_u32_dpp", v, "row_half_mirror", "0xf");
+    PLP_W_DPP("v_max_u32_dpp", v, "row_mirror", "0xf");
+    PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:15", "0xa");
+    PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:31", "0xc");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double rcpn(double a) {
+    const double x0 = __builtin_amdgcn_rcp(a);
+    const double x1 = fma(x0, fma(-a, x0, 1.0), x0);
+    return fma(x1, fma(-a, x1, 1.0), x1);
+}
+
+// The row of a lane: NC <= 17 doubles held as a 16-wide register vector (+ one scalar for the 17th column), so that
+// T[e] for a wave-uniform e is ONE indexed register move (s_set_gpr_idx / v_movrel: the compiler lowers a dynamic
+// element access with a uniform index that way) instead of a select chain or a branch tree.
+typedef double v16d __attribute__((ext_vector_type(16)));
+// (plain local variables, not a struct: the struct form was kept in scratch memory by the compiler)
+#define ROW_GET(j) ((j) < 16 ? Tv[(j) & 15] : T16)
+#define ROW_SET(j, val) do { if ((j) < 16) Tv[(j) & 15] = (val); else T16 = (val); } while (0)
+template <int NC>
+__device__ __forceinline__ double row_at(const v16d& Tv, const double& T16, int e) {  // wave-uniform e
+    if constexpr (NC <= 16) return Tv[e & 15];
+    else return e < 16 ? Tv[e & 15] : T16;
+}
+template <int NC>
+__device__ __forceinline__ void row_put(v16d& Tv, double& T16, int e, double val) {   // wave-uniform e
+    if constexpr (NC <= 16) {
+        Tv[e & 15] = val;
+    } else {  // (written as two selects on single elements: a branch here is if-converted into a select of the whole vector)
+        const double old = Tv[e & 15];
+        Tv[e & 15] = e < 16 ? val : old;
+        T16 = e < 16 ? T16 : val;
+    }
+}
+
+// Per-wavefront LDS: reduced costs, the scaled pivot row, the nonbasic variable of every column
+template <int NC>
+struct WideShared {
+    double cost[NC + 1];
+    double rho[NC + 1];   // rho[NC] = scaled right-hand side of the pivot row
+    int cv[NC + 1];       // (id + 1) << 1 | negated
+};
+
+// Solve from a dictionary whose rows sit in T/beta (one per lane).  `forced`: first pivot = column NC-1 enters, the
+// leaving row is the active one with the smallest signed ratio q0 (F1).  Returns the status; the optimal dictionary
+// stays in T/beta/rowvar/rowneg.
+template <int NC>
+__device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, double& T16, double& beta, int& rowvar,
+                                        int& rowneg, bool& rowact, WideShared<NC>& sh, const int nfree, bool forced,
+                                        const double q0, int& iters_out) {
+    unsigned cfree = nfree >= 32 ? 0xffffffffu : ((1u << nfree) - 1u);
+    int ndeg = 0, iters = 0;
+    const int maxit = 50 * (m + nfree) + 100;
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    int status = -1;
+    for (;;) {
+        const bool bland = ndeg >= BLAND_AFTER;
+        int e;
+        double ce;       // reduced cost of the entering column as stored
+        bool flip = false;
+        if (forced) {
+            e = NC - 1;
+            ce = sh.cost[NC - 1];
+        } else {
+            // ---- pricing: lane j looks after column j
+            const double c = lane < NC ? sh.cost[lane] : 0.0;
+            const bool elig = (lane < NC) & (fabs(c) > TOL_D) & ((((cfree >> (lane & 31)) & 1u) != 0u) | (c < 0.0));
+            const uint64_t eb = __ballot(elig);
+            if (eb == 0) { status = ST_OPT; break; }
+            if (iters >= maxit) { status = ST_ITER; break; }
+            if (!bland) {  // largest |c|: its bit pattern orders like an unsigned integer
+                const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
+                const unsigned mh = wave_max_u32(kh);
+                const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
+                const unsigned ml = wave_max_u32(kl);
+                e = __ffsll((long long)__ballot(elig & (kh == mh) & (kl == ml))) - 1;
+            } else {  // Bland: lowest variable id among the eligible columns
+                const int id = elig ? sh.cv[lane] : 0x7fffffff;
+                const int idmin = wave_min_i32(id);
+                e = __ffsll((long long)__ballot(elig & (id == idmin))) - 1;
+            }
+            e = __builtin_amdgcn_readfirstlane(e);
+            ce = uniform_lane(c, e);
+            flip = ce > 0.0;  // free variable entering downwards: x := -x
+        }
+        // ---- ratio test
+        double a = row_at<NC>(Tv, T16, e);
+        a = flip ? -a : a;
+        const double pinv = rcpn(a);
+        bool erow;
+        double q;
+        if (forced) { erow = rowact; q = q0; }
+        else { erow = rowact & (a > TOL_PIV); q = (beta > 0.0 ? beta : 0.0) * pinv; }
+        q = erow ? q : pinf;
+        // exact f64 minimum on the order-preserving u64 key (hi dword, then lo dword among the hi-minima)
+        const int qh = __double2hiint(q), ql = __double2loint(q);
+        const int sm = qh >> 31;
+        const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
+        const unsigned kl = (unsigned)(ql ^ sm);
+        const unsigned mh = wave_min_u32(kh);
+        const unsigned ml = wave_min_u32((kh == mh) ? kl : 0xffffffffu);
+        if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; break; }
+        const bool tie = erow & (kh == mh) & (kl == ml);
+        const int mhs = (int)(mh ^ 0x80000000u);   // (the minimum is >= 0 in a normal pivot; the forced one ignores ndeg)
+        const double qmin = __hiloint2double(mhs >= 0 ? mhs : (int)~mh, mhs >= 0 ? (int)ml : (int)~ml);
+        int r;
+        if (bland & !forced) {  // lowest basic-variable id among the ties
+            const int id = tie ? rowvar + 1 : 0x7fffffff;
+            const int idmin = wave_min_i32(id);
+            r = __ffsll((long long)__ballot(tie & (id == idmin))) - 1;
+        } else {
+            r = __ffsll((long long)__ballot(tie)) - 1;  // lowest row among ties
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (!forced) ndeg = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
+        // ---- the pivot row scales itself in place and goes to LDS
+        const double p = uniform_lane(pinv, r);
+        const int vin = sh.cv[e];
+        const bool efree = (cfree >> e) & 1u;
+        const bool is_r = lane == r;
+        if (is_r) {   // (LDS stores and scalars only inside the branch: the row vector itself is updated branch-free below)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) sh.rho[j] = ROW_GET(j) * pinv;
+            sh.rho[NC] = beta * pinv;
+            sh.cv[e] = ((rowvar + 1) << 1) | rowneg;
+            rowvar = (vin >> 1) - 1;
+            rowneg = (vin & 1) ^ (flip ? 1 : 0);
+            rowact = !efree;  // a free variable never leaves again
+        }
+        __syncthreads();
+        {
+            // row r: T * (1/a_r)  (f = 0);  every other row: T - a_i * rho  (scale 1)
+            const double f = is_r ? 0.0 : a;
+            const double sc = is_r ? pinv : 1.0;
+            const double rb = sh.rho[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j) * sc));
+            row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
+            beta = fma(-f, rb, beta * sc);
+        }
+        // ---- reduced costs (lane j = column j); the entering column is sign-normalised first
+        if (lane < NC) {
+            const double fc = flip ? -ce : ce;
+            const double cj = sh.cost[lane];
+            sh.cost[lane] = (lane == e) ? -(fc * p) : fma(-fc, sh.rho[lane], cj);
+        }
+        cfree &= ~(1u << e);
+        iters += 1;
+        if (forced) {
+            if (rowact & (beta < 0.0)) beta = 0.0;  // rounding of the forced pivot
+            forced = false;
+        }
+        __syncthreads();
+    }
+    iters_out = iters;
+    return status;
+}
+
+}  // namespace
+
+template <int D>
+__global__ __launch_bounds__(64) void cheby_w_kernel(long long B, int m_max, const double* __restrict__ A,
+                                                     const double* __restrict__ b, const int* __restrict__ mrows,
+                                                     double* __restrict__ r_out, double* __restrict__ xc,
+                                                     int* __restrict__ status) {
+    constexpr int NC = D + 1;
+    __shared__ WideShared<NC> sh;
+    const int lane = threadIdx.x;
+    const long long p = blockIdx.x;
+    if (p >= B) return;
+    const int m = mrows ? mrows[p] : m_max;
+    const bool has = lane < m;
+    v16d Tv = (v16d)(0.0);
+    double T16 = 0.0;
+    double nrm2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = has ? A[(p * m_max + lane) * D + k] : 0.0;
+        ROW_SET(k, v);
+        nrm2 = nrm2 + v * v;
+        finite = finite & isfinite(v);
+    }
+    const double bi = has ? b[p * m_max + lane] : 0.0;
+    finite = finite & isfinite(bi);
+    const double nrm = sqrt(nrm2);
+    const bool zero = !(nrm > 0.0);
+    bool rowact = has & !zero;
+    ROW_SET(D, rowact ? nrm : 0.0);
+    double beta = rowact ? bi : 0.0;
+    int rowvar = NC + lane, rowneg = 0;
+    if (lane <= NC) {
+        sh.cost[lane] = lane == D ? -1.0 : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+    const bool bad = (__ballot(!finite) != 0) | (m > 64);
+    __syncthreads();
+    int st, iters = 0;
+    if (bad) st = ST_NUM;
+    else if (infeasible0) st = ST_INFEAS;
+    else st = wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double mine = rowneg ? -beta : beta;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const uint64_t ob = __ballot(rowvar == j);
+        const double v = ob ? uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+        const double xj = (st == ST_OPT) ? v : qnan;
+        if (lane == 0) {
+            if (j < D) xc[p * D + j] = xj; else r_out[p] = xj;
+        }
+    }
+    if (lane == 0) status[p] = st;
+}
+
+template <int D>
+static int launch_cheby_w_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
+                            double* xc, int* status, hipStream_t st) {
+    if (B > 2147483647ll) return 2;
+    hipLaunchKernelGGL((cheby_w_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows, r, xc,
+                       status);
+    return 0;
+}
+
+// one LP per wavefront (m_max <= 64); returns 1 when it does not apply
+int launch_cheby_w(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                   double* xc, int* status, hipStream_t st) {
+    if (m_max < 1 || m_max > 64) return 1;
+    switch (d) {
+        case 5: return launch_cheby_w_d<5>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 6: return launch_cheby_w_d<6>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 7: return launch_cheby_w_d<7>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 8: return launch_cheby_w_d<8>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 9: return launch_cheby_w_d<9>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 10: return launch_cheby_w_d<10>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 11: return launch_cheby_w_d<11>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 12: return launch_cheby_w_d<12>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 13: return launch_cheby_w_d<13>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 14: return launch_cheby_w_d<14>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 15: return launch_cheby_w_d<15>(B, m_max, A, b, mrows, r, xc, status, st);
+        case 16: return launch_cheby_w_d<16>(B, m_max, A, b, mrows, r, xc, status, st);
+        default: return 1;
+    }
+}
+
+}  // namespace plp

@@ -843,3 +843,49 @@ def test_region_diff_library_search_equals_host_loop(pa):
     finally:
         pcm._RDIFF_NATIVE = True
         solvers.default_solver = old
+
+
+def test_wide_engine_one_lp_per_wavefront(pa, oracle, monkeypatch):
+    """csrc/plp_wide.hip (one LP per wavefront, wave-uniform pivot column, reduced costs in LDS) serves Chebyshev
+    batches with d >= 9 and more than 32 rows; PLP_CHEBY_WIDE=1 sends every shape with d >= 5 to it.  Against the
+    lane-group kernels (same pivot rules: statuses equal, radii to 1e-12) and the oracle, on random, ragged, unbounded,
+    empty, zero-row and degenerate (duplicated cube faces) inputs."""
+    rng = np.random.default_rng(164)
+    for (B, m, d) in [(300, 64, 16), (200, 64, 12), (200, 40, 9), (200, 64, 7), (200, 20, 5), (64, 1, 6), (100, 17, 16)]:
+        A = rng.standard_normal((B, m, d))
+        A /= np.linalg.norm(A, axis=2, keepdims=True)
+        b = 1.0 + rng.random((B, m))
+        if m >= 2 * d:
+            A[::2, :2 * d] = np.vstack([np.eye(d), -np.eye(d)])[None]      # bounded ones
+            b[::2, :2 * d] = 3.0
+        b[3::10] -= 2.5                                                      # empty (r < 0)
+        A[4::10, m // 2:] = 0.0                                              # zero rows (b > 0: vacuous)
+        if m >= 4 * d:                                                       # duplicated cube faces: degenerate vertices
+            I = np.vstack([np.eye(d), -np.eye(d), np.eye(d), -np.eye(d)])
+            A[5::10, :4 * d] = I[None]
+            b[5::10, :4 * d] = np.r_[np.ones(d), np.zeros(d), np.ones(d), np.zeros(d)]
+        ms = rng.integers(max(1, m - 5), m + 1, B).astype(np.int32)
+        monkeypatch.setenv("PLP_CHEBY_WIDE", "0")
+        ref = pa.cheby_ball_batch(A, b, m=ms)
+        monkeypatch.setenv("PLP_CHEBY_WIDE", "1")
+        got = pa.cheby_ball_batch(A, b, m=ms)
+        monkeypatch.delenv("PLP_CHEBY_WIDE")
+        assert np.array_equal(got["status"], ref["status"]), (m, d)
+        ok = got["status"] == 0
+        assert np.allclose(got["r"][ok], ref["r"][ok], rtol=0, atol=1e-12), (m, d)
+        assert {0, 3} >= set(np.unique(got["status"])) or m < d + 1
+        for k in range(0, B, 3):
+            so, ro, _ = oracle.cheby(A[k, :ms[k]], b[k, :ms[k]])
+            assert got["status"][k] == so, (m, d, k, got["status"][k], so)
+            if so == 0:
+                assert abs(got["r"][k] - ro) <= TOL * max(1.0, abs(ro)), (m, d, k)
+                nrm = np.linalg.norm(A[k, :ms[k]], axis=1)
+                assert np.max(A[k, :ms[k]] @ got["xc"][k] + nrm * got["r"][k] - b[k, :ms[k]]) <= 1e-8
+    # the default dispatch takes it for the large shapes
+    A = rng.standard_normal((50, 64, 16))
+    A /= np.linalg.norm(A, axis=2, keepdims=True)
+    b = 1.0 + rng.random((50, 64))
+    dflt = pa.cheby_ball_batch(A, b)
+    monkeypatch.setenv("PLP_CHEBY_WIDE", "1")
+    forced = pa.cheby_ball_batch(A, b)
+    assert np.array_equal(dflt["r"], forced["r"], equal_nan=True) and np.array_equal(dflt["status"], forced["status"])
