@@ -49,6 +49,11 @@ struct plp_ctx {
     double* rd_tab = nullptr;    // the constraint table A | b (device)
     size_t rd_tab_bytes = 0;
     unsigned long long rd_seq = 0;
+    // containment on the matrix cores: packed operand tiles (plp_contains_mfma.hip)
+    void* mf_buf = nullptr;
+    size_t mf_bytes = 0;
+    hipStream_t mf_stream = nullptr;
+    bool mf_used = false;
 };
 
 namespace {
@@ -211,6 +216,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_pin) (void)hipHostFree(ctx->rd_pin);
     if (ctx->rd_out) (void)hipFree(ctx->rd_out);
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
+    if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PLP_OK;
@@ -411,7 +417,22 @@ int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const 
     if (!X || !out || ((!A || !b) && P > 0 && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
-    if (plp::launch_contains(P, m_max, d, A, b, m, N, X, abs_tol, mode, out, st))
+    // operand tiles for the matrix-core path: a grow-only buffer of the context, handed from stream to stream in order
+    void* scratch = nullptr;
+    if (P > 0 && m_max > 0) {
+        const size_t need = plp::contains_mfma_scratch_bytes(P, m_max, d);
+        if (need > ctx->mf_bytes) {
+            if (ctx->mf_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->mf_buf); }
+            ctx->mf_buf = nullptr;
+            ctx->mf_bytes = 0;
+            if (hipMalloc(&ctx->mf_buf, need + need / 4) == hipSuccess) ctx->mf_bytes = need + need / 4;
+            else (void)hipGetLastError();
+        } else if (ctx->mf_used && ctx->mf_stream != st) {
+            (void)hipStreamSynchronize(ctx->mf_stream);  // the previous user of the buffer ran on another stream
+        }
+        if (ctx->mf_buf) { scratch = ctx->mf_buf; ctx->mf_stream = st; ctx->mf_used = true; }
+    }
+    if (plp::launch_contains(P, m_max, d, A, b, m, N, X, abs_tol, mode, out, scratch, st))
         return fail(PLP_EUNSUPPORTED, "contains kernel: unsupported size");
     return check_launch("contains_kernel");
 }

@@ -13,6 +13,8 @@
 // assign: one lane owns one point ([N][d] rows as in quickhull); facets are staged in LDS;
 // per-facet furthest point by LDS u64 max -> global u64 max, then an arg-min-index pass so
 // that the FIRST maximum wins as in Facet.get_furthest.
+#include <stdlib.h>
+
 #include "plp_kernels.hpp"
 
 namespace plp {
@@ -109,9 +111,18 @@ static void launch_contains_d(int P, int m_max, const double* A, const double* b
 #define PLP_CASE_C(K) case K: launch_contains_d<K>(P, m_max, A, b, mrows, N, X, abs_tol, mode, out, st); break;
 
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
-                    const double* X, double abs_tol, int mode, unsigned char* out, hipStream_t st) {
+                    const double* X, double abs_tol, int mode, unsigned char* out, void* scratch, hipStream_t st) {
     if (d < 1 || d > MAX_D || m_max < 0 || P < 0 || N < 0) return 2;
     if (N == 0) return 0;
+    // PLP_CONTAINS_MFMA=1: dot products by v_mfma_f64_16x16x4_f64 (plp_contains_mfma.hip), verdicts bit-identical.
+    // Off by default: measured on MI355X the f64 matrix pipe peaks where the vector FMA pipe does (75.6 vs 58 TFLOP/s in
+    // scripts/microbench/mfma_f64_rate.hip, 78.6 nominal for both) and the contraction must pad k = d + 1 to a multiple
+    // of 4 (C3: 7 -> 8), so the matrix form of C3 cannot finish before 34 ms while this kernel needs 39 ms; the first
+    // matrix-core version takes 78 ms (one accumulator, operand loads not double-buffered).
+    const char* mf = getenv("PLP_CONTAINS_MFMA");
+    if (scratch && mf && mf[0] == '1' &&
+        launch_contains_mfma(P, m_max, d, A, b, mrows, N, X, abs_tol, mode, out, scratch, st) == 0)
+        return 0;
     switch (d) {
         PLP_CASE_C(1) PLP_CASE_C(2) PLP_CASE_C(3) PLP_CASE_C(4) PLP_CASE_C(5) PLP_CASE_C(6)
         PLP_CASE_C(7) PLP_CASE_C(8) PLP_CASE_C(9) PLP_CASE_C(10) PLP_CASE_C(11) PLP_CASE_C(12)
