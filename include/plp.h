@@ -220,6 +220,25 @@ int plp_adjacent_pairs_range_dev(plp_ctx *ctx, void *stream, int n, int m_max, i
                                  int64_t pair_hi, uint8_t *out);
 
 /*
+ * Quickhull's main loop (polytope/quickhull.py:224-345) as native host code over a plp_hull session: facet graph,
+ * visibility search, horizon, new facets and their links on the host, every pass over the points one plp_hull_reassign.
+ * X0[N][d]: the points translated so that the start simplex' centroid is the origin (:188-192); simplex[d + 1]: the
+ * indices of the start simplex (chosen by the caller, who owns the random number stream, :165-185).
+ * lapack_dgesv: optional pointer to LAPACK's dgesv (Fortran calling convention) for the facet hyperplanes (:66-85);
+ * with the one numpy.linalg.solve runs, the rows come out bit-identical to the reference's; NULL = built-in LU.
+ * Result: the hull's facets in the reference's order: normals[n][d] (unit, outward), offsets[n] (translated
+ * coordinates: n.x = offset), verts[n][d] point indices.  PLP_EINVAL + plp_quickhull_last_error() for a singular
+ * hyperplane system / degenerate neighbouring facets (where the reference raises).
+ */
+typedef struct plp_qh_result plp_qh_result;
+int plp_quickhull_run(plp_ctx *ctx, int64_t N, int d, const double *X0, const int64_t *simplex, double abs_tol,
+                      void *lapack_dgesv, plp_qh_result **out);
+int plp_qh_result_sizes(const plp_qh_result *r, int64_t *n_facets, int64_t *iterations, int64_t *facets_made);
+int plp_qh_result_copy(const plp_qh_result *r, double *normals, double *offsets, int64_t *verts);
+int plp_qh_result_free(plp_qh_result *r);
+const char *plp_quickhull_last_error(void);
+
+/*
  * The search of region_diff: poly minus the union of N cells (polytope/polytope.py:2201-2281), run by the library.
  * The caller has done the reference's preparation (:2144-2199): cells sorted by the Chebyshev radius of their stack
  * with poly, mi[j] >= 1 new constraints per cell, and the table  A[m + 2M][d], b[m + 2M]  (M = sum mi) = poly's m rows,

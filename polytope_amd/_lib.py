@@ -60,6 +60,11 @@ SIGNATURES = {
     "plp_rdiff_result_sizes": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "plp_rdiff_result_copy": (C.c_int, [_vp, _vp, _vp, _vp]),
     "plp_rdiff_result_free": (C.c_int, [_vp]),
+    "plp_quickhull_run": (C.c_int, [_vp, C.c_int64, C.c_int, _vp, _vp, C.c_double, _vp, C.POINTER(_vp)]),
+    "plp_qh_result_sizes": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "plp_qh_result_copy": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "plp_qh_result_free": (C.c_int, [_vp]),
+    "plp_quickhull_last_error": (C.c_char_p, []),
     "plp_selftest": (C.c_int, [_vp, C.c_int, _vp, _vp]),
 }
 

@@ -480,3 +480,57 @@ def region_diff_search(A, b, m, mi, abs_tol=1e-7):
         lib.plp_rdiff_result_free(h)
     pieces = [(int(kind[k]), rows[off[k]:off[k + 1]].copy()) for k in range(nl.value)]
     return pieces, dict(lps=int(nlp.value), batches=int(nb.value))
+
+
+_DGESV = None
+
+
+def _lapack_dgesv_pointer():
+    """Address of the dgesv numpy.linalg.solve's results agree with bit for bit (scipy's LAPACK; checked in the
+    tests), or None when scipy is not importable -- the library then uses its own LU."""
+    global _DGESV
+    if _DGESV is None:
+        try:
+            from scipy.linalg import cython_lapack
+            cap = cython_lapack.__pyx_capi__["dgesv"]
+            C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+            C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+            C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+            C.pythonapi.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+            _DGESV = C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap)) or 0
+        except Exception:
+            _DGESV = 0
+    return _DGESV or None
+
+
+def quickhull_run(X0, simplex, abs_tol=1e-7):
+    """Quickhull's main loop in the library (include/plp.h: plp_quickhull_run): X0[N, d] translated points, simplex =
+    indices of the start simplex -> (normals[n, d], offsets[n], verts int64[n, d], stats) of the hull's facets in the
+    reference's order."""
+    lib = _lib.load()
+    X0 = _np(X0)
+    N, d = X0.shape
+    simplex = np.ascontiguousarray(simplex, dtype=np.int64).ravel()
+    if simplex.size != d + 1:
+        raise ValueError("quickhull_run: the start simplex has d + 1 points")
+    _finite_or_raise("quickhull_run", X0)
+    h = C.c_void_p()
+    rc = lib.plp_quickhull_run(_lib.context().handle, N, d, _ptr(X0), _ptr(simplex), float(abs_tol),
+                               C.c_void_p(_lapack_dgesv_pointer()), C.byref(h))
+    if rc:
+        msg = lib.plp_quickhull_last_error().decode("utf-8", "replace")
+        if "Singular matrix" in msg:
+            raise np.linalg.LinAlgError("Singular matrix")
+        if "identical vertices" in msg:
+            raise RuntimeError(msg)
+        _lib.check(rc, "plp_quickhull_run")
+    try:
+        nf, it, made = C.c_int64(), C.c_int64(), C.c_int64()
+        lib.plp_qh_result_sizes(h, C.byref(nf), C.byref(it), C.byref(made))
+        normals = np.empty((nf.value, d))
+        offsets = np.empty(nf.value)
+        verts = np.empty((nf.value, d), np.int64)
+        lib.plp_qh_result_copy(h, _ptr(normals), _ptr(offsets), _ptr(verts))
+    finally:
+        lib.plp_qh_result_free(h)
+    return normals, offsets, verts, dict(iterations=int(it.value), facets_made=int(made.value))

@@ -32,6 +32,7 @@ import numpy as np
 from . import solvers
 
 logger = logging.getLogger(__name__)
+_NATIVE_LOOP = True   # 'hip' backend: main loop in the library (False: the Python facet graph below, for A/B runs)
 
 
 class _NumpySession:
@@ -157,6 +158,15 @@ def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
         xc += startsimplex[ii, :] / (dim + 1)
     X0 = POINTS - xc  # all coordinates below are relative to the simplex centroid (:188-192)
 
+    if npt > dim + 1 and session_factory is None and solvers.default_solver == "hip" and _NATIVE_LOOP:
+        # the main loop runs in the library (csrc/plp_quickhull_host.hip): same order, same arithmetic, the facet graph
+        # in native code instead of Python lists and dicts
+        from .batch import quickhull_run
+        FNl, FOl, Vl, _ = quickhull_run(X0, ind, abs_tol)
+        vid = np.unique(Vl.ravel())
+        vert = POINTS[vid]
+        vert = vert[np.lexsort(vert.T[::-1])]
+        return FNl, FOl + np.dot(FNl, xc), vert
     # ---- facet table, indexed by slot (a facet keeps its slot for life; slots are never reused)
     FN = np.empty((64, dim))   # unit outward normals
     FO = np.empty(64)          # offsets: n.x = offset on the facet (translated coordinates)
