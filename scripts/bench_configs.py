@@ -23,7 +23,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import polytope_amd as pa  # noqa: E402
-from polytope_amd import synth  # noqa: E402
+from polytope_amd import solvers, synth  # noqa: E402
+
+solvers.default_solver = "hip"  # the engine is opt-in (the default follows the reference's rule: scipy)
 
 HBM_PEAK = 8000.0   # GB/s   (MI355X_MICROARCH.md)
 FP64_PEAK = 78.6    # TFLOP/s vector = matrix on MI355X
@@ -97,7 +99,7 @@ def c5():
 
 
 def lp():
-    for (B, m, d) in [(100000, 16, 3), (20000, 64, 16)]:
+    for (B, m, d) in [(100000, 16, 3), (20000, 64, 16), (20000, 64, 12), (20000, 48, 9)]:
         A, b = synth.random_hpolytopes(B, m, d, seed=1)
         At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
         ms = timeit(lambda: pa.cheby_ball_batch(At, bt))
@@ -175,17 +177,40 @@ def c4():
     print(json.dumps({"config": "C4 find_adjacent_regions 1000 cells d=4", "pairs": npairs, "s_first": t_adj,
                       "s": t_adj2, "pair_lps_per_s": npairs / t_adj2,
                       "equals_grid_neighbourhood": bool(np.array_equal(adj, want))}), flush=True)
+    from polytope_amd import batch
+    stats = {}
+    orig = batch.region_diff_search
+
+    def spy(*a, **k):
+        t = time.perf_counter()
+        out = orig(*a, **k)
+        stats.update(out[1], search_s=time.perf_counter() - t)
+        return out
+    batch.region_diff_search = spy
+    half = [c for c, idx in zip(cells, index) if idx[0] < 5]  # the 500 cells with x0 < 0.5
     A, b = synth.random_hpolytopes(1, 12, 4, seed=4, bounded=True)
     P = pc.Polytope(A[0], 0.1 * b[0] + A[0] @ (0.5 * np.ones(4)))
+    pc.region_diff(P.copy(), pc.Region(half))
     t0 = time.perf_counter()
-    half = [c for c, idx in zip(cells, index) if idx[0] < 5]  # the 500 cells with x0 < 0.5
     D = pc.region_diff(P.copy(), pc.Region(half))
     t_diff = time.perf_counter() - t0
     r, _ = pc.cheby_ball(P)
-    print(json.dumps({"config": "C4 region_diff P(m=12,d=4) minus the 500 cells with x0<0.5 of the 1000-cell grid",
-                      "s": t_diff,
+    print(json.dumps({"config": "C4 region_diff P(m=12,d=4, r=0.13) minus the 500 cells with x0<0.5 of the 1000-cell grid",
+                      "s": t_diff, "library_search": dict(stats),
                       "pieces": len(D) if isinstance(D, pc.Region) else int(D.A.size > 0), "P_radius": float(r)}),
           flush=True)
+    # the fixture case (tests/golden g12): P(m=16) of radius ~0.3-0.6, the reference needs 99 039 LPs and 186 s
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    g = load_golden("g12_config4.npz")
+    P = pc.Polytope(g["c4_PA"], g["c4_Pb"], normalize=False)
+    pc.region_diff(P.copy(), pc.Region(cells[:500]), _order=g["c4_order"])
+    t0 = time.perf_counter()
+    D = pc.region_diff(P.copy(), pc.Region(cells[:500]), _order=g["c4_order"])
+    t_diff = time.perf_counter() - t0
+    print(json.dumps({"config": "C4 region_diff, fixture g12 (234 pieces; reference: 99 039 LPs, 186 s)", "s": t_diff,
+                      "library_search": dict(stats), "pieces": len(D), "reference_lps": int(g["c4_diff_nlp"]),
+                      "lps_per_s_reference_count": int(g["c4_diff_nlp"]) / t_diff}), flush=True)
 
 
 def hull():
@@ -193,7 +218,7 @@ def hull():
     library (scipy.spatial.ConvexHull) on the same points; per-iteration cost = one plp_hull_reassign."""
     from scipy.spatial import ConvexHull
     from polytope_amd.quickhull import quickhull
-    for (N, d) in [(1000000, 3), (1000000, 2), (200000, 4), (1000000, 8)]:
+    for (N, d) in [(1000000, 3), (1000000, 2), (200000, 4), (100000, 5), (1000000, 8)]:
         rng = np.random.default_rng(N + d)
         P = rng.standard_normal((N, d))
         if d == 8:  # a full d=8 hull of 1M Gaussian points has ~1e6 facets: time single passes instead

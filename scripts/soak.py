@@ -22,7 +22,9 @@ for seed, extra in [("11", {}), ("12", {}), ("13", {"PLP_REDUCE_RETRY_ALL": "1",
 
 import numpy as np  # noqa: E402
 from scipy.spatial import ConvexHull  # noqa: E402
+from polytope_amd import solvers  # noqa: E402
 from polytope_amd.quickhull import quickhull  # noqa: E402
+solvers.default_solver = "hip"  # the engine is opt-in
 rng = np.random.default_rng(2024)
 nb = 0
 for trial in range(120):
