@@ -70,11 +70,6 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st);
 
-// small polytopes (rows <= 16, d <= 3): one polytope per lane; returns 1 when it does not apply
-int launch_reduce_tpl(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
-                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
-                      hipStream_t st);
-
 // `scratch` (contains_mfma_scratch_bytes(P, m_max, d) bytes of device memory, or nullptr): with it the dot products
 // run on the matrix cores (plp_contains_mfma.hip), near-threshold values redone in the reference's operation order
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,

@@ -316,13 +316,6 @@ int launch_reduce(long long B, int m_max, int d, const double* A, const double* 
                   unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
     const int gs = group_size_for(m_max);
     if (gs < 0 || d < 1 || d > MAX_D) return 2;
-    // PLP_TPL=1 sends small polytopes (rows <= 16, d <= 3) to the one-polytope-per-lane kernel
-    // (plp_reduce_tpl.hip).  Measured on MI355X it only pays off for very large batches: at 100k
-    // polytopes it has 1563 wavefronts for 1024 SIMDs at one wave per SIMD (0.72 ms vs 0.69 ms here).
-    const char* tpl = getenv("PLP_TPL");
-    if (tpl && tpl[0] == '1' &&
-        launch_reduce_tpl(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
-        return 0;
     // default for d <= 8: four rows per lane (plp_reduce_r.hip); PLP_REDUCE_1ROW=1 keeps this kernel
     // Its F2/F3 LPs run on the fast pivot path, which hands a polytope back (RF_RETRY) when an LP
     // needs Bland's rule; the second launch below redoes exactly those with this file's kernel.

@@ -521,7 +521,7 @@ def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
         assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
-@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_TPL", "PLP_REDUCE_RETRY_ALL"])
+@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_REDUCE_RETRY_ALL"])
 def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
     """The three mappings of the fused reduce (4 rows per lane = default, 1 row per lane, 1 polytope
     per lane) must agree with the oracle; the non-default ones are selected by environment.
