@@ -869,7 +869,7 @@ struct plp_rdiff_result {
     std::vector<int32_t> kind;   // per leaf: 0 = piece as is (ref :2229), 1 = piece to be reduce()d (ref :2276)
     std::vector<int32_t> off;    // leaf k holds rows[off[k] .. off[k+1])
     std::vector<int32_t> rows;
-    long long n_lps = 0, n_batches = 0, n_requests = 0;
+    long long n_lps = 0, n_batches = 0, n_requests = 0, n_scan_miss = 0, n_node_miss = 0;
 };
 
 namespace {
@@ -1141,7 +1141,54 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
         if (old == 0 && v != 0) open_cells.insert(std::lower_bound(open_cells.begin(), open_cells.end(), L), L);
         else if (old != 0 && v == 0) open_cells.erase(std::lower_bound(open_cells.begin(), open_cells.end(), L));
     };
-    auto sum_counter = [&]() { return sumc; };
+    // the move after a piece was emitted (ref :2230-2245: "level - 1", then re-open the cell there) on an explicit state
+    auto leaf_on = [&](std::vector<int>& cnt, std::vector<int>& open, std::vector<long long>& ix, long long& lvl,
+                       long long& sc) -> bool {
+        lvl = lvl - 1;
+        const int nz = (int)open.size();
+        for (int t = 0; t < nz; ++t) {
+            const int L = at(lvl);
+            if (cnt[L] <= mi[L]) {
+                ix.back() -= M;
+                ix.push_back(beg[L] + cnt[L] + M);
+                return false;
+            }
+            sc -= cnt[L];
+            cnt[L] = 0;
+            open.erase(std::lower_bound(open.begin(), open.end(), L));
+            const long long keep_n = m + sc;
+            if ((long long)ix.size() > keep_n) ix.resize(keep_n < 0 ? 0 : keep_n);
+            if (lvl == -1) return true;
+        }
+        return false;
+    };
+    // the "next sibling" move (ref :2246-2271) on an explicit state, so that it can also be run on a COPY to see which
+    // nodes follow when the current one turns out empty; returns true when the search ends
+    auto advance_on = [&](std::vector<int>& cnt, std::vector<int>& open, std::vector<long long>& ix, long long& lvl,
+                          long long& sc) -> bool {
+        auto setc = [&](int L, int v) {
+            const int old = cnt[L];
+            sc += v - old;
+            cnt[L] = v;
+            if (old == 0 && v != 0) open.insert(std::lower_bound(open.begin(), open.end(), L), L);
+            else if (old != 0 && v == 0) open.erase(std::lower_bound(open.begin(), open.end(), L));
+        };
+        while (!open.empty()) {   // deepest open cell first (the reference walks nzcount backwards)
+            lvl = open.back();
+            setc((int)lvl, cnt[lvl] + 1);
+            if (cnt[lvl] <= mi[lvl]) {
+                ix.back() -= M;
+                ix.push_back(beg[lvl] + cnt[lvl] + M - 1);
+                return false;
+            }
+            setc((int)lvl, 0);
+            const long long keep_n = m + sc;
+            if ((long long)ix.size() > keep_n) ix.resize(keep_n < 0 ? 0 : keep_n);
+            lvl = lvl - 1;
+            if (lvl == -1) return true;
+        }
+        return false;
+    };
     // ---- what earlier scans already decided.  A cell whose stack with the rows of an ANCESTOR node had radius
     // <= abs_tol / 2 cannot reach abs_tol with more rows added (the set only shrinks; LP values are exact to ~1e-12),
     // so its LP is not issued again below that node: it counts as "no hit", which is what the reference would find.
@@ -1188,7 +1235,47 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                 child.push_back((int32_t)(beg[j] + M));
                 queue_scan1(alive, (long long)j + 1, key_push(kbase, (int32_t)(beg[j] + M)), child);
             }
+            // ... and its whole sibling chain (rows 1..c-1 of the cell kept, row c negated) with the scans they need when
+            // they are not empty, as long as that stays a few hundred lists
+            long long n_after = 0;
+            for (int a : alive) n_after += a > j;
+            if ((long long)mi[j] * (2 * n_after + 1) <= 600) {
+                child = cur;
+                Key kc = kbase;
+                for (int c = 2; c <= mi[j]; ++c) {
+                    child.push_back((int32_t)(beg[j] + c - 2));
+                    kc = key_push(kc, (int32_t)(beg[j] + c - 2));
+                    const int32_t neg = (int32_t)(beg[j] + c - 1 + M);
+                    R.want(key_push(kc, neg), child.data(), child.size(), &neg, 1);
+                    if (j < N - 1) {
+                        child.push_back(neg);
+                        queue_scan1(alive, (long long)j + 1, key_push(kc, neg), child);
+                        child.pop_back();
+                    }
+                }
+            }
             break;
+        }
+    };
+    // queue the nodes the search visits from the state (c2, o2, i2, l2, s2) on while every node turns out empty: its own
+    // moves run on the copy, so the lists are exactly the ones it will form (odd turns of the INDICES arithmetic included)
+    std::vector<int32_t> sim;
+    auto want_state = [&](const std::vector<long long>& i2) -> bool {
+        sim.resize(i2.size());
+        for (size_t k = 0; k < i2.size(); ++k) {
+            long long r = i2[k] < 0 ? i2[k] + nrows : i2[k];
+            if (r < 0 || r >= nrows) return false;
+            sim[k] = (int32_t)r;
+        }
+        R.want(key_of_list(sim.data(), sim.size()), sim.data(), sim.size(), nullptr, 0);
+        return true;
+    };
+    auto queue_empty_chain = [&](std::vector<int>& c2, std::vector<int>& o2, std::vector<long long>& i2, long long l2,
+                                 long long s2, int steps) {
+        for (int step = 0; step < steps; ++step) {
+            if (l2 == -1 || c2[at(l2)] == 0) break;               // the next move would be a scan (or the end)
+            if (advance_on(c2, o2, i2, l2, s2)) break;
+            if (!want_state(i2)) break;
         }
     };
     rc = PLP_OK;
@@ -1209,7 +1296,14 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                     if (!R.memo.find(k)) { miss = true; break; }
                 }
                 if (!miss) break;
+                res->n_scan_miss++;
                 queue_scan(alive, level, kbase);
+                {   // the outcome "no cell hits": a piece is emitted, then the node the search re-opens and what follows it
+                    std::vector<int> c2 = counter, o2 = open_cells;
+                    std::vector<long long> i2 = idx;
+                    long long l2 = level, s2 = sumc;
+                    if (!leaf_on(c2, o2, i2, l2, s2) && want_state(i2)) queue_empty_chain(c2, o2, i2, l2, s2, 6);
+                }
                 rc = R.flush();
                 if (rc) break;
             }
@@ -1237,67 +1331,24 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                 idx.push_back(beg[level] + M);
             }
             if (Rl < abs_tol) {  // nothing left to subtract: the current rows are a piece (ref :2226-2245)
-                level = level - 1;
                 emit(0);
-                const int nz = (int)open_cells.size();
-                bool returned = false;
-                for (int t = 0; t < nz; ++t) {
-                    const int L = at(level);
-                    if (counter[L] <= mi[L]) {
-                        idx.back() -= M;
-                        idx.push_back(beg[L] + counter[L] + M);
-                        break;
-                    }
-                    set_counter(L, 0);
-                    const long long keep_n = m + sum_counter();
-                    if ((long long)idx.size() > keep_n) idx.resize(keep_n < 0 ? 0 : keep_n);
-                    if (level == -1) { returned = true; break; }
-                }
-                if (returned) break;
+                if (leaf_on(counter, open_cells, idx, level, sumc)) break;
             }
         } else {
             // ---- next sibling of the deepest open cell, closing exhausted cells on the way (ref :2246-2271)
-            bool returned = false;
-            while (!open_cells.empty()) {   // deepest open cell first (the reference walks nzcount backwards)
-                level = open_cells.back();
-                set_counter((int)level, counter[level] + 1);
-                if (counter[level] <= mi[level]) {
-                    idx.back() -= M;
-                    idx.push_back(beg[level] + counter[level] + M - 1);
-                    break;
-                }
-                set_counter((int)level, 0);
-                const long long keep_n = m + sum_counter();
-                if ((long long)idx.size() > keep_n) idx.resize(keep_n < 0 ? 0 : keep_n);
-                level = level - 1;
-                if (level == -1) { returned = true; break; }
-            }
-            if (returned) break;
+            if (advance_on(counter, open_cells, idx, level, sumc)) break;
         }
         // ---- the node itself
         resolve();
         if (!cur_ok) { bad_index = true; break; }
         const Key knode = key_of_list(cur.data(), cur.size());
         if (!R.memo.find(knode)) {
+            res->n_node_miss++;
             R.want(knode, cur.data(), cur.size(), nullptr, 0);
-            const int L = at(level);
-            const int c = counter[L];
-            // the siblings that follow when this node is empty, with the rows the search will form for them
-            if (c >= 1 && !idx.empty()) {
-                std::vector<int32_t> sib(cur.begin(), cur.end() - 1);
-                long long flipped = idx.back() - M;
-                flipped = flipped < 0 ? flipped + nrows : flipped;
-                bool ok = flipped >= 0 && flipped < nrows;
-                if (ok) sib.push_back((int32_t)flipped);
-                for (int t = c + 1; ok && t <= mi[L]; ++t) {
-                    // rows beg+c .. beg+t-2 kept, row beg+t-1 negated
-                    if (t > c + 1) sib.push_back((int32_t)(beg[L] + t - 2));
-                    const long long neg = beg[L] + t - 1 + M;
-                    if (neg >= nrows) break;
-                    const int32_t n32 = (int32_t)neg;
-                    Key k = key_push(key_of_list(sib.data(), sib.size()), n32);
-                    R.want(k, sib.data(), sib.size(), &n32, 1);
-                }
+            {
+                std::vector<int> c2 = counter, o2 = open_cells;
+                std::vector<long long> i2 = idx;
+                queue_empty_chain(c2, o2, i2, level, sumc, 8);
             }
             // what it needs next when it is NOT empty: its scan and the first child of every cell still alive
             if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode);
@@ -1314,8 +1365,8 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     res->n_lps = R.n_lps;
     res->n_batches = R.n_batches;
     if (getenv("PLP_RDIFF_STATS"))
-        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches, %lld requests, launch %.1f ms, device wait %.1f ms\n",
-                R.n_lps, R.n_batches, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3);
+        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms\n",
+                R.n_lps, R.n_batches, res->n_scan_miss, res->n_node_miss, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3);
     R.release();
     if (rc == PLP_OK && bad_index) rc = fail(PLP_EINVAL, "region_diff: row index out of range (the reference raises IndexError here)");
     if (rc) { delete res; return rc; }
