@@ -168,7 +168,7 @@ bool is_gfx950(int dev) {
 
 extern "C" {
 
-int plp_version(void) { return 100; }
+int plp_version(void) { return 200; }  // 200: round 2 (LPs beyond 64 rows, plp_region_diff_search, plp_quickhull_run)
 
 int plp_device_count(void) {
     int n = 0;

@@ -43,6 +43,39 @@ int main(void)
       double lb[4], ub[4]; int32_t st[2];
       CHECK(plp_bbox_batch(ctx, 2, 4, 2, A, b, NULL, lb, ub, st));
       printf("bbox status %d lb %.9f %.9f ub %.9f %.9f | status %d\n", st[0], lb[0], lb[1], ub[0], ub[1], st[1]); }
+    /* quickhull of the unit cube's corners + 3 interior points (built-in LU, no LAPACK): 12 triangles, 8 vertices */
+    { double X[33]; int n = 0;
+      for (int i = 0; i < 8; ++i) { X[n++] = (i & 1) - 0.5; X[n++] = ((i >> 1) & 1) - 0.5; X[n++] = ((i >> 2) & 1) - 0.5; }
+      const double in[9] = {0.1, 0.0, -0.2, -0.3, 0.2, 0.1, 0.0, 0.0, 0.05};
+      for (int i = 0; i < 9; ++i) X[n++] = in[i];
+      int64_t simplex[4] = {0, 1, 2, 4};
+      /* translate to the simplex centroid, as the caller of plp_quickhull_run has to (quickhull.py:188-192) */
+      double xc[3] = {0, 0, 0};
+      for (int k = 0; k < 4; ++k) for (int c = 0; c < 3; ++c) xc[c] += X[simplex[k] * 3 + c] / 4;
+      for (int i = 0; i < 11; ++i) for (int c = 0; c < 3; ++c) X[i * 3 + c] -= xc[c];
+      plp_qh_result *res = NULL;
+      CHECK(plp_quickhull_run(ctx, 11, 3, X, simplex, 1e-7, NULL, &res));
+      int64_t nf = 0, it = 0, made = 0;
+      CHECK(plp_qh_result_sizes(res, &nf, &it, &made));
+      double nrm[36 * 3], off[36]; int64_t verts[36 * 3]; int used[11] = {0}, nv = 0;
+      if (nf <= 36) { CHECK(plp_qh_result_copy(res, nrm, off, verts));
+        for (int i = 0; i < nf * 3; ++i) if (!used[verts[i]]) { used[verts[i]] = 1; ++nv; } }
+      printf("quickhull facets %lld vertices %d\n", (long long)nf, nv);
+      CHECK(plp_qh_result_free(res)); }
+    /* region_diff search: unit square minus the strip 0.5 <= x <= 1.5: one piece, the square's rows + "x <= 0.5" */
+    { const double A[24] = {1, 0, 0, 1, -1, 0, 0, -1,   -1, 0, 1, 0, 0, -1, 0, 1,   1, 0, -1, 0, 0, 1, 0, -1},
+                   b[12] = {1, 1, 0, 0,   -0.5, 1.5, 1, 2,   0.5, -1.5, -1, -2};
+      int32_t mi[1] = {4};
+      plp_rdiff_result *res = NULL;
+      CHECK(plp_region_diff_search(ctx, 2, 4, 1, mi, A, b, 1e-7, &res));
+      int64_t nl = 0, nr = 0, nlp = 0, nb = 0;
+      CHECK(plp_rdiff_result_sizes(res, &nl, &nr, &nlp, &nb));
+      int32_t kind[8], off[9], rows[64];
+      if (nl <= 8 && nr <= 64) { CHECK(plp_rdiff_result_copy(res, kind, off, rows));
+        printf("region_diff pieces %lld:", (long long)nl);
+        for (int k = 0; k < nl; ++k) { printf(" kind %d rows", kind[k]); for (int t = off[k]; t < off[k + 1]; ++t) printf(" %d", rows[t]); }
+        printf("\n"); }
+      CHECK(plp_rdiff_result_free(res)); }
     /* misuse is reported, not crashed on */
     { double c[1] = {1.0}; int rc = plp_lp_solve_batch(ctx, 1, 100000, 1, c, c, c, NULL, c, c, (int32_t *)c, NULL);  /* no LDS for 100000 rows */
       printf("envelope rc %d (%s)\n", rc, rc == PLP_EUNSUPPORTED ? "PLP_EUNSUPPORTED" : "?"); }

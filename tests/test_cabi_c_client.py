@@ -42,4 +42,7 @@ def test_c_client_results(tmp_path):
     assert any(l.startswith("reduce keep 0x1d flags 4 nlp ") for l in out), out   # rows 0,2,3,4 kept, minrep
     assert "bbox status 0 lb 2.000000000 -1.000000000 ub 5.000000000 3.000000000 | status 1" in out, out
     assert "contains 1 0 1 0" in out      # the corner (1,1): A x - b = 0 < abs_tol counts as inside
+    assert "quickhull facets 12 vertices 8" in out, out      # the cube's 6 faces as 12 triangles, interior points dropped
+    # one piece: the square's 4 rows + the strip's first new row negated (table row 4 + 4 = 8: x <= 0.5), reduced (kind 1)
+    assert "region_diff pieces 1: kind 1 rows 0 1 2 3 8" in out, out
     assert "envelope rc 2 (PLP_EUNSUPPORTED)" in out and out[-1] == "done"
