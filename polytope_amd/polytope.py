@@ -1063,9 +1063,6 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
     beg = m + np.concatenate([[0], np.cumsum(mi[:-1])]).astype(int)
     A = np.vstack([A, -A[m:m + M, :]])
     B = np.hstack([B, -B[m:m + M]])
-    counter = [0] * N   # python list: negative `level` wraps around exactly as the reference's array does
-    idx = list(range(m))
-    level = 0
     res = Polytope()
 
     def poly_of(rows):
@@ -1125,71 +1122,122 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
                 res[k] = np.double(out["r"][t]) if ok[t] else 0
         return res
 
-    # The children of a node (constraint 1 violated; 1 kept and 2 violated; ...) are all visited, one
-    # after the other, so their LPs are solved together when the first of them is reached.
-    ahead = {}
-
-    def node_radius(rows, lvl):
-        key = tuple(rows)
-        if key not in ahead:
-            ahead.clear()
-            c = counter[lvl]
-            sibs = [list(rows)]
-            for t in range(c + 1, mi[lvl] + 1):
-                sibs.append(rows[:-1] + [rows[-1] - M] + list(range(beg[lvl] + c, beg[lvl] + t - 1))
-                            + [beg[lvl] + t - 1 + M])
-            for sr, rr in zip(sibs, radii_rows(sibs)):
-                ahead[tuple(sr)] = rr
-        return ahead.pop(key)
-
-    while level != -1:
-        if counter[level] == 0:
-            radii = radii_rows([idx + list(range(beg[j], beg[j] + mi[j])) for j in range(level, N)])
-            R = radii[-1]
-            for off, Rj in enumerate(radii):
-                if Rj > abs_tol:
-                    R = Rj
-                    level = level + off
-                    counter[level] = 1
-                    idx = idx + [beg[level] + M]
-                    break
-            if R < abs_tol:
-                level = level - 1
-                res = union(res, poly_of(idx), False)
-                nz = [k for k in range(N) if counter[k] != 0]
-                for _ in range(len(nz)):
-                    if counter[level] <= mi[level]:
-                        idx[-1] = idx[-1] - M
-                        idx = idx + [beg[level] + counter[level] + M]
-                        break
-                    counter[level] = 0
-                    idx = idx[0:m + sum(counter)]
-                    if level == -1:
-                        logger.debug("returning res from 1st point")
-                        return res
-        else:
-            nz = [k for k in range(N) if counter[k] != 0]
-            for jj in range(len(nz) - 1, -1, -1):
-                level = nz[jj]
-                counter[level] += 1
-                if counter[level] <= mi[level]:
-                    idx[-1] = idx[-1] - M
-                    idx = idx + [beg[level] + counter[level] + M - 1]
-                    break
-                counter[level] = 0
-                idx = idx[0:m + sum(counter)]
-                level = level - 1
-                if level == -1:
-                    logger.debug("returning res from 2nd point")
-                    return res
-        rc = node_radius(idx, level)
-        if rc > abs_tol:
-            if level == N - 1:
-                res = union(res, reduce(poly_of(idx)), False)
-            else:
-                level = level + 1
-    logger.debug("returning res from end")
+    # Host twin of the library's search (csrc/plp_capi.hip, plp_region_diff_search): the same state, moves and
+    # inheritance of empty cells, driven through `radii_rows` -- what the non-'hip' backends run, and the A/B partner
+    # of the library search on the GPU (tests: both must return the same pieces).
+    search = _DiffSearch(m, mi, beg, M, abs_tol, radii_rows, look_ahead=packed)
+    for kind, rows in search.run():
+        piece = poly_of(rows)
+        res = union(res, reduce(piece) if kind == 1 else piece, False)
     return res
+
+
+class _DiffSearch:
+    """The search of region_diff (ref :2201-2281) over row lists of one constraint table: m rows of the minuend, then
+    M = sum(mi) new rows of the cells (cell j from beg[j]), then their M negations.
+
+    State: `counter[j]` (0 = cell j closed; c = its first c - 1 new rows kept, row c negated), `rows` (the reference's
+    INDICES, Python's negative indices included) and `level`.  Moves: `scan` (first cell from `level` on whose stack
+    with the current rows is full-dimensional), `next_sibling`, `reopen_after_piece`.  `run()` yields the pieces as
+    (kind, rows): kind 0 = as is, 1 = to be reduce()d.  A cell whose stack had radius <= abs_tol / 2 at a scan is not
+    solved again while the current rows contain that scan's rows (the set only shrinks below it)."""
+
+    def __init__(self, m, mi, beg, M, abs_tol, radii_rows, look_ahead):
+        self.m, self.mi, self.beg, self.M, self.tol = int(m), [int(v) for v in mi], [int(v) for v in beg], int(M), abs_tol
+        self.N = len(self.mi)
+        self.radii_rows = radii_rows
+        self.look_ahead = look_ahead      # batched backends: solve the chain of siblings with the node
+        self.counter = [0] * self.N       # a list: level == -1 reads the LAST cell, as the reference's array does
+        self.rows = list(range(self.m))
+        self.level = 0
+        self.frames = []                  # (rows of a scan as a set, cells still alive after it)
+        self.memo = {}
+
+    # ---- moves on an explicit state (so that they can be tried on a copy)
+    def _next_sibling(self, counter, rows, level):
+        for j in [k for k in range(self.N - 1, -1, -1) if counter[k] != 0]:
+            level = j
+            counter[j] += 1
+            if counter[j] <= self.mi[j]:
+                rows[-1] -= self.M
+                rows.append(self.beg[j] + counter[j] + self.M - 1)
+                return level, False
+            counter[j] = 0
+            del rows[self.m + sum(counter):]
+            level = j - 1
+            if level == -1:
+                return level, True
+        return level, False
+
+    def _reopen_after_piece(self, counter, rows, level):
+        level -= 1
+        for _ in range(sum(1 for c in counter if c != 0)):
+            if counter[level] <= self.mi[level]:
+                rows[-1] -= self.M
+                rows.append(self.beg[level] + counter[level] + self.M)
+                return level, False
+            counter[level] = 0
+            del rows[self.m + sum(counter):]
+            if level == -1:
+                return level, True
+        return level, False
+
+    def _alive(self):
+        have = set(self.rows)
+        while self.frames and not self.frames[-1][0] <= have:
+            self.frames.pop()
+        return self.frames[-1][1] if self.frames else list(range(self.N))
+
+    def _radius(self, rows):
+        key = tuple(rows)
+        if key not in self.memo:
+            want = [list(rows)]
+            if self.look_ahead:   # the nodes that follow while every node turns out empty, from a copy of the state
+                c2, r2, l2 = list(self.counter), list(rows), self.level
+                for _ in range(8):
+                    if l2 == -1 or c2[l2] == 0:
+                        break
+                    l2, ended = self._next_sibling(c2, r2, l2)
+                    if ended or any(not -self.m - 2 * self.M <= v < self.m + 2 * self.M for v in r2):
+                        break
+                    want.append(list(r2))
+            self.memo.clear()
+            for w, rad in zip(want, self.radii_rows(want)):
+                self.memo[tuple(w)] = rad
+        return self.memo[key]
+
+    def run(self):
+        N, tol = self.N, self.tol
+        while self.level != -1:
+            if self.counter[self.level] == 0:
+                alive = [j for j in self._alive() if j >= self.level]
+                stacks = [self.rows + list(range(self.beg[j], self.beg[j] + self.mi[j])) for j in alive]
+                radii = self.radii_rows(stacks) if stacks else []
+                self.frames.append((set(self.rows), [j for j, r in zip(alive, radii) if r > 0.5 * tol]))
+                last = 0   # the reference's R after its loop: the radius of the last cell it looked at
+                for j, r in zip(alive, radii):
+                    if r > tol:
+                        last = r
+                        self.level = j
+                        self.counter[j] = 1
+                        self.rows.append(self.beg[j] + self.M)
+                        break
+                    if j == N - 1:
+                        last = r
+                if last < tol:
+                    yield 0, list(self.rows)
+                    self.level, ended = self._reopen_after_piece(self.counter, self.rows, self.level)
+                    if ended:
+                        return
+            else:
+                self.level, ended = self._next_sibling(self.counter, self.rows, self.level)
+                if ended:
+                    return
+            if self._radius(self.rows) > tol:
+                if self.level == N - 1:
+                    yield 1, list(self.rows)
+                else:
+                    self.level += 1
 
 
 # ====================================================================================== volume
