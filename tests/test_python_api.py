@@ -469,6 +469,24 @@ def test_config4_grid81_region_intersect():
         solvers.default_solver = old
 
 
+def test_config4_full_size_region_diff_reference_backend():
+    """BASELINE configs[3] at its stated size through the PUBLIC call on the reference's own LP backend (scipy: the radii,
+    and with them the tie order among the 301 cells of equal radius, are the reference's): the 234 pieces of the fixture,
+    same order, rows and radii.  The Python-side search (_DiffSearch) issues ~13 000 LPs for it where the reference
+    issues 99 039 (cells an ancestor scan found empty are not solved again): ~30 s on one core."""
+    import polytope_amd.polytope as pcm
+    from polytope_amd import solvers
+    g = load_golden("g12_config4.npz")
+    old, solvers.default_solver = solvers.default_solver, "scipy"
+    try:
+        cells = _grid_cells(pcm, tuple(int(v) for v in g["c4_shape"]))
+        P = pcm.Polytope(g["c4_PA"], g["c4_Pb"], normalize=False)
+        D = pcm.region_diff(P.copy(), pcm.Region(cells[: int(g["c4_nsub"])]))
+        _assert_same_pieces(pcm, _pieces(pcm, D), _pieces_from(g, "c4_diff", 4), "c4_diff")
+    finally:
+        solvers.default_solver = old
+
+
 @pytest.mark.gpu
 def test_config4_full_size_region_diff_and_adjacency():
     """BASELINE configs[3] at its stated size: the 10x10x5x2 grid of 1000 box cells in d = 4.
