@@ -588,3 +588,42 @@ def test_subset_and_comparisons_match_reference(pc):
                bool(X.copy() == Y.copy()), bool(X.copy() <= Y.copy()), bool(X.copy() >= Y.copy()),
                bool(X.copy() != Y.copy())]
         assert got == want, (tag, got, want)
+
+
+@pytest.mark.gpu
+def test_stacks_beyond_64_rows_through_the_python_layer():
+    """intersect / reduce / cheby_ball / bounding_box / is_adjacent on polytopes whose stacks pass 64 rows (the fused
+    kernels' limit): the 'hip' backend takes the LDS-resident LP engine for them and must agree with the scipy backend
+    (the reference's arithmetic) -- same kept rows, radii and boxes to 1e-9."""
+    import polytope_amd.polytope as pcm
+    from polytope_amd import solvers
+    rng = np.random.default_rng(70)
+
+    def rand_poly(m, d, shift=0.0):
+        A = rng.standard_normal((m, d))
+        A /= np.linalg.norm(A, axis=1)[:, None]
+        return A, 1.0 + 0.3 * rng.random(m) + A @ (shift * np.ones(d))
+
+    cases = [(rand_poly(40, 3), rand_poly(45, 3, 0.2)), (rand_poly(70, 2), rand_poly(10, 2, 0.1)),
+             (rand_poly(50, 4), rand_poly(50, 4, -0.15))]
+    out = {}
+    for backend in ("scipy", "hip"):
+        old, solvers.default_solver = solvers.default_solver, backend
+        try:
+            res = []
+            for (A1, b1), (A2, b2) in cases:
+                P, Q = pcm.Polytope(A1, b1), pcm.Polytope(A2, b2)
+                I = P.intersect(Q)                       # stack of 85 / 80 / 100 rows -> reduce
+                big = pcm.Polytope(np.vstack([A1, A2]), np.r_[b1, b2])
+                r, xc = pcm.cheby_ball(big)
+                l, u = big.bounding_box
+                res.append((I.A.copy(), I.b.copy(), float(r), l.ravel().copy(), u.ravel().copy(),
+                            bool(pcm.is_adjacent(P, Q)), bool(pcm.is_fulldim(big))))
+            out[backend] = res
+        finally:
+            solvers.default_solver = old
+    for (Ia, ib, r, l, u, adj, fd), (Ja, jb, r2, l2, u2, adj2, fd2) in zip(out["scipy"], out["hip"]):
+        assert Ia.shape == Ja.shape and np.allclose(Ia, Ja, atol=1e-9, rtol=0) and np.allclose(ib, jb, atol=1e-9, rtol=0)
+        assert abs(r - r2) <= TOL and np.allclose(l, l2, atol=1e-9) and np.allclose(u, u2, atol=1e-9)
+        assert adj == adj2 and fd == fd2
+        assert Ia.shape[0] > 3
