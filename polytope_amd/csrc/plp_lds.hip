@@ -37,10 +37,6 @@ struct LdsDict {
     int ld;
 };
 
-__device__ __forceinline__ size_t lds_dict_bytes(int m, int ld) {
-    return (size_t)m * ld * 8 + (size_t)m * 16 + (size_t)m * 8 + 3 * LDS_MAXC * 8 + LDS_MAXC * 4;
-}
-
 __device__ __forceinline__ LdsDict lds_carve(unsigned char* base, int m, int ld) {
     LdsDict D;
     D.ld = ld;

@@ -28,48 +28,6 @@ namespace {
 #define PLP_DPP_BCAST15 0x142
 #define PLP_DPP_BCAST31 0x143
 
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_d_rm(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double min_raw(double a, double b) {  // one v_min_f64 (fmin() canonicalises its operands first)
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double max_raw2(double a, double b) {
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// wave-wide max / min of a double; the result is returned wave-uniform (read from lane 63)
-__device__ __forceinline__ double wave_max_f64(double v) {
-    v = max_raw2(v, dpp_d<PLP_DPP_XOR1>(v));
-    v = max_raw2(v, dpp_d<PLP_DPP_XOR2>(v));
-    v = max_raw2(v, dpp_d<PLP_DPP_HMIRROR>(v));
-    v = max_raw2(v, dpp_d<PLP_DPP_MIRROR>(v));
-    v = max_raw2(v, dpp_d_rm<PLP_DPP_BCAST15, 0xA>(v));
-    v = max_raw2(v, dpp_d_rm<PLP_DPP_BCAST31, 0xC>(v));
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_min_f64(double v) {
-    v = min_raw(v, dpp_d<PLP_DPP_XOR1>(v));
-    v = min_raw(v, dpp_d<PLP_DPP_XOR2>(v));
-    v = min_raw(v, dpp_d<PLP_DPP_HMIRROR>(v));
-    v = min_raw(v, dpp_d<PLP_DPP_MIRROR>(v));
-    v = min_raw(v, dpp_d_rm<PLP_DPP_BCAST15, 0xA>(v));
-    v = min_raw(v, dpp_d_rm<PLP_DPP_BCAST31, 0xC>(v));
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ int wave_min_i32(int v) {
     int t;
     t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR1, 0xF, 0xF, false); v = t < v ? t : v;
