@@ -395,7 +395,7 @@ def main():
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "reduce_r_kernel<3, 4, 4>", "kernel_ms": kern_ms,
+                         "kernel": "reduce_r_mix_kernel<3>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
                              nlp_local / (kern_ms * 1e-3))},

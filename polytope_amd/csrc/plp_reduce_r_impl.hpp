@@ -82,9 +82,11 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 #define PLP_REDUCE_R8_WAVES 2
 #endif
 
-template <int D, int GS, int R = RR>
-__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
-    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+// One tile = the NG = RBLOCK / GS polytopes starting at polytope `tile` (the body of reduce_r_kernel; a device function
+// so that reduce_r_mix_kernel can give the last tiles of a launch a different shape).
+template <int D, int GS, int R>
+__device__ __forceinline__ void reduce_r_tile(
+    const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
     int* __restrict__ nlp_out) {
@@ -107,8 +109,7 @@ __global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
-    {  // one tile per workgroup (grid.x = number of tiles: no values kept live across a tile loop)
-        const long long tile = (long long)blockIdx.x * NG;
+    {  // one tile per workgroup (no values kept live across a tile loop)
         const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
         __syncthreads();
         {
@@ -476,6 +477,34 @@ __global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_
 }
 
 template <int D, int GS, int R = RR>
+__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    reduce_r_tile<D, GS, R>((long long)blockIdx.x * (RBLOCK / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                            flags_out, r_out, xc_out, nlp_out);
+}
+
+// Polytopes of up to 16 rows: the first `nbig` workgroups take tiles of 16 polytopes (4 lanes x 4 rows each), the rest
+// tiles of 8 (8 lanes x 2 rows each), which finish in about half the time.  The launch drains over one tile lifetime
+// (the wavefronts that started last run on while the CUs empty: 213 us at steady state, 277 us for one C2 launch); with
+// short tiles dispatched last that window shrinks.
+template <int D>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_mix_kernel(
+    int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    if ((int)blockIdx.x < nbig)
+        reduce_r_tile<D, 4, 4>((long long)blockIdx.x * (RBLOCK / 4), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                               flags_out, r_out, xc_out, nlp_out);
+    else
+        reduce_r_tile<D, 8, 2>((long long)nbig * (RBLOCK / 4) + (long long)((int)blockIdx.x - nbig) * (RBLOCK / 8), B, m_max,
+                               Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out);
+}
+
+template <int D, int GS, int R = RR>
 static int launch_reduce_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows,
                              double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                              hipStream_t st) {
@@ -488,6 +517,24 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
+    if constexpr (GS == 4 && R == 4 && D <= 4) {
+        // more tiles than the chip holds at once (4096 wavefront slots): the last 1/16 of the tiles (at most 1024) are
+        // split into half-size ones.  Measured at C2 (6250 tiles): 0.2765 ms without, 0.2579-0.2609 ms with 2/64 .. 9/64
+        // of the batch in half-size tiles (a flat optimum), 0.27-0.29 ms beyond 10/64.  PLP_REDUCE_MIX=k: k/64 (0: off).
+        const char* mx = getenv("PLP_REDUCE_MIX");
+        long long tail_tiles = blocks / 16 < 1024 ? blocks / 16 : 1024;
+        if (mx) tail_tiles = blocks * atoi(mx) / 64;
+        if (tail_tiles > 0 && tail_tiles < blocks && blocks > 4096) {
+            long long nbig = blocks - tail_tiles;
+            const long long rest = B - nbig * NG;
+            const long long nsmall = (rest + NG / 2 - 1) / (NG / 2);
+            const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
+            hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
+                               smem > smem2 ? smem : smem2, st, (int)nbig, B, m_max, A, b, mrows, abs_tol,
+                               (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+            return 0;
+        }
+    }
     hipLaunchKernelGGL((reduce_r_kernel<D, GS, R>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
                        abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
     return 0;

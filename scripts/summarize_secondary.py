@@ -66,7 +66,7 @@ def ctr(passname, kernel_sub, counter, full_grid_only=True):
 
 
 # bench kernel: measured counters (passes bench_pmc_1..7 of gpu_profile_all.sh)
-K = "reduce_r_kernel<3, 4, 4>"
+K = "reduce_r_mix_kernel<3>"   # the bench kernel: tiles of 16 polytopes, the last 1/16 of them split into tiles of 8
 vals = {}
 for p in sorted(summ):
     if not p.startswith("bench_pmc_"):
