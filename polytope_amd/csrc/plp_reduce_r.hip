@@ -50,3 +50,15 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
 }
 
 }  // namespace plp
+
+#ifdef PLP_STAGE_STATS
+extern "C" __attribute__((visibility("default"))) int plp_debug_stage_stats(unsigned long long* out16, int reset) {
+    (void)hipDeviceSynchronize();
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(plp::plp_stage_stats), 128) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(plp::plp_stage_stats), z, 128) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -16,6 +16,16 @@
 
 namespace plp {
 
+#ifdef PLP_STAGE_STATS
+// debug build only (scripts/debug/stage_stats.sh): wave-level iterations against per-group pivots, per stage
+static __device__ unsigned long long plp_stage_stats[16];
+__device__ __forceinline__ int stat_wave_max(int v) {
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+#define PLP_STAT_ADD(i, v) atomicAdd(&plp_stage_stats[i], (unsigned long long)(v))
+#endif
+
 constexpr int RR = 4;  // rows per lane (default; R8 variant: 8 rows per lane, groups of 2 lanes for m <= 16)
 
 #ifndef PLP_REDUCE_R_BLOCK
@@ -91,8 +101,8 @@ __device__ __forceinline__ void reduce_r_tile(
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
     int* __restrict__ nlp_out) {
     constexpr unsigned RMASK = (1u << R) - 1u;
-    constexpr int RSH = R == 8 ? 3 : (R == 4 ? 2 : 1);  // log2(R)
-    static_assert(R == 2 || R == 4 || R == 8, "rows per lane");
+    constexpr int RSH = R == 8 ? 3 : (R == 4 ? 2 : (R == 2 ? 1 : 0));  // log2(R)
+    static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int gs = GS;
     const Grp g(gs);
@@ -193,6 +203,13 @@ __device__ __forceinline__ void reduce_r_tile(
 #if PLP_R_FAST
             S.template run_fast<GS, true>(g, qi, actb);
             retry = retry | (valid & (S.status == ST_RETRY));
+#ifdef PLP_STAGE_STATS
+            {
+                const int wm = stat_wave_max(valid ? S.iters : 0);
+                if (threadIdx.x == 0) { PLP_STAT_ADD(0, 1); PLP_STAT_ADD(1, wm); }
+                if (valid & (g.gl == 0)) { PLP_STAT_ADD(2, S.iters); PLP_STAT_ADD(11, 1); }
+            }
+#endif
 #else
             S.run(g);
 #endif
@@ -310,6 +327,13 @@ __device__ __forceinline__ void reduce_r_tile(
 #if PLP_R_FAST
                 S.template run_fast<GS>(g);
                 retry = retry | (go & (S.status == ST_RETRY));
+#ifdef PLP_STAGE_STATS
+                {
+                    const int wm = stat_wave_max(go ? S.iters : 0);
+                    if (threadIdx.x == 0) { PLP_STAT_ADD(3, wm); PLP_STAT_ADD(10, 1); }
+                    if (go & (g.gl == 0)) { PLP_STAT_ADD(4, S.iters); PLP_STAT_ADD(5, 1); }
+                }
+#endif
 #else
                 S.run(g);
 #endif
@@ -366,7 +390,14 @@ __device__ __forceinline__ void reduce_r_tile(
             for (;;) {
                 const bool fin = busy & (S.mode == M_DONE);
                 const bool start = (fin | !busy) & (todo != 0ull);
+#ifdef PLP_STAGE_STATS
+                if (threadIdx.x == 0) PLP_STAT_ADD(6, 1);
+#endif
                 if (__any(fin | start)) {
+#ifdef PLP_STAGE_STATS
+                    if (threadIdx.x == 0) PLP_STAT_ADD(7, 1);
+                    if (fin & (g.gl == 0)) { PLP_STAT_ADD(8, S.iters); PLP_STAT_ADD(9, 1); }
+#endif
                     if (fin) {
                         retry = retry | (S.status == ST_RETRY);
                         const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
@@ -521,6 +552,8 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
         // more tiles than the chip holds at once (4096 wavefront slots): the last 1/16 of the tiles (at most 1024) are
         // split into half-size ones.  Measured at C2 (6250 tiles): 0.2765 ms without, 0.2579-0.2609 ms with 2/64 .. 9/64
         // of the batch in half-size tiles (a flat optimum), 0.27-0.29 ms beyond 10/64.  PLP_REDUCE_MIX=k: k/64 (0: off).
+        // A third class of quarter-size tiles (16 lanes x 1 row) behind the half-size ones was measured too: no gain
+        // (0.2557-0.2602 ms for the last 2/256 .. 12/256 of the batch), not kept.
         const char* mx = getenv("PLP_REDUCE_MIX");
         long long tail_tiles = blocks / 16 < 1024 ? blocks / 16 : 1024;
         if (mx) tail_tiles = blocks * atoi(mx) / 64;
