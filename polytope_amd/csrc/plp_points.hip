@@ -19,7 +19,36 @@
 
 namespace plp {
 
-template <int D, int PPL>
+// (s - b_i) < tol  <=>  s < thr_i for EVERY double s: fl(s - b) is monotone in s, so the predicate holds on a
+// down-set of the ordered doubles and fails at +inf (inf - b is +inf or NaN); thr_i is the smallest double at which it
+// fails, found by bisection over the order-preserving integer image of the doubles (64 evaluations of the reference's
+// own expression).  NaN in b_i or tol: never true, thr_i = NaN.  One subtraction less per (row, point) in the kernel.
+__device__ __forceinline__ unsigned long long ord_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double ord_val(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+__global__ __launch_bounds__(BLOCK) void contains_thr_kernel(long long n, const double* __restrict__ b, double tol,
+                                                             double* __restrict__ thr) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double bi = b[i];
+    if (isnan(bi) || isnan(tol)) { thr[i] = __longlong_as_double(0x7ff8000000000000ll); return; }
+    // invariant: the predicate holds below lo (or lo is the first double), fails at hi
+    unsigned long long lo = ord_key(-__longlong_as_double(0x7ff0000000000000ll));
+    unsigned long long hi = ord_key(__longlong_as_double(0x7ff0000000000000ll));
+    if (!((ord_val(lo) - bi) < tol)) { thr[i] = ord_val(lo); return; }  // fails everywhere
+    while (hi - lo > 1ull) {  // holds at lo, fails at hi
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        if ((ord_val(mid) - bi) < tol) lo = mid; else hi = mid;
+    }
+    thr[i] = ord_val(hi);
+}
+
+template <int D, int PPL, bool THR>
 __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const double* __restrict__ A,
                                                          const double* __restrict__ b,
                                                          const int* __restrict__ mrows, long long N,
@@ -65,7 +94,9 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
                     double s = ar[0] * x[t][0];
 #pragma unroll
                     for (int k = 1; k < D; ++k) s = fma(ar[k], x[t][k], s);
-                    ok_m[t] &= __ballot((s - bi) < tol);
+                    // THR: `b` holds the thresholds of contains_thr_kernel
+                    if constexpr (THR) ok_m[t] &= __ballot(s < bi);
+                    else ok_m[t] &= __ballot((s - bi) < tol);
                 }
             }
             if (mode == 1) {
@@ -93,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
 
 template <int D>
 static void launch_contains_d(int P, int m_max, const double* A, const double* b, const int* mrows, long long N,
-                              const double* X, double tol, int mode, unsigned char* out, hipStream_t st) {
+                              const double* X, double tol, int mode, unsigned char* out, double* thr, hipStream_t st) {
     constexpr int PPL = (D <= 8) ? 4 : 2;
     long long blocks = (N + (long long)BLOCK * PPL - 1) / ((long long)BLOCK * PPL);
     if (blocks > 256ll * 32) blocks = 256ll * 32;
@@ -104,11 +135,19 @@ static void launch_contains_d(int P, int m_max, const double* A, const double* b
     if (chunks > (P + 31) / 32) chunks = (P + 31) / 32;
     if (chunks < 1) chunks = 1;
     if (mode == 0) (void)hipMemsetAsync(out, 0, (size_t)N, st);
-    hipLaunchKernelGGL((contains_kernel<D, PPL>), dim3((unsigned)blocks, (unsigned)chunks), dim3(BLOCK), 0, st, P,
+    if (thr && P > 0 && m_max > 0) {  // per-row thresholds first (P * m_max values: microseconds)
+        const long long n = (long long)P * m_max;
+        hipLaunchKernelGGL(contains_thr_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, n, b, tol,
+                           thr);
+        hipLaunchKernelGGL((contains_kernel<D, PPL, true>), dim3((unsigned)blocks, (unsigned)chunks), dim3(BLOCK), 0, st,
+                           P, m_max, A, thr, mrows, N, X, tol, mode, out);
+        return;
+    }
+    hipLaunchKernelGGL((contains_kernel<D, PPL, false>), dim3((unsigned)blocks, (unsigned)chunks), dim3(BLOCK), 0, st, P,
                        m_max, A, b, mrows, N, X, tol, mode, out);
 }
 
-#define PLP_CASE_C(K) case K: launch_contains_d<K>(P, m_max, A, b, mrows, N, X, abs_tol, mode, out, st); break;
+#define PLP_CASE_C(K) case K: launch_contains_d<K>(P, m_max, A, b, mrows, N, X, abs_tol, mode, out, thr, st); break;
 
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
                     const double* X, double abs_tol, int mode, unsigned char* out, void* scratch, hipStream_t st) {
@@ -117,12 +156,16 @@ int launch_contains(int P, int m_max, int d, const double* A, const double* b, c
     // PLP_CONTAINS_MFMA=1: dot products by v_mfma_f64_16x16x4_f64 (plp_contains_mfma.hip), verdicts bit-identical.
     // Off by default: measured on MI355X the f64 matrix pipe peaks where the vector FMA pipe does (75.6 vs 58 TFLOP/s in
     // scripts/microbench/mfma_f64_rate.hip, 78.6 nominal for both) and the contraction must pad k = d + 1 to a multiple
-    // of 4 (C3: 7 -> 8), so the matrix form of C3 cannot finish before 34 ms while this kernel needs 39 ms; the first
+    // of 4 (C3: 7 -> 8), so the matrix form of C3 cannot finish before 34 ms while this kernel needs 35 ms; the first
     // matrix-core version takes 78 ms (one accumulator, operand loads not double-buffered).
     const char* mf = getenv("PLP_CONTAINS_MFMA");
     if (scratch && mf && mf[0] == '1' &&
         launch_contains_mfma(P, m_max, d, A, b, mrows, N, X, abs_tol, mode, out, scratch, st) == 0)
         return 0;
+    // thresholds live in the context's scratch buffer (P * m_max doubles; PLP_CONTAINS_THR=0: the subtraction stays in
+    // the kernel, for A/B runs)
+    const char* th = getenv("PLP_CONTAINS_THR");
+    double* thr = (scratch && !(th && th[0] == '0')) ? reinterpret_cast<double*>(scratch) : nullptr;
     switch (d) {
         PLP_CASE_C(1) PLP_CASE_C(2) PLP_CASE_C(3) PLP_CASE_C(4) PLP_CASE_C(5) PLP_CASE_C(6)
         PLP_CASE_C(7) PLP_CASE_C(8) PLP_CASE_C(9) PLP_CASE_C(10) PLP_CASE_C(11) PLP_CASE_C(12)

@@ -652,6 +652,42 @@ def test_contains_vs_oracle(pa, oracle):
         pa.contains_batch(A, b, np.zeros((3, 4)))
 
 
+def test_contains_threshold_form_is_the_subtraction(pa, monkeypatch):
+    """contains_kernel compares the dot product with a per-row threshold thr = the smallest double at which
+    `(s - b) < tol` (polytope.py:217) stops holding, instead of subtracting per point.  One-dimensional polytopes with
+    a = 1 make s = x exactly, so points placed on and around every threshold probe the equivalence directly: b over 40
+    decades, both signs, zero, infinities and NaN; tol positive, zero, negative and infinite; x = b + tol and its 4
+    neighbours on either side, +-0, +-inf, NaN, the largest doubles (overflowing differences).  Must equal numpy's
+    evaluation of the reference expression and the kernel with the subtraction left in (PLP_CONTAINS_THR=0)."""
+    rng = np.random.default_rng(77)
+    mags = 10.0 ** rng.uniform(-20, 20, 120)
+    bs = np.concatenate([mags * rng.choice([-1.0, 1.0], mags.size), [0.0, -0.0, 1.0, 0.1, 1e308, -1e308, 5e-324,
+                                                                     np.inf, -np.inf, np.nan]])
+    P = bs.size
+    A = np.ones((P, 1, 1))
+    b = bs.reshape(P, 1)
+    for tol in (1e-7, 0.0, -1e-7, 1.0, 1e-300, np.inf, -np.inf):
+        xs = [0.0, -0.0, np.inf, -np.inf, np.nan, np.finfo(float).max, -np.finfo(float).max]
+        with np.errstate(all="ignore"):
+            for bi in bs:
+                c = bi + tol
+                lo = hi = c
+                xs.append(c)
+                for _ in range(4):
+                    lo = np.nextafter(lo, -np.inf)
+                    hi = np.nextafter(hi, np.inf)
+                    xs += [lo, hi]
+                xs += [bi, np.nextafter(bi, np.inf), np.nextafter(bi, -np.inf)]
+            X = np.array(xs, dtype=np.float64).reshape(1, -1)
+            want = ((X - b) < tol)  # [P, N]: one row per polytope, the reference's expression
+        got = pa.contains_batch(A, b, X, abs_tol=tol, region=False)
+        assert np.array_equal(got.astype(bool), want), (tol, int((got.astype(bool) != want).sum()))
+        monkeypatch.setenv("PLP_CONTAINS_THR", "0")
+        plain = pa.contains_batch(A, b, X, abs_tol=tol, region=False)
+        monkeypatch.delenv("PLP_CONTAINS_THR")
+        assert np.array_equal(plain, got), tol
+
+
 # ------------------------------------------------------------------------------ quickhull kernels
 @pytest.mark.parametrize("d", [2, 3, 5, 8])
 def test_assign_golden(pa, d):
