@@ -43,6 +43,7 @@ extern "C" {
 #define PLP_EUNSUPPORTED 2 /* size outside the engine's envelope (d > 16, too many rows)  */
 #define PLP_EHIP 3         /* HIP runtime error                                          */
 #define PLP_ENODEVICE 4    /* no gfx950 device visible                                   */
+#define PLP_ENONFINITE 5   /* an input held inf or nan (only with plp_ctx_set_check_finite) */
 
 /* flags[] bits written by plp_reduce_batch (see polytope/polytope.py:1053-1163) */
 #define PLP_RF_EMPTY 1  /* not full-dimensional: reduce() returns Polytope()       (:1081-1082) */
@@ -58,6 +59,12 @@ int plp_device_count(void);
 const char *plp_last_error(void);
 
 int plp_ctx_create(int device, plp_ctx **out);
+/* on != 0: the host-pointer entry points plp_lp_solve_batch / plp_cheby_batch / plp_bbox_batch / plp_reduce_batch return
+ * PLP_ENONFINITE, writing no output, when c / G / h resp. A / b hold an inf or a nan -- the ValueError
+ * scipy.optimize.linprog raises for such input behind solvers.lpsolve (solvers.py:152-154).  Large batches are checked
+ * by the threads that stage them for upload, at no extra pass over the data.  Off by default: the kernels then report
+ * such LPs with status 4. */
+int plp_ctx_set_check_finite(plp_ctx *ctx, int on);
 int plp_ctx_destroy(plp_ctx *ctx);
 /* block until everything enqueued on `stream` (NULL = default stream) has finished */
 int plp_ctx_synchronize(plp_ctx *ctx, void *stream);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PLP_LIB overrides the path (A/B runs of kernel variants); it must still be a libplp_hip build
 LIB_PATH = os.environ.get("PLP_LIB") or os.path.join(_HERE, "libplp_hip.so")
 
-PLP_OK, PLP_EINVAL, PLP_EUNSUPPORTED, PLP_EHIP, PLP_ENODEVICE = 0, 1, 2, 3, 4
+PLP_OK, PLP_EINVAL, PLP_EUNSUPPORTED, PLP_EHIP, PLP_ENODEVICE, PLP_ENONFINITE = 0, 1, 2, 3, 4, 5
 RF_EMPTY, RF_EARLY, RF_MINREP, RF_LPFAIL = 1, 2, 4, 8
 
 _dp = C.POINTER(C.c_double)
@@ -27,6 +27,7 @@ SIGNATURES = {
     "plp_device_count": (C.c_int, []),
     "plp_last_error": (C.c_char_p, []),
     "plp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "plp_ctx_set_check_finite": (C.c_int, [_vp, C.c_int]),
     "plp_ctx_destroy": (C.c_int, [_vp]),
     "plp_ctx_synchronize": (C.c_int, [_vp, _vp]),
     "plp_lp_solve_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -122,6 +123,8 @@ def check(rc, what):
             raise ValueError("%s: %s" % (what, msg))
         if rc == PLP_EINVAL:
             raise ValueError("%s: %s" % (what, msg))
+        if rc == PLP_ENONFINITE:  # the exception class scipy.optimize.linprog raises on inf/nan input
+            raise ValueError("%s: %s" % (what, msg))
         raise PlpError("%s failed (code %d): %s" % (what, rc, msg))
 
 
@@ -132,6 +135,8 @@ class Context:
         lib = load()
         h = _vp()
         check(lib.plp_ctx_create(int(device), C.byref(h)), "plp_ctx_create")
+        # inf / nan in the inputs of the host-pointer LP batches: found by the library while it stages them (ValueError)
+        check(lib.plp_ctx_set_check_finite(h, 1), "plp_ctx_set_check_finite")
         self.handle = h
         self.device = int(device)
 

@@ -84,7 +84,7 @@ def lpsolve_batch(c, G, h, m=None):
     c = _np(c).reshape(B, n)
     h = _np(h).reshape(B, m_max)
     mm = None if m is None else _np(m, np.int32).reshape(B)
-    _finite_or_raise("lpsolve_batch", c, G, h)
+    # (inf / nan in the inputs: ValueError from the library, which checks them while staging -- plp_ctx_set_check_finite)
     x = np.empty((B, n))
     fun = np.empty(B)
     status = np.empty(B, np.int32)
@@ -119,7 +119,7 @@ def cheby_ball_batch(A, b, m=None):
     B, m_max, d = A.shape
     b = _np(b).reshape(B, m_max)
     mm = None if m is None else _np(m, np.int32).reshape(B)
-    _finite_or_raise("cheby_ball_batch", A, b)
+    # (inf / nan in the inputs: ValueError from the library, which checks them while staging -- plp_ctx_set_check_finite)
     r = np.empty(B)
     xc = np.empty((B, d))
     status = np.empty(B, np.int32)
@@ -154,7 +154,7 @@ def bbox_batch(A, b, m=None):
     B, m_max, d = A.shape
     b = _np(b).reshape(B, m_max)
     mm = None if m is None else _np(m, np.int32).reshape(B)
-    _finite_or_raise("bbox_batch", A, b)
+    # (inf / nan in the inputs: ValueError from the library, which checks them while staging -- plp_ctx_set_check_finite)
     lb = np.empty((B, d))
     ub = np.empty((B, d))
     status = np.empty(B, np.int32)
@@ -203,7 +203,7 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     B, m_max, d = A.shape
     b = _np(b).reshape(B, m_max)
     mm = None if m is None else _np(m, np.int32).reshape(B)
-    _finite_or_raise("reduce_batch", A, b)
+    # (inf / nan in the inputs: ValueError from the library, which checks them while staging -- plp_ctx_set_check_finite)
     keep = np.empty(B, np.uint64)
     flags = np.empty(B, np.int32)
     r = np.empty(B)

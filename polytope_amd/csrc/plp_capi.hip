@@ -10,11 +10,13 @@
 #include <algorithm>
 #include <initializer_list>
 #include <string>
+#include <utility>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/plp.h"
 #include "plp_kernels.hpp"
+#include "plp_stage.hpp"
 
 namespace {
 
@@ -54,6 +56,14 @@ struct plp_ctx {
     size_t mf_bytes = 0;
     hipStream_t mf_stream = nullptr;
     bool mf_used = false;
+    // large host-pointer batches (plp_stage.hpp): staging threads, pinned staging buffer, copy stream, one event per chunk
+    plp::StagePool* pool = nullptr;
+    char* stage = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t stage_ev[16] = {};
+    int stage_nev = 0;
+    bool check_finite = false;  // plp_ctx_set_check_finite
 };
 
 namespace {
@@ -129,8 +139,151 @@ int copy_in(plp_ctx* ctx, hipStream_t st, std::initializer_list<Span> spans) {
     return PLP_OK;
 }
 
+// Large host-pointer batch: the per-unit input arrays go to the device chunk by chunk (plp_stage.hpp) and `launch(lo, hi)`
+// enqueues the kernels of units [lo, hi) on `st` behind the arrival of their chunk.  *staged = false: not applicable
+// (small batch, PLP_STAGE=0, or a resource could not be had) and nothing was done -- the caller copies as before.
+struct StageArray {
+    const void* host;
+    void* dev;
+    size_t unit_bytes;
+    bool f64 = false;  // doubles (checked for inf / nan when the context asks for it)
+};
+
+const char* const NONFINITE_MSG = "input must not contain values inf, nan, or None";
+
+// plp_ctx_set_check_finite, inputs that are not staged chunk-wise: one pass over each array
+int finite_or_fail(plp_ctx* ctx, std::initializer_list<std::pair<const double*, size_t>> arrays) {
+    if (!ctx->check_finite) return PLP_OK;
+    for (const auto& a : arrays)
+        if (a.first && a.second && plp::any_nonfinite_f64(reinterpret_cast<const char*>(a.first), a.second * 8))
+            return fail(PLP_ENONFINITE, "%s", NONFINITE_MSG);
+    return PLP_OK;
+}
+
+template <typename F>
+int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::initializer_list<StageArray> arrays, F launch,
+               bool* staged) {
+    *staged = false;
+    size_t unit = 0;
+    for (const StageArray& a : arrays)
+        if (a.host) unit += a.unit_bytes;
+    const size_t total = unit * (size_t)B;
+    const char* off = getenv("PLP_STAGE");
+    if ((off && off[0] == '0') || total < (8u << 20) || B < 4 * align) return PLP_OK;
+    if (!ctx->pool) {
+        const char* nt = getenv("PLP_STAGE_THREADS");
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = nt ? atoi(nt) : (hw >= 16 ? 7 : (hw >= 4 ? (int)hw / 2 - 1 : 1));
+        if (n < 1) n = 1;
+        if (n > 32) n = 32;
+        ctx->pool = new plp::StagePool(n);
+    }
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->copy_stream = nullptr;
+        return PLP_OK;
+    }
+    while (ctx->stage_nev < 16) {
+        if (hipEventCreateWithFlags(&ctx->stage_ev[ctx->stage_nev], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return PLP_OK;
+        }
+        ++ctx->stage_nev;
+    }
+    if (total > ctx->stage_bytes) {
+        if (ctx->stage) (void)hipHostFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_bytes = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->stage), total + total / 4, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return PLP_OK;
+        }
+        ctx->stage_bytes = total + total / 4;
+    }
+    int64_t nch = (int64_t)(total / (4u << 20));
+    nch = nch < 2 ? 2 : (nch > 16 ? 16 : nch);
+    int64_t per = (B + nch - 1) / nch;
+    per = (per + align - 1) / align * align;
+    nch = (B + per - 1) / per;
+    std::vector<std::vector<plp::StagePiece>> chunks((size_t)nch);
+    size_t so = 0;
+    for (int64_t c = 0; c < nch; ++c) {
+        const int64_t lo = c * per, hi = lo + per < B ? lo + per : B;
+        for (const StageArray& a : arrays) {
+            if (!a.host) continue;
+            const size_t bytes = (size_t)(hi - lo) * a.unit_bytes;
+            chunks[(size_t)c].push_back({static_cast<const char*>(a.host) + (size_t)lo * a.unit_bytes, ctx->stage + so,
+                                         static_cast<char*>(a.dev) + (size_t)lo * a.unit_bytes, bytes,
+                                         a.f64 && ctx->check_finite});
+            so += (bytes + 63) & ~(size_t)63;
+            if (so > ctx->stage_bytes) return fail(PLP_EINVAL, "staging layout overflow");  // cannot happen (25 % slack)
+        }
+    }
+    // the copy stream must not overwrite device inputs an earlier call on `st` may still be reading
+    HIP_TRY(hipEventRecord(ctx->stage_ev[15], st));
+    HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, ctx->stage_ev[15], 0));
+    const bool timing = getenv("PLP_STAGE_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    ctx->pool->start(chunks);
+    *staged = true;
+    int rc = PLP_OK;
+    for (int64_t c = 0; c < nch && rc == PLP_OK; ++c) {
+        ctx->pool->wait((int)c);
+        if (timing) fprintf(stderr, "[stage] chunk %d staged at %.0f us\n", (int)c, us());
+        if (ctx->pool->nonfinite()) break;  // (set only when the context checks its inputs)
+        for (const plp::StagePiece& p : chunks[(size_t)c]) {
+            const hipError_t e = hipMemcpyAsync(p.dev, p.dst, p.bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e != hipSuccess) rc = fail(PLP_EHIP, "staged upload: %s", hipGetErrorString(e));
+        }
+        if (rc == PLP_OK && (hipEventRecord(ctx->stage_ev[c % 15], ctx->copy_stream) != hipSuccess ||
+                             hipStreamWaitEvent(st, ctx->stage_ev[c % 15], 0) != hipSuccess))
+            rc = fail(PLP_EHIP, "staged upload: event");
+        const int64_t lo = c * per, hi = lo + per < B ? lo + per : B;
+        if (rc == PLP_OK) rc = launch(lo, hi);
+    }
+    ctx->pool->finish();
+    if (timing) {
+        fprintf(stderr, "[stage] all enqueued at %.0f us\n", us());
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        fprintf(stderr, "[stage] copies done at %.0f us\n", us());
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[stage] kernels done at %.0f us (%d chunks, %zu bytes)\n", us(), (int)nch, total);
+    }
+    if (rc == PLP_OK && ctx->pool->nonfinite()) rc = fail(PLP_ENONFINITE, "%s", NONFINITE_MSG);
+    if (rc != PLP_OK) {  // nothing of this call may still be in flight when the caller sees the error
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(st);
+    }
+    return rc;
+}
+
 // copies the outputs to the host and synchronises the stream
 int copy_out(plp_ctx* ctx, hipStream_t st, std::initializer_list<Span> spans) {
+    // after a staged upload (plp_stage.hpp): the outputs (neighbours in the arena) come back as ONE copy into the pinned
+    // staging buffer and the staging threads hand them out -- five pageable D2H copies of a C2 batch cost 1.5 ms
+    if (ctx->pool && ctx->stage) {
+        size_t lo = ~(size_t)0, hi = 0;
+        for (const Span& sp : spans) {
+            if (!sp.bytes || !sp.host_out) continue;
+            const size_t off = (size_t)(static_cast<char*>(sp.dev) - ctx->arena);
+            lo = off < lo ? off : lo;
+            hi = off + sp.bytes > hi ? off + sp.bytes : hi;
+        }
+        if (hi > lo && hi - lo >= SMALL_XFER && hi - lo <= ctx->stage_bytes) {
+            HIP_TRY(hipMemcpyAsync(ctx->stage, ctx->arena + lo, hi - lo, hipMemcpyDeviceToHost, st));
+            std::vector<std::vector<plp::StagePiece>> one(1);
+            for (const Span& sp : spans)
+                if (sp.bytes && sp.host_out)
+                    one[0].push_back({ctx->stage + ((size_t)(static_cast<char*>(sp.dev) - ctx->arena) - lo),
+                                      static_cast<char*>(sp.host_out), nullptr, sp.bytes});
+            HIP_TRY(hipStreamSynchronize(st));
+            ctx->pool->start(one);
+            ctx->pool->wait(0);
+            ctx->pool->finish();
+            return PLP_OK;
+        }
+    }
     if (fits_small(ctx, spans) && ensure_pin(ctx) == PLP_OK) {
         size_t lo = SMALL_XFER, hi = 0;
         for (const Span& sp : spans) {
@@ -208,6 +361,12 @@ int plp_ctx_create(int device, plp_ctx** out) {
     return PLP_OK;
 }
 
+int plp_ctx_set_check_finite(plp_ctx* ctx, int on) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    ctx->check_finite = on != 0;
+    return PLP_OK;
+}
+
 int plp_ctx_destroy(plp_ctx* ctx) {
     if (!ctx) return PLP_OK;
     (void)hipSetDevice(ctx->device);
@@ -217,6 +376,10 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_out) (void)hipFree(ctx->rd_out);
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
+    delete ctx->pool;
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    for (int i = 0; i < ctx->stage_nev; ++i) (void)hipEventDestroy(ctx->stage_ev[i]);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PLP_OK;
@@ -268,11 +431,26 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
     int32_t* dst = a.take<int32_t>(B);
     int32_t* dit = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    rc = copy_in(ctx, st, {{dc, c, nullptr, nc * 8}, {dG, G, nullptr, nG * 8}, {dh, h, nullptr, nh * 8},
-                           {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
+    const size_t mn = (size_t)m_max * n;
+    rc = staged_run(ctx, st, B, 64,
+                    {{c, dc, (size_t)n * 8, true}, {G, dG, mn * 8, true}, {h, dh, (size_t)m_max * 8, true}, {m, dm, 4}},
+                    [&](int64_t lo, int64_t hi) {
+                        return plp_lp_solve_batch_dev(ctx, st, hi - lo, m_max, n, dc + (size_t)lo * n, dG + (size_t)lo * mn,
+                                                      dh + (size_t)lo * m_max, m ? dm + lo : nullptr, dx + (size_t)lo * n,
+                                                      dfun + lo, dst + lo, dit + lo);
+                    },
+                    &staged);
     if (rc) return rc;
-    rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
-    if (rc) return rc;
+    if (!staged) {
+        rc = finite_or_fail(ctx, {{c, nc}, {G, nG}, {h, nh}});
+        if (rc) return rc;
+        rc = copy_in(ctx, st, {{dc, c, nullptr, nc * 8}, {dG, G, nullptr, nG * 8}, {dh, h, nullptr, nh * 8},
+                               {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+        if (rc) return rc;
+        rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
+        if (rc) return rc;
+    }
     return copy_out(ctx, st, {{dx, nullptr, x, nc * 8}, {dfun, nullptr, fun, (size_t)B * 8},
                               {dst, nullptr, status, (size_t)B * 4}, {dit, nullptr, iters, iters ? (size_t)B * 4 : 0}});
 }
@@ -312,10 +490,23 @@ int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, 
     double* dxc = a.take<double>(nx);
     int32_t* dst = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
+    const size_t md = (size_t)m_max * d;
+    rc = staged_run(ctx, st, B, 64, {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
+                    [&](int64_t lo, int64_t hi) {
+                        return plp_cheby_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
+                                                   m ? dm + lo : nullptr, dr + lo, dxc + (size_t)lo * d, dst + lo);
+                    },
+                    &staged);
     if (rc) return rc;
-    rc = plp_cheby_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dr, dxc, dst);
-    if (rc) return rc;
+    if (!staged) {
+        rc = finite_or_fail(ctx, {{A, nA}, {b, nb}});
+        if (rc) return rc;
+        rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+        if (rc) return rc;
+        rc = plp_cheby_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dr, dxc, dst);
+        if (rc) return rc;
+    }
     return copy_out(ctx, st, {{dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
                               {dst, nullptr, status, (size_t)B * 4}});
 }
@@ -354,10 +545,23 @@ int plp_bbox_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, c
     double* dub = a.take<double>(nx);
     int32_t* dst = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
+    const size_t md = (size_t)m_max * d;
+    rc = staged_run(ctx, st, B, 64, {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
+                    [&](int64_t lo, int64_t hi) {
+                        return plp_bbox_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
+                                                  m ? dm + lo : nullptr, dlb + (size_t)lo * d, dub + (size_t)lo * d, dst + lo);
+                    },
+                    &staged);
     if (rc) return rc;
-    rc = plp_bbox_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dlb, dub, dst);
-    if (rc) return rc;
+    if (!staged) {
+        rc = finite_or_fail(ctx, {{A, nA}, {b, nb}});
+        if (rc) return rc;
+        rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+        if (rc) return rc;
+        rc = plp_bbox_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, dlb, dub, dst);
+        if (rc) return rc;
+    }
     return copy_out(ctx, st, {{dlb, nullptr, lb, nx * 8}, {dub, nullptr, ub, nx * 8}, {dst, nullptr, status, (size_t)B * 4}});
 }
 
@@ -399,10 +603,26 @@ int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A,
     double* dxc = a.take<double>(nx);
     int32_t* dnlp = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
-    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    // large batches: chunked upload with the kernels of earlier chunks running meanwhile (tiles hold 16 polytopes)
+    bool staged = false;
+    const size_t md = (size_t)m_max * d;
+    rc = staged_run(ctx, st, B, 16,
+                    {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
+                    [&](int64_t lo, int64_t hi) {
+                        return plp_reduce_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
+                                                    m ? dm + lo : nullptr, abs_tol, dkeep + lo, dfl + lo, dr + lo,
+                                                    dxc + (size_t)lo * d, dnlp + lo);
+                    },
+                    &staged);
     if (rc) return rc;
-    rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
-    if (rc) return rc;
+    if (!staged) {
+        rc = finite_or_fail(ctx, {{A, nA}, {b, nb}});
+        if (rc) return rc;
+        rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+        if (rc) return rc;
+        rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
+        if (rc) return rc;
+    }
     return copy_out(ctx, st, {{dkeep, nullptr, keep, (size_t)B * 8}, {dfl, nullptr, flags, (size_t)B * 4},
                               {dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
                               {dnlp, nullptr, nlp, (size_t)B * 4}});

@@ -652,6 +652,66 @@ def test_contains_vs_oracle(pa, oracle):
         pa.contains_batch(A, b, np.zeros((3, 4)))
 
 
+def test_reduce_host_batch_chunked_upload_equals_one_copy(pa, monkeypatch):
+    """Host-pointer batches of 8 MB and more go to the device in chunks staged by a thread pool while the kernels of
+    earlier chunks run (plp_stage.hpp); PLP_STAGE=0 is the single-copy path.  Same outputs bit for bit -- ragged row
+    counts, a batch size that is no multiple of the chunk or the tile, two shapes, repeated calls on one context."""
+    from polytope_amd.synth import random_hpolytopes
+    for (B, m, d, seed) in [(40013, 16, 3, 5), (100000, 16, 3, 6), (9001, 64, 16, 7)]:
+        A, b = random_hpolytopes(B, m, d, seed=seed, stream=0)
+        rows = np.random.default_rng(seed).integers(max(d + 2, m - 5), m + 1, B).astype(np.int32)
+        for mr in (None, rows):
+            monkeypatch.setenv("PLP_STAGE", "0")
+            ref = pa.reduce_batch(A, b, m=mr)
+            monkeypatch.delenv("PLP_STAGE")
+            for _ in range(2):
+                got = pa.reduce_batch(A, b, m=mr)
+                for k in ref:
+                    assert np.array_equal(np.asarray(ref[k]).view(np.uint8), np.asarray(got[k]).view(np.uint8)), (B, m, d, k)
+    # the other host-pointer LP batches take the same route
+    A, b = random_hpolytopes(70001, 16, 3, seed=11, stream=0)
+    rows = np.random.default_rng(11).integers(5, 17, 70001).astype(np.int32)
+    c = np.random.default_rng(12).standard_normal((70001, 3))
+    calls = [lambda: pa.cheby_ball_batch(A, b, m=rows), lambda: pa.bbox_batch(A, b, m=rows),
+             lambda: pa.lpsolve_batch(c, A, b, m=rows)]
+    for call in calls:
+        monkeypatch.setenv("PLP_STAGE", "0")
+        ref = call()
+        monkeypatch.delenv("PLP_STAGE")
+        got = call()
+        for k in ref:
+            assert np.array_equal(np.asarray(ref[k]).view(np.uint8), np.asarray(got[k]).view(np.uint8)), k
+
+
+def test_host_batches_reject_inf_and_nan_like_linprog(pa, monkeypatch):
+    """inf / nan in c, G, h resp. A, b of a host-pointer LP batch: ValueError (what scipy.optimize.linprog raises behind
+    solvers.lpsolve, solvers.py:152-154), found by the library (plp_ctx_set_check_finite) -- by the staging threads of a
+    large batch, by one pass before the copy otherwise -- wherever the value sits, and the context keeps working."""
+    from polytope_amd.synth import random_hpolytopes
+    A, b = random_hpolytopes(60000, 16, 3, seed=9, stream=0)
+    good = pa.reduce_batch(A, b)
+    for stage in ("1", "0"):
+        monkeypatch.setenv("PLP_STAGE", stage)
+        for (arr, idx, val) in [(A, (0, 0, 0), np.nan), (A, (59999, 15, 2), np.inf), (b, (31234, 7), -np.inf),
+                                (b, (12345, 0), np.nan)]:
+            old = arr[idx]
+            arr[idx] = val
+            with pytest.raises(ValueError, match="inf, nan"):
+                pa.reduce_batch(A, b)
+            arr[idx] = old
+        again = pa.reduce_batch(A, b)
+        for k in good:
+            assert np.array_equal(good[k], again[k]), k
+    monkeypatch.delenv("PLP_STAGE")
+    As, bs = A[:50].copy(), b[:50].copy()
+    bs[3, 2] = np.nan
+    for fn in (pa.reduce_batch, pa.cheby_ball_batch, pa.bbox_batch):
+        with pytest.raises(ValueError, match="inf, nan"):
+            fn(As, bs)
+    with pytest.raises(ValueError, match="inf, nan"):
+        pa.lpsolve_batch(np.array([[np.nan]]), np.array([[[1.0], [-1.0]]]), np.array([[1.0, 1.0]]))
+
+
 def test_contains_threshold_form_is_the_subtraction(pa, monkeypatch):
     """contains_kernel compares the dot product with a per-row threshold thr = the smallest double at which
     `(s - b) < tol` (polytope.py:217) stops holding, instead of subtracting per point.  One-dimensional polytopes with
