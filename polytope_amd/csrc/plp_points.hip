@@ -200,24 +200,12 @@ __global__ __launch_bounds__(BLOCK) void assign_kernel(long long N, const double
     __syncthreads();
     const long long stride = (long long)gridDim.x * BLOCK;
     const long long nloop = (N + stride - 1) / stride;
-    // the point of the NEXT pass is requested before this pass's facet scan: with ~16 wavefronts per CU and 4 KB per
-    // wavefront in flight the loads of one pass alone cover HBM's latency only up to ~3 TB/s
-    double xn[D];
-    const long long q_first = (long long)blockIdx.x * BLOCK + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < D; ++k) xn[k] = q_first < N ? X[q_first * D + k] : 0.0;
     for (long long it = 0; it < nloop; ++it) {
         const long long q = it * stride + (long long)blockIdx.x * BLOCK + threadIdx.x;
         const bool inb = q < N;
         double x[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = xn[k];
-        {
-            const long long qn = q + stride;
-            const bool inn = (it + 1 < nloop) && qn < N;
-#pragma unroll
-            for (int k = 0; k < D; ++k) xn[k] = inn ? X[qn * D + k] : 0.0;
-        }
+        for (int k = 0; k < D; ++k) x[k] = inb ? X[q * D + k] : 0.0;
         int fop = -1;
         double dd = 0.0;
         for (int f0 = 0; f0 < F; f0 += FCHUNK) {
@@ -277,7 +265,8 @@ static void launch_assign_d(long long N, const double* X, int F, const double* n
     // few blocks when there are few facets (HBM/atomic bound: one global atomic per (block, facet));
     // more when the per-point facet scan dominates (VALU bound from F ~ 32 on)
     long long cap = 256ll * 4 * (F <= 16 ? 1 : (F <= 128 ? F / 16 : 8));
-    if (const char* ab = getenv("PLP_ASSIGN_BLOCKS")) cap = atoll(ab);  // A/B runs
+    // (requesting the next pass's point before this pass's facet scan was measured: 29.8 us against 27.8 us per launch
+    // at C5 / F = 9 under rocprofv3 -- no gain, not kept; 512 .. 8192 workgroups instead of this cap: equal or slower)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     unsigned long long* mb = reinterpret_cast<unsigned long long*>(maxd);

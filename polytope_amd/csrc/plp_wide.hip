@@ -131,9 +131,13 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             if (!bland) {  // largest |c|: its bit pattern orders like an unsigned integer
                 const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
                 const unsigned mh = wave_max_u32(kh);
-                const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
-                const unsigned ml = wave_max_u32(kl);
-                e = __ffsll((long long)__ballot(elig & (kh == mh) & (kl == ml))) - 1;
+                uint64_t top = __ballot(elig & (kh == mh));
+                if (top & (top - 1ull)) {  // several columns share the high word (rare): the low words decide
+                    const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
+                    const unsigned ml = wave_max_u32(kl);
+                    top = __ballot(elig & (kh == mh) & (kl == ml));
+                }
+                e = __ffsll((long long)top) - 1;
             } else {  // Bland: lowest variable id among the eligible columns
                 const int id = elig ? sh.cv[lane] : 0x7fffffff;
                 const int idmin = wave_min_i32(id);
@@ -158,7 +162,11 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
         const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
         const unsigned kl = (unsigned)(ql ^ sm);
         const unsigned mh = wave_min_u32(kh);
-        const unsigned ml = wave_min_u32((kh == mh) ? kl : 0xffffffffu);
+        // one row alone at the minimal high word (the usual case): its low word is the minimum, no second reduction
+        const uint64_t hib = __ballot(kh == mh);
+        unsigned ml;
+        if (hib & (hib - 1ull)) ml = wave_min_u32((kh == mh) ? kl : 0xffffffffu);
+        else ml = (unsigned)__builtin_amdgcn_readlane((int)kl, __ffsll((long long)hib) - 1);
         if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; break; }
         const bool tie = erow & (kh == mh) & (kl == ml);
         const int mhs = (int)(mh ^ 0x80000000u);   // (the minimum is >= 0 in a normal pivot; the forced one ignores ndeg)
@@ -190,6 +198,8 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
         __syncthreads();
         {
             // row r: T * (1/a_r)  (f = 0);  every other row: T - a_i * rho  (scale 1)
+            // (scaling the pivot row in place inside the branch above -- inline asm, so that it stays a branch -- costs
+            // a copy of the row vector: 136 VGPRs instead of 102, three waves per SIMD; not kept)
             const double f = is_r ? 0.0 : a;
             const double sc = is_r ? pinv : 1.0;
             const double rb = sh.rho[NC];
