@@ -7,6 +7,14 @@ namespace plp {
 template <int D>
 static int launch_r2_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
                        unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    // PLP_REDUCE_R1=1 (A/B): one row per lane, one polytope of up to 64 rows per wavefront -- twice the wavefronts
+    const char* r1 = getenv("PLP_REDUCE_R1");
+    if (r1 && r1[0] == '1' && m_max > 32)
+        return launch_reduce_r_dg<D, 64, 1>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    // PLP_REDUCE_LAZY=1: one polytope per wavefront, F3 / F2 without a stored dictionary (plp_lazy.hpp)
+    const char* lz = getenv("PLP_REDUCE_LAZY");
+    if (lz && lz[0] == '1')
+        return launch_reduce_lazy<D>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     if (m_max <= 32) return launch_reduce_r_dg<D, 16, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     return launch_reduce_r_dg<D, 32, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
 }

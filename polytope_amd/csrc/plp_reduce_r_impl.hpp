@@ -13,6 +13,7 @@
 
 #include "plp_kernels.hpp"
 #include "plp_simplex_r.hpp"
+#include "plp_lazy.hpp"
 
 namespace plp {
 
@@ -60,6 +61,7 @@ __device__ __forceinline__ uint64_t spread4(uint64_t x) {
 template <int R, int GS>
 __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
     if constexpr (R == 4) return spread4(x);
+    if constexpr (R == 1) return x;
     uint64_t out = 0ull;
 #pragma unroll
     for (int l = 0; l < GS; ++l) out |= ((x >> l) & 1ull) << (R * l);
@@ -94,7 +96,9 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 
 // One tile = the NG = RBLOCK / GS polytopes starting at polytope `tile` (the body of reduce_r_kernel; a device function
 // so that reduce_r_mix_kernel can give the last tiles of a launch a different shape).
-template <int D, int GS, int R>
+// LAZY (GS = 64, R = 1: one polytope per wavefront): the F3 / F2 LPs run on plp_lazy.hpp -- no dictionary is carried,
+// the K_STEPS * D doubles of LDS behind the tile's arrays hold the pivot rows of the LP in progress.
+template <int D, int GS, int R, bool LAZY = false>
 __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -103,6 +107,7 @@ __device__ __forceinline__ void reduce_r_tile(
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int RSH = R == 8 ? 3 : (R == 4 ? 2 : (R == 2 ? 1 : 0));  // log2(R)
     static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows per lane");
+    static_assert(!LAZY || (GS == 64 && R == 1 && RBLOCK == 64), "lazy LPs: one polytope per wavefront and workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int gs = GS;
     const Grp g(gs);
@@ -116,6 +121,7 @@ __device__ __forceinline__ void reduce_r_tile(
     double* myA = sA + (size_t)gib * rows * D;
     double* myb = sb + (size_t)gib * rows;
     double* myan = san + (size_t)gib * rows;
+    double* lzrho = san + (size_t)NG * rows;  // [K_STEPS][D] (LAZY)
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
@@ -148,6 +154,57 @@ __device__ __forceinline__ void reduce_r_tile(
         // (force_retry: test hook, PLP_REDUCE_RETRY_ALL=1 sends every polytope through that second pass)
         bool retry = force_retry != 0;
         // ---------------------------------------------------------------- F1: Chebyshev ball
+        if constexpr (LAZY) {
+            // one polytope per wavefront: F1 on the one-LP-per-wavefront engine (plp_wide.hpp: the entering column is
+            // wave-uniform, the row a register vector); set-up and read-out as in the branch below
+            constexpr int NC = D + 1;
+            wide::WideShared<NC>& sh = *reinterpret_cast<wide::WideShared<NC>*>(lzrho);
+            static_assert(sizeof(wide::WideShared<NC>) <= lazy::lds_bytes<D>(), "F1's LDS block fits the pivot-row area");
+            const int lane = g.lane;
+            const bool h = valid & (lane < m) & (m <= rows);
+            has = h ? 1u : 0u;
+            wide::v16d Tv = (wide::v16d)(0.0);
+            double T16 = 0.0;
+            double nrm2 = 0.0;
+            bool finite = true;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                const double v = h ? myA[row0 * D + kk] : 0.0;
+                ROW_SET(kk, v);
+                nrm2 = nrm2 + v * v;
+                finite = finite & isfinite(v);
+            }
+            const double bk = h ? myb[row0] : 0.0;
+            finite = finite & isfinite(bk);
+            const double nrm = sqrt(nrm2);
+            myan[row0] = 1.0 / nrm;
+            const bool zero = !(nrm > 0.0);
+            bool rowact = h & !zero;
+            ROW_SET(D, rowact ? nrm : 0.0);
+            double beta = rowact ? bk : 0.0;
+            int rowvar = NC + lane, rowneg = 0;
+            if (lane <= NC) {
+                sh.cost[lane] = lane == D ? -1.0 : 0.0;
+                sh.cv[lane] = (lane + 1) << 1;
+            }
+            const bool infeasible0 = __ballot(h & zero & (bk < -TOL_FEAS)) != 0;
+            const bool bad = (__ballot(!finite) != 0) | (m > rows);
+            __syncthreads();
+            int st1, it1 = 0;
+            if (!valid | bad) st1 = ST_NUM;
+            else if (infeasible0) st1 = ST_INFEAS;
+            else st1 = wide::wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bk / nrm, it1);
+            const double mine = rowneg ? -beta : beta;
+#pragma unroll
+            for (int j = 0; j <= D; ++j) {
+                const uint64_t ob = __ballot(rowvar == j);
+                const double xj = ob ? wide::uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+                if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
+            }
+            ball = (st1 == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+            fulldim = ball & (rr > abs_tol);
+            __syncthreads();  // (the pivot-row area is reused by the F3 / F2 LPs)
+        } else
         {
 #if PLP_R_FAST
             SimplexR<D + 1, R, false, true> S;  // forced first pivot handed to run_fast
@@ -296,6 +353,9 @@ __device__ __forceinline__ void reduce_r_tile(
             if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
             else stage = (neq > 3 * D) ? 1 : 2;
         }
+#ifdef PLP_DEBUG_SKIP_LPS
+        stage = 0;  // debug timing build: F1 + dedupe only
+#endif
         // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
         if (__any(stage == 1)) {
             const bool go = stage == 1;
@@ -309,34 +369,46 @@ __device__ __forceinline__ void reduce_r_tile(
                 const int kx = it >> 1;
                 const bool up = it & 1;
                 double xck = 0.0;
-                SimplexR<D, R, false, false> S;
-                S.reset(D, __popcll(live), row0);
 #pragma unroll
-                for (int kk = 0; kk < D; ++kk) {
-                    xck = (kk == kx) ? xc[kk] : xck;
-                    S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
+                for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
+                struct { int status; double negz; } S;
+                if constexpr (LAZY) {
+                    S.status = ST_NUM;
+                    S.negz = 0.0;
+                    if (go)  // (wave-uniform: one polytope per wavefront)
+                        S.status = lazy::solve<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                                  fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, lzrho, S.negz);
+                    retry = retry | (go & (S.status == ST_RETRY));
                 }
+                SimplexR<D, R, false, false> S_;
+                if constexpr (!LAZY) {
+                S_.reset(D, __popcll(live), row0);
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) S_.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
 #pragma unroll
-                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
-                    S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
+                    for (int kk = 0; kk < D; ++kk) S_.T[k][kk] = myA[(row0 + k) * D + kk];
+                    S_.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
                 }
-                S.ract = lloc;
-                S.mode = go ? M_P2 : M_DONE;
+                S_.ract = lloc;
+                S_.mode = go ? M_P2 : M_DONE;
 #if PLP_R_FAST
-                S.template run_fast<GS>(g);
-                retry = retry | (go & (S.status == ST_RETRY));
+                S_.template run_fast<GS>(g);
+                retry = retry | (go & (S_.status == ST_RETRY));
 #ifdef PLP_STAGE_STATS
                 {
-                    const int wm = stat_wave_max(go ? S.iters : 0);
+                    const int wm = stat_wave_max(go ? S_.iters : 0);
                     if (threadIdx.x == 0) { PLP_STAT_ADD(3, wm); PLP_STAT_ADD(10, 1); }
-                    if (go & (g.gl == 0)) { PLP_STAT_ADD(4, S.iters); PLP_STAT_ADD(5, 1); }
+                    if (go & (g.gl == 0)) { PLP_STAT_ADD(4, S_.iters); PLP_STAT_ADD(5, 1); }
                 }
 #endif
 #else
-                S.run(g);
+                S_.run(g);
 #endif
+                S.status = S_.status;
+                S.negz = S_.negz;
+                }
                 // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
                 double val;
                 if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
@@ -370,6 +442,35 @@ __device__ __forceinline__ void reduce_r_tile(
             }
         }
         // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+        if constexpr (LAZY) {
+            // one polytope per wavefront: its rows one after the other, each LP on plp_lazy.hpp (nothing to set up but
+            // the cost vector: lane j holds -A[k][j]; c.xc = -(a_k.xc) = -s_k exactly, the two FMA chains mirror each other)
+            if (stage == 2) {
+                const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
+                uint64_t todo = live;
+                nlp += __popcll(live);
+                while (todo != 0ull) {
+                    const int kr = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const double ck = g.lane < D ? -myA[kr * D + (g.lane < D ? g.lane : 0)] : 0.0;  // f = -A[k,:]  (:1145)
+                    const double cxc = -myan[kr];
+                    const bool owner = kr == row0;
+                    if (owner) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149), undone below (:1151)
+                    double negz2 = 0.0;
+                    const int st2 = lazy::solve<D>(g.lane, __popcll(live), myA, ck, fmax(myb[row0] - myan[row0], 0.0),
+                                                   (lloc & 1u) != 0u, lzrho, negz2);
+                    retry = retry | (st2 == ST_RETRY);
+                    const double fun = cxc - negz2;  // c.xc + zeta, zeta = -negz
+                    double hk_own = 0.0;
+                    if (owner) { hk_own = myb[kr] - 0.1; myb[kr] = hk_own; }
+                    const double hk = bcast(hk_own, kr);
+                    const double obj = -fun - hk;  // (:1156)
+                    const bool keepk = ((st2 == ST_OPT) & (obj > abs_tol)) | (st2 == ST_UNBND);
+                    keep |= keepk ? (1ull << kr) : 0ull;
+                }
+                flags |= RF_MINREP;
+            }
+        } else {
 #if PLP_R_ASYNC && PLP_R_FAST
         // The 16 polytopes of a wavefront need different numbers of LPs (rows that survived the dedupe and
         // the prefilter) and their LPs different numbers of pivots; in lock-step every LP costs the wave the
@@ -495,6 +596,7 @@ __device__ __forceinline__ void reduce_r_tile(
             if (stage == 2) flags |= RF_MINREP;
         }
 #endif
+        }
         // ---------------------------------------------------------------- results
         if (valid & (g.gl == 0)) {
             keep_out[pg] = keep;
@@ -505,6 +607,31 @@ __device__ __forceinline__ void reduce_r_tile(
             for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
         }
     }
+}
+
+// One polytope of up to 64 rows per wavefront, F3 / F2 on plp_lazy.hpp (d = 9..16, see there).
+#ifndef PLP_REDUCE_LAZY_WAVES
+#define PLP_REDUCE_LAZY_WAVES 3
+#endif
+template <int D>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    reduce_r_tile<D, 64, 1, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
+                                  r_out, xc_out, nlp_out);
+}
+
+template <int D>
+static int launch_reduce_lazy(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
+                              unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    const size_t smem = reduce_r_smem_bytes(64, D, 1) + lazy::lds_bytes<D>();
+    if (B > 2147483647ll) return 2;
+    const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
+    hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
+                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+    return 0;
 }
 
 template <int D, int GS, int R = RR>

@@ -20,213 +20,11 @@
 
 #include "plp_kernels.hpp"
 #include "plp_wave.hpp"
+#include "plp_wide.hpp"
 
 namespace plp {
 
-namespace {
-
-#define PLP_DPP_BCAST15 0x142
-#define PLP_DPP_BCAST31 0x143
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-    int t;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR1, 0xF, 0xF, false); v = t < v ? t : v;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR2, 0xF, 0xF, false); v = t < v ? t : v;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_HMIRROR, 0xF, 0xF, false); v = t < v ? t : v;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_MIRROR, 0xF, 0xF, false); v = t < v ? t : v;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_BCAST15, 0xA, 0xF, false); v = t < v ? t : v;
-    t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_BCAST31, 0xC, 0xF, false); v = t < v ? t : v;
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ double uniform_lane(double v, int lane) {  // value of `lane` (wave-uniform index)
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-// wave-wide min / max of a u32 with the DPP operand folded into the VALU op (one instruction per level; hipcc does
-// not fold v_mov_dpp into the consumer by itself); result wave-uniform (lane 63 holds it after the row_bcast levels)
-#define PLP_W_DPP(OP, v, CTRL, RM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:" RM " bank_mask:0xf" : "+v"(v))
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-    PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
-    PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1]", "0xf");
-    PLP_W_DPP("v_min_u32_dpp", v, "row_half_mirror", "0xf");
-    PLP_W_DPP("v_min_u32_dpp", v, "row_mirror", "0xf");
-    PLP_W_DPP("v_min_u32_dpp", v, "row_bcast:15", "0xa");
-    PLP_W_DPP("v_min_u32_dpp", v, "row_bcast:31", "0xc");
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    PLP_W_DPP("v_max_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
-    PLP_W_DPP("v_max_u32_dpp", v, "quad_perm:[2,3,0,1]", "0xf");
-    PLP_W_DPP("v_max_u32_dpp", v, "row_half_mirror", "0xf");
-    PLP_W_DPP("v_max_u32_dpp", v, "row_mirror", "0xf");
-    PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:15", "0xa");
-    PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:31", "0xc");
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ double rcpn(double a) {
-    const double x0 = __builtin_amdgcn_rcp(a);
-    const double x1 = fma(x0, fma(-a, x0, 1.0), x0);
-    return fma(x1, fma(-a, x1, 1.0), x1);
-}
-
-// The row of a lane: NC <= 17 doubles held as a 16-wide register vector (+ one scalar for the 17th column), so that
-// T[e] for a wave-uniform e is ONE indexed register move (s_set_gpr_idx / v_movrel: the compiler lowers a dynamic
-// element access with a uniform index that way) instead of a select chain or a branch tree.
-typedef double v16d __attribute__((ext_vector_type(16)));
-// (plain local variables, not a struct: the struct form was kept in scratch memory by the compiler)
-#define ROW_GET(j) ((j) < 16 ? Tv[(j) & 15] : T16)
-#define ROW_SET(j, val) do { if ((j) < 16) Tv[(j) & 15] = (val); else T16 = (val); } while (0)
-template <int NC>
-__device__ __forceinline__ double row_at(const v16d& Tv, const double& T16, int e) {  // wave-uniform e
-    if constexpr (NC <= 16) return Tv[e & 15];
-    else return e < 16 ? Tv[e & 15] : T16;
-}
-template <int NC>
-__device__ __forceinline__ void row_put(v16d& Tv, double& T16, int e, double val) {   // wave-uniform e
-    if constexpr (NC <= 16) {
-        Tv[e & 15] = val;
-    } else {  // (written as two selects on single elements: a branch here is if-converted into a select of the whole vector)
-        const double old = Tv[e & 15];
-        Tv[e & 15] = e < 16 ? val : old;
-        T16 = e < 16 ? T16 : val;
-    }
-}
-
-// Per-wavefront LDS: reduced costs, the scaled pivot row, the nonbasic variable of every column
-template <int NC>
-struct WideShared {
-    double cost[NC + 1];
-    double rho[NC + 1];   // rho[NC] = scaled right-hand side of the pivot row
-    int cv[NC + 1];       // (id + 1) << 1 | negated
-};
-
-// Solve from a dictionary whose rows sit in T/beta (one per lane).  `forced`: first pivot = column NC-1 enters, the
-// leaving row is the active one with the smallest signed ratio q0 (F1).  Returns the status; the optimal dictionary
-// stays in T/beta/rowvar/rowneg.
-template <int NC>
-__device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, double& T16, double& beta, int& rowvar,
-                                        int& rowneg, bool& rowact, WideShared<NC>& sh, const int nfree, bool forced,
-                                        const double q0, int& iters_out) {
-    unsigned cfree = nfree >= 32 ? 0xffffffffu : ((1u << nfree) - 1u);
-    int ndeg = 0, iters = 0;
-    const int maxit = 50 * (m + nfree) + 100;
-    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
-    int status = -1;
-    for (;;) {
-        const bool bland = ndeg >= BLAND_AFTER;
-        int e;
-        double ce;       // reduced cost of the entering column as stored
-        bool flip = false;
-        if (forced) {
-            e = NC - 1;
-            ce = sh.cost[NC - 1];
-        } else {
-            // ---- pricing: lane j looks after column j
-            const double c = lane < NC ? sh.cost[lane] : 0.0;
-            const bool elig = (lane < NC) & (fabs(c) > TOL_D) & ((((cfree >> (lane & 31)) & 1u) != 0u) | (c < 0.0));
-            const uint64_t eb = __ballot(elig);
-            if (eb == 0) { status = ST_OPT; break; }
-            if (iters >= maxit) { status = ST_ITER; break; }
-            if (!bland) {  // largest |c|: its bit pattern orders like an unsigned integer
-                const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
-                const unsigned mh = wave_max_u32(kh);
-                uint64_t top = __ballot(elig & (kh == mh));
-                if (top & (top - 1ull)) {  // several columns share the high word (rare): the low words decide
-                    const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
-                    const unsigned ml = wave_max_u32(kl);
-                    top = __ballot(elig & (kh == mh) & (kl == ml));
-                }
-                e = __ffsll((long long)top) - 1;
-            } else {  // Bland: lowest variable id among the eligible columns
-                const int id = elig ? sh.cv[lane] : 0x7fffffff;
-                const int idmin = wave_min_i32(id);
-                e = __ffsll((long long)__ballot(elig & (id == idmin))) - 1;
-            }
-            e = __builtin_amdgcn_readfirstlane(e);
-            ce = uniform_lane(c, e);
-            flip = ce > 0.0;  // free variable entering downwards: x := -x
-        }
-        // ---- ratio test
-        double a = row_at<NC>(Tv, T16, e);
-        a = flip ? -a : a;
-        const double pinv = rcpn(a);
-        bool erow;
-        double q;
-        if (forced) { erow = rowact; q = q0; }
-        else { erow = rowact & (a > TOL_PIV); q = (beta > 0.0 ? beta : 0.0) * pinv; }
-        q = erow ? q : pinf;
-        // exact f64 minimum on the order-preserving u64 key (hi dword, then lo dword among the hi-minima)
-        const int qh = __double2hiint(q), ql = __double2loint(q);
-        const int sm = qh >> 31;
-        const unsigned kh = (unsigned)(qh ^ (sm | (int)0x80000000));
-        const unsigned kl = (unsigned)(ql ^ sm);
-        const unsigned mh = wave_min_u32(kh);
-        // one row alone at the minimal high word (the usual case): its low word is the minimum, no second reduction
-        const uint64_t hib = __ballot(kh == mh);
-        unsigned ml;
-        if (hib & (hib - 1ull)) ml = wave_min_u32((kh == mh) ? kl : 0xffffffffu);
-        else ml = (unsigned)__builtin_amdgcn_readlane((int)kl, __ffsll((long long)hib) - 1);
-        if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; break; }
-        const bool tie = erow & (kh == mh) & (kl == ml);
-        const int mhs = (int)(mh ^ 0x80000000u);   // (the minimum is >= 0 in a normal pivot; the forced one ignores ndeg)
-        const double qmin = __hiloint2double(mhs >= 0 ? mhs : (int)~mh, mhs >= 0 ? (int)ml : (int)~ml);
-        int r;
-        if (bland & !forced) {  // lowest basic-variable id among the ties
-            const int id = tie ? rowvar + 1 : 0x7fffffff;
-            const int idmin = wave_min_i32(id);
-            r = __ffsll((long long)__ballot(tie & (id == idmin))) - 1;
-        } else {
-            r = __ffsll((long long)__ballot(tie)) - 1;  // lowest row among ties
-        }
-        r = __builtin_amdgcn_readfirstlane(r);
-        if (!forced) ndeg = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
-        // ---- the pivot row scales itself in place and goes to LDS
-        const double p = uniform_lane(pinv, r);
-        const int vin = sh.cv[e];
-        const bool efree = (cfree >> e) & 1u;
-        const bool is_r = lane == r;
-        if (is_r) {   // (LDS stores and scalars only inside the branch: the row vector itself is updated branch-free below)
-#pragma unroll
-            for (int j = 0; j < NC; ++j) sh.rho[j] = ROW_GET(j) * pinv;
-            sh.rho[NC] = beta * pinv;
-            sh.cv[e] = ((rowvar + 1) << 1) | rowneg;
-            rowvar = (vin >> 1) - 1;
-            rowneg = (vin & 1) ^ (flip ? 1 : 0);
-            rowact = !efree;  // a free variable never leaves again
-        }
-        __syncthreads();
-        {
-            // row r: T * (1/a_r)  (f = 0);  every other row: T - a_i * rho  (scale 1)
-            // (scaling the pivot row in place inside the branch above -- inline asm, so that it stays a branch -- costs
-            // a copy of the row vector: 136 VGPRs instead of 102, three waves per SIMD; not kept)
-            const double f = is_r ? 0.0 : a;
-            const double sc = is_r ? pinv : 1.0;
-            const double rb = sh.rho[NC];
-#pragma unroll
-            for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j) * sc));
-            row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
-            beta = fma(-f, rb, beta * sc);
-        }
-        // ---- reduced costs (lane j = column j); the entering column is sign-normalised first
-        if (lane < NC) {
-            const double fc = flip ? -ce : ce;
-            const double cj = sh.cost[lane];
-            sh.cost[lane] = (lane == e) ? -(fc * p) : fma(-fc, sh.rho[lane], cj);
-        }
-        cfree &= ~(1u << e);
-        iters += 1;
-        if (forced) {
-            if (rowact & (beta < 0.0)) beta = 0.0;  // rounding of the forced pivot
-            forced = false;
-        }
-        __syncthreads();
-    }
-    iters_out = iters;
-    return status;
-}
-
-}  // namespace
+using namespace wide;
 
 template <int D>
 __global__ __launch_bounds__(64) void cheby_w_kernel(long long B, int m_max, const double* __restrict__ A,
