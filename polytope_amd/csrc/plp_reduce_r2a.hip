@@ -11,9 +11,11 @@ static int launch_r2_d(long long B, int m_max, const double* A, const double* b,
     const char* r1 = getenv("PLP_REDUCE_R1");
     if (r1 && r1[0] == '1' && m_max > 32)
         return launch_reduce_r_dg<D, 64, 1>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
-    // PLP_REDUCE_LAZY=1: one polytope per wavefront, F3 / F2 without a stored dictionary (plp_lazy.hpp)
+    // more than 32 rows: one polytope per wavefront, F3 / F2 without a stored dictionary (plp_lazy.hpp) -- measured 1.2x
+    // (48 rows, d = 9) to 2.1x (36 rows, d = 14) faster than two rows per lane, outputs bitwise equal; with 32 rows and
+    // fewer the four-polytopes-per-wavefront form below wins or ties.  PLP_REDUCE_LAZY=0 / 1: never / always (A/B).
     const char* lz = getenv("PLP_REDUCE_LAZY");
-    if (lz && lz[0] == '1')
+    if ((lz && lz[0] == '1') || (m_max > 32 && !(lz && lz[0] == '0')))
         return launch_reduce_lazy<D>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     if (m_max <= 32) return launch_reduce_r_dg<D, 16, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     return launch_reduce_r_dg<D, 32, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);

@@ -14,7 +14,7 @@ def run(A, b, env):
     for _ in range(5): pa.reduce_batch(A, b)
     ev[1].record(); torch.cuda.synchronize()
     return res, ev[0].elapsed_time(ev[1]) / 5
-shapes = [(5000, 64, 16), (20000, 64, 16), (5000, 64, 12), (20000, 64, 12), (5000, 48, 9), (20000, 48, 9), (5000, 40, 10), (3000, 64, 13)]
+shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]] or [(5000, 64, 16), (20000, 64, 16), (5000, 64, 12), (20000, 64, 12), (5000, 48, 9), (20000, 48, 9), (5000, 40, 10), (3000, 64, 13)]
 for (B, m, d) in shapes:
     A, b = random_hpolytopes(B, m, d, seed=1, stream=0)
     A = torch.as_tensor(A).cuda(); b = torch.as_tensor(b).cuda()

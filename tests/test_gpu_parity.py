@@ -487,10 +487,13 @@ def test_reduce_degenerate_vertices(pa, oracle):
             assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
-@pytest.mark.parametrize("variant", [None, "PLP_REDUCE_RETRY_ALL", "PLP_REDUCE_R2=0"])
+@pytest.mark.parametrize("variant", [None, "PLP_REDUCE_RETRY_ALL", "PLP_REDUCE_R2=0", "PLP_REDUCE_LAZY=0", "PLP_REDUCE_LAZY=1",
+                                     "PLP_REDUCE_R1=1"])
 def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
-    """d = 9..16: the fused reduce on two rows per lane (groups of 16 / 32 lanes), its hand-over to the general
-    engine, and the one-row-per-lane kernel it replaced -- random, degenerate and ragged polytopes vs the oracle."""
+    """d = 9..16: the fused reduce on two rows per lane (groups of 16 / 32 lanes; PLP_REDUCE_LAZY=0: also beyond 32 rows),
+    on the kernel without a stored dictionary (default beyond 32 rows; PLP_REDUCE_LAZY=1: always), its one-row-per-lane
+    arithmetic twin (PLP_REDUCE_R1), the hand-over to the general engine, and the one-row-per-lane kernel of round 1 --
+    random, degenerate and ragged polytopes vs the oracle."""
     from polytope_amd.synth import random_hpolytopes
     if variant:
         name, _, val = variant.partition("=")
@@ -650,6 +653,56 @@ def test_contains_vs_oracle(pa, oracle):
             assert np.array_equal(reg.astype(bool), out.astype(bool).any(axis=0))
     with pytest.raises(ValueError):
         pa.contains_batch(A, b, np.zeros((3, 4)))
+
+
+def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
+    """reduce_lazy_kernel (plp_lazy.hpp) evaluates the entering column and the leaving row of every F2 / F3 pivot from
+    the polytope's rows and the pivots so far with the operations, in the order, the dense engine applies to its stored
+    dictionary: every output must be bit-identical to the two-rows-per-lane kernel and to the one-row-per-lane instance
+    -- ragged, duplicated, infeasible rows; pyramids (degenerate vertices: Bland hand-over); shapes whose LPs run past
+    the four pivots kept in registers into the private-array steps; a sample against the oracle."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(5)
+
+    def three(A, b, m=None):
+        out = []
+        for env in ({"PLP_REDUCE_LAZY": "0"}, {"PLP_REDUCE_LAZY": "0", "PLP_REDUCE_R1": "1"}, {"PLP_REDUCE_LAZY": "1"}):
+            for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out.append(pa.reduce_batch(A, b, m=m))
+        for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1"):
+            monkeypatch.delenv(k, raising=False)
+        return out
+
+    steps_seen = 0
+    for (B, m, d) in [(600, 64, 16), (600, 64, 12), (600, 48, 9), (500, 33, 9), (400, 36, 14), (300, 64, 13), (300, 40, 10),
+                      (300, 20, 12), (200, 64, 11), (200, 57, 15)]:
+        A, b = random_hpolytopes(B, m, d, seed=7 * m + d, stream=0)
+        for k in range(0, B, 5):
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.05])
+        for k in range(3, B, 11):
+            b[k, 0] = -4.0
+        rows = rng.integers(max(d + 2, m - 9), m + 1, B).astype(np.int32)
+        for mr in (None, rows):
+            dense, one_row, lazy = three(A, b, mr)
+            for key in dense:
+                assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
+                assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
+        masks = pa.keep_to_bool(lazy["keep"], m)
+        for k in range(0, B, 37):
+            o = oracle.reduce(A[k, :rows[k]], b[k, :rows[k]])
+            assert int(lazy["flags"][k]) == o["flags"] and np.array_equal(masks[k, :rows[k]], o["keep"]), (m, d, k)
+            assert abs(lazy["r"][k] - o["r"]) <= TOL and int(lazy["nlp"][k]) == o["nlp"]
+        steps_seen += int((lazy["nlp"] > 1).sum())
+    assert steps_seen > 0
+    A, b = _pyramids(40, 40, 9, rng)
+    dense, one_row, lazy = three(A, b)
+    for key in dense:
+        assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
 
 
 def test_reduce_host_batch_chunked_upload_equals_one_copy(pa, monkeypatch):
