@@ -76,10 +76,11 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
     double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
     static_assert(K_REG == 4, "u0..u3");
     double ux[K - K_REG];
-    int steps = 0;  // lane s: e_s | r_s << 8
+    int steps = 0;  // lane s: e_s | r_s << 8 (steps beyond the first K_REG; those sit in scalars)
+    int st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     unsigned cfree = (1u << D) - 1u;
     int t = 0, ndeg = 0;
-    const int maxit = 50 * (m_rows + D) + 100;
+    const int maxit = 50 * (__builtin_amdgcn_readfirstlane(m_rows) + D) + 100;  // (wave-uniform: keeps the loop scalar)
     double negz = 0.0;
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     int status;
@@ -94,20 +95,20 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         const bool efree = ((cfree >> e) & 1u) != 0u;
         // ---- entering column of my row as of now
         double a = sA[lane * D + e];
-#define PLP_LZ_COL(S_, US_)                                                          \
+#define PLP_LZ_COL(S_, US_, ST_)                                                     \
         {                                                                            \
-            const int st_ = __builtin_amdgcn_readlane(steps, (S_));                  \
+            const int st_ = (ST_);                                                   \
             const int e_s = st_ & 0xff, r_s = st_ >> 8;                              \
             const double pe = rho[(S_) * D + e];                                     \
             const double us = (US_);                                                 \
             const double an = (e == e_s) ? -(us * pe) : fma(-us, pe, a);             \
             a = (lane == r_s) ? pe : an;                                             \
         }
-        if (t > 0) PLP_LZ_COL(0, u0)
-        if (t > 1) PLP_LZ_COL(1, u1)
-        if (t > 2) PLP_LZ_COL(2, u2)
-        if (t > 3) PLP_LZ_COL(3, u3)
-        for (int s = K_REG; s < t; ++s) PLP_LZ_COL(s, ux[s - K_REG])
+        if (t > 0) PLP_LZ_COL(0, u0, st0)
+        if (t > 1) PLP_LZ_COL(1, u1, st1)
+        if (t > 2) PLP_LZ_COL(2, u2, st2)
+        if (t > 3) PLP_LZ_COL(3, u3, st3)
+        for (int s = K_REG; s < t; ++s) PLP_LZ_COL(s, ux[s - K_REG], __builtin_amdgcn_readlane(steps, s))
         a = __hiloint2double(__double2hiint(a) ^ (flip ? (int)0x80000000 : 0), __double2loint(a));
         // ---- ratio test (one row per lane), exact f64 minimum on the order-preserving key, lowest lane on ties
         const double bi = max0_raw(beta);
@@ -131,25 +132,25 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; break; }
         const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot((kh == mh) & (kl == ml))) - 1);
         const double qmin = __hiloint2double((int)(mh ^ 0x80000000u), (int)ml);
-        ndeg = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
+        ndeg = __builtin_amdgcn_readfirstlane((qmin <= DEGEN_EPS) ? ndeg + 1 : 0);
         const double p = lane_value(pinv, r);
         const double rhob = lane_value(pb, r) * p;
         // ---- the pivot row as of now, lane j computing its entry j, then scaled: rho_t (its entry e is p)
         double v = lane < D ? sA[r * D + lane] : 0.0;
-#define PLP_LZ_ROW(S_, US_)                                                          \
+#define PLP_LZ_ROW(S_, US_, ST_)                                                     \
         {                                                                            \
-            const int st_ = __builtin_amdgcn_readlane(steps, (S_));                  \
+            const int st_ = (ST_);                                                   \
             const int e_s = st_ & 0xff, r_s = st_ >> 8;                              \
             const double ur = lane_value((US_), r);                                  \
             const double rj_ = lane < D ? rho[(S_) * D + lane] : 0.0;                \
             const double vn = (lane == e_s) ? -(ur * rj_) : fma(-ur, rj_, v);        \
             v = (r == r_s) ? rj_ : vn;                                               \
         }
-        if (t > 0) PLP_LZ_ROW(0, u0)
-        if (t > 1) PLP_LZ_ROW(1, u1)
-        if (t > 2) PLP_LZ_ROW(2, u2)
-        if (t > 3) PLP_LZ_ROW(3, u3)
-        for (int s = K_REG; s < t; ++s) PLP_LZ_ROW(s, ux[s - K_REG])
+        if (t > 0) PLP_LZ_ROW(0, u0, st0)
+        if (t > 1) PLP_LZ_ROW(1, u1, st1)
+        if (t > 2) PLP_LZ_ROW(2, u2, st2)
+        if (t > 3) PLP_LZ_ROW(3, u3, st3)
+        for (int s = K_REG; s < t; ++s) PLP_LZ_ROW(s, ux[s - K_REG], __builtin_amdgcn_readlane(steps, s))
         const double rj = (lane == e) ? p : v * p;
         if (lane < D) rho[t * D + lane] = rj;
         // ---- reduced costs, objective, my row
@@ -158,15 +159,16 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         negz = fma(-fc, rhob, negz);
         const bool is_r = lane == r;
         const double f = is_r ? 0.0 : a;
-        if (t == 0) u0 = f;
-        else if (t == 1) u1 = f;
-        else if (t == 2) u2 = f;
-        else if (t == 3) u3 = f;
+        const int stt = e | (r << 8);
+        if (t == 0) { u0 = f; st0 = stt; }
+        else if (t == 1) { u1 = f; st1 = stt; }
+        else if (t == 2) { u2 = f; st2 = stt; }
+        else if (t == 3) { u3 = f; st3 = stt; }
         else ux[t - K_REG] = f;
         beta = is_r ? rhob : fma(-f, rhob, beta);
         if (is_r & efree) rowact = false;  // a free variable never leaves again
         cfree &= ~(1u << e);
-        steps = (lane == t) ? (e | (r << 8)) : steps;
+        steps = (lane == t) ? stt : steps;
         ++t;
         __syncthreads();  // (one wavefront per workgroup: orders the LDS store of rho_t before the loads of the next pivots)
         if (!price<D>(lane, c, cfree, e, best, chi)) { status = ST_OPT; break; }

@@ -375,7 +375,7 @@ __device__ __forceinline__ void reduce_r_tile(
                 if constexpr (LAZY) {
                     S.status = ST_NUM;
                     S.negz = 0.0;
-                    if (go)  // (wave-uniform: one polytope per wavefront)
+                    if (__builtin_amdgcn_readfirstlane((int)go))  // (wave-uniform: one polytope per wavefront)
                         S.status = lazy::solve<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
                                                   fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, lzrho, S.negz);
                     retry = retry | (go & (S.status == ST_RETRY));
@@ -445,9 +445,10 @@ __device__ __forceinline__ void reduce_r_tile(
         if constexpr (LAZY) {
             // one polytope per wavefront: its rows one after the other, each LP on plp_lazy.hpp (nothing to set up but
             // the cost vector: lane j holds -A[k][j]; c.xc = -(a_k.xc) = -s_k exactly, the two FMA chains mirror each other)
-            if (stage == 2) {
+            if (__builtin_amdgcn_readfirstlane(stage) == 2) {  // (wave-uniform, and said so: the LP loops stay scalar)
                 const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
-                uint64_t todo = live;
+                uint64_t todo = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(live >> 32)) << 32) |
+                                (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)live);
                 nlp += __popcll(live);
                 while (todo != 0ull) {
                     const int kr = __ffsll((long long)todo) - 1;

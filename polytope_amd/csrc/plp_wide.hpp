@@ -131,6 +131,8 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             flip = ce > 0.0;  // free variable entering downwards: x := -x
         }
         // ---- ratio test
+        e = __builtin_amdgcn_readfirstlane(e);  // (wave-uniform on both paths; said again where the forced and the priced
+                                                // column merge, or the indexed register access below becomes a select chain)
         double a = row_at<NC>(Tv, T16, e);
         a = flip ? -a : a;
         const double pinv = rcpn(a);
