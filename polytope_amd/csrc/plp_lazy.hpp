@@ -9,7 +9,8 @@
 //     T_s[i][e_s] = -(u_s[i] * p_s),   T_s[r_s][j] = rho_s[j],   rho_s[e_s] = p_s
 // with u_s = the entering column of pivot s (0 in the pivot row), rho_s = its scaled pivot row.  One polytope per
 // wavefront: lane i keeps u_s[i] of ITS row in registers (two per pivot), lane j < d looks after column j (reduced
-// cost, its entry of every rho_s, which sits in LDS), e_s / r_s are wave-uniform.  A pivot costs O(m t + d t) instead of
+// cost and its entry of every rho_s, in registers too: what the other lanes need of rho_s is the one entry rho_s[e],
+// a read-lane), e_s / r_s are wave-uniform.  No LDS traffic beyond the polytope's own rows.  A pivot costs O(m t + d t) instead of
 // O(m d) and an LP starts with nothing to load but its cost vector.
 // The recurrences are evaluated with the same operations in the same order as SimplexR::pivot_core applies them to the
 // stored dictionary, so every number -- and therefore every pivot choice and every result -- is bit-identical to the
@@ -34,12 +35,16 @@ __device__ __forceinline__ unsigned row0_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
 }
 
-constexpr int K_STEPS = 32;  // pivots an LP may take here (D doubles of LDS each)
-constexpr int K_REG = 4;     // ... of which the first K_REG keep u_s in named registers: nine LPs in ten end within them;
-                             // the later ones index a private array (scratch memory: slow, rare)
+constexpr int K_STEPS = 32;  // pivots an LP may take here
+#ifndef PLP_LAZY_KREG
+#define PLP_LAZY_KREG 4
+#endif
+constexpr int K_REG = PLP_LAZY_KREG;     // ... of which the first K_REG keep u_s / rho_s in named registers: nine LPs in ten end
+                             // within them; the later ones index private arrays (scratch memory: slow, rare)
 
+// LDS behind the tile's arrays: only F1's block of the one-LP-per-wavefront engine (reduced costs, pivot row, column ids)
 template <int D>
-__host__ __device__ constexpr size_t lds_bytes() { return (size_t)K_STEPS * D * 8; }
+__host__ __device__ constexpr size_t lds_bytes() { return (sizeof(wide::WideShared<D + 1>) + 255) & ~(size_t)255; }
 
 // Dantzig choice over the d reduced costs (lane j holds c_j): SimplexR::scan_enter's key -- |c| for a free column,
 // -c otherwise -- largest key above TOL_D, lowest column on ties.  false: the dictionary is optimal.
@@ -67,17 +72,20 @@ __device__ __forceinline__ bool price(const int lane, const double c, const unsi
 }
 
 // min c.x' over { A x' <= beta } from x' = 0 (the rows of A in LDS at sA[i * D + j], row i = lane i; beta >= 0 in
-// lane i; rowact: row i exists).  c: lane j < D holds c_j.  rho: K_STEPS * D doubles of LDS owned by this wavefront.
+// lane i; rowact: row i exists).  c: lane j < D holds c_j.
 // Returns the status (ST_OPT / ST_UNBND / ST_NUM / ST_ITER / ST_RETRY); negz = -(optimal value) as in SimplexR.
 template <int D>
 __device__ __forceinline__ int solve(const int lane, const int m_rows, const double* sA, double c, double beta, bool rowact,
-                                     double* rho, double& negz_out) {
+                                     double& negz_out) {
     constexpr int K = K_STEPS;
-    double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
-    static_assert(K_REG == 4, "u0..u3");
+    // (ur / qr / str are only ever indexed by unrolled loop counters: registers; ux / qx by t: private memory)
+    double ur_[K_REG], qr_[K_REG];  // u_s of my row; my entry of rho_s (lanes j < D)
+    int str_[K_REG];                // e_s | r_s << 8
+#pragma unroll
+    for (int s = 0; s < K_REG; ++s) { ur_[s] = 0.0; qr_[s] = 0.0; str_[s] = 0; }
     double ux[K - K_REG];
-    int steps = 0;  // lane s: e_s | r_s << 8 (steps beyond the first K_REG; those sit in scalars)
-    int st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    double qx[K - K_REG];
+    int steps = 0;  // lane s: e_s | r_s << 8 (steps beyond the first K_REG)
     unsigned cfree = (1u << D) - 1u;
     int t = 0, ndeg = 0;
     const int maxit = 50 * (__builtin_amdgcn_readfirstlane(m_rows) + D) + 100;  // (wave-uniform: keeps the loop scalar)
@@ -95,20 +103,19 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         const bool efree = ((cfree >> e) & 1u) != 0u;
         // ---- entering column of my row as of now
         double a = sA[lane * D + e];
-#define PLP_LZ_COL(S_, US_, ST_)                                                     \
+#define PLP_LZ_COL(US_, QS_, ST_)                                                    \
         {                                                                            \
             const int st_ = (ST_);                                                   \
             const int e_s = st_ & 0xff, r_s = st_ >> 8;                              \
-            const double pe = rho[(S_) * D + e];                                     \
+            const double pe = lane_value((QS_), e);                                  \
             const double us = (US_);                                                 \
             const double an = (e == e_s) ? -(us * pe) : fma(-us, pe, a);             \
             a = (lane == r_s) ? pe : an;                                             \
         }
-        if (t > 0) PLP_LZ_COL(0, u0, st0)
-        if (t > 1) PLP_LZ_COL(1, u1, st1)
-        if (t > 2) PLP_LZ_COL(2, u2, st2)
-        if (t > 3) PLP_LZ_COL(3, u3, st3)
-        for (int s = K_REG; s < t; ++s) PLP_LZ_COL(s, ux[s - K_REG], __builtin_amdgcn_readlane(steps, s))
+#pragma unroll
+        for (int s = 0; s < K_REG; ++s)
+            if (t > s) PLP_LZ_COL(ur_[s], qr_[s], str_[s])
+        for (int s = K_REG; s < t; ++s) PLP_LZ_COL(ux[s - K_REG], qx[s - K_REG], __builtin_amdgcn_readlane(steps, s))
         a = __hiloint2double(__double2hiint(a) ^ (flip ? (int)0x80000000 : 0), __double2loint(a));
         // ---- ratio test (one row per lane), exact f64 minimum on the order-preserving key, lowest lane on ties
         const double bi = max0_raw(beta);
@@ -137,22 +144,20 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         const double rhob = lane_value(pb, r) * p;
         // ---- the pivot row as of now, lane j computing its entry j, then scaled: rho_t (its entry e is p)
         double v = lane < D ? sA[r * D + lane] : 0.0;
-#define PLP_LZ_ROW(S_, US_, ST_)                                                     \
+#define PLP_LZ_ROW(US_, QS_, ST_)                                                    \
         {                                                                            \
             const int st_ = (ST_);                                                   \
             const int e_s = st_ & 0xff, r_s = st_ >> 8;                              \
             const double ur = lane_value((US_), r);                                  \
-            const double rj_ = lane < D ? rho[(S_) * D + lane] : 0.0;                \
+            const double rj_ = (QS_);                                                \
             const double vn = (lane == e_s) ? -(ur * rj_) : fma(-ur, rj_, v);        \
             v = (r == r_s) ? rj_ : vn;                                               \
         }
-        if (t > 0) PLP_LZ_ROW(0, u0, st0)
-        if (t > 1) PLP_LZ_ROW(1, u1, st1)
-        if (t > 2) PLP_LZ_ROW(2, u2, st2)
-        if (t > 3) PLP_LZ_ROW(3, u3, st3)
-        for (int s = K_REG; s < t; ++s) PLP_LZ_ROW(s, ux[s - K_REG], __builtin_amdgcn_readlane(steps, s))
-        const double rj = (lane == e) ? p : v * p;
-        if (lane < D) rho[t * D + lane] = rj;
+#pragma unroll
+        for (int s = 0; s < K_REG; ++s)
+            if (t > s) PLP_LZ_ROW(ur_[s], qr_[s], str_[s])
+        for (int s = K_REG; s < t; ++s) PLP_LZ_ROW(ux[s - K_REG], qx[s - K_REG], __builtin_amdgcn_readlane(steps, s))
+        const double rj = lane < D ? ((lane == e) ? p : v * p) : 0.0;
         // ---- reduced costs, objective, my row
         const double fc = -best;
         c = (lane == e) ? -(fc * p) : fma(-fc, rj, c);
@@ -160,17 +165,15 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         const bool is_r = lane == r;
         const double f = is_r ? 0.0 : a;
         const int stt = e | (r << 8);
-        if (t == 0) { u0 = f; st0 = stt; }
-        else if (t == 1) { u1 = f; st1 = stt; }
-        else if (t == 2) { u2 = f; st2 = stt; }
-        else if (t == 3) { u3 = f; st3 = stt; }
-        else ux[t - K_REG] = f;
+#pragma unroll
+        for (int s = 0; s < K_REG; ++s)
+            if (t == s) { ur_[s] = f; qr_[s] = rj; str_[s] = stt; }
+        if (t >= K_REG) { ux[t - K_REG] = f; qx[t - K_REG] = rj; }
         beta = is_r ? rhob : fma(-f, rhob, beta);
         if (is_r & efree) rowact = false;  // a free variable never leaves again
         cfree &= ~(1u << e);
         steps = (lane == t) ? stt : steps;
         ++t;
-        __syncthreads();  // (one wavefront per workgroup: orders the LDS store of rho_t before the loads of the next pivots)
         if (!price<D>(lane, c, cfree, e, best, chi)) { status = ST_OPT; break; }
     }
     negz_out = negz;

@@ -96,8 +96,8 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 
 // One tile = the NG = RBLOCK / GS polytopes starting at polytope `tile` (the body of reduce_r_kernel; a device function
 // so that reduce_r_mix_kernel can give the last tiles of a launch a different shape).
-// LAZY (GS = 64, R = 1: one polytope per wavefront): the F3 / F2 LPs run on plp_lazy.hpp -- no dictionary is carried,
-// the K_STEPS * D doubles of LDS behind the tile's arrays hold the pivot rows of the LP in progress.
+// LAZY (GS = 64, R = 1: one polytope per wavefront): F1 on the one-LP-per-wavefront engine (its LDS block sits behind the
+// tile's arrays), the F3 / F2 LPs on plp_lazy.hpp -- no dictionary is carried.
 template <int D, int GS, int R, bool LAZY = false>
 __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
@@ -121,7 +121,7 @@ __device__ __forceinline__ void reduce_r_tile(
     double* myA = sA + (size_t)gib * rows * D;
     double* myb = sb + (size_t)gib * rows;
     double* myan = san + (size_t)gib * rows;
-    double* lzrho = san + (size_t)NG * rows;  // [K_STEPS][D] (LAZY)
+    double* lzrho = san + (size_t)NG * rows;  // (LAZY) F1's block of the one-LP-per-wavefront engine
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
@@ -159,7 +159,7 @@ __device__ __forceinline__ void reduce_r_tile(
             // wave-uniform, the row a register vector); set-up and read-out as in the branch below
             constexpr int NC = D + 1;
             wide::WideShared<NC>& sh = *reinterpret_cast<wide::WideShared<NC>*>(lzrho);
-            static_assert(sizeof(wide::WideShared<NC>) <= lazy::lds_bytes<D>(), "F1's LDS block fits the pivot-row area");
+            static_assert(sizeof(wide::WideShared<NC>) <= lazy::lds_bytes<D>(), "F1's LDS block");
             const int lane = g.lane;
             const bool h = valid & (lane < m) & (m <= rows);
             has = h ? 1u : 0u;
@@ -203,7 +203,6 @@ __device__ __forceinline__ void reduce_r_tile(
             }
             ball = (st1 == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
             fulldim = ball & (rr > abs_tol);
-            __syncthreads();  // (the pivot-row area is reused by the F3 / F2 LPs)
         } else
         {
 #if PLP_R_FAST
@@ -377,7 +376,7 @@ __device__ __forceinline__ void reduce_r_tile(
                     S.negz = 0.0;
                     if (__builtin_amdgcn_readfirstlane((int)go))  // (wave-uniform: one polytope per wavefront)
                         S.status = lazy::solve<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
-                                                  fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, lzrho, S.negz);
+                                                  fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, S.negz);
                     retry = retry | (go & (S.status == ST_RETRY));
                 }
                 SimplexR<D, R, false, false> S_;
@@ -459,7 +458,7 @@ __device__ __forceinline__ void reduce_r_tile(
                     if (owner) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149), undone below (:1151)
                     double negz2 = 0.0;
                     const int st2 = lazy::solve<D>(g.lane, __popcll(live), myA, ck, fmax(myb[row0] - myan[row0], 0.0),
-                                                   (lloc & 1u) != 0u, lzrho, negz2);
+                                                   (lloc & 1u) != 0u, negz2);
                     retry = retry | (st2 == ST_RETRY);
                     const double fun = cxc - negz2;  // c.xc + zeta, zeta = -negz
                     double hk_own = 0.0;
