@@ -658,8 +658,8 @@ def test_contains_vs_oracle(pa, oracle):
 def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
     """reduce_lazy_kernel (plp_lazy.hpp) evaluates the entering column and the leaving row of every F2 / F3 pivot from
     the polytope's rows and the pivots so far with the operations, in the order, the dense engine applies to its stored
-    dictionary: every output must be bit-identical to the two-rows-per-lane kernel and to the one-row-per-lane instance
-    -- ragged, duplicated, infeasible rows; pyramids (degenerate vertices: Bland hand-over); shapes whose LPs run past
+    dictionary: every output must be bit-identical to the one-row-per-lane instance of that engine, and to the
+    two-rows-per-lane kernel in everything but the last bit of a Chebyshev centre -- ragged, duplicated, infeasible rows; pyramids (degenerate vertices: Bland hand-over); shapes whose LPs run past
     the four pivots kept in registers into the private-array steps; a sample against the oracle."""
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(5)
@@ -690,8 +690,12 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
         for mr in (None, rows):
             dense, one_row, lazy = three(A, b, mr)
             for key in dense:
-                assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
                 assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
+                if key != "xc":
+                    assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
+            # (two rows per lane compare the two ratios of a lane by cross-multiplication, one row per lane by quotient:
+            # a near-tie can send F1 through another vertex order -- seen once in 130 000 polytopes, centre off by one ulp)
+            assert np.allclose(dense["xc"], lazy["xc"], rtol=0, atol=1e-12, equal_nan=True), (B, m, d)
         masks = pa.keep_to_bool(lazy["keep"], m)
         for k in range(0, B, 37):
             o = oracle.reduce(A[k, :rows[k]], b[k, :rows[k]])
@@ -702,7 +706,9 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
     A, b = _pyramids(40, 40, 9, rng)
     dense, one_row, lazy = three(A, b)
     for key in dense:
-        assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
+        assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), key
+        if key != "xc":
+            assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
 
 
 def test_reduce_host_batch_chunked_upload_equals_one_copy(pa, monkeypatch):
