@@ -97,13 +97,14 @@ int plp_cheby_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d,
                         const double *b, const int32_t *m, double *r, double *xc, int32_t *status);
 
 /*
- * Bounding boxes of a batch of polytopes (1 <= d <= 8): per polytope the Chebyshev LP and then the 2d LPs
- * min +-e_i.x (form F3) started from its centre -- one launch instead of 2d generic LPs per polytope.
+ * Bounding boxes of a batch of polytopes (1 <= d <= 16, m_max <= 64): per polytope the Chebyshev LP and then the 2d LPs
+ * min +-e_i.x (form F3) started from its centre -- one launch instead of 2d generic LPs per polytope (d > 8: one
+ * polytope per wavefront, the 2d LPs without a stored dictionary).
  * Replaces: the LP loops of bounding_box (polytope/polytope.py:1367-1409).
  * Out: lb[B][d], ub[B][d] (-inf / +inf where the LP is unbounded, :1376 / :1398) and status[B]:
  *      0 = lb/ub hold the box,
  *      1 = not handled here (no Chebyshev centre with r >= 1e-6: empty, flat or unbounded-ball polytopes; LPs that
- *          need Bland's rule): lb/ub are NaN and the caller solves the 2d generic LPs (plp_lp_solve_batch), whose
+ *          need Bland's rule, for d > 8 also LPs of more than 32 pivots): lb/ub are NaN and the caller solves the 2d generic LPs (plp_lp_solve_batch), whose
  *          statuses 2 / 3 then take the reference's branches (:1378-1380, :1400-1402).
  */
 int plp_bbox_batch(plp_ctx *ctx, int64_t B, int m_max, int d, const double *A, const double *b, const int32_t *m,

@@ -129,7 +129,7 @@ def cheby_ball_batch(A, b, m=None):
 
 
 def bbox_batch(A, b, m=None):
-    """Bounding boxes of B polytopes with 1 <= d <= 8 (bounding_box's LP loops, polytope.py:1367-1409): the
+    """Bounding boxes of B polytopes with 1 <= d <= 16 (bounding_box's LP loops, polytope.py:1367-1409): the
     Chebyshev LP and 2d LPs from its centre per polytope, one launch.
 
     -> dict(lb[B,d], ub[B,d], status[B]): status 0 = box valid (+-inf where unbounded), 1 = polytope not handled

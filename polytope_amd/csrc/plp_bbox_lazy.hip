@@ -1,0 +1,122 @@
+// plp_bbox_lazy.hip -- fused bounding boxes for d = 9..16 (polytope/polytope.py:1314-1411): one polytope of up to 64
+// rows per wavefront, the Chebyshev LP on the one-LP-per-wavefront engine (plp_wide.hpp), then the 2d LPs
+// min / max x_k from its centre WITHOUT a stored dictionary (plp_lazy.hpp).  Same contract as bbox_r_kernel
+// (plp_cheby_r_impl.hpp, d <= 8): status 0 = lb / ub hold the box (+-inf where an LP is unbounded, :1376 / :1398),
+// status 1 = not handled here (empty / flat / unbounded-ball polytopes, LPs that ask for Bland's rule or run past the
+// step limit): the caller solves the generic LPs for those.
+#include <stdlib.h>
+
+#include "plp_kernels.hpp"
+#include "plp_lazy.hpp"
+#include "plp_wide.hpp"
+
+namespace plp {
+
+namespace {
+constexpr double BBOX_LAZY_MIN_R = 1e-6;  // (bbox_r_kernel's BBOX_MIN_R)
+}
+
+template <int D>
+__global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max, const double* __restrict__ A,
+                                                          const double* __restrict__ b, const int* __restrict__ mrows,
+                                                          double* __restrict__ lb, double* __restrict__ ub,
+                                                          int* __restrict__ status) {
+    constexpr int NC = D + 1;
+    __shared__ __attribute__((aligned(16))) double sA[64 * D];
+    __shared__ wide::WideShared<NC> sh;
+    const int lane = threadIdx.x;
+    const long long p = blockIdx.x;
+    if (p >= B) return;
+    const int m = mrows ? mrows[p] : m_max;
+    const bool has = lane < m;
+    // ---- F1 (set-up as cheby_w_kernel); my row also goes to LDS for the lazy LPs
+    wide::v16d Tv = (wide::v16d)(0.0);
+    double T16 = 0.0;
+    double nrm2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = has ? A[(p * m_max + lane) * D + k] : 0.0;
+        ROW_SET(k, v);
+        sA[lane * D + k] = v;
+        nrm2 = nrm2 + v * v;
+        finite = finite & isfinite(v);
+    }
+    const double bi = has ? b[p * m_max + lane] : 0.0;
+    finite = finite & isfinite(bi);
+    const double nrm = sqrt(nrm2);
+    const bool zero = !(nrm > 0.0);
+    bool rowact = has & !zero;
+    ROW_SET(D, rowact ? nrm : 0.0);
+    double beta = rowact ? bi : 0.0;
+    int rowvar = NC + lane, rowneg = 0;
+    if (lane <= NC) {
+        sh.cost[lane] = lane == D ? -1.0 : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+    const bool bad = (__ballot(!finite) != 0) | (m > 64);
+    __syncthreads();
+    int st, iters = 0;
+    if (bad) st = ST_NUM;
+    else if (infeasible0) st = ST_INFEAS;
+    else st = wide::wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+    const double mine = rowneg ? -beta : beta;
+    double x[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const uint64_t ob = __ballot(rowvar == j);
+        x[j] = ob ? wide::uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+    }
+    const bool ok = (st == ST_OPT) & (x[D] >= BBOX_LAZY_MIN_R);
+    bool handed = !ok;
+    // ---- my slack at the centre (bbox_r_kernel: s by an fma chain, beta = max(b - s, 0))
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = fma(has ? sA[lane * D + k] : 0.0, ok ? x[k] : 0.0, s);
+    const double be0 = (ok & has) ? fmax(bi - s, 0.0) : 0.0;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
+        const int kx = it >> 1;
+        const bool up = it & 1;
+        double xck = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xck = (k == kx) ? x[k] : xck;
+        double val = qnan;
+        if (__builtin_amdgcn_readfirstlane((int)ok)) {
+            double negz = 0.0;
+            const int s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
+            // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
+            if (s2 == ST_OPT) val = up ? (xck + negz) : (xck - negz);
+            else if (s2 == ST_UNBND) val = up ? pinf : -pinf;
+            else handed = true;
+        }
+        if (lane == 0) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
+    }
+    if (lane == 0) status[p] = handed ? 1 : 0;
+}
+
+template <int D>
+static int launch_bbox_lazy_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
+                              double* ub, int* status, hipStream_t st) {
+    if (B > 2147483647ll) return 1;
+    hipLaunchKernelGGL((bbox_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows, lb, ub,
+                       status);
+    return 0;
+}
+
+#define PLP_CASE_BL(K) case K: return launch_bbox_lazy_d<K>(B, m_max, A, b, mrows, lb, ub, status, st);
+
+// d = 9..16, m_max <= 64; returns 1 when it does not apply
+int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
+                     double* ub, int* status, hipStream_t st) {
+    if (m_max < 1 || m_max > 64 || B < 1) return 1;
+    switch (d) {
+        PLP_CASE_BL(9) PLP_CASE_BL(10) PLP_CASE_BL(11) PLP_CASE_BL(12)
+        PLP_CASE_BL(13) PLP_CASE_BL(14) PLP_CASE_BL(15) PLP_CASE_BL(16)
+        default: return 1;
+    }
+}
+
+}  // namespace plp

@@ -22,14 +22,14 @@ static int launch_bbox_r_d(long long B, int m_max, const double* A, const double
 
 #define PLP_CASE_BB(K) case K: return launch_bbox_r_d<K>(B, m_max, A, b, mrows, lb, ub, status, st);
 
-// returns 0 when launched, 1 when this kernel does not apply (d > 8: the caller uses the generic LPs)
+// returns 0 when launched, 1 when no fused kernel applies (the caller uses the generic LPs); d = 9..16: plp_bbox_lazy.hip
 int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
                 double* ub, int* status, hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || B < 1) return 1;
     switch (d) {
         PLP_CASE_BB(1) PLP_CASE_BB(2) PLP_CASE_BB(3) PLP_CASE_BB(4)
         PLP_CASE_BB(5) PLP_CASE_BB(6) PLP_CASE_BB(7) PLP_CASE_BB(8)
-        default: return 1;
+        default: return launch_bbox_lazy(B, m_max, d, A, b, mrows, lb, ub, status, st);
     }
 }
 

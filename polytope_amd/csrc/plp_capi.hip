@@ -520,7 +520,7 @@ int plp_bbox_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, 
     if (!lb || !ub || !status || ((!A || !b) && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (m_max > plp::MAX_M || d > plp::MAX_D)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
-    if (m_max < 1 || d > 8) return fail(PLP_EUNSUPPORTED, "bbox kernel: d=%d m_max=%d (needs 1 <= d <= 8, m_max >= 1)", d, m_max);
+    if (m_max < 1) return fail(PLP_EUNSUPPORTED, "bbox kernel: m_max=%d (needs m_max >= 1)", m_max);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_bbox(B, m_max, d, A, b, m, lb, ub, status, st))
         return fail(PLP_EUNSUPPORTED, "bbox kernel: unsupported size");

@@ -53,6 +53,9 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 // valid, 1 = polytope left to the generic LPs; returns 1 when the kernel does not apply
 int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
                 double* ub, int* status, hipStream_t st);
+// d = 9..16 (plp_bbox_lazy.hip); same contract
+int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
+                     double* ub, int* status, hipStream_t st);
 
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8) into the n x n matrix adj (compact == nullptr),
 // or of the pairs p_lo <= p < p_hi, p = i (i - 1) / 2 + j, j < i, into compact[p - p_lo]

@@ -520,8 +520,9 @@ def is_subset(small, big, abs_tol=ABS_TOL):
 # ====================================================================================== bounding box
 def _bbox_packed(polys):
     """_bbox_raw for polytopes of one dimension on the 'hip' backend, with array operations only (no per-LP
-    Python objects).  d <= 8: the fused kernel (Chebyshev LP + 2d LPs from its centre per polytope, one launch);
-    polytopes it hands back (empty, flat, unbounded ball) and d > 8 go down as ONE batch of 2d generic LPs each.
+    Python objects).  The fused kernel (Chebyshev LP + 2d LPs from its centre per polytope, one launch; for d > 8 the
+    2d LPs without a stored dictionary, at most 64 rows); polytopes it hands back (empty, flat, unbounded ball) and
+    longer d > 8 stacks go down as ONE batch of 2d generic LPs each.
     Same status handling as the reference (:1372-1409)."""
     from .batch import bbox_batch, lpsolve_batch
     d = polys[0].A.shape[1]
@@ -536,7 +537,7 @@ def _bbox_packed(polys):
     lo = np.empty((B, d))
     hi = np.empty((B, d))
     rest = np.arange(B)
-    if d <= 8 and int(ms.min()) >= 1:
+    if int(ms.min()) >= 1 and (d <= 8 or m_max <= 64):
         res = bbox_batch(A3, b3, m=ms)
         done = res["status"] == 0
         lo[done], hi[done] = res["lb"][done], res["ub"][done]

@@ -604,7 +604,7 @@ def test_fuzz_random_shapes(pa, oracle):
         masks = pa.keep_to_bool(rd["keep"], m)
         c = rng.standard_normal((B, d))
         lp = pa.lpsolve_batch(c, A, b, m=mrows)
-        bb = pa.bbox_batch(A, b, m=mrows) if d <= 8 else None
+        bb = pa.bbox_batch(A, b, m=mrows)
         for k in range(B):
             Ak, bk = A[k, :mrows[k]], b[k, :mrows[k]]
             if bb is not None and bb["status"][k] == 0:   # fused boxes vs the generic LPs of the oracle
@@ -709,6 +709,36 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
         assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), key
         if key != "xc":
             assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
+
+
+def test_bbox_large_dimensions(pa, oracle):
+    """Fused bounding boxes for d = 9..16 (bbox_lazy_kernel: Chebyshev LP on the one-LP-per-wavefront engine, the 2d LPs
+    from its centre without a stored dictionary): boxes of bounded polytopes against the oracle's generic LPs (1e-9),
+    +-inf on the unbounded sides of half-open polytopes, status 1 (handed back, NaN) for empty ones; ragged rows."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(31)
+    for (B, m, d) in [(40, 64, 16), (40, 40, 9), (30, 33, 12), (30, 20, 10), (20, 57, 13)]:
+        A, b = random_hpolytopes(B, m, d, seed=m + d, stream=0)
+        A[:, :2 * d] = np.vstack([np.eye(d), -np.eye(d)])[None] if m >= 2 * d else A[:, :2 * d]
+        if m >= 2 * d:
+            b[:, :2 * d] = 1.5 + rng.random((B, 2 * d))
+            A[::4, 0] = A[::4, 1]                  # x_0 <= .. dropped in favour of a duplicate: unbounded below? no, above
+            b[::4, 0] = b[::4, 1]
+        b[3::9, 5] = -50.0                         # empty
+        rows = rng.integers(max(2 * d if m >= 2 * d else d + 2, m - 5), m + 1, B).astype(np.int32)
+        res = pa.bbox_batch(A, b, m=rows)
+        nok = 0
+        for k in range(B):
+            lo, hi, bad = oracle.bounding_box(A[k, :rows[k]], b[k, :rows[k]])
+            if res["status"][k] == 0:
+                nok += 1
+                assert bad == 0, (m, d, k)
+                assert np.allclose(res["lb"][k], lo, rtol=0, atol=TOL) and np.allclose(res["ub"][k], hi, rtol=0, atol=TOL), (
+                    m, d, k, res["lb"][k], lo, res["ub"][k], hi)
+            else:
+                assert np.isnan(res["lb"][k]).all() and np.isnan(res["ub"][k]).all()
+        assert nok >= B // 2, (m, d, nok)
+        assert (res["status"][3::9] == 1).all()
 
 
 def test_reduce_host_batch_chunked_upload_equals_one_copy(pa, monkeypatch):

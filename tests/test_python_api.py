@@ -591,6 +591,48 @@ def test_subset_and_comparisons_match_reference(pc):
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+def test_high_dimensional_box_and_reduce_match_the_scipy_backend():
+    """d = 12: bounding_box and reduce of random polytopes with box rows on the 'hip' backend (fused kernels that keep no
+    dictionary for the 2d / per-row LPs) against the same calls on the reference's scipy backend -- boxes within 1e-9,
+    identical rows kept; one half-open polytope (+inf side) and one empty one."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    rng = np.random.default_rng(12)
+    d, m = 12, 40
+    polys = []
+    for k in range(6):
+        A = rng.standard_normal((m, d))
+        A /= np.linalg.norm(A, axis=1, keepdims=True)
+        b = 1.0 + rng.random(m)
+        A[:2 * d] = np.vstack([np.eye(d), -np.eye(d)])
+        b[:2 * d] = 1.2 + rng.random(2 * d)
+        if k == 4:
+            A, b = A[1:2 * d].copy(), b[1:2 * d].copy()          # the box without x_0 <= ..: unbounded above
+        if k == 5:
+            b[30] = -40.0                                        # empty
+        polys.append((A, b))
+    out = {}
+    old = solvers.default_solver
+    try:
+        for backend in ("scipy", "hip"):
+            solvers.default_solver = backend
+            res = []
+            for A, b in polys:
+                p = pc.Polytope(A.copy(), b.copy())
+                l, u = pc.bounding_box(p)
+                q = pc.reduce(pc.Polytope(A.copy(), b.copy()))
+                res.append((l.ravel(), u.ravel(), q.A.copy(), q.b.copy()))
+            out[backend] = res
+    finally:
+        solvers.default_solver = old
+    for (l0, u0, A0, b0), (l1, u1, A1, b1) in zip(out["scipy"], out["hip"]):
+        assert np.allclose(l0, l1, rtol=0, atol=TOL) and np.allclose(u0, u1, rtol=0, atol=TOL)
+        assert A0.shape == A1.shape and np.allclose(A0, A1, rtol=0, atol=1e-12) and np.allclose(b0, b1, rtol=0, atol=1e-12)
+        assert np.array_equal(np.isinf(u0), np.isinf(u1)) and np.array_equal(np.isinf(l0), np.isinf(l1))
+    assert np.isinf(out["hip"][4][1][0]) and out["hip"][5][2].size == 0
+
+
 def test_stacks_beyond_64_rows_through_the_python_layer():
     """intersect / reduce / cheby_ball / bounding_box / is_adjacent on polytopes whose stacks pass 64 rows (the fused
     kernels' limit): the 'hip' backend takes the LDS-resident LP engine for them and must agree with the scipy backend
