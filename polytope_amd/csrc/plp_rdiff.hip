@@ -10,12 +10,14 @@
 //   (lists beyond 64 rows, and d > 8: cheby_gather_lds_kernel in plp_lds.hip, dictionary in LDS)
 //
 // out[p] = the radius as cheby_ball reads it (:1289-1297): x[-1] if the LP is optimal with r >= 0, else 0.
+#include <stdlib.h>
+
 #include "plp_cheby_r_impl.hpp"
 
 namespace plp {
 
 // one lane group = one LP of the size class GS (lists of up to 4 * GS rows); q = position inside the class
-template <int D, int GS>
+template <int D, int GS, int R = RowsPerLane<D>::value>
 __device__ __forceinline__ void gather_body(long long q0, long long nlp, const int* __restrict__ off,
                                             const int* __restrict__ rows, const int* __restrict__ sel,
                                             const double* __restrict__ A, const double* __restrict__ b,
@@ -23,7 +25,6 @@ __device__ __forceinline__ void gather_body(long long q0, long long nlp, const i
     const Grp g(GS);
     constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
-    constexpr int R = RowsPerLane<D>::value;
     const int row0 = g.gl * R;
     const long long q = q0 * gpb + gib;
     const bool valid = q < nlp;
@@ -53,6 +54,23 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void cheby_gather_r_kernel(
     else gather_body<D, 16>(bid - nb0 - nb1, n2, off, rows, sel + n0 + n1, A, b, out, force_retry);
 }
 
+// The same with ONE row per lane (groups of 16 / 32 / 64 lanes): a pivot costs the wavefront about half the instructions,
+// so a lone wavefront finishes its LP sooner.  A search batch is a few dozen to a few hundred LPs -- far fewer
+// wavefronts than the chip holds either way -- and the search waits for the slowest of them: latency, not throughput.
+template <int D>
+__global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void cheby_gather_r1_kernel(int nb0, int nb1, long long n0, long long n1,
+                                                                                  long long n2, const int* __restrict__ off,
+                                                                                  const int* __restrict__ rows,
+                                                                                  const int* __restrict__ sel,
+                                                                                  const double* __restrict__ A,
+                                                                                  const double* __restrict__ b,
+                                                                                  double* __restrict__ out, int force_retry) {
+    const int bid = blockIdx.x;
+    if (bid < nb0) gather_body<D, 16, 1>(bid, n0, off, rows, sel, A, b, out, force_retry);
+    else if (bid < nb0 + nb1) gather_body<D, 32, 1>(bid - nb0, n1, off, rows, sel + n0, A, b, out, force_retry);
+    else gather_body<D, 64, 1>(bid - nb0 - nb1, n2, off, rows, sel + n0 + n1, A, b, out, force_retry);
+}
+
 // After the LP kernels of a batch (same stream): copy the n radii to host-mapped memory and raise the batch's sequence
 // number there; the host spins on that word instead of paying a stream synchronisation per batch.
 __global__ __launch_bounds__(256) void rdiff_publish_kernel(long long n, const double* __restrict__ src,
@@ -70,6 +88,17 @@ __global__ __launch_bounds__(256) void rdiff_publish_kernel(long long n, const d
 template <int D>
 static int launch_gather_d(long long n0, long long n1, long long n2, const int* off, const int* rows, const int* sel,
                            const double* A, const double* b, double* out, hipStream_t st) {
+    // small batches (the search's): one row per lane; PLP_RDIFF_R1=0 / 1: never / always (A/B)
+    static const char* r1 = getenv("PLP_RDIFF_R1");
+    const bool lowlat = r1 ? r1[0] == '1' : (n0 + n1 + n2 <= 2048);
+    if (lowlat) {
+        const long long b0 = (n0 + RBLK / 16 - 1) / (RBLK / 16), b1 = (n1 + RBLK / 32 - 1) / (RBLK / 32),
+                        b2 = (n2 + RBLK / 64 - 1) / (RBLK / 64);
+        if (b0 + b1 + b2 < 1) return 0;
+        hipLaunchKernelGGL((cheby_gather_r1_kernel<D>), dim3((unsigned)(b0 + b1 + b2)), dim3(RBLK), 0, st, (int)b0, (int)b1, n0,
+                           n1, n2, off, rows, sel, A, b, out, force_retry_env());
+        return 0;
+    }
     const long long nb0 = (n0 + RBLK / 4 - 1) / (RBLK / 4), nb1 = (n1 + RBLK / 8 - 1) / (RBLK / 8),
                     nb2 = (n2 + RBLK / 16 - 1) / (RBLK / 16);
     const long long blocks = nb0 + nb1 + nb2;
