@@ -89,7 +89,7 @@ template <int D>
 static int launch_gather_d(long long n0, long long n1, long long n2, const int* off, const int* rows, const int* sel,
                            const double* A, const double* b, double* out, hipStream_t st) {
     // small batches (the search's): one row per lane; PLP_RDIFF_R1=0 / 1: never / always (A/B)
-    static const char* r1 = getenv("PLP_RDIFF_R1");
+    const char* r1 = getenv("PLP_RDIFF_R1");
     const bool lowlat = r1 ? r1[0] == '1' : (n0 + n1 + n2 <= 2048);
     if (lowlat) {
         const long long b0 = (n0 + RBLK / 16 - 1) / (RBLK / 16), b1 = (n1 + RBLK / 32 - 1) / (RBLK / 32),
