@@ -176,7 +176,12 @@ int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::init
         int n = nt ? atoi(nt) : (hw >= 16 ? 7 : (hw >= 4 ? (int)hw / 2 - 1 : 1));
         if (n < 1) n = 1;
         if (n > 32) n = 32;
-        ctx->pool = new plp::StagePool(n);
+        try {
+            ctx->pool = new plp::StagePool(n);
+        } catch (...) {  // no threads to be had: the caller copies as before
+            ctx->pool = nullptr;
+            return PLP_OK;
+        }
     }
     if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
@@ -205,7 +210,13 @@ int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::init
     int64_t per = (B + nch - 1) / nch;
     per = (per + align - 1) / align * align;
     nch = (B + per - 1) / per;
-    std::vector<std::vector<plp::StagePiece>> chunks((size_t)nch);
+    std::vector<std::vector<plp::StagePiece>> chunks;
+    try {
+        chunks.resize((size_t)nch);
+        for (auto& c : chunks) c.reserve(arrays.size());
+    } catch (...) {
+        return PLP_OK;
+    }
     size_t so = 0;
     for (int64_t c = 0; c < nch; ++c) {
         const int64_t lo = c * per, hi = lo + per < B ? lo + per : B;
