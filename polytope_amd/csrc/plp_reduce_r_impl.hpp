@@ -98,7 +98,14 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 // so that reduce_r_mix_kernel can give the last tiles of a launch a different shape).
 // LAZY (GS = 64, R = 1: one polytope per wavefront): F1 on the one-LP-per-wavefront engine (its LDS block sits behind the
 // tile's arrays), the F3 / F2 LPs on plp_lazy.hpp -- no dictionary is carried.
-template <int D, int GS, int R, bool LAZY = false>
+// SPLIT (small batches): ONE polytope per wavefront, its INDEPENDENT LPs spread over the RBLOCK / GS lane groups -- every
+// group runs F1 and the dedupe on the same rows (identical results, nothing to exchange), then group g solves the g-th
+// of the 2d box LPs and the g-th surviving row's redundancy LP (round-robin when there are more LPs than groups).  The
+// in-place h[k] +- 0.1 round trip becomes a rule (rows that had their LP before k: (b + 0.1) - 0.1; row k: b + 0.1), the
+// results meet in LDS.  Same engine, same arithmetic per LP: outputs bitwise equal to the batch form; a polytope takes
+// ~12 pivot times instead of ~60 (latency), at ~3x the instruction slots (throughput): for batches that cannot fill
+// the chip anyway.
+template <int D, int GS, int R, bool LAZY = false, bool SPLIT = false>
 __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -111,9 +118,12 @@ __device__ __forceinline__ void reduce_r_tile(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int gs = GS;
     const Grp g(gs);
-    constexpr int NG = RBLOCK / gs;
+    constexpr int NGRP = RBLOCK / gs;             // lane groups per workgroup
+    constexpr int NG = SPLIT ? 1 : NGRP;          // polytopes per tile
     constexpr int rows = gs * R;  // row slots per polytope
-    const int gib = threadIdx.x / gs;
+    const int grp = threadIdx.x / gs;             // my lane group
+    const int gib = SPLIT ? 0 : grp;              // my polytope inside the tile
+    static_assert(!(SPLIT && LAZY), "one or the other");
     const int row0 = g.gl * R;  // my first row
     double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
     double* sb = sA + (size_t)NG * rows * D;            // [NG][rows]
@@ -122,6 +132,10 @@ __device__ __forceinline__ void reduce_r_tile(
     double* myb = sb + (size_t)gib * rows;
     double* myan = san + (size_t)gib * rows;
     double* lzrho = san + (size_t)NG * rows;  // (LAZY) F1's block of the one-LP-per-wavefront engine
+    // (SPLIT) where the groups' results meet: box values [2D], kept-row mask, flags (bit 0: an LP failed, bit 1: retry)
+    double* sval = san + (size_t)NG * rows;
+    unsigned long long* skeep = reinterpret_cast<unsigned long long*>(sval + 2 * D);
+    unsigned* sflag = reinterpret_cast<unsigned*>(skeep + 1);
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
 
@@ -140,6 +154,9 @@ __device__ __forceinline__ void reduce_r_tile(
                 const int p = idx / m_max, row = idx - p * m_max;
                 sb[p * rows + row] = srcb[idx];
             }
+        }
+        if constexpr (SPLIT) {
+            if (threadIdx.x == 0) { *skeep = 0ull; *sflag = 0u; }  // (visible after the barrier that follows F1)
         }
         __syncthreads();
         const long long pg = tile + gib;
@@ -364,6 +381,56 @@ __device__ __forceinline__ void reduce_r_tile(
             for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
             bool lpfail = false;
             double lbk = 0.0;
+            if constexpr (SPLIT) {
+                for (int round = 0; round * NGRP < 2 * D; ++round) {  // group g: LP g, g + NGRP, ...
+                    const int itq = round * NGRP + grp;
+                    const bool mine = go & (itq < 2 * D);
+                    const int it = itq < 2 * D ? itq : 0;
+                    const int kx = it >> 1;
+                    const bool up = it & 1;
+                    double xck = 0.0;
+                    SimplexR<D, R, false, false> S;
+                    S.reset(D, __popcll(live), row0);
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) {
+                        xck = (kk == kx) ? xc[kk] : xck;
+                        S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+#pragma unroll
+                        for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
+                        S.beta[k] = fmax(myb[row0 + k] - myan[row0 + k], 0.0);  // 0 for the zeroed rows
+                    }
+                    S.ract = lloc;
+                    S.mode = mine ? M_P2 : M_DONE;
+                    S.template run_fast<GS>(g);
+                    double val;
+                    unsigned fl = 0u;
+                    if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+                    else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+                    else { val = qnan; fl = 1u; }
+                    if (S.status == ST_RETRY) fl |= 2u;
+                    if (mine & (g.gl == 0)) {
+                        sval[it] = val;
+                        if (fl) atomicOr(sflag, fl);
+                    }
+                }
+                __syncthreads();
+                for (int kx = 0; kx < D; ++kx) {  // prefilter sums, accumulated in k order (:1131-1134)
+                    const double lo = sval[2 * kx], hi = sval[2 * kx + 1];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const double aik = myA[(row0 + k) * D + kx];
+                        const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                        s1[k] = s1[k] + pa * (hi - lo);
+                        s2[k] = s2[k] + aik * lo;
+                    }
+                }
+                const unsigned fl = *sflag;
+                lpfail = go & ((fl & 1u) != 0u);
+                retry = retry | (go & ((fl & 2u) != 0u));
+            } else
             for (int it = 0; it < 2 * D; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
                 const int kx = it >> 1;
                 const bool up = it & 1;
@@ -441,7 +508,60 @@ __device__ __forceinline__ void reduce_r_tile(
             }
         }
         // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
-        if constexpr (LAZY) {
+        if constexpr (SPLIT) {
+            if (__any(stage == 2)) {
+                const bool go2 = stage == 2;
+                const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
+                const int nlive = __popcll(live);
+                if (go2) nlp += nlive;
+                for (int round = 0; round * NGRP < rows; ++round) {  // group g: the g-th surviving row, g + NGRP-th, ...
+                    if (!__any(go2 & (round * NGRP < nlive))) break;
+                    const int idx = round * NGRP + grp;
+                    const bool mine = go2 & (idx < nlive);
+                    uint64_t t = live;
+                    for (int i = 0; i < rows; ++i) t = (i < idx) ? (t & (t - 1ull)) : t;
+                    const int kr = (mine & (t != 0ull)) ? __ffsll((long long)t) - 1 : 0;
+                    SimplexR<D, R, false, false> S;
+                    S.reset(D, nlive, row0);
+                    double cxc = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) {
+                        const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
+                        S.cost[kk] = ck;
+                        cxc = fma(ck, xc[kk], cxc);
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+#pragma unroll
+                        for (int kk = 0; kk < D; ++kk) S.T[k][kk] = myA[(row0 + k) * D + kk];
+                        // h as the reference holds it when row kr has its turn (:1149-1151): rows before it carry the round trip
+                        const int rw = row0 + k;
+                        const double h0 = myb[rw];
+                        const double hp = h0 + 0.1;
+                        const bool lv = ((lloc >> k) & 1u) != 0u;
+                        const double hh = (lv & (rw < kr)) ? hp - 0.1 : ((lv & (rw == kr)) ? hp : h0);
+                        S.beta[k] = fmax(hh - myan[rw], 0.0);  // 0 for the zeroed rows
+                    }
+                    S.ract = lloc;
+                    S.mode = mine ? M_P2 : M_DONE;
+                    S.template run_fast<GS>(g);
+                    const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
+                    const double hk = (myb[kr] + 0.1) - 0.1;
+                    const double obj = -fun - hk;  // (:1156)
+                    const bool keepk = mine & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
+                    if (g.gl == 0) {
+                        if (keepk) atomicOr(skeep, 1ull << kr);
+                        if (mine & (S.status == ST_RETRY)) atomicOr(sflag, 2u);
+                    }
+                }
+                __syncthreads();
+                if (go2) {
+                    keep = *skeep;
+                    retry = retry | ((*sflag & 2u) != 0u);
+                    flags |= RF_MINREP;
+                }
+            }
+        } else if constexpr (LAZY) {
             // one polytope per wavefront: its rows one after the other, each LP on plp_lazy.hpp (nothing to set up but
             // the cost vector: lane j holds -A[k][j]; c.xc = -(a_k.xc) = -s_k exactly, the two FMA chains mirror each other)
             if (__builtin_amdgcn_readfirstlane(stage) == 2) {  // (wave-uniform, and said so: the LP loops stay scalar)
@@ -598,7 +718,7 @@ __device__ __forceinline__ void reduce_r_tile(
 #endif
         }
         // ---------------------------------------------------------------- results
-        if (valid & (g.gl == 0)) {
+        if (valid & (g.gl == 0) & (!SPLIT || grp == 0)) {
             keep_out[pg] = keep;
             flags_out[pg] = retry ? (int)RF_RETRY : flags;
             nlp_out[pg] = nlp;
@@ -633,6 +753,25 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
                        abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
     return 0;
 }
+
+// Small batches: one polytope per wavefront, its LPs spread over the lane groups (reduce_r_tile, SPLIT).
+template <int D, int GS, int R = RR>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_split_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    reduce_r_tile<D, GS, R, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                                         flags_out, r_out, xc_out, nlp_out);
+}
+
+// Batches up to this size take the latency form.  Measured (device time per call, batch form -> latency form): (16,3)
+// B = 1: 49 -> 21 us, 256: 77 -> 25, 4096: 81 -> 50, 16384: 90 -> 153; (32,6) 256: 274 -> 79, 4096: 306 -> 202;
+// (64,8) 256: 652 -> 257, 4096: 896 -> 728; (16,8) 256: 80 -> 75, 4096: 82 -> 111 (16 rows at d >= 7 gain nothing:
+// the 2d box LPs already fill the 16 groups).  ~20 us of every figure are the launches of a call.
+#ifndef PLP_REDUCE_SPLIT_MAXB
+#define PLP_REDUCE_SPLIT_MAXB(D, GS) (((GS) == 4 && (D) >= 7) ? 1024 : 4096)
+#endif
 
 template <int D, int GS, int R = RR>
 __global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
@@ -675,6 +814,16 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
+    if constexpr (R == 4 && D <= 8) {
+        // small batches: one polytope per wavefront, LPs in parallel (PLP_REDUCE_SPLIT=0 / 1: never / always)
+        const char* sp = getenv("PLP_REDUCE_SPLIT");
+        if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= PLP_REDUCE_SPLIT_MAXB(D, GS))) {
+            const size_t sm1 = (((size_t)GS * R * (D + 2) + 2 * D + 2) * 8 + 15) & ~(size_t)15;
+            hipLaunchKernelGGL((reduce_split_kernel<D, GS, R>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), sm1, st, B, m_max,
+                               A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+            return 0;
+        }
+    }
     if constexpr (GS == 4 && R == 4 && D <= 4) {
         // more tiles than the chip holds at once (4096 wavefront slots): the last 1/16 of the tiles (at most 1024) are
         // split into half-size ones.  Measured at C2 (6250 tiles): 0.2765 ms without, 0.2579-0.2609 ms with 2/64 .. 9/64

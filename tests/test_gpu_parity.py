@@ -524,14 +524,18 @@ def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
         assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
-@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_REDUCE_RETRY_ALL"])
+@pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_REDUCE_RETRY_ALL", "PLP_REDUCE_SPLIT=0", "PLP_REDUCE_SPLIT=1",
+                                     "PLP_REDUCE_SPLIT=0,PLP_REDUCE_RETRY_ALL=1", "PLP_REDUCE_SPLIT=1,PLP_REDUCE_RETRY_ALL=1"])
 def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
-    """The three mappings of the fused reduce (4 rows per lane = default, 1 row per lane, 1 polytope
-    per lane) must agree with the oracle; the non-default ones are selected by environment.
-    PLP_REDUCE_RETRY_ALL sends every polytope of the default kernel through its second pass (the
-    hand-over used when the fast pivot path meets a dictionary that needs Bland's rule)."""
+    """The mappings of the fused reduce (4 rows per lane with several polytopes per wavefront = the batch form,
+    PLP_REDUCE_SPLIT=0; one polytope per wavefront with its LPs spread over the lane groups = the latency form, default
+    for small batches; 1 row per lane, round 1) must agree with the oracle; the non-default ones are selected by
+    environment.  PLP_REDUCE_RETRY_ALL sends every polytope through the second pass (the hand-over used when the fast
+    pivot path meets a dictionary that needs Bland's rule)."""
     from polytope_amd.synth import random_hpolytopes
-    monkeypatch.setenv(variant, "1")
+    for item in variant.split(","):
+        name, _, val = item.partition("=")
+        monkeypatch.setenv(name, val or "1")
     rng = np.random.default_rng(21)
     for (m, d, B) in [(16, 3, 700), (10, 2, 130), (8, 3, 65), (13, 1, 40)]:
         A, b = random_hpolytopes(B, m, d, seed=7 * m + d, bounded=True)
@@ -654,6 +658,55 @@ def test_contains_vs_oracle(pa, oracle):
             assert np.array_equal(reg.astype(bool), out.astype(bool).any(axis=0))
     with pytest.raises(ValueError):
         pa.contains_batch(A, b, np.zeros((3, 4)))
+
+
+def test_reduce_latency_form_bitwise(pa, monkeypatch):
+    """Small batches take the latency form of the fused reduce (reduce_split_kernel: one polytope per wavefront, every
+    lane group runs F1 / dedupe on the same rows, then the 2d box LPs and the redundancy LPs are spread over the groups;
+    the in-place h[k] +- 0.1 round trip becomes a rule).  Same engine per LP: every output bitwise equal to the batch
+    form -- d = 1..8, 3..64 rows, ragged, duplicated and infeasible rows, pyramids, golden fixture g2, batch sizes
+    around the switch-over."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(9)
+
+    def both(A, b, m=None):
+        monkeypatch.setenv("PLP_REDUCE_SPLIT", "0")
+        batch = pa.reduce_batch(A, b, m=m)
+        monkeypatch.setenv("PLP_REDUCE_SPLIT", "1")
+        lat = pa.reduce_batch(A, b, m=m)
+        monkeypatch.delenv("PLP_REDUCE_SPLIT")
+        for key in batch:
+            assert np.array_equal(batch[key].view(np.uint8), lat[key].view(np.uint8)), key
+        return lat
+
+    for (m, d) in [(16, 3), (12, 4), (16, 2), (10, 1), (3, 2), (32, 6), (24, 5), (20, 8), (64, 8), (40, 7), (16, 8), (33, 3)]:
+        for B in (1, 7, 130, 1100):
+            A, b = random_hpolytopes(B, m, d, seed=11 * m + d + B, stream=0)
+            for k in range(0, B, 5):
+                j = rng.integers(m)
+                A[k, (j + 1) % m] = A[k, j]
+                b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.05])
+            for k in range(3, B, 11):
+                b[k, 0] = -4.0
+            rows = rng.integers(max(1, m - 5), m + 1, B).astype(np.int32)
+            both(A, b)
+            both(A, b, rows)
+    A, b = _pyramids(60, 16, 3, rng)
+    both(A, b)
+    A, b = _pyramids(30, 40, 6, rng)
+    both(A, b)
+    g = load_golden("g2_reduce.npz")
+    for i in range(len(g["m"])):
+        m, d = int(g["m"][i]), int(g["d"][i])
+        both(g["A"][i, :m * d].reshape(1, m, d), g["b"][i, :m].reshape(1, m))
+    A, b = random_hpolytopes(5000, 16, 3, seed=77, stream=0)   # default dispatch around the switch-over
+    for B in (4095, 4096, 4097):
+        monkeypatch.setenv("PLP_REDUCE_SPLIT", "0")
+        ref = pa.reduce_batch(A[:B], b[:B])
+        monkeypatch.delenv("PLP_REDUCE_SPLIT")
+        got = pa.reduce_batch(A[:B], b[:B])
+        for key in ref:
+            assert np.array_equal(ref[key].view(np.uint8), got[key].view(np.uint8)), (B, key)
 
 
 def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
