@@ -626,14 +626,37 @@ int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A,
                     },
                     &staged);
     if (rc) return rc;
+    bool two_step = false;
     if (!staged) {
         rc = finite_or_fail(ctx, {{A, nA}, {b, nb}});
         if (rc) return rc;
         rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
         if (rc) return rc;
-        rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
+        // small batches: only the first launch now; the pass that redoes polytopes flagged for the general engine runs
+        // when the flags, host-visible below anyway, ask for it (it is a launch that normally finds nothing to do)
+        two_step = B <= 16384 && m_max <= plp::MAX_M && d <= plp::MAX_D;
+        if (two_step) {
+            if (plp::launch_reduce_phase(B, m_max, d, dA, db, m ? dm : nullptr, abs_tol,
+                                         reinterpret_cast<unsigned long long*>(dkeep), dfl, dr, dxc, dnlp, st, 1))
+                return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
+            rc = check_launch("reduce_kernel");
+        } else {
+            rc = plp_reduce_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
+        }
         if (rc) return rc;
     }
+    rc = copy_out(ctx, st, {{dkeep, nullptr, keep, (size_t)B * 8}, {dfl, nullptr, flags, (size_t)B * 4},
+                            {dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
+                            {dnlp, nullptr, nlp, (size_t)B * 4}});
+    if (rc || !two_step) return rc;
+    bool again = false;
+    for (int64_t k = 0; k < B && !again; ++k) again = (flags[k] & plp::RF_RETRY) != 0;
+    if (!again) return PLP_OK;
+    if (plp::launch_reduce_phase(B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, reinterpret_cast<unsigned long long*>(dkeep),
+                                 dfl, dr, dxc, dnlp, st, 2))
+        return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
+    rc = check_launch("reduce_kernel");
+    if (rc) return rc;
     return copy_out(ctx, st, {{dkeep, nullptr, keep, (size_t)B * 8}, {dfl, nullptr, flags, (size_t)B * 4},
                               {dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
                               {dnlp, nullptr, nlp, (size_t)B * 4}});

@@ -67,6 +67,8 @@ int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, c
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                   hipStream_t st);
+int launch_reduce_phase(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                        unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st, int phase);
 
 // four dictionary rows per lane (d <= 8); returns 1 when it does not apply
 int launch_reduce_r(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,

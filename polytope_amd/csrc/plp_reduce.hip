@@ -312,6 +312,29 @@ static int launch_reduce_d(long long B, int m_max, int gs, const double* A, cons
 #define PLP_CASE_R(K) \
     case K: return launch_reduce_d<K>(B, m_max, gs, A, b, mrows, abs_tol, retry, keep, flags, r, xc, nlp, st);
 
+// phase 0: everything (the fast kernel, then the pass that redoes what it flagged RF_RETRY);  phase 1: the first launch
+// only -- the caller looks at the flags itself and asks for phase 2 (that second pass) when it finds RF_RETRY.  The
+// synchronous host entry point does so for small batches: the normally idle second launch is half of their device time.
+int launch_reduce_phase(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                        unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st, int phase) {
+    const int gs = group_size_for(m_max);
+    if (gs < 0 || d < 1 || d > MAX_D) return 2;
+    const char* one = getenv("PLP_REDUCE_1ROW");
+    int retry = 0;
+    if (phase == 2) retry = 1;
+    else if (!(one && one[0] == '1') &&
+             launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0) {
+        if (phase == 1) return 0;
+        retry = 1;
+    }
+    switch (d) {
+        PLP_CASE_R(1) PLP_CASE_R(2) PLP_CASE_R(3) PLP_CASE_R(4) PLP_CASE_R(5) PLP_CASE_R(6)
+        PLP_CASE_R(7) PLP_CASE_R(8) PLP_CASE_R(9) PLP_CASE_R(10) PLP_CASE_R(11) PLP_CASE_R(12)
+        PLP_CASE_R(13) PLP_CASE_R(14) PLP_CASE_R(15) PLP_CASE_R(16)
+        default: return 2;
+    }
+}
+
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
                   unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
     const int gs = group_size_for(m_max);
