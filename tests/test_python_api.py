@@ -591,7 +591,6 @@ def test_subset_and_comparisons_match_reference(pc):
 
 
 @pytest.mark.gpu
-@pytest.mark.gpu
 def test_high_dimensional_box_and_reduce_match_the_scipy_backend():
     """d = 12: bounding_box and reduce of random polytopes with box rows on the 'hip' backend (fused kernels that keep no
     dictionary for the 2d / per-row LPs) against the same calls on the reference's scipy backend -- boxes within 1e-9,
@@ -633,6 +632,7 @@ def test_high_dimensional_box_and_reduce_match_the_scipy_backend():
     assert np.isinf(out["hip"][4][1][0]) and out["hip"][5][2].size == 0
 
 
+@pytest.mark.gpu
 def test_stacks_beyond_64_rows_through_the_python_layer():
     """intersect / reduce / cheby_ball / bounding_box / is_adjacent on polytopes whose stacks pass 64 rows (the fused
     kernels' limit): the 'hip' backend takes the LDS-resident LP engine for them and must agree with the scipy backend
