@@ -225,6 +225,81 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lon
     if (valid & (g.gl == 0)) status[p] = handed ? 1 : 0;
 }
 
+// The same for small batches (latency form, cf. reduce_split_kernel): ONE polytope per wavefront, every lane group solves
+// the Chebyshev LP on the same rows (identical results, nothing to exchange), then group g takes the g-th of the 2d LPs
+// (round-robin).  Same engine and arithmetic per LP: outputs bitwise equal to bbox_r_kernel.
+template <int D, int GS>
+__global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_split_kernel(long long B, int m_max,
+                                                                             const double* __restrict__ A,
+                                                                             const double* __restrict__ b,
+                                                                             const int* __restrict__ mrows,
+                                                                             double* __restrict__ lb,
+                                                                             double* __restrict__ ub,
+                                                                             int* __restrict__ status, int force_retry) {
+    static_assert(RBLK == 64, "one wavefront per workgroup: the polytope's verdict is a wave-wide vote");
+    const Grp g(GS);
+    constexpr int NGRP = RBLK / GS;
+    const int grp = threadIdx.x / GS;
+    constexpr int R = RowsPerLane<D>::value;
+    const int row0 = g.gl * R;
+    const long long p = blockIdx.x;
+    const bool valid = p < B;
+    const int m = valid ? (mrows ? mrows[p] : m_max) : 0;
+    double x[D + 1];
+    const int st = cheby_r_solve<D, GS, R>(
+        g, valid, m, row0, [&](int rr, int kk) { return A[(p * m_max + rr) * D + kk]; },
+        [&](int rr) { return b[p * m_max + rr]; }, x, force_retry);
+    const bool ok = valid & (st == ST_OPT) & (x[D] >= BBOX_MIN_R);
+    bool handed = !ok;
+    double T0[R][D], be0[R];
+    unsigned has = 0u;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const bool h = ok & (row0 + k < m);
+        has |= h ? (1u << k) : 0u;
+        double s = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            T0[k][kk] = h ? A[(p * m_max + row0 + k) * D + kk] : 0.0;
+            s = fma(T0[k][kk], ok ? x[kk] : 0.0, s);
+        }
+        be0[k] = h ? fmax(b[p * m_max + row0 + k] - s, 0.0) : 0.0;
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int round = 0; round * NGRP < 2 * D; ++round) {  // group g: LP g, g + NGRP, ...
+        const int itq = round * NGRP + grp;
+        const bool mine = itq < 2 * D;
+        const int it = mine ? itq : 0;
+        const int kx = it >> 1;
+        const bool up = it & 1;
+        double xck = 0.0;
+        SimplexR<D, R, false, false> S;
+        S.reset(D, m, row0);
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            xck = (kk == kx) ? x[kk] : xck;
+            S.cost[kk] = (kk == kx) ? (up ? -1.0 : 1.0) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) S.T[k][kk] = T0[k][kk];
+            S.beta[k] = be0[k];
+        }
+        S.ract = has;
+        S.mode = (ok & mine) ? M_P2 : M_DONE;
+        S.template run_fast<GS>(g);
+        double val;
+        if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+        else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+        else { val = qnan; handed = handed | mine; }
+        if (valid & mine & (g.gl == 0)) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
+    }
+    const bool any_handed = __any(handed);  // (all lanes of the wavefront work on this one polytope)
+    if (valid & (threadIdx.x == 0)) status[p] = any_handed ? 1 : 0;
+}
+
 // One lane group per pair (i, j < i): the rows of both cells are stacked with b + inflate, and the pair
 // counts iff the Chebyshev LP of the stack is optimal with r > thresh.  Adjacency: inflate = abs_tol,
 // thresh = abs_tol / 10 (`is_fulldim(dummy, abs_tol / 10)`, polytope.py:1860-1866); overlap

@@ -765,6 +765,27 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
             assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
 
 
+def test_bbox_latency_form_bitwise(pa, monkeypatch):
+    """Small batches of fused bounding boxes run one polytope per wavefront with the 2d LPs spread over the lane groups
+    (bbox_split_kernel); PLP_BBOX_SPLIT=0 is the batch form.  Same engine per LP: lb / ub / status bitwise equal --
+    d = 1..8, ragged rows, empty and unbounded polytopes."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(13)
+    for (m, d) in [(16, 3), (12, 4), (10, 1), (5, 2), (32, 6), (24, 5), (64, 8), (40, 7), (16, 8)]:
+        for B in (1, 9, 300):
+            A, b = random_hpolytopes(B, m, d, seed=3 * m + d + B, stream=0)
+            b[2::7, 0] = -5.0
+            rows = rng.integers(max(1, m - 5), m + 1, B).astype(np.int32)
+            for mr in (None, rows):
+                monkeypatch.setenv("PLP_BBOX_SPLIT", "0")
+                ref = pa.bbox_batch(A, b, m=mr)
+                monkeypatch.setenv("PLP_BBOX_SPLIT", "1")
+                got = pa.bbox_batch(A, b, m=mr)
+                monkeypatch.delenv("PLP_BBOX_SPLIT")
+                for key in ref:
+                    assert np.array_equal(ref[key].view(np.uint8), got[key].view(np.uint8)), (m, d, B, key)
+
+
 def test_bbox_large_dimensions(pa, oracle):
     """Fused bounding boxes for d = 9..16 (bbox_lazy_kernel: Chebyshev LP on the one-LP-per-wavefront engine, the 2d LPs
     from its centre without a stored dictionary): boxes of bounded polytopes against the oracle's generic LPs (1e-9),
