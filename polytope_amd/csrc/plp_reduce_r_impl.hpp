@@ -124,6 +124,7 @@ __device__ __forceinline__ void reduce_r_tile(
     const int grp = threadIdx.x / gs;             // my lane group
     const int gib = SPLIT ? 0 : grp;              // my polytope inside the tile
     static_assert(!(SPLIT && LAZY), "one or the other");
+    static_assert(!SPLIT || RBLOCK == 64, "SPLIT: the lane groups of ONE wavefront share a polytope (same-value LDS writes in program order)");
     const int row0 = g.gl * R;  // my first row
     double* sA = reinterpret_cast<double*>(smem_raw);  // [NG][rows][D]
     double* sb = sA + (size_t)NG * rows * D;            // [NG][rows]
