@@ -443,6 +443,7 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
     int32_t* dit = a.take<int32_t>(B);
     hipStream_t st = ctx->stream;
     bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
+    int more = 0;
     const size_t mn = (size_t)m_max * n;
     rc = staged_run(ctx, st, B, 64,
                     {{c, dc, (size_t)n * 8, true}, {G, dG, mn * 8, true}, {h, dh, (size_t)m_max * 8, true}, {m, dm, 4}},
@@ -459,9 +460,26 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
         rc = copy_in(ctx, st, {{dc, c, nullptr, nc * 8}, {dG, G, nullptr, nG * 8}, {dh, h, nullptr, nh * 8},
                                {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
         if (rc) return rc;
-        rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
+        // small batches: the fast kernels now; the general kernel only if a status, host-visible below anyway, asks for it
+        if (B <= 16384) {
+            if (plp::launch_lp_phase(B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit, st, 1, &more))
+                return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
+            rc = check_launch("lp_kernel");
+        } else {
+            rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
+        }
         if (rc) return rc;
     }
+    rc = copy_out(ctx, st, {{dx, nullptr, x, nc * 8}, {dfun, nullptr, fun, (size_t)B * 8},
+                            {dst, nullptr, status, (size_t)B * 4}, {dit, nullptr, iters, iters ? (size_t)B * 4 : 0}});
+    if (rc || !more) return rc;
+    bool again = false;
+    for (int64_t k = 0; k < B && !again; ++k) again = status[k] == plp::ST_RETRY;
+    if (!again) return PLP_OK;
+    if (plp::launch_lp_phase(B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit, st, 2, nullptr))
+        return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
+    rc = check_launch("lp_kernel");
+    if (rc) return rc;
     return copy_out(ctx, st, {{dx, nullptr, x, nc * 8}, {dfun, nullptr, fun, (size_t)B * 8},
                               {dst, nullptr, status, (size_t)B * 4}, {dit, nullptr, iters, iters ? (size_t)B * 4 : 0}});
 }

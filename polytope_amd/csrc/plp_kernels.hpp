@@ -16,6 +16,8 @@ static inline int group_size_for(int m_max) {
 
 int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
               double* x, double* fun, int* status, int* iters, hipStream_t st);
+int launch_lp_phase(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                    double* x, double* fun, int* status, int* iters, hipStream_t st, int phase, int* more);
 
 int launch_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                  double* xc, int* status, hipStream_t st);

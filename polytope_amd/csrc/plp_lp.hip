@@ -220,6 +220,35 @@ static void launch_cheby_d(long long B, int m_max, int gs, const double* A, cons
 #define PLP_CASE_N(K) case K: launch_lp_n<K>(B, m_max, gs, c, G, h, mrows, x, fun, status, iters, retry, st); break;
 #define PLP_CASE_D(K) case K: launch_cheby_d<K>(B, m_max, gs, A, b, mrows, r, xc, status, st); break;
 
+// phase 1: the fast kernels only -- returns 0 with *more = 1 when LPs they hand over (status ST_RETRY) may exist and the
+// caller has to look; phase 2: the general kernel over exactly those.  (launch_lp below = both, back to back.)  The
+// synchronous host entry point uses the phases for small batches: the normally idle general pass is a launch saved.
+int launch_lp_phase(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                    double* x, double* fun, int* status, int* iters, hipStream_t st, int phase, int* more) {
+    if (more) *more = 0;
+    const char* lds = getenv("PLP_LDS");
+    if (m_max > MAX_M || (lds && lds[0] == '1')) {
+        if (phase == 2) return 0;
+        return launch_lp_lds(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st);
+    }
+    const int gs = group_size_for(m_max);
+    if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
+    const char* one = getenv("PLP_LP_1ROW");
+    int retry = 0;
+    if (phase == 2) retry = 1;
+    else if (!(one && one[0] == '1') && launch_lp_r(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st) == 0) {
+        if (more) *more = 1;
+        return 0;
+    }
+    switch (n) {
+        PLP_CASE_N(1) PLP_CASE_N(2) PLP_CASE_N(3) PLP_CASE_N(4) PLP_CASE_N(5) PLP_CASE_N(6)
+        PLP_CASE_N(7) PLP_CASE_N(8) PLP_CASE_N(9) PLP_CASE_N(10) PLP_CASE_N(11) PLP_CASE_N(12)
+        PLP_CASE_N(13) PLP_CASE_N(14) PLP_CASE_N(15) PLP_CASE_N(16) PLP_CASE_N(17)
+        default: return 2;
+    }
+    return 0;
+}
+
 int launch_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
               double* x, double* fun, int* status, int* iters, hipStream_t st) {
     // more than 64 rows (or PLP_LDS=1: A/B, tests): the LDS-resident engine, one LP per wavefront (plp_lds.hip)

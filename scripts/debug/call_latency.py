@@ -17,3 +17,10 @@ for (m, d) in [(16, 3), (12, 4), (32, 6)]:
     print("(%d,%d): reduce_batch B=1 %.1f us, B=64 %.1f us | cheby_ball_batch B=1 %.1f us | pc.reduce(Polytope) %.1f us | Polytope.intersect %.1f us"
           % (m, d, t(lambda: pa.reduce_batch(A[:1], b[:1])), t(lambda: pa.reduce_batch(A, b)), t(lambda: pa.cheby_ball_batch(A[:1], b[:1])),
              t(lambda: pc.reduce(pc.Polytope(A[0], b[0]))), t(lambda: pc.Polytope(A[0], b[0]).intersect(pc.Polytope(A[1], b[1])))))
+# one solvers.lpsolve call (the plug-in boundary): origin feasible / origin infeasible (phase 1)
+rng = np.random.default_rng(1)
+G = rng.standard_normal((16, 3)); G /= np.linalg.norm(G, axis=1)[:, None]
+c = rng.standard_normal(3)
+h1 = 1.0 + rng.random(16)
+h2 = h1 + G @ np.array([3.0, -2.0, 1.0])          # same polytope moved away from the origin
+print("solvers.lpsolve: origin feasible %.1f us, phase 1 needed %.1f us" % (t(lambda: solvers.lpsolve(c, G, h1)), t(lambda: solvers.lpsolve(c, G, h2))))
