@@ -815,7 +815,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (blocks < 1) blocks = 1;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    if constexpr (R == 4 && D <= 8) {
+    if constexpr ((R == 4 && D <= 8) || (R == 2 && D > 8)) {
         // small batches: one polytope per wavefront, LPs in parallel (PLP_REDUCE_SPLIT=0 / 1: never / always)
         const char* sp = getenv("PLP_REDUCE_SPLIT");
         if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= PLP_REDUCE_SPLIT_MAXB(D, GS))) {

@@ -664,7 +664,7 @@ def test_reduce_latency_form_bitwise(pa, monkeypatch):
     """Small batches take the latency form of the fused reduce (reduce_split_kernel: one polytope per wavefront, every
     lane group runs F1 / dedupe on the same rows, then the 2d box LPs and the redundancy LPs are spread over the groups;
     the in-place h[k] +- 0.1 round trip becomes a rule).  Same engine per LP: every output bitwise equal to the batch
-    form -- d = 1..8, 3..64 rows, ragged, duplicated and infeasible rows, pyramids, golden fixture g2, batch sizes
+    form -- d = 1..16, 3..64 rows, ragged, duplicated and infeasible rows, pyramids, golden fixture g2, batch sizes
     around the switch-over."""
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(9)
@@ -679,7 +679,8 @@ def test_reduce_latency_form_bitwise(pa, monkeypatch):
             assert np.array_equal(batch[key].view(np.uint8), lat[key].view(np.uint8)), key
         return lat
 
-    for (m, d) in [(16, 3), (12, 4), (16, 2), (10, 1), (3, 2), (32, 6), (24, 5), (20, 8), (64, 8), (40, 7), (16, 8), (33, 3)]:
+    for (m, d) in [(16, 3), (12, 4), (16, 2), (10, 1), (3, 2), (32, 6), (24, 5), (20, 8), (64, 8), (40, 7), (16, 8), (33, 3),
+                   (32, 12), (20, 9), (24, 16), (30, 13)]:   # (d >= 9 with up to 32 rows: two rows per lane, 4 groups)
         for B in (1, 7, 130, 1100):
             A, b = random_hpolytopes(B, m, d, seed=11 * m + d + B, stream=0)
             for k in range(0, B, 5):
