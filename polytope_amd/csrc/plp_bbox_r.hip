@@ -11,7 +11,8 @@ static int launch_bbox_r_dg(long long B, int m_max, const double* A, const doubl
     // small batches: one polytope per wavefront, its 2d LPs over the lane groups (PLP_BBOX_SPLIT=0 / 1: never / always).
     // Measured device time per call, batch form: (16,3) B = 64 34 us, (32,6) 123 us, (64,8) 251 us.
     const char* sp = getenv("PLP_BBOX_SPLIT");
-    if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= 4096)) {
+    // ((64,8) at B = 4096: 275 us batch form, 345 us latency form -- four groups per wavefront there)
+    if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= (GS >= 16 ? 1024 : 4096))) {
         hipLaunchKernelGGL((bbox_split_kernel<D, GS>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLK), 0, st, B, m_max, A, b, mrows,
                            lb, ub, status, force_retry_env());
         return 0;

@@ -771,7 +771,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_split_ke
 // (64,8) 256: 652 -> 257, 4096: 896 -> 728; (16,8) 256: 80 -> 75, 4096: 82 -> 111 (16 rows at d >= 7 gain nothing:
 // the 2d box LPs already fill the 16 groups).  ~20 us of every figure are the launches of a call.
 #ifndef PLP_REDUCE_SPLIT_MAXB
-#define PLP_REDUCE_SPLIT_MAXB(D, GS) (((GS) == 4 && (D) >= 7) ? 1024 : 4096)
+#define PLP_REDUCE_SPLIT_MAXB(D, GS) ((((GS) == 4 && (D) >= 7) || (D) > 8) ? 1024 : 4096)  // (d > 8: four groups only; (32,12) B = 4096: 154 -> 201 us)
 #endif
 
 template <int D, int GS, int R = RR>

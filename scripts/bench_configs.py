@@ -251,6 +251,29 @@ def hull():
                           "same_vertex_set": bool(same)}))
 
 
+def lat():
+    """Small batches (what single-polytope calls of the Python layer issue): device time per call of the fused reduce
+    and the fused bounding boxes, latency form (default) against the batch form, outputs compared bitwise."""
+    import os
+    for (m, d) in ((16, 3), (32, 6), (64, 8), (32, 12)):
+        for B in (1, 256, 4096):
+            A, b = synth.random_hpolytopes(B, m, d, seed=3, stream=0)
+            At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+            rec = {"config": "small batch B=%d m=%d d=%d" % (B, m, d)}
+            for name, fn, env in (("reduce", lambda: pa.reduce_batch(At, bt), "PLP_REDUCE_SPLIT"),
+                                  ("bbox", lambda: pa.bbox_batch(At, bt), "PLP_BBOX_SPLIT")):
+                outs = {}
+                for form, val in (("batch_form", "0"), ("latency_form", "1")):
+                    os.environ[env] = val
+                    outs[form] = fn()
+                    rec["%s_%s_us" % (name, form)] = timeit(fn, reps=50, warm=5) * 1e3
+                os.environ.pop(env)
+                rec["%s_bitwise_equal" % name] = bool(all(torch.equal(outs["batch_form"][k].view(torch.uint8),
+                                                                      outs["latency_form"][k].view(torch.uint8))
+                                                          for k in outs["batch_form"]))
+            print(json.dumps(rec), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c5", "lp", "red", "bbox"]
     for w in which:
