@@ -951,6 +951,12 @@ def mldivide(a, b, save=False):
     if isinstance(a, Region):
         out = Region()
         subs = b.list_poly
+        # the subtrahends' rows, packed once for the per-minuend screening batches below (stacking 1000 small arrays
+        # per minuend was a third of is_subset(200 cells, 1000 cells))
+        live_all = [c for c in subs if c.A.size]
+        packed = None
+        if _use_hip() and len(live_all) > 1 and len({c.A.shape for c in live_all}) == 1:
+            packed = (np.stack([c.A for c in live_all]), np.stack([c.b for c in live_all]))
         for poly in a:
             # Which subtrahends touch this polytope at all?  One batch of Chebyshev LPs on the stacked rows
             # instead of one region_diff call per subtrahend: a subtrahend whose intersection with `poly` has
@@ -958,8 +964,8 @@ def mldivide(a, b, save=False):
             # returns its minuend when nothing intersects, ref :2154-2158), so the chain below skips it.
             touching = subs
             if _use_hip() and len(subs) > 1 and not is_empty(poly):
-                live = [c for c in subs if c.A.size]
-                keep = iter(_radii_stacked(poly, live))
+                live = live_all
+                keep = iter(_radii_stacked(poly, live, packed))
                 touching = [c for c in subs if not c.A.size or next(keep) >= ABS_TOL]
             rest = poly
             for sub in touching:
@@ -971,18 +977,20 @@ def mldivide(a, b, save=False):
     raise Exception("a neither Region nor Polytope")
 
 
-def _radii_stacked(poly, others):
+def _radii_stacked(poly, others, packed=None):
     """Chebyshev radius (0 when the ball LP fails) of the stack [poly; c] for every c of `others`, as
     region_diff's own scan computes it (ref :2148-2152) -- including the constructor's row normalisation
-    (ref :130-138) -- but packed straight into one batch instead of one Polytope object per stack."""
+    (ref :130-138) -- but packed straight into one batch instead of one Polytope object per stack.
+    `packed`: (A[n, m, d], b[n, m]) of `others` when the caller has stacked them already (same shapes)."""
     if not others:
         return []
-    same = _use_hip() and len({c.A.shape for c in others}) == 1 and \
+    same = _use_hip() and (packed is not None or len({c.A.shape for c in others}) == 1) and \
         _fits_lp(poly.A.shape[0] + others[0].A.shape[0], poly.A.shape[1])
     if same:
         n = len(others)
-        A3 = np.concatenate([np.broadcast_to(poly.A, (n,) + poly.A.shape), np.stack([c.A for c in others])], axis=1)
-        b3 = np.concatenate([np.broadcast_to(poly.b, (n,) + poly.b.shape), np.stack([c.b for c in others])], axis=1)
+        oA, ob = packed if packed is not None else (np.stack([c.A for c in others]), np.stack([c.b for c in others]))
+        A3 = np.concatenate([np.broadcast_to(poly.A, (n,) + poly.A.shape), oA], axis=1)
+        b3 = np.concatenate([np.broadcast_to(poly.b, (n,) + poly.b.shape), ob], axis=1)
         norms = np.sqrt(np.sum(A3 * A3, 2))
         if np.all(norms > 1e-10):
             from .batch import cheby_ball_batch
