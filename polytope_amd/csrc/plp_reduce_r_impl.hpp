@@ -834,6 +834,16 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
         const char* mx = getenv("PLP_REDUCE_MIX");
         long long tail_tiles = blocks / 16 < 1024 ? blocks / 16 : 1024;
         if (mx) tail_tiles = blocks * atoi(mx) / 64;
+        // medium batches (fewer full tiles than half the chip's wavefront slots): half-size tiles only -- twice the
+        // wavefronts, each done in about half the time.  PLP_REDUCE_HALF=0 / 1: never / whenever blocks <= 4096 (A/B).
+        const char* hf = getenv("PLP_REDUCE_HALF");
+        if (!mx && blocks <= 4096 && ((hf && hf[0] == '1') || (!(hf && hf[0] == '0') && blocks <= 2048))) {
+            const long long nsmall = (B + NG / 2 - 1) / (NG / 2);
+            const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
+            hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)nsmall), dim3(RBLOCK), smem > smem2 ? smem : smem2, st,
+                               0, B, m_max, A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+            return 0;
+        }
         if (tail_tiles > 0 && tail_tiles < blocks && blocks > 4096) {
             long long nbig = blocks - tail_tiles;
             const long long rest = B - nbig * NG;

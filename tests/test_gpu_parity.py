@@ -700,6 +700,18 @@ def test_reduce_latency_form_bitwise(pa, monkeypatch):
     for i in range(len(g["m"])):
         m, d = int(g["m"][i]), int(g["d"][i])
         both(g["A"][i, :m * d].reshape(1, m, d), g["b"][i, :m].reshape(1, m))
+    A, b = random_hpolytopes(9000, 16, 3, seed=78, stream=0)   # medium batches: half-size tiles only
+    monkeypatch.setenv("PLP_REDUCE_SPLIT", "0")
+    monkeypatch.setenv("PLP_REDUCE_HALF", "0")
+    full = pa.reduce_batch(A, b)
+    monkeypatch.setenv("PLP_REDUCE_HALF", "1")
+    half = pa.reduce_batch(A, b)
+    monkeypatch.delenv("PLP_REDUCE_HALF")
+    monkeypatch.delenv("PLP_REDUCE_SPLIT")
+    dflt = pa.reduce_batch(A, b)
+    for key in full:
+        assert np.array_equal(full[key].view(np.uint8), half[key].view(np.uint8)), key
+        assert np.array_equal(full[key].view(np.uint8), dflt[key].view(np.uint8)), key
     A, b = random_hpolytopes(5000, 16, 3, seed=77, stream=0)   # default dispatch around the switch-over
     for B in (4095, 4096, 4097):
         monkeypatch.setenv("PLP_REDUCE_SPLIT", "0")
