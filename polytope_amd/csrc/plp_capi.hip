@@ -160,16 +160,19 @@ int finite_or_fail(plp_ctx* ctx, std::initializer_list<std::pair<const double*, 
     return PLP_OK;
 }
 
+// The arrays' device regions (neighbours in the arena, `blk` .. `blk + blk_bytes`) are used as ONE block in which every
+// chunk's pieces sit back to back -- the layout of the staging buffer -- so that a chunk crosses PCIe as one copy;
+// `launch(lo, hi, ptrs)` gets the device address of each array's rows lo.. (ptrs[i] for arrays[i], NULL where host is).
 template <typename F>
-int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::initializer_list<StageArray> arrays, F launch,
-               bool* staged) {
+int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::initializer_list<StageArray> arrays, char* blk,
+               size_t blk_bytes, F launch, bool* staged) {
     *staged = false;
     size_t unit = 0;
     for (const StageArray& a : arrays)
         if (a.host) unit += a.unit_bytes;
     const size_t total = unit * (size_t)B;
     const char* off = getenv("PLP_STAGE");
-    if ((off && off[0] == '0') || total < (8u << 20) || B < 4 * align) return PLP_OK;
+    if ((off && off[0] == '0') || total < (8u << 20) || B < 4 * align || total > blk_bytes || arrays.size() > 8) return PLP_OK;
     if (!ctx->pool) {
         const char* nt = getenv("PLP_STAGE_THREADS");
         unsigned hw = std::thread::hardware_concurrency();
@@ -217,17 +220,15 @@ int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::init
     } catch (...) {
         return PLP_OK;
     }
-    size_t so = 0;
+    size_t so = 0;  // (unit sizes are multiples of 4 and chunk lengths multiples of `align` >= 16: every piece 8-byte aligned)
     for (int64_t c = 0; c < nch; ++c) {
         const int64_t lo = c * per, hi = lo + per < B ? lo + per : B;
         for (const StageArray& a : arrays) {
             if (!a.host) continue;
             const size_t bytes = (size_t)(hi - lo) * a.unit_bytes;
-            chunks[(size_t)c].push_back({static_cast<const char*>(a.host) + (size_t)lo * a.unit_bytes, ctx->stage + so,
-                                         static_cast<char*>(a.dev) + (size_t)lo * a.unit_bytes, bytes,
-                                         a.f64 && ctx->check_finite});
-            so += (bytes + 63) & ~(size_t)63;
-            if (so > ctx->stage_bytes) return fail(PLP_EINVAL, "staging layout overflow");  // cannot happen (25 % slack)
+            chunks[(size_t)c].push_back({static_cast<const char*>(a.host) + (size_t)lo * a.unit_bytes, ctx->stage + so, blk + so,
+                                         bytes, a.f64 && ctx->check_finite});
+            so += bytes;
         }
     }
     // the copy stream must not overwrite device inputs an earlier call on `st` may still be reading
@@ -243,15 +244,22 @@ int staged_run(plp_ctx* ctx, hipStream_t st, int64_t B, int64_t align, std::init
         ctx->pool->wait((int)c);
         if (timing) fprintf(stderr, "[stage] chunk %d staged at %.0f us\n", (int)c, us());
         if (ctx->pool->nonfinite()) break;  // (set only when the context checks its inputs)
-        for (const plp::StagePiece& p : chunks[(size_t)c]) {
-            const hipError_t e = hipMemcpyAsync(p.dev, p.dst, p.bytes, hipMemcpyHostToDevice, ctx->copy_stream);
+        void* ptrs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        {
+            const std::vector<plp::StagePiece>& pc = chunks[(size_t)c];
+            size_t bytes = 0, k = 0, i = 0;
+            for (const StageArray& a : arrays) {
+                if (a.host) { ptrs[i] = pc[k].dev; bytes += pc[k].bytes; ++k; }
+                ++i;
+            }
+            const hipError_t e = hipMemcpyAsync(pc[0].dev, pc[0].dst, bytes, hipMemcpyHostToDevice, ctx->copy_stream);
             if (e != hipSuccess) rc = fail(PLP_EHIP, "staged upload: %s", hipGetErrorString(e));
         }
         if (rc == PLP_OK && (hipEventRecord(ctx->stage_ev[c % 15], ctx->copy_stream) != hipSuccess ||
                              hipStreamWaitEvent(st, ctx->stage_ev[c % 15], 0) != hipSuccess))
             rc = fail(PLP_EHIP, "staged upload: event");
         const int64_t lo = c * per, hi = lo + per < B ? lo + per : B;
-        if (rc == PLP_OK) rc = launch(lo, hi);
+        if (rc == PLP_OK) rc = launch(lo, hi, ptrs);
     }
     ctx->pool->finish();
     if (timing) {
@@ -447,10 +455,12 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
     const size_t mn = (size_t)m_max * n;
     rc = staged_run(ctx, st, B, 64,
                     {{c, dc, (size_t)n * 8, true}, {G, dG, mn * 8, true}, {h, dh, (size_t)m_max * 8, true}, {m, dm, 4}},
-                    [&](int64_t lo, int64_t hi) {
-                        return plp_lp_solve_batch_dev(ctx, st, hi - lo, m_max, n, dc + (size_t)lo * n, dG + (size_t)lo * mn,
-                                                      dh + (size_t)lo * m_max, m ? dm + lo : nullptr, dx + (size_t)lo * n,
-                                                      dfun + lo, dst + lo, dit + lo);
+                    reinterpret_cast<char*>(dc), (size_t)(reinterpret_cast<char*>(dm + B) - reinterpret_cast<char*>(dc)),
+                    [&](int64_t lo, int64_t hi, void* const* q) {
+                        return plp_lp_solve_batch_dev(ctx, st, hi - lo, m_max, n, static_cast<double*>(q[0]),
+                                                      static_cast<double*>(q[1]), static_cast<double*>(q[2]),
+                                                      static_cast<int32_t*>(q[3]), dx + (size_t)lo * n, dfun + lo, dst + lo,
+                                                      dit + lo);
                     },
                     &staged);
     if (rc) return rc;
@@ -522,9 +532,11 @@ int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, 
     bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
     const size_t md = (size_t)m_max * d;
     rc = staged_run(ctx, st, B, 64, {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
-                    [&](int64_t lo, int64_t hi) {
-                        return plp_cheby_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
-                                                   m ? dm + lo : nullptr, dr + lo, dxc + (size_t)lo * d, dst + lo);
+                    reinterpret_cast<char*>(dA), (size_t)(reinterpret_cast<char*>(dm + B) - reinterpret_cast<char*>(dA)),
+                    [&](int64_t lo, int64_t hi, void* const* q) {
+                        return plp_cheby_batch_dev(ctx, st, hi - lo, m_max, d, static_cast<double*>(q[0]),
+                                                   static_cast<double*>(q[1]), static_cast<int32_t*>(q[2]), dr + lo,
+                                                   dxc + (size_t)lo * d, dst + lo);
                     },
                     &staged);
     if (rc) return rc;
@@ -577,9 +589,11 @@ int plp_bbox_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, c
     bool staged = false;  // large batches: chunked upload, kernels of earlier chunks running meanwhile (plp_stage.hpp)
     const size_t md = (size_t)m_max * d;
     rc = staged_run(ctx, st, B, 64, {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
-                    [&](int64_t lo, int64_t hi) {
-                        return plp_bbox_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
-                                                  m ? dm + lo : nullptr, dlb + (size_t)lo * d, dub + (size_t)lo * d, dst + lo);
+                    reinterpret_cast<char*>(dA), (size_t)(reinterpret_cast<char*>(dm + B) - reinterpret_cast<char*>(dA)),
+                    [&](int64_t lo, int64_t hi, void* const* q) {
+                        return plp_bbox_batch_dev(ctx, st, hi - lo, m_max, d, static_cast<double*>(q[0]),
+                                                  static_cast<double*>(q[1]), static_cast<int32_t*>(q[2]),
+                                                  dlb + (size_t)lo * d, dub + (size_t)lo * d, dst + lo);
                     },
                     &staged);
     if (rc) return rc;
@@ -637,10 +651,11 @@ int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A,
     const size_t md = (size_t)m_max * d;
     rc = staged_run(ctx, st, B, 16,
                     {{A, dA, md * 8, true}, {b, db, (size_t)m_max * 8, true}, {m, dm, 4}},
-                    [&](int64_t lo, int64_t hi) {
-                        return plp_reduce_batch_dev(ctx, st, hi - lo, m_max, d, dA + (size_t)lo * md, db + (size_t)lo * m_max,
-                                                    m ? dm + lo : nullptr, abs_tol, dkeep + lo, dfl + lo, dr + lo,
-                                                    dxc + (size_t)lo * d, dnlp + lo);
+                    reinterpret_cast<char*>(dA), (size_t)(reinterpret_cast<char*>(dm + B) - reinterpret_cast<char*>(dA)),
+                    [&](int64_t lo, int64_t hi, void* const* q) {
+                        return plp_reduce_batch_dev(ctx, st, hi - lo, m_max, d, static_cast<double*>(q[0]),
+                                                    static_cast<double*>(q[1]), static_cast<int32_t*>(q[2]), abs_tol,
+                                                    dkeep + lo, dfl + lo, dr + lo, dxc + (size_t)lo * d, dnlp + lo);
                     },
                     &staged);
     if (rc) return rc;
