@@ -900,6 +900,39 @@ def test_host_batches_reject_inf_and_nan_like_linprog(pa, monkeypatch):
         pa.lpsolve_batch(np.array([[np.nan]]), np.array([[[1.0], [-1.0]]]), np.array([[1.0, 1.0]]))
 
 
+def test_staged_batches_from_several_threads(pa):
+    """Contexts are per thread (include/plp.h: re-entrant across contexts): four threads push large host batches --
+    each through its own staging pool, copy stream and arena -- and small ones in between; every result must equal
+    the single-threaded one."""
+    import threading
+    from polytope_amd.synth import random_hpolytopes
+    jobs = [random_hpolytopes(30000 + 1000 * k, 16, 3, seed=40 + k, stream=0) for k in range(4)]
+    ref = [pa.reduce_batch(A, b) for A, b in jobs]
+    small = random_hpolytopes(50, 12, 4, seed=9, stream=0)
+    ref_small = pa.reduce_batch(*small)
+    errors = []
+
+    def work(k):
+        try:
+            A, b = jobs[k]
+            for _ in range(3):
+                got = pa.reduce_batch(A, b)
+                for key in got:
+                    assert np.array_equal(got[key].view(np.uint8), ref[k][key].view(np.uint8)), (k, key)
+                gs = pa.reduce_batch(*small)
+                for key in gs:
+                    assert np.array_equal(gs[key].view(np.uint8), ref_small[key].view(np.uint8)), (k, key)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_contains_threshold_form_is_the_subtraction(pa, monkeypatch):
     """contains_kernel compares the dot product with a per-row threshold thr = the smallest double at which
     `(s - b) < tol` (polytope.py:217) stops holding, instead of subtracting per point.  One-dimensional polytopes with
