@@ -5,6 +5,7 @@ gfx950 device is visible, every entry point raises -- there is no CPU fallback.
 """
 import ctypes as C
 import os
+import sys
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -156,12 +157,13 @@ def context(device=None):
     """Per-thread default context on `device` (default: torch's current device, else 0)."""
     if device is None:
         device = 0
-        try:
-            import torch
-            if torch.cuda.is_available():
-                device = torch.cuda.current_device()
-        except Exception:  # pragma: no cover
-            pass
+        torch = sys.modules.get("torch")  # (a caller that never imported torch never chose a device through it)
+        if torch is not None:
+            try:
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+            except Exception:  # pragma: no cover
+                pass
     cache = getattr(_tls, "ctx", None)
     if cache is None:
         cache = _tls.ctx = {}
