@@ -79,6 +79,10 @@ class PlpError(RuntimeError):
     pass
 
 
+class UnsupportedSize(ValueError):
+    """PLP_EUNSUPPORTED: a size outside what the kernels (or their staging buffers) hold."""
+
+
 def load():
     """dlopen libplp_hip.so (once).  Raises if the library has not been built."""
     global _lib
@@ -121,7 +125,7 @@ def check(rc, what):
     if rc != PLP_OK:
         msg = load().plp_last_error().decode("utf-8", "replace")
         if rc == PLP_EUNSUPPORTED:
-            raise ValueError("%s: %s" % (what, msg))
+            raise UnsupportedSize("%s: %s" % (what, msg))
         if rc == PLP_EINVAL:
             raise ValueError("%s: %s" % (what, msg))
         if rc == PLP_ENONFINITE:  # the exception class scipy.optimize.linprog raises on inf/nan input

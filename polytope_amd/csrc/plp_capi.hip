@@ -54,7 +54,7 @@ struct plp_ctx {
     // containment on the matrix cores: packed operand tiles (plp_contains_mfma.hip)
     void* mf_buf = nullptr;
     size_t mf_bytes = 0;
-    hipStream_t mf_stream = nullptr;
+    hipEvent_t mf_ev = nullptr;  // recorded after every launch that uses mf_buf: the next user (any stream) waits on it
     bool mf_used = false;
     // large host-pointer batches (plp_stage.hpp): staging threads, pinned staging buffer, copy stream, one event per chunk
     plp::StagePool* pool = nullptr;
@@ -395,6 +395,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_out) (void)hipFree(ctx->rd_out);
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
+    if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
     delete ctx->pool;
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int i = 0; i < ctx->stage_nev; ++i) (void)hipEventDestroy(ctx->stage_ev[i]);
@@ -708,20 +709,39 @@ int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const 
     void* scratch = nullptr;
     if (P > 0 && m_max > 0) {
         const size_t need = plp::contains_mfma_scratch_bytes(P, m_max, d);
+        if (!ctx->mf_ev && hipEventCreateWithFlags(&ctx->mf_ev, hipEventDisableTiming) != hipSuccess) {
+            ctx->mf_ev = nullptr;
+            (void)hipGetLastError();
+        }
         if (need > ctx->mf_bytes) {
-            if (ctx->mf_buf) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->mf_buf); }
+            // growing: the last launch that used the old buffer must have finished before it is freed (an event of
+            // the context, not the caller's stream handle, which may no longer exist)
+            if (ctx->mf_buf) {
+                if (ctx->mf_used && ctx->mf_ev) (void)hipEventSynchronize(ctx->mf_ev);
+                else if (ctx->mf_used) (void)hipDeviceSynchronize();
+                (void)hipFree(ctx->mf_buf);
+            }
             ctx->mf_buf = nullptr;
             ctx->mf_bytes = 0;
+            ctx->mf_used = false;
             if (hipMalloc(&ctx->mf_buf, need + need / 4) == hipSuccess) ctx->mf_bytes = need + need / 4;
             else (void)hipGetLastError();
-        } else if (ctx->mf_used && ctx->mf_stream != st) {
-            (void)hipStreamSynchronize(ctx->mf_stream);  // the previous user of the buffer ran on another stream
+        } else if (ctx->mf_used) {
+            // the previous user of the buffer may have run on another stream: order the streams on the device, the host
+            // does not wait (a no-op when it is the same stream)
+            if (ctx->mf_ev) HIP_TRY(hipStreamWaitEvent(st, ctx->mf_ev, 0));
+            else (void)hipDeviceSynchronize();
         }
-        if (ctx->mf_buf) { scratch = ctx->mf_buf; ctx->mf_stream = st; ctx->mf_used = true; }
+        if (ctx->mf_buf) scratch = ctx->mf_buf;
     }
     if (plp::launch_contains(P, m_max, d, A, b, m, N, X, abs_tol, mode, out, scratch, st))
         return fail(PLP_EUNSUPPORTED, "contains kernel: unsupported size");
-    return check_launch("contains_kernel");
+    int rc = check_launch("contains_kernel");
+    if (scratch && rc == PLP_OK) {
+        ctx->mf_used = true;
+        if (ctx->mf_ev) HIP_TRY(hipEventRecord(ctx->mf_ev, st));
+    }
+    return rc;
 }
 
 int plp_contains(plp_ctx* ctx, int P, int m_max, int d, const double* A, const double* b, const int32_t* m,
@@ -1253,12 +1273,23 @@ struct RadiusOracle {
         const size_t blk = (2 * cap_lp + 1 + cap_rows) * 4;
         if (!ctx->rd_pin) {
             // host-mapped, coherent: the kernels read the index block and publish the radii through it (no copies, no
-            // stream synchronisation per batch: the host spins on a sequence word the last kernel of the batch raises)
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->rd_pin), blk + cap_lp * 8 + 64,
-                                  hipHostMallocMapped | hipHostMallocCoherent));
-            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->rd_pin_dev), ctx->rd_pin, 0));
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->rd_out), cap_lp * 8));
-            *reinterpret_cast<volatile unsigned long long*>(ctx->rd_pin + blk + cap_lp * 8) = 0ull;
+            // stream synchronisation per batch: the host spins on a sequence word the last kernel of the batch raises).
+            // Allocated into locals and committed to the context only when all three calls succeeded.
+            char *hp = nullptr, *hp_dev = nullptr;
+            double* dout = nullptr;
+            hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&hp), blk + cap_lp * 8 + 64,
+                                         hipHostMallocMapped | hipHostMallocCoherent);
+            if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void**>(&hp_dev), hp, 0);
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dout), cap_lp * 8);
+            if (e != hipSuccess) {
+                if (hp) (void)hipHostFree(hp);
+                (void)hipGetLastError();
+                return fail(PLP_EHIP, "region_diff: staging buffers: %s", hipGetErrorString(e));
+            }
+            *reinterpret_cast<volatile unsigned long long*>(hp + blk + cap_lp * 8) = 0ull;
+            ctx->rd_pin = hp;
+            ctx->rd_pin_dev = hp_dev;
+            ctx->rd_out = dout;
             ctx->rd_seq = 0;
         }
         const size_t need = (size_t)nrows * (d + 1) * 8 + 64;
@@ -1285,9 +1316,11 @@ struct RadiusOracle {
         if (ctx) { (void)hipStreamSynchronize(ctx->stream); ctx->rd_seq = seq; }
     }
     // queue the list base[0..nb) + suf[0..ns) (key given) for the next batch unless known or queued already
-    void want(const Key& k, const int32_t* base, size_t nb, const int32_t* suf, size_t ns) {
+    // `required`: the search cannot continue without this radius; only speculative lists are subject to the bound
+    // on one batch
+    void want(const Key& k, const int32_t* base, size_t nb, const int32_t* suf, size_t ns, bool required = false) {
         if (memo.find(k) || pending.find(k)) return;
-        if (pkey.size() >= (1u << 16)) return;  // bound on one batch (speculation only: the lists the search needs come first)
+        if (!required && pkey.size() >= (1u << 16)) return;
         pending.put(k, (double)pkey.size());
         pkey.push_back(k);
         prow.insert(prow.end(), base, base + nb);
@@ -1298,6 +1331,10 @@ struct RadiusOracle {
     int flush() {
         const size_t total = pkey.size();
         size_t done = 0;
+        // radii are consumed soon after they are computed.  The memo is emptied only BEFORE the first sub-batch, never
+        // between two of them, so everything this call stores is there when it returns (a caller that skipped a list
+        // because it was known before the call asks again: see the retry loops of the search)
+        if (memo.count + total > (1u << 20)) memo.clear();
         while (done < total) {
             size_t n = 0, nr = 0;
             while (done + n < total && n < cap_lp && nr + (size_t)(poff[done + n + 1] - poff[done + n]) <= cap_rows) {
@@ -1358,7 +1395,6 @@ struct RadiusOracle {
             const auto tp2 = std::chrono::steady_clock::now();
             t_launch += std::chrono::duration<double>(tp1 - tp0).count();
             t_wait += std::chrono::duration<double>(tp2 - tp1).count();
-            if (memo.count + n > (1u << 20)) memo.clear();  // radii are consumed soon after they are computed
             for (size_t k = 0; k < n; ++k) memo.put(pkey[done + k], out[k]);
             n_lps += (long long)n;
             n_batches += 1;
@@ -1500,27 +1536,33 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     // queue, for every alive cell j >= from: the stack of the current rows with ALL its new rows (the scan, ref
     // :2212-2224) and with its first new row negated (the node the search enters when j is the first hit)
     std::vector<int32_t> child;
-    auto queue_scan1 = [&](const std::vector<int>& alive, long long from, const Key& kbase, const std::vector<int32_t>& base) {
+    // `required`: the scan lists are what the search is waiting for (queued first, exempt from the bound on a batch);
+    // the first children are speculation
+    auto queue_scan1 = [&](const std::vector<int>& alive, long long from, const Key& kbase, const std::vector<int32_t>& base,
+                           bool required) {
         for (int j : alive) {
             if (j < from) continue;
             suf.resize(mi[j]);
             Key k = kbase;
             for (int t = 0; t < mi[j]; ++t) { suf[t] = (int32_t)(beg[j] + t); k = key_push(k, suf[t]); }
-            R.want(k, base.data(), base.size(), suf.data(), suf.size());
+            R.want(k, base.data(), base.size(), suf.data(), suf.size(), required);
+        }
+        for (int j : alive) {
+            if (j < from) continue;
             const int32_t neg = (int32_t)(beg[j] + M);
             R.want(key_push(kbase, neg), base.data(), base.size(), &neg, 1);
         }
     };
     // ... and the same one level further down for the cell the scan will most likely stop at (the first one still
     // alive): when that guess is right the search descends two levels on one batch
-    auto queue_scan = [&](const std::vector<int>& alive, long long from, const Key& kbase) {
-        queue_scan1(alive, from, kbase, cur);
+    auto queue_scan = [&](const std::vector<int>& alive, long long from, const Key& kbase, bool required) {
+        queue_scan1(alive, from, kbase, cur, required);
         for (int j : alive) {
             if (j < from) continue;
             if (j < N - 1) {
                 child = cur;
                 child.push_back((int32_t)(beg[j] + M));
-                queue_scan1(alive, (long long)j + 1, key_push(kbase, (int32_t)(beg[j] + M)), child);
+                queue_scan1(alive, (long long)j + 1, key_push(kbase, (int32_t)(beg[j] + M)), child, false);
             }
             // ... and its whole sibling chain (rows 1..c-1 of the cell kept, row c negated) with the scans they need when
             // they are not empty, as long as that stays a few hundred lists
@@ -1536,7 +1578,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                     R.want(key_push(kc, neg), child.data(), child.size(), &neg, 1);
                     if (j < N - 1) {
                         child.push_back(neg);
-                        queue_scan1(alive, (long long)j + 1, key_push(kc, neg), child);
+                        queue_scan1(alive, (long long)j + 1, key_push(kc, neg), child, false);
                         child.pop_back();
                     }
                 }
@@ -1574,6 +1616,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
             if (!cur_ok) { bad_index = true; break; }
             const Key kbase = key_of_list(cur.data(), cur.size());
             const std::vector<int>& alive = alive_now();
+            bool have_all = false;
             for (int attempt = 0; attempt < 3; ++attempt) {  // (a full memo is emptied by flush(): ask again then)
                 bool miss = false;
                 for (int j : alive) {
@@ -1582,9 +1625,9 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                     for (int t = 0; t < mi[j]; ++t) k = key_push(k, (int32_t)(beg[j] + t));
                     if (!R.memo.find(k)) { miss = true; break; }
                 }
-                if (!miss) break;
+                if (!miss) { have_all = true; break; }
                 res->n_scan_miss++;
-                queue_scan(alive, level, kbase);
+                queue_scan(alive, level, kbase, true);
                 {   // the outcome "no cell hits": a piece is emitted, then the node the search re-opens and what follows it
                     std::vector<int> c2 = counter, o2 = open_cells;
                     std::vector<long long> i2 = idx;
@@ -1595,6 +1638,15 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                 if (rc) break;
             }
             if (rc) break;
+            if (!have_all) {   // the last attempt flushed: everything it stored is in the memo unless the memo cannot hold one scan
+                for (int j : alive) {
+                    if (j < level) continue;
+                    Key k = kbase;
+                    for (int t = 0; t < mi[j]; ++t) k = key_push(k, (int32_t)(beg[j] + t));
+                    if (!R.memo.find(k)) { rc = fail(PLP_EUNSUPPORTED, "region_diff: a scan over %d cells does not fit the radius memo", N); break; }
+                }
+                if (rc) break;
+            }
             double Rl = 0.0;  // the reference's R after the loop: the radius of the LAST cell looked at
             Frame fr;
             fr.rows = cur;
@@ -1603,8 +1655,12 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                 if (j < level) continue;
                 Key k = kbase;
                 for (int t = 0; t < mi[j]; ++t) k = key_push(k, (int32_t)(beg[j] + t));
-                const double Rj = *R.memo.find(k);
-                if (Rj > 0.5 * abs_tol) fr.alive.push_back(j);
+                const double Rraw = *R.memo.find(k);
+                // NaN = the LP ended without a verdict (unbounded ball, iteration limit): the reference reads radius 0
+                // there (ref :1294-1297) and solves the cell again at every node below, so only a cell whose LP was
+                // SOLVED with a radius <= abs_tol / 2 is dropped from the scans below this node
+                if (!(Rraw <= 0.5 * abs_tol)) fr.alive.push_back(j);
+                const double Rj = Rraw != Rraw ? 0.0 : Rraw;
                 if (hit < 0) {
                     res->n_requests++;
                     if (Rj > abs_tol) { hit = j; Rl = Rj; }
@@ -1631,18 +1687,20 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
         const Key knode = key_of_list(cur.data(), cur.size());
         if (!R.memo.find(knode)) {
             res->n_node_miss++;
-            R.want(knode, cur.data(), cur.size(), nullptr, 0);
+            R.want(knode, cur.data(), cur.size(), nullptr, 0, true);
             {
                 std::vector<int> c2 = counter, o2 = open_cells;
                 std::vector<long long> i2 = idx;
                 queue_empty_chain(c2, o2, i2, level, sumc, 8);
             }
             // what it needs next when it is NOT empty: its scan and the first child of every cell still alive
-            if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode);
+            if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode, false);
             rc = R.flush();
             if (rc) break;
         }
-        const double rcv = *R.memo.find(knode);
+        const double* pnode = R.memo.find(knode);
+        if (!pnode) { rc = fail(PLP_EHIP, "region_diff: the radius of the current node is missing after its batch"); break; }
+        const double rcv = *pnode != *pnode ? 0.0 : *pnode;
         res->n_requests++;
         if (rcv > abs_tol) {
             if (level == N - 1) emit(1);

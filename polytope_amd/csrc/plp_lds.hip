@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64) void cheby_gather_lds_kernel(long long nlp, int
         __syncthreads();
         while (S.mode != M_DONE) lds_step(S, D, lane);
         const double rr = lds_x_of(D, m, d, lane);
-        if (lane == 0) out[p] = ((S.status == ST_OPT) & (rr >= 0.0)) ? rr : 0.0;
+        if (lane == 0) out[p] = S.status != ST_OPT ? __builtin_nan("") : (rr >= 0.0 ? rr : 0.0);
     }
 }
 
@@ -551,12 +551,9 @@ int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, con
     if (d < 1 || d > MAX_D || nlp < 1) return nlp < 1 ? 0 : 2;
     const size_t smem = lds_lp_bytes(m_cap < 1 ? 1 : m_cap, d + 1);
     if (!smem) return 2;
-    static size_t attr = 0;
-    if (smem > 48 * 1024 && smem > attr) {
+    if (smem > 48 * 1024)   // per device and cheap: set on every launch that needs it, like the other LDS launchers
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cheby_gather_lds_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = smem;
-    }
     hipLaunchKernelGGL(cheby_gather_lds_kernel, dim3(lds_grid(nlp, smem)), dim3(64), smem, st, nlp, m_cap, d, off, rows, sel,
                        A, b, out);
     return 0;

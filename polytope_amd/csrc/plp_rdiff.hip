@@ -9,7 +9,9 @@
 //   cheby_gather_r_kernel<D> : lists of up to 16 / 32 / 64 rows (three size classes, one launch) on the four-rows-per-lane engine (d <= 8)
 //   (lists beyond 64 rows, and d > 8: cheby_gather_lds_kernel in plp_lds.hip, dictionary in LDS)
 //
-// out[p] = the radius as cheby_ball reads it (:1289-1297): x[-1] if the LP is optimal with r >= 0, else 0.
+// out[p] = the radius as cheby_ball reads it (:1289-1297): x[-1] if the LP is optimal with r >= 0, 0 if optimal with
+// r < 0, NaN if the LP ended with any other status (the reference reads 0 there; the search must know the difference:
+// a cell without a verdict is solved again below, a cell SOLVED as empty is not).
 #include <stdlib.h>
 
 #include "plp_cheby_r_impl.hpp"
@@ -35,7 +37,7 @@ __device__ __forceinline__ void gather_body(long long q0, long long nlp, const i
     const int st = cheby_r_solve<D, GS, R>(
         g, valid, m, row0, [&](int rr, int kk) { return A[(long long)rows[o + rr] * D + kk]; },
         [&](int rr) { return b[rows[o + rr]]; }, x, force_retry);
-    if (valid & (g.gl == 0)) out[p] = ((st == ST_OPT) & (x[D] >= 0.0)) ? x[D] : 0.0;
+    if (valid & (g.gl == 0)) out[p] = st != ST_OPT ? __builtin_nan("") : (x[D] >= 0.0 ? x[D] : 0.0);
 }
 
 // All three size classes in ONE launch (the search pays per launch, not per LP): workgroups [0, nb0) take the n0 lists

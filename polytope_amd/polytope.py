@@ -414,8 +414,9 @@ def _ball_from_lp(status, r, xc):
     return np.double(r), np.array(xc)
 
 
-def _cheby_raw(polys):
-    """Chebyshev LP (F1) of each non-empty polytope -> list of (r, xc) or None."""
+def _cheby_raw(polys, failed=None):
+    """Chebyshev LP (F1) of each non-empty polytope -> list of (r, xc) or None.
+    `failed` (a list, optional) receives the positions whose LP ended with a status other than 0."""
     if not polys:
         return []
     d = polys[0].A.shape[1]
@@ -432,6 +433,8 @@ def _cheby_raw(polys):
             res = cheby_ball_batch(A, b, m=ms)
             for t, k in enumerate(idx):
                 out[k] = _ball_from_lp(int(res["status"][t]), float(res["r"][t]), res["xc"][t])
+                if failed is not None and int(res["status"][t]) != 0:
+                    failed.append(k)
         return out
     out = []
     for p in polys:
@@ -440,6 +443,8 @@ def _cheby_raw(polys):
         G = np.c_[p.A, np.sqrt(np.sum(p.A * p.A, axis=1))]
         sol = lpsolve(c, G, p.b)
         out.append(_ball_from_lp(sol["status"], sol["x"][-1], sol["x"][0:-1]) if sol["status"] == 0 else None)
+        if failed is not None and sol["status"] != 0:
+            failed.append(len(out) - 1)
     return out
 
 
@@ -1001,12 +1006,14 @@ def _radii_stacked(poly, others, packed=None):
     return _radii([Polytope(np.vstack([poly.A, c.A]), np.hstack([poly.b, c.b])) for c in others])
 
 
-def _radii(polys):
-    """Chebyshev radius of freshly built polytopes (0 when the ball LP fails), one batch."""
+def _radii(polys, nan_without_verdict=False):
+    """Chebyshev radius of freshly built polytopes (0 when the ball LP fails), one batch.
+    `nan_without_verdict`: NaN instead of 0 where the LP ended with a status other than 0."""
     out = []
-    for p, ball in zip(polys, _cheby_raw(polys)):
+    failed = [] if nan_without_verdict else None
+    for k, (p, ball) in enumerate(zip(polys, _cheby_raw(polys, failed))):
         if ball is None:
-            out.append(0)
+            out.append(float("nan") if failed and k in failed else 0)
         else:
             p._chebR, p._chebXc = ball
             out.append(ball[0])
@@ -1092,12 +1099,18 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
         # visiting order and tests, LPs gathered on the device from the resident table by row index, one launch and
         # one synchronisation per visited node.  What comes back are the pieces as row lists, in order.
         from .batch import region_diff_search
+        from ._lib import UnsupportedSize
         try:
             leaves, _stats = region_diff_search(An, Bn, m, mi, abs_tol)
+        except UnsupportedSize:
+            leaves = None   # a stack beyond what the library's search stages: the host twin below takes the call
         except ValueError as e:
             if "out of range" in str(e):
                 raise IndexError("index out of bounds in region_diff (the reference's INDICES arithmetic, ref :2233)")
             raise
+    else:
+        leaves = None
+    if leaves is not None:
         todo = [poly_of(list(rows)) for kind, rows in leaves if kind == 1]   # leaves the reference reduces (:2276)
         done = [None] * len(todo)
         small = [k for k, p in enumerate(todo) if p.A.size > 0 and _fits(p.A.shape[0], p.A.shape[1])]
@@ -1110,10 +1123,12 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
         return res
 
     def radii_rows(row_lists):
-        """Chebyshev radius (0 when the ball LP fails) of the polytope of each row list, one batch."""
+        """Chebyshev radius of the polytope of each row list, one batch: 0 for a ball LP solved with r < 0, NaN for one
+        that ended without a verdict (any status but 0: the reference reads radius 0 there, ref :1294-1297, and
+        solves again at every node below -- `_DiffSearch` must not take such a cell for empty for good)."""
         lens = [len(r) for r in row_lists]
         if not packed or max(lens) > _max_rows_lp(A.shape[1]):
-            return _radii([poly_of(r) for r in row_lists])
+            return _radii([poly_of(r) for r in row_lists], nan_without_verdict=True)
         res = [0] * len(row_lists)
         # stacks of more than 64 rows go to the LDS-resident engine in a batch of their own
         for sel in ([k for k, n_ in enumerate(lens) if n_ <= _MAX_ROWS], [k for k, n_ in enumerate(lens) if n_ > _MAX_ROWS]):
@@ -1128,7 +1143,7 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
             out = cheby_ball_batch(A3, b3, m=np.asarray([lens[k] for k in sel], dtype=np.int32))
             ok = (out["status"] == 0) & (out["r"] >= 0)
             for t, k in enumerate(sel):
-                res[k] = np.double(out["r"][t]) if ok[t] else 0
+                res[k] = np.double(out["r"][t]) if ok[t] else (0 if out["status"][t] == 0 else float("nan"))
         return res
 
     # Host twin of the library's search (csrc/plp_capi.hip, plp_region_diff_search): the same state, moves and
@@ -1212,7 +1227,7 @@ class _DiffSearch:
                     want.append(list(r2))
             self.memo.clear()
             for w, rad in zip(want, self.radii_rows(want)):
-                self.memo[tuple(w)] = rad
+                self.memo[tuple(w)] = rad if rad == rad else 0   # NaN (no verdict) reads as radius 0 (ref :1294-1297)
         return self.memo[key]
 
     def run(self):
@@ -1222,7 +1237,10 @@ class _DiffSearch:
                 alive = [j for j in self._alive() if j >= self.level]
                 stacks = [self.rows + list(range(self.beg[j], self.beg[j] + self.mi[j])) for j in alive]
                 radii = self.radii_rows(stacks) if stacks else []
-                self.frames.append((set(self.rows), [j for j, r in zip(alive, radii) if r > 0.5 * tol]))
+                # only a cell whose LP was SOLVED with a radius <= tol / 2 stays out of the scans below this node; one
+                # without a verdict (NaN: unbounded ball, iteration limit) reads as radius 0 here and is solved again
+                self.frames.append((set(self.rows), [j for j, r in zip(alive, radii) if not r <= 0.5 * tol]))
+                radii = [r if r == r else 0 for r in radii]
                 last = 0   # the reference's R after its loop: the radius of the last cell it looked at
                 for j, r in zip(alive, radii):
                     if r > tol:

@@ -11,13 +11,15 @@ Same contract as the reference:
 
 Backends here:
   'hip'    the MI355X engine (hand-written HIP kernels behind the C ABI of include/plp.h).
-           Installed iff libplp_hip.so loads and a gfx950 device is visible.  It is this
-           package's default and it never falls back to a CPU solver: without the library or
-           the device, `lpsolve` raises RuntimeError exactly like a missing GLPK does in the
-           reference (polytope/solvers.py:200-207).
+           Installed iff libplp_hip.so loads and a gfx950 device is visible.  It is OPT-IN
+           (`solvers.default_solver = 'hip'` or `solver='hip'`), never the module default, and
+           it never falls back to a CPU solver: without the library or the device, `lpsolve`
+           raises RuntimeError exactly like a missing GLPK does in the reference
+           (polytope/solvers.py:200-207).
   'scipy'  scipy.optimize.linprog called with the reference's argument convention
-           (polytope/solvers.py:152-154).  Only used when explicitly selected; it is what
-           the CPU baseline in bench.py and the A/B tests time.
+           (polytope/solvers.py:152-154).  The module default (the reference's rule picks glpk
+           when cvxopt is importable, else scipy; this package ships no glpk binding, so the
+           rule always lands on scipy); also what the CPU baseline in bench.py times.
   'glpk', 'mosek', 'gurobi' are recognised names (RuntimeError when absent) but not provided.
 """
 import logging
@@ -34,8 +36,9 @@ except ImportError:  # pragma: no cover
     _optimize = None
 
 _KNOWN = ("hip", "scipy", "glpk", "mosek", "gurobi")
-# The default is chosen from the installed choices by the reference's own rule (solvers.py:66-73: glpk, else
-# scipy); 'hip' is never made the default behind the user's back -- select it like any other backend:
+# The reference's rule (solvers.py:66-73) is "glpk if installed, else scipy".  This package provides no glpk
+# backend ('glpk' is a recognised name that raises RuntimeError), so the rule always yields 'scipy' here.
+# 'hip' is never made the default behind the user's back -- select it like any other backend:
 #     from polytope_amd import solvers;  solvers.default_solver = 'hip'
 # Selecting it on a machine without the library or a gfx950 device raises RuntimeError (no CPU fallback).
 default_solver = "scipy"

@@ -669,3 +669,69 @@ def test_stacks_beyond_64_rows_through_the_python_layer():
         assert abs(r - r2) <= TOL and np.allclose(l, l2, atol=1e-9) and np.allclose(u, u2, atol=1e-9)
         assert adj == adj2 and fd == fd2
         assert Ia.shape[0] > 3
+
+
+def test_region_diff_keeps_a_cell_whose_lp_ended_without_a_verdict(monkeypatch):
+    """The search drops a cell from the scans below a node only when its ball LP was SOLVED with a radius <= tol / 2.
+    An LP that ends with another status (iteration limit, numerical trouble, unbounded ball) reads as radius 0 in the
+    reference (polytope.py:1294-1297), which solves the cell again at every node below: one transient failure must
+    not remove the cell from the whole subtree."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    monkeypatch.setattr(solvers, "default_solver", "scipy")
+    P = pc.box2poly([[0.0, 3.0], [0.0, 1.0]])
+    cells = [pc.box2poly([[0.0, 1.0], [0.0, 1.0]]), pc.box2poly([[1.0, 2.0], [0.0, 1.0]])]
+    want = pc.region_diff(P.copy(), pc.Region([c.copy() for c in cells]))
+    assert isinstance(want, pc.Polytope) or len(want) == 1
+    lo, hi = pc.bounding_box(want)
+    assert np.allclose(lo.ravel(), [2.0, 0.0]) and np.allclose(hi.ravel(), [3.0, 1.0])
+    real, hits = pc.lpsolve, []
+
+    def flaky(c, G, h, solver=None):
+        # the root scan's stack for the second cell: P's four rows + the cell's two new rows (x <= 2, -x <= -1)
+        if G.shape[0] == 6 and not hits and np.any(np.isclose(h, 2.0)) and np.any(np.isclose(h, -1.0)):
+            hits.append(1)
+            return dict(status=1, x=None, fun=None)
+        return real(c, G, h, solver)
+
+    monkeypatch.setattr(pc, "lpsolve", flaky)
+    got = pc.region_diff(P.copy(), pc.Region([c.copy() for c in cells]))
+    assert hits, "the injected failure was not reached"
+    gp, wp = _pieces(pc, got), _pieces(pc, want)
+    assert len(gp) == len(wp)
+    for q, w in zip(gp, wp):
+        assert np.allclose(q.A, w.A, atol=1e-12) and np.allclose(q.b, w.b, atol=1e-12)
+
+
+def test_bounding_box_where_the_one_deviating_status_shows(pc):
+    """g1 holds ONE LP (form F3, (5,3): min x_2 over an unbounded polytope) on which HiGHS's presolve reports status 2
+    where a simplex finds 3 (tests/test_gpu_parity.py::test_lp_golden).  `bounding_box` of that polytope is the one
+    caller where it shows (ref :1372-1384): the reference -- and this mirror on the scipy backend -- writes
+    l[2] = 0 for status 2; the 'hip' backend, whose LP says "unbounded", writes -inf.  Both behaviours pinned here,
+    every other entry of the box equal on both backends."""
+    from polytope_amd import solvers
+    g = load_golden("g1_lp.npz")
+    dev = np.nonzero(g["status"] != g["status_nopresolve"])[0]
+    assert len(dev) == 1
+    i = int(dev[0])
+    m, n = int(g["m"][i]), int(g["n"][i])
+    assert (m, n) == (5, 3) and np.array_equal(g["c"][i, :n], [0.0, 0.0, 1.0])
+    G, h = g["G"][i, :m * n].reshape(m, n), g["h"][i, :m]
+    lo, hi = pc.bounding_box(pc.Polytope(G.copy(), h.copy(), normalize=False))
+    if solvers.default_solver == "scipy":
+        assert lo[2, 0] == 0.0                      # status 2 branch of the reference (:1380-1382)
+    else:
+        assert lo[2, 0] == -np.inf                  # status 3 branch (:1377-1379): the documented deviation
+        solvers.default_solver = "scipy"
+        try:
+            lo_s, hi_s = pc.bounding_box(pc.Polytope(G.copy(), h.copy(), normalize=False))
+        finally:
+            solvers.default_solver = "hip"
+        rest = np.ones((3, 1), bool)
+        rest[2, 0] = False
+        assert lo_s[2, 0] == 0.0
+        assert np.array_equal(np.isinf(lo)[rest], np.isinf(lo_s)[rest]) and np.array_equal(np.isinf(hi), np.isinf(hi_s))
+        fin = np.isfinite(hi_s)
+        assert np.allclose(hi[fin], hi_s[fin], atol=TOL, rtol=0)
+        fin = np.isfinite(lo_s) & rest
+        assert np.allclose(lo[fin], lo_s[fin], atol=TOL, rtol=0)
