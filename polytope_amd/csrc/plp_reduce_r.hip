@@ -1,8 +1,13 @@
 // plp_reduce_r.hip -- dispatch of the fused reduce() on R rows per lane (kernel: plp_reduce_r_impl.hpp).
-//   d <= 8 : four rows per lane, groups of 4 / 8 / 16 lanes (this file)
+//   d <= 8 : four rows per lane, groups of 4 / 8 / 16 lanes (this file); d = 5..8 beyond the latency form's batch sizes:
+//            two rows per lane (plp_reduce_r2c.hip)
 //   d >= 9 : two rows per lane, groups of 16 / 32 lanes (plp_reduce_r2a.hip d = 9..12, plp_reduce_r2b.hip d = 13..16;
 //            separate translation units only to keep the build parallel)
 #include "plp_reduce_r_impl.hpp"
+
+#ifndef PLP_REDUCE_LAZY_MID
+#define PLP_REDUCE_LAZY_MID 0  // d = 5..8 with more than 32 rows on reduce_lazy_kernel by default (measured below)
+#endif
 
 namespace plp {
 
@@ -10,6 +15,9 @@ int launch_reduce_r2a(long long B, int m_max, int d, const double* A, const doub
                       double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                       hipStream_t st);
 int launch_reduce_r2b(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
+                      double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
+                      hipStream_t st);
+int launch_reduce_r2c(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                       double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                       hipStream_t st);
 
@@ -21,6 +29,22 @@ static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, co
         const char* e8 = getenv("PLP_REDUCE_R8");
         if (gs == 4 && !(e8 && e8[0] == '0'))
             return launch_reduce_r_dg<D, 2, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    }
+    if constexpr (D >= 5) {
+        // more than 32 rows: one polytope per wavefront without a stored dictionary (plp_lazy.hpp), as for d >= 9;
+        // PLP_REDUCE_LAZY=0 / 1: never / always (A/B)
+        const char* lz = getenv("PLP_REDUCE_LAZY");
+        if ((lz && lz[0] == '1') || (PLP_REDUCE_LAZY_MID && m_max > 32 && !(lz && lz[0] == '0')))
+            return launch_reduce_lazy<D>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    }
+    if constexpr (D >= 5) {
+        // d = 5..8 beyond the latency form's batch sizes: two rows per lane (plp_reduce_r2c.hip: three wavefronts per SIMD
+        // instead of two); PLP_REDUCE_MIDR2=0 / 1: never / always (A/B)
+        const char* r2 = getenv("PLP_REDUCE_MIDR2");
+        const char* sp = getenv("PLP_REDUCE_SPLIT");
+        const bool latency_form = (sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= PLP_REDUCE_SPLIT_MAXB(D, gs));
+        if ((r2 && r2[0] == '1') || (!(r2 && r2[0] == '0') && !latency_form))
+            return launch_reduce_r2c(B, m_max, D, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     }
     if (gs == 4) return launch_reduce_r_dg<D, 4>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     if (gs == 8) return launch_reduce_r_dg<D, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);

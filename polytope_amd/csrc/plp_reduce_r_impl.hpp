@@ -76,6 +76,10 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 #define PLP_REDUCE_R_WAVES(D) ((D) <= 3 ? 4 : ((D) <= 4 ? 3 : 1))
 #endif
 
+#ifndef PLP_REDUCE_R2MID_WAVES
+#define PLP_REDUCE_R2MID_WAVES 3  // d = 5..8 on two rows per lane (plp_reduce_r2c.hip)
+#endif
+
 #ifndef PLP_R_ASYNC
 #define PLP_R_ASYNC 1  // F2: every lane group walks its own LP list inside one pivot loop (0: lock-step, for A/B runs)
 #endif
@@ -702,6 +706,14 @@ __device__ __forceinline__ void reduce_r_tile(
                 uint64_t todo = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(live >> 32)) << 32) |
                                 (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)live);
                 nlp += __popcll(live);
+#if PLP_R_PRESOLVE
+                {   // rows the presolve settles as "keep" need no LP (lane i = row i: the ballot is the row mask)
+                    const uint64_t cert = __ballot((f2_presolve<D, 1>(myA, myb, myan, row0, m_max, lloc & 1u, abs_tol) & 1u) != 0u);
+                    keep |= cert;
+                    todo &= ~(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(cert >> 32)) << 32) |
+                              (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cert));
+                }
+#endif
                 while (todo != 0ull) {
                     const int kr = __ffsll((long long)todo) - 1;
                     todo &= todo - 1ull;
@@ -913,11 +925,14 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_split_ke
 // (64,8) 256: 652 -> 257, 4096: 896 -> 728; (16,8) 256: 80 -> 75, 4096: 82 -> 111 (16 rows at d >= 7 gain nothing:
 // the 2d box LPs already fill the 16 groups).  ~20 us of every figure are the launches of a call.
 #ifndef PLP_REDUCE_SPLIT_MAXB
-#define PLP_REDUCE_SPLIT_MAXB(D, GS) ((((GS) == 4 && (D) >= 7) || (D) > 8) ? 1024 : 4096)  // (d > 8: four groups only; (32,12) B = 4096: 154 -> 201 us)
+// (round 3, with the F2 presolve and d = 5..8 on two rows per lane beyond this size: (32,6) B = 2048: 0.121 ms here vs 0.181,
+// B = 4096: 0.222 vs 0.187; (64,8) B = 1024: 0.302 vs 0.366, B = 2000: 0.426 vs 0.404)
+#define PLP_REDUCE_SPLIT_MAXB(D, GS) \
+    ((((GS) == 4 && (D) >= 7) || (D) > 8 || ((D) >= 5 && (GS) == 16)) ? 1024 : ((D) >= 5 ? 2048 : 4096))  // (d > 8: four groups only; (32,12) B = 4096: 154 -> 201 us)
 #endif
 
 template <int D, int GS, int R = RR>
-__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : PLP_REDUCE_R_WAVES(D))) void reduce_r_kernel(
+__global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : (R == 2 && D <= 8 ? PLP_REDUCE_R2MID_WAVES : PLP_REDUCE_R_WAVES(D)))) void reduce_r_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
