@@ -130,6 +130,20 @@ int plp_reduce_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d
                          int32_t *flags, double *r, double *xc, int32_t *nlp);
 
 /*
+ * The same for polytopes of ANY row count whose rows and dictionary fit the LDS of a CU (about 500 rows at d = 16,
+ * 2000 at d = 3): `reduce` has no row limit in the reference (polytope/polytope.py:1053-1163), Polytope.intersect
+ * stacks m1 + m2 rows (:268-275) and region_diff's leaves as many as the search collected (:2276).
+ * keep[B][W], W = (m_max + 63) / 64 words per polytope, bit i of word i / 64 <=> input row i is kept; everything else
+ * as plp_reduce_batch (to which m_max <= 64 is passed on, W = 1).  PLP_EUNSUPPORTED when a polytope does not fit.
+ */
+int plp_reduce_wide_batch(plp_ctx *ctx, int64_t B, int m_max, int d, const double *A, const double *b,
+                          const int32_t *m, double abs_tol, uint64_t *keep, int32_t *flags, double *r,
+                          double *xc, int32_t *nlp);
+int plp_reduce_wide_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d, const double *A,
+                              const double *b, const int32_t *m, double abs_tol, uint64_t *keep,
+                              int32_t *flags, double *r, double *xc, int32_t *nlp);
+
+/*
  * Containment of N points in P polytopes:  all_i( A_p[i,:].x - b_p[i] < abs_tol ).
  * Replaces: Polytope.contains (polytope/polytope.py:206-218), Region.contains (:732-746),
  *           is_inside (:1017-1029), __contains__ (:191-204, :723-730).

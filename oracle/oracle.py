@@ -118,15 +118,18 @@ def reduce(A, b, abs_tol=1e-7):
     """
     A, b = _d(A), _d(b).ravel()
     m, d = A.shape
-    keep = C.c_uint64(0)
+    keep = (C.c_uint64 * 4)()   # PLPO_KEEP_WORDS words: polytopes of up to 256 rows
     bout = np.empty(max(m, 1))
     r = C.c_double()
     xc = np.empty(d)
     nlp = C.c_int()
-    flags = lib().plpo_reduce(m, d, _p(A), _p(b), abs_tol, C.byref(keep), _p(bout),
+    if m > 256:
+        raise ValueError("oracle.reduce: up to 256 rows (PLPO_MAXM)")
+    flags = lib().plpo_reduce(m, d, _p(A), _p(b), abs_tol, keep, _p(bout),
                               C.byref(r), _p(xc), C.byref(nlp))
-    mask = np.array([(keep.value >> i) & 1 for i in range(m)], dtype=bool)
-    return dict(keep=mask, mask=keep.value, flags=flags, b=bout[:m], r=r.value, xc=xc, nlp=nlp.value)
+    mask = np.array([(keep[i >> 6] >> (i & 63)) & 1 for i in range(m)], dtype=bool)
+    return dict(keep=mask, mask=int(keep[0]), words=[int(w) for w in keep], flags=flags, b=bout[:m], r=r.value, xc=xc,
+                nlp=nlp.value)
 
 
 def contains(A, b, X, abs_tol=1e-7, mrows=None, region=False):

@@ -47,7 +47,8 @@
 #include <string.h>
 
 #define PLPO_MAXM 256 /* rows of one LP (the HIP engine goes past 64 rows with its LDS-resident dictionary) */
-#define PLPO_MAXM_RED 64 /* rows of a polytope handed to plpo_reduce: the keep mask is one 64-bit word */
+#define PLPO_MAXM_RED PLPO_MAXM /* rows of a polytope handed to plpo_reduce: the keep mask is PLPO_KEEP_WORDS 64-bit words */
+#define PLPO_KEEP_WORDS ((PLPO_MAXM + 63) / 64)
 #define PLPO_MAXN 18 /* d+1 structural columns (<=17) + phase-1 artificial */
 
 #define TOL_D 1e-9     /* reduced-cost (dual feasibility) tolerance            */
@@ -331,9 +332,10 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
 {
     int idx[PLPO_MAXM], neq = 0, flags = 0;
     double Aw[PLPO_MAXM * 16], bw[PLPO_MAXM];
-    *keep = 0; *nlp = 0;
+    for (int w = 0; w < PLPO_KEEP_WORDS; ++w) keep[w] = 0;   /* keep[PLPO_KEEP_WORDS]: bit i of word i / 64 <=> row i kept */
+    *nlp = 0;
     for (int i = 0; i < m; ++i) bout[i] = b[i];
-    if (m > PLPO_MAXM_RED) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; return RF_EMPTY; } /* one-word mask */
+    if (m > PLPO_MAXM_RED) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; return RF_EMPTY; }
     /* :1081 is_fulldim -> cheby_ball -> F1 */
     int st = plpo_cheby(m, d, A, b, r, xc, NULL);
     ++*nlp;
@@ -368,7 +370,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     }
     /* :1114-1116 */
     if (neq <= d + 1) {
-        for (int p = 0; p < neq; ++p) *keep |= (uint64_t)1 << idx[p];
+        for (int p = 0; p < neq; ++p) keep[idx[p] >> 6] |= (uint64_t)1 << (idx[p] & 63);
         return RF_EARLY;
     }
     for (int p = 0; p < neq; ++p) {
@@ -400,7 +402,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     }
     /* :1136-1138 */
     if (neq <= d + 1) {
-        for (int p = 0; p < neq; ++p) *keep |= (uint64_t)1 << idx[p];
+        for (int p = 0; p < neq; ++p) keep[idx[p] >> 6] |= (uint64_t)1 << (idx[p] & 63);
         return flags | RF_EARLY;
     }
     /* :1142-1160 one redundancy LP per row; h[k] +0.1 / -0.1 round trip persists */
@@ -413,9 +415,9 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
         bw[k] -= 0.1;
         if (st == ST_OPT) {
             const double obj = -fun - bw[k];
-            if (obj > abs_tol) *keep |= (uint64_t)1 << idx[k];
+            if (obj > abs_tol) keep[idx[k] >> 6] |= (uint64_t)1 << (idx[k] & 63);
         } else if (st == ST_UNBND) {
-            *keep |= (uint64_t)1 << idx[k];
+            keep[idx[k] >> 6] |= (uint64_t)1 << (idx[k] & 63);
         }
         bout[idx[k]] = bw[k];
     }

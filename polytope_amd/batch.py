@@ -168,6 +168,8 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
 
     -> dict(keep uint64[B] (bit i = input row i kept), flags int32[B] (RF_*), r[B], xc[B,d],
             nlp int32[B] = LPs the reference would have issued for that polytope)
+    Polytopes of more than 64 rows (m_max > 64; the reference has no row limit): keep is [B, W], W = ceil(m_max / 64)
+    words per polytope (plp_reduce_wide_batch; `keep_to_bool` reads either shape).
     `out` (device path only): a dict of preallocated, contiguous CUDA tensors keep int64[B], flags
     int32[B], r float64[B], xc float64[B,d], nlp int32[B] to write into (e.g. views of one exchange buffer,
     polytope_amd.dist.ResultBuffer).
@@ -179,6 +181,19 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
         b = _tprep(torch, b, torch.float64)
         m = _tprep(torch, m, torch.int32)
         B, m_max, d = A.shape
+        if m_max > 64:
+            if out is not None:
+                raise ValueError("reduce_batch: `out` is for polytopes of up to 64 rows (one keep word each)")
+            W = (m_max + 63) // 64
+            keep = torch.empty((B, W), dtype=torch.int64, device=A.device)
+            flags = torch.empty((B,), dtype=torch.int32, device=A.device)
+            r = torch.empty((B,), dtype=torch.float64, device=A.device)
+            xc = torch.empty((B, d), dtype=torch.float64, device=A.device)
+            nlp = torch.empty((B,), dtype=torch.int32, device=A.device)
+            _lib.check(lib.plp_reduce_wide_batch_dev(ctx.handle, stream, B, m_max, d, _ptr(A), _ptr(b), _ptr(m),
+                                                     float(abs_tol), _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)),
+                       "plp_reduce_wide_batch_dev")
+            return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
         if out is not None:
             keep, flags, r, xc, nlp = out["keep"], out["flags"], out["r"], out["xc"], out["nlp"]
             want = ((keep, torch.int64, (B,)), (flags, torch.int32, (B,)), (r, torch.float64, (B,)),
@@ -204,20 +219,26 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     b = _np(b).reshape(B, m_max)
     mm = None if m is None else _np(m, np.int32).reshape(B)
     # (inf / nan in the inputs: ValueError from the library, which checks them while staging -- plp_ctx_set_check_finite)
-    keep = np.empty(B, np.uint64)
+    wide = m_max > 64
+    keep = np.empty((B, (m_max + 63) // 64) if wide else B, np.uint64)
     flags = np.empty(B, np.int32)
     r = np.empty(B)
     xc = np.empty((B, d))
     nlp = np.empty(B, np.int32)
-    _lib.check(lib.plp_reduce_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
-                                    _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)), "plp_reduce_batch")
+    fn, name = (lib.plp_reduce_wide_batch, "plp_reduce_wide_batch") if wide else (lib.plp_reduce_batch, "plp_reduce_batch")
+    _lib.check(fn(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
+                  _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)), name)
     return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
 
 
 def keep_to_bool(keep, m_max):
-    """uint64 keep masks -> bool[B, m_max]."""
+    """uint64 keep masks (one word per polytope, or [B, W] words for more than 64 rows) -> bool[B, m_max]."""
     keep = np.asarray(keep).astype(np.uint64)
-    return ((keep[:, None] >> np.arange(m_max, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    if keep.ndim == 1:
+        keep = keep[:, None]
+    rows = np.arange(m_max)
+    words = keep[:, rows // 64]
+    return ((words >> (rows % 64).astype(np.uint64)[None, :]) & np.uint64(1)).astype(bool)
 
 
 def contains_batch(A, b, X, abs_tol=1e-7, m=None, region=True):

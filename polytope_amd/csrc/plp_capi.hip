@@ -696,6 +696,58 @@ int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A,
                               {dnlp, nullptr, nlp, (size_t)B * 4}});
 }
 
+// ------------------------------------------------------------------------------- reduce beyond 64 rows
+int plp_reduce_wide_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, const double* A,
+                              const double* b, const int32_t* m, double abs_tol, uint64_t* keep, int32_t* flags,
+                              double* r, double* xc, int32_t* nlp) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!keep || !flags || !r || !xc || !nlp || !A || !b) return fail(PLP_EINVAL, "NULL pointer");
+    if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
+    hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
+    if (m_max <= plp::MAX_M)  // one word per polytope: the register-resident kernels
+        return plp_reduce_batch_dev(ctx, stream, B, m_max, d, A, b, m, abs_tol, keep, flags, r, xc, nlp);
+    if (plp::launch_reduce_lds(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r, xc,
+                               nlp, st))
+        return fail(PLP_EUNSUPPORTED, "reduce: a polytope of %d rows in dimension %d does not fit the LDS of a CU", m_max, d);
+    return check_launch("reduce_lds_kernel");
+}
+
+int plp_reduce_wide_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b,
+                          const int32_t* m, double abs_tol, uint64_t* keep, int32_t* flags, double* r, double* xc,
+                          int32_t* nlp) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (B < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (B == 0) return PLP_OK;
+    if (!keep || !flags || !r || !xc || !nlp || !A || !b) return fail(PLP_EINVAL, "NULL pointer");
+    if (m_max <= plp::MAX_M) return plp_reduce_batch(ctx, B, m_max, d, A, b, m, abs_tol, keep, flags, r, xc, nlp);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t W = (size_t)(m_max + 63) / 64;
+    const size_t nA = (size_t)B * m_max * d, nb = (size_t)B * m_max, nx = (size_t)B * d;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(nx * 8) + pad(B * W * 8) + pad(B * 8) + pad(B * 4) * 3 + 4096);
+    if (rc) return rc;
+    rc = finite_or_fail(ctx, {{A, nA}, {b, nb}});
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA);
+    double* db = a.take<double>(nb);
+    int32_t* dm = a.take<int32_t>(B);
+    uint64_t* dkeep = a.take<uint64_t>(B * W);
+    int32_t* dfl = a.take<int32_t>(B);
+    double* dr = a.take<double>(B);
+    double* dxc = a.take<double>(nx);
+    int32_t* dnlp = a.take<int32_t>(B);
+    hipStream_t st = ctx->stream;
+    rc = copy_in(ctx, st, {{dA, A, nullptr, nA * 8}, {db, b, nullptr, nb * 8}, {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
+    if (rc) return rc;
+    rc = plp_reduce_wide_batch_dev(ctx, st, B, m_max, d, dA, db, m ? dm : nullptr, abs_tol, dkeep, dfl, dr, dxc, dnlp);
+    if (rc) return rc;
+    return copy_out(ctx, st, {{dkeep, nullptr, keep, (size_t)B * W * 8}, {dfl, nullptr, flags, (size_t)B * 4},
+                              {dr, nullptr, r, (size_t)B * 8}, {dxc, nullptr, xc, nx * 8},
+                              {dnlp, nullptr, nlp, (size_t)B * 4}});
+}
+
 // ------------------------------------------------------------------------------- contains
 int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const double* A, const double* b,
                      const int32_t* m, int64_t N, const double* X, double abs_tol, int mode, uint8_t* out) {

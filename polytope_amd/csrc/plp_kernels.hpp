@@ -38,6 +38,11 @@ void launch_rdiff_publish(long long n, const double* src, double* host_out, unsi
 int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, const int* rows, const int* sel,
                             const double* A, const double* b, double* out, hipStream_t st);
 
+// fused reduce() of polytopes with more than 64 rows: rows and dictionary in LDS, keep = ceil(m_max / 64) words per
+// polytope (plp_lds.hip); returns 2 when a polytope does not fit the CU's LDS
+int launch_reduce_lds(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                      unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st);
+
 // one LP per wavefront, one row per lane, wave-uniform pivot column (plp_wide.hip): the engine for d >= 9
 int launch_cheby_w(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                    double* xc, int* status, hipStream_t st);

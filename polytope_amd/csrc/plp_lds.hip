@@ -503,6 +503,316 @@ __global__ __launch_bounds__(64) void cheby_gather_lds_kernel(long long nlp, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// reduce_lds_kernel -- fused reduce() (polytope/polytope.py:1053-1163) of polytopes with MORE THAN 64 ROWS: the stacks
+// Polytope.intersect builds (m1 + m2 rows, :268-275) and the leaves of region_diff (:2276) have no row limit in the
+// reference.  One polytope per wavefront; its rows (A, b, s = A xc, a state word per row) stay in LDS next to the
+// dictionary of the LP being solved; lane l owns rows l, l + 64, ...  The pipeline and every reference step are those
+// of reduce_r_tile (plp_reduce_r_impl.hpp): F1 -> parallel-row dedupe -> 2d F3 LPs + prefilter (rows > 3d) -> the F2
+// presolve (same two witness points) -> one F2 LP per row it leaves, each on lds_step (the general engine: Bland's rule
+// in the loop, no hand-over pass).  keep is W = ceil(m_max / 64) words per polytope.
+namespace {
+
+constexpr int ROW_DEAD = 0, ROW_LIVE = 1, ROW_SETTLED = 2;  // ROW_SETTLED: live and settled as "keep" by the presolve
+
+struct RedRows {
+    double* A;    // [m][d]
+    double* b;    // [m]
+    double* s;    // [m]  1 / ||a_i|| during the dedupe, then a_i . xc
+    double* w1;   // [m]  prefilter sums (:1131-1134)
+    double* w2;   // [m]
+    double* xc;   // [16] the Chebyshev centre (every lane reads it; no cross-lane reads inside loops of uneven trip count)
+    int* state;   // [m]
+};
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dictionary of an F2 / F3 LP: rows as they are (dead rows are zero), beta = max(b - s, 0), given cost row
+__device__ __forceinline__ void red_setup_lp(LdsState& S, const LdsDict& D, const RedRows& R, int m, int d, int nlive,
+                                             int lane, double cost_lane) {
+    const int ld = D.ld;
+    S.m = m; S.n = d; S.nc = d;
+    S.cfree = d >= 32 ? 0xffffffffu : ((1u << d) - 1u);
+    S.dead = 0u; S.ndeg = 0; S.iters = 0; S.maxit = 50 * (nlive + d) + 100;
+    S.mode = M_P2; S.status = -1; S.init_col = -1; S.mode_after_init = M_P2;
+    S.negz = 0.0; S.negz2 = 0.0; S.carry = false;
+    for (int i = lane; i < m; i += 64) {
+        double* Ti = D.T + (size_t)i * ld;
+        for (int k = 0; k < d; ++k) Ti[k] = R.A[i * d + k];
+        D.beta[i] = fmax(R.b[i] - R.s[i], 0.0);
+        D.rowvar[i] = d + i;
+        D.rowfl[i] = R.state[i] != ROW_DEAD ? 2 : 0;
+    }
+    if (lane < d) {
+        D.cost[lane] = cost_lane;
+        D.cost2[lane] = 0.0;
+        D.cv[lane] = (lane + 1) << 1;
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, int d, int W, const double* __restrict__ Ag,
+                                                        const double* __restrict__ bg, const int* __restrict__ mrows,
+                                                        double abs_tol, unsigned long long* __restrict__ keep_out,
+                                                        int* __restrict__ flags_out, double* __restrict__ r_out,
+                                                        double* __restrict__ xc_out, int* __restrict__ nlp_out,
+                                                        size_t dict_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int nc1 = d + 1;
+    const int ld = nc1 | 1;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    RedRows R;
+    R.A = reinterpret_cast<double*>(smem_raw + dict_bytes);
+    R.b = R.A + (size_t)m_max * d;
+    R.s = R.b + m_max;
+    R.w1 = R.s + m_max;
+    R.w2 = R.w1 + m_max;
+    R.xc = R.w2 + m_max;
+    R.state = reinterpret_cast<int*>(R.xc + 16);
+    for (long long p = blockIdx.x; p < B; p += gridDim.x) {
+        const int m = mrows ? mrows[p] : m_max;
+        const LdsDict D = lds_carve(smem_raw, m_max, ld);
+        __syncthreads();
+        // ---------------------------------------------------------------- rows -> LDS; F1 (as cheby_lds_kernel)
+        LdsState S;
+        S.m = m; S.n = nc1; S.nc = nc1;
+        S.cfree = (1u << nc1) - 1u;
+        S.dead = 0u; S.ndeg = 0; S.iters = 0; S.maxit = 50 * (m + nc1) + 100;
+        S.mode = M_INIT; S.status = -1; S.init_col = d; S.mode_after_init = M_P2;
+        S.negz = 0.0; S.negz2 = 0.0; S.carry = false;
+        bool finite = true, inf0 = false;
+        for (int i = lane; i < m_max; i += 64) {
+            const bool h = i < m;
+            double* Ti = D.T + (size_t)i * ld;
+            double nrm2 = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double v = h ? Ag[(p * m_max + i) * d + k] : 0.0;
+                R.A[i * d + k] = v;
+                if (h) Ti[k] = v;
+                nrm2 = nrm2 + v * v;
+                finite = finite & isfinite(v);
+            }
+            const double bi = h ? bg[p * m_max + i] : 0.0;
+            finite = finite & isfinite(bi);
+            R.b[i] = bi;
+            const double nrm = sqrt(nrm2);
+            R.s[i] = 1.0 / nrm;
+            R.state[i] = h ? ROW_LIVE : ROW_DEAD;
+            if (h) {
+                const bool zero = !(nrm > 0.0);
+                Ti[d] = zero ? 0.0 : nrm;
+                D.beta[i] = zero ? 0.0 : bi;
+                D.qk[i] = bi / nrm;
+                D.rowvar[i] = nc1 + i;
+                D.rowfl[i] = zero ? 0 : 2;
+                inf0 = inf0 | (zero & (bi < -TOL_FEAS));
+            }
+        }
+        if (lane < nc1) {
+            D.cost[lane] = lane == d ? -1.0 : 0.0;
+            D.cost2[lane] = 0.0;
+            D.cv[lane] = (lane + 1) << 1;
+        }
+        if (__ballot(!finite) != 0) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (__ballot(inf0) != 0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+        __syncthreads();
+        while (S.mode != M_DONE) lds_step(S, D, lane);
+        double xcl = 0.0;  // lane j < d: xc[j]
+        for (int j = 0; j < d; ++j) {
+            const double xj = lds_x_of(D, m, j, lane);
+            xcl = (lane == j) ? xj : xcl;
+        }
+        const double rr = lds_x_of(D, m, d, lane);
+        if (lane < d) R.xc[lane] = xcl;
+        const bool ball = (S.status == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        const bool fulldim = ball & (rr > abs_tol);
+        int flags = fulldim ? 0 : RF_EMPTY;
+        int nlp = 1;
+        int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
+        int neq = 0;
+        __syncthreads();
+        if (fulldim) {
+            // ---------------------------------------------------------------- dedupe (:1094-1110), as reduce_r_tile
+            for (int i = lane; i < m; i += 64) {
+                const double an_i = R.s[i];
+                const double bin_ = R.b[i] * an_i;
+                bool removed = false;
+                for (int j = 0; j < m; ++j) {
+                    const double an_j = R.s[j];
+                    double dot = 0.0;
+                    for (int k = 0; k < d; ++k) dot = dot + (R.A[i * d + k] * an_i) * (R.A[j * d + k] * an_j);
+                    const double bjn = R.b[j] * an_j;
+                    const bool par = (j != i) & (dot > 1.0 - abs_tol);
+                    removed = removed | (par & ((i < j) ? !(bin_ < bjn) : (bjn < bin_)));
+                }
+                if (removed) R.state[i] = ROW_DEAD;
+            }
+            __syncthreads();
+            // s_i = a_i . xc replaces 1 / ||a_i||; dead rows are zeroed (A, b, s) so that the LP set-ups load them as they are
+            int cnt = 0;
+            for (int i = lane; i < m_max; i += 64) {
+                const bool alive = R.state[i] != ROW_DEAD;
+                double sk = 0.0;
+                for (int k = 0; k < d; ++k) {
+                    const double v = alive ? R.A[i * d + k] : 0.0;
+                    R.A[i * d + k] = v;
+                    sk = fma(v, R.xc[k], sk);
+                }
+                R.s[i] = sk;
+                if (!alive) R.b[i] = 0.0;
+                cnt += alive ? 1 : 0;
+            }
+            neq = wave_sum_i(cnt);
+            __syncthreads();
+            if (neq <= d + 1) flags = RF_EARLY;
+            else stage = (neq > 3 * d) ? 1 : 2;
+        }
+        // ---------------------------------------------------------------- F3: bounding box (:1367-1409) + prefilter (:1118-1134)
+        if (stage == 1) {
+            for (int i = lane; i < m; i += 64) { R.w1[i] = 0.0; R.w2[i] = 0.0; }
+            bool lpfail = false;
+            double lbk = 0.0;
+            for (int it = 0; it < 2 * d; ++it) {  // lower_0, upper_0, lower_1, upper_1, ...
+                const int kx = it >> 1;
+                const bool up = it & 1;
+                red_setup_lp(S, D, R, m, d, neq, lane, lane == kx ? (up ? -1.0 : 1.0) : 0.0);
+                while (S.mode != M_DONE) lds_step(S, D, lane);
+                const double xck = R.xc[kx];
+                double val;
+                if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
+                else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
+                else { val = qnan; lpfail = true; }
+                if (!up) {
+                    lbk = val;
+                } else {
+                    for (int i = lane; i < m; i += 64) {
+                        const double aik = R.A[i * d + kx];
+                        const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                        R.w1[i] = R.w1[i] + pa * (val - lbk);
+                        R.w2[i] = R.w2[i] + aik * lbk;
+                    }
+                }
+                __syncthreads();
+            }
+            int cnt = 0;
+            for (int i = lane; i < m; i += 64) {
+                const bool alive = R.state[i] != ROW_DEAD;
+                const bool out = alive & ((R.w1[i] - (R.b[i] - R.w2[i])) < -1e-4);
+                if (out) {
+                    R.state[i] = ROW_DEAD;
+                    for (int k = 0; k < d; ++k) R.A[i * d + k] = 0.0;
+                    R.b[i] = 0.0;
+                    R.s[i] = 0.0;
+                }
+                cnt += (alive & !out) ? 1 : 0;
+            }
+            neq = wave_sum_i(cnt);
+            nlp += 2 * d;
+            if (lpfail) flags |= RF_LPFAIL;
+            if (neq <= d + 1) { flags |= RF_EARLY; stage = 0; }
+            else stage = 2;
+            __syncthreads();
+        }
+        // ---------------------------------------------------------------- F2: presolve, then one LP per row it leaves (:1142-1160)
+        if (stage == 2) {
+            nlp += neq;
+            const bool presolve = abs_tol < 0.04;
+            for (int k = lane; presolve && k < m; k += 64) {   // (see f2_presolve in plp_reduce_r_impl.hpp: same witnesses)
+                if (R.state[k] == ROW_DEAD) continue;
+                double gkk = 0.0;
+                for (int c = 0; c < d; ++c) gkk = fma(R.A[k * d + c], R.A[k * d + c], gkk);
+                const double bk = R.b[k];
+                const double sk = fmax(bk - R.s[k], 0.0);
+                const double tau = abs_tol + 1e-9 * (1.0 + fabs(bk) + sk);
+                const double skt = sk + tau;
+                if (!((gkk > 0.0) & (tau < 0.05))) continue;
+                bool ok = true;
+                int jb = 0;
+                for (int i = 0; i < m; ++i) {
+                    double gik = 0.0;
+                    for (int c = 0; c < d; ++c) gik = fma(R.A[i * d + c], R.A[k * d + c], gik);
+                    const double si = fmax(R.b[i] - R.s[i], 0.0);
+                    const bool fine = (i == k) | (skt * gik <= si * gkk);
+                    ok = ok & fine;
+                    jb = fine ? jb : i;
+                }
+                if (!ok) {  // second witness: up to the blocking row jb, then along its plane
+                    double gjk = 0.0, gjj = 0.0;
+                    for (int c = 0; c < d; ++c) {
+                        gjk = fma(R.A[jb * d + c], R.A[k * d + c], gjk);
+                        gjj = fma(R.A[jb * d + c], R.A[jb * d + c], gjj);
+                    }
+                    const double sj = fmax(R.b[jb] - R.s[jb], 0.0);
+                    const double rho = gjk / gjj;
+                    const double t1 = (sj / gjk) * (1.0 - 0x1p-40);
+                    const double akd = fma(-rho, gjk, gkk);
+                    const double t2 = fma(-t1, gkk, skt) / akd;
+                    const double c1 = t1 + t2, c2 = t2 * rho;
+                    ok = (gjk > 0.0) & (akd > 1e-12 * gkk) & (t2 >= 0.0) & (t2 < 1e300);
+                    for (int i = 0; ok && i < m; ++i) {
+                        double gik = 0.0, gij = 0.0;
+                        for (int c = 0; c < d; ++c) {
+                            gik = fma(R.A[i * d + c], R.A[k * d + c], gik);
+                            gij = fma(R.A[i * d + c], R.A[jb * d + c], gij);
+                        }
+                        const double si = fmax(R.b[i] - R.s[i], 0.0);
+                        const double lhs = fma(-c2, gij, c1 * gik);
+                        ok = ok & ((i == k) | (lhs <= si));
+                    }
+                }
+                if (ok) R.state[k] = ROW_SETTLED;
+            }
+            __syncthreads();
+            // settled rows: the reference's in-place round trip of h[k] right away (see f2_presolve)
+            for (int k = lane; k < m; k += 64)
+                if (R.state[k] == ROW_SETTLED) R.b[k] = (R.b[k] + 0.1) - 0.1;
+            __syncthreads();
+            for (int kr = 0; kr < m; ++kr) {
+                if (R.state[kr] != ROW_LIVE) continue;   // (wave-uniform: an LDS word)
+                double cxc = 0.0;
+                for (int c = 0; c < d; ++c) cxc = fma(-R.A[kr * d + c], R.xc[c], cxc);
+                __syncthreads();
+                if (lane == 0) R.b[kr] = R.b[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
+                __syncthreads();
+                red_setup_lp(S, D, R, m, d, neq, lane, lane < d ? -R.A[kr * d + (lane < d ? lane : 0)] : 0.0);
+                while (S.mode != M_DONE) lds_step(S, D, lane);
+                const double fun = cxc - S.negz;  // c.xc + zeta, zeta = -negz
+                const double hk = R.b[kr] - 0.1;  // (:1151)
+                __syncthreads();
+                if (lane == 0) R.b[kr] = hk;
+                const double obj = -fun - hk;     // (:1156)
+                const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
+                if (!keepk && lane == 0) R.state[kr] = ROW_DEAD;   // (state now means: kept)
+                __syncthreads();
+            }
+            flags |= RF_MINREP;
+        }
+        // ---------------------------------------------------------------- results
+        __syncthreads();
+        for (int w = 0; w < W; ++w) {
+            const int i = w * 64 + lane;
+            const bool kept = (flags & (RF_EARLY | RF_MINREP)) && i < m && R.state[i] != ROW_DEAD;
+            const unsigned long long word = __ballot(kept);
+            if (lane == 0) keep_out[p * W + w] = word;
+        }
+        if (lane == 0) {
+            flags_out[p] = flags;
+            nlp_out[p] = nlp;
+            r_out[p] = ball ? rr : 0.0;
+        }
+        if (lane < d) xc_out[p * d + lane] = ball ? xcl : qnan;
+        __syncthreads();
+    }
+}
+
 // LDS bytes one LP of (m_max, columns nc) needs; 0 when it does not fit a workgroup (160 KB per CU on gfx950)
 size_t lds_lp_bytes(int m_max, int nc) {
     const int ld = nc | 1;
@@ -556,6 +866,24 @@ int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(cheby_gather_lds_kernel, dim3(lds_grid(nlp, smem)), dim3(64), smem, st, nlp, m_cap, d, off, rows, sel,
                        A, b, out);
+    return 0;
+}
+
+// fused reduce() beyond 64 rows (reduce_lds_kernel); returns 2 when the polytope does not fit the CU's LDS
+int launch_reduce_lds(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                      unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    if (d < 1 || d > MAX_D || m_max < 1) return 2;
+    const size_t dict = lds_lp_bytes(m_max, d + 1);
+    if (!dict) return 2;
+    const size_t rows = ((size_t)m_max * (d + 4) * 8 + 16 * 8 + (size_t)m_max * 4 + 15) & ~(size_t)15;
+    const size_t smem = dict + rows;
+    if (smem > 160 * 1024) return 2;
+    const int W = (m_max + 63) / 64;
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(reduce_lds_kernel, dim3(lds_grid(B, smem)), dim3(64), smem, st, B, m_max, d, W, A, b, mrows, abs_tol,
+                       keep, flags, r, xc, nlp, dict);
     return 0;
 }
 

@@ -48,6 +48,20 @@ def _fits(m, d):
     return 1 <= d <= _MAX_DIM and m <= _MAX_ROWS
 
 
+def _max_rows_reduce(d):
+    """Rows the fused reduce takes: up to 64 on the register-resident kernels, beyond that one polytope per wavefront
+    with its rows and the dictionary of the LP being solved in LDS (csrc/plp_lds.hip: reduce_lds_kernel) -- what fits
+    the CU's 160 KB (about 500 rows at d = 16, 2000 at d = 3)."""
+    per_row = (((d + 1) | 1) * 8 + 24) + ((d + 4) * 8 + 4)
+    return max(_MAX_ROWS, (160 * 1024 - 1400) // per_row)
+
+
+def _fits_reduce(m, d):
+    """reduce() on the 'hip' backend (the reference has no row limit: Polytope.intersect stacks m1 + m2 rows, ref
+    :268-275, region_diff's leaves whatever the search collected, :2276)."""
+    return 1 <= d <= _MAX_DIM and m <= _max_rows_reduce(d)
+
+
 def _max_rows_lp(d):
     """Rows a stand-alone LP may have: beyond 64 the engine keeps the dictionary in LDS (csrc/plp_lds.hip), one LP
     per wavefront, and the limit is what fits the CU's 160 KB (d + 1 structural columns + the artificial one)."""
@@ -689,6 +703,15 @@ def _reduce_many(polys, abs_tol):
     Side effects as in the reference: the Chebyshev ball and `fulldim` of each INPUT polytope
     are cached (is_fulldim at ref :1081)."""
     from .batch import reduce_batch, keep_to_bool
+    big = [k for k, p in enumerate(polys) if p.A.shape[0] > _MAX_ROWS]
+    if big and len(big) < len(polys):
+        # polytopes of more than 64 rows take the LDS-resident kernel, one per wavefront: a batch of their own
+        out = [None] * len(polys)
+        small = [k for k, p in enumerate(polys) if p.A.shape[0] <= _MAX_ROWS]
+        for sel in (small, big):
+            for k, q in zip(sel, _reduce_many([polys[k] for k in sel], abs_tol)):
+                out[k] = q
+        return out
     A, b, ms = _pack(polys)
     res = reduce_batch(A, b, m=ms, abs_tol=abs_tol)
     masks = keep_to_bool(res["keep"], A.shape[1])
@@ -731,7 +754,7 @@ def reduce(poly, nonEmptyBounded=1, abs_tol=ABS_TOL):
         if _use_hip() and nonEmptyBounded:
             todo = [k for k, p in enumerate(members)
                     if not p.minrep and p.fulldim is not False and p.A.size > 0
-                    and _fits(p.A.shape[0], p.A.shape[1]) and np.all(np.isfinite(p.b))]
+                    and _fits_reduce(p.A.shape[0], p.A.shape[1]) and np.all(np.isfinite(p.b))]
             if todo and len({members[k].A.shape[1] for k in todo}) == 1:
                 for k, q in zip(todo, _reduce_many([members[k] for k in todo], ABS_TOL)):
                     results[k] = q
@@ -743,7 +766,7 @@ def reduce(poly, nonEmptyBounded=1, abs_tol=ABS_TOL):
         return Region(lst, poly.props) if lst else Polytope()
     if poly.minrep:
         return poly
-    if _use_hip() and nonEmptyBounded and poly.A.size > 0 and _fits(poly.A.shape[0], poly.A.shape[1]) \
+    if _use_hip() and nonEmptyBounded and poly.A.size > 0 and _fits_reduce(poly.A.shape[0], poly.A.shape[1]) \
             and np.all(np.isfinite(poly.b)) and poly.fulldim is not False:
         return _reduce_many([poly], abs_tol)[0]
     if not is_fulldim(poly):
@@ -771,7 +794,7 @@ def _intersect_pairs(pairs, abs_tol):
         stacks.append(Polytope(np.vstack([p0.A, p1.A]), np.hstack([p0.b, p1.b])))
         where.append(k)
     if stacks:
-        batchable = _use_hip() and all(_fits(s.A.shape[0], s.A.shape[1]) for s in stacks) \
+        batchable = _use_hip() and all(_fits_reduce(s.A.shape[0], s.A.shape[1]) for s in stacks) \
             and len({s.A.shape[1] for s in stacks}) == 1
         reduced = _reduce_many(stacks, abs_tol) if batchable else [reduce(s, abs_tol=abs_tol) for s in stacks]
         for k, q in zip(where, reduced):
@@ -1113,7 +1136,7 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
     if leaves is not None:
         todo = [poly_of(list(rows)) for kind, rows in leaves if kind == 1]   # leaves the reference reduces (:2276)
         done = [None] * len(todo)
-        small = [k for k, p in enumerate(todo) if p.A.size > 0 and _fits(p.A.shape[0], p.A.shape[1])]
+        small = [k for k, p in enumerate(todo) if p.A.size > 0 and _fits_reduce(p.A.shape[0], p.A.shape[1])]
         if small:   # one fused reduce launch for all of them
             for k, q in zip(small, _reduce_many([todo[k] for k in small], ABS_TOL)):
                 done[k] = q

@@ -30,6 +30,7 @@ Sets:
   g12_config4.npz  BASELINE config 4: region_diff / Region.intersect / adjacency on the 81-cell 3x3x3x3 grid and
                    region_diff + an adjacency sample on the full 1000-cell 10x10x5x2 grid  (polytope.py:2117-2282)
   g13_volume_subset.npz  seeded volume(), is_subset, == / <= / >= on polytopes and Regions (polytope.py:1529-1594, :1032-1050)
+  g14_wide_reduce.npz  reduce() / Polytope.intersect() on inputs of more than 64 rows    (polytope.py:1053-1163, :255-275)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -828,7 +829,39 @@ def gen_g13():
     np.savez_compressed(os.path.join(HERE, "g13_volume_subset.npz"), **out)
 
 
+def gen_g14():
+    """reduce() and Polytope.intersect() beyond 64 rows (polytope.py:1053-1163 has no row limit; intersect stacks
+    m1 + m2 rows, :268-275): kept-row masks of the stacked input, the reduced rows, radii."""
+    rng = np.random.default_rng(1414)
+    out = {}
+    k = 0
+    for (m1, m2, d) in [(40, 40, 3), (50, 30, 4), (70, 0, 2), (64, 64, 5), (33, 48, 3), (100, 28, 6), (45, 45, 8)]:
+        A1, b1 = rand_hpoly(rng, m1, d, bounded=True)
+        P = pc.Polytope(A1, b1)
+        if m2:
+            A2, b2 = rand_hpoly(rng, m2, d, bounded=True)
+            shift = 0.25 * rng.standard_normal(d)
+            Q = pc.Polytope(A2, 0.9 * b2 + A2 @ shift)
+            R = P.copy().intersect(Q.copy())
+            Ain, bin_ = np.vstack([P.A, Q.A]), np.hstack([P.b, Q.b])
+            out["c%d_QA" % k], out["c%d_Qb" % k] = Q.A, Q.b
+        else:
+            R = alg.reduce(P.copy())
+            Ain, bin_ = P.A, P.b
+        assert Ain.shape[0] > 64
+        out["c%d_PA" % k], out["c%d_Pb" % k] = P.A, P.b
+        out["c%d_has_Q" % k] = np.int8(1 if m2 else 0)
+        out["c%d_A" % k], out["c%d_b" % k] = R.A, R.b
+        out["c%d_mask" % k] = match_rows(Ain, bin_, R.A, R.b)
+        out["c%d_minrep" % k] = np.int8(bool(R.minrep))
+        out["c%d_r" % k] = np.float64(alg.cheby_ball(R)[0])
+        print("g14 case %d: %d + %d rows, d = %d -> %d rows, r = %.6f" % (k, m1, m2, d, R.A.shape[0], out["c%d_r" % k]))
+        k += 1
+    out["n"] = np.int32(k)
+    np.savez_compressed(os.path.join(HERE, "g14_wide_reduce.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()["gen_" + w]()

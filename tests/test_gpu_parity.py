@@ -446,6 +446,44 @@ def test_reduce_vs_oracle_batches(pa, oracle):
         assert nlp_total >= B
 
 
+def test_reduce_beyond_64_rows_vs_oracle(pa, oracle):
+    """Fused reduce of polytopes with 65..256 rows (reduce_lds_kernel: rows and dictionary in LDS, keep = W words per
+    polytope): keep masks, flags and LP counts exactly the oracle's (polytope.py:1053-1163 has no row limit; the
+    stacks of Polytope.intersect, :268-275, and the leaves of region_diff pass 64 rows)."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(19)
+    for (m, d, B) in [(80, 3, 48), (100, 4, 40), (128, 8, 24), (65, 2, 32), (250, 16, 4), (200, 6, 10), (96, 12, 8)]:
+        A, b = random_hpolytopes(B, m, d, seed=300 + m + d, bounded=True)
+        for k in range(0, B, 5):   # duplicated rows (dedupe), shifted copies
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.1])
+        for k in range(3, B, 9):
+            b[k, 0] = -5.0  # cuts everything away -> empty
+        mrows = rng.integers(m - 20, m + 1, B).astype(np.int32)
+        mrows[0] = m
+        res = pa.reduce_batch(A, b, m=mrows)
+        assert res["keep"].shape == (B, (m + 63) // 64)
+        masks = pa.keep_to_bool(res["keep"], m)
+        for k in range(B):
+            mk = mrows[k]
+            o = oracle.reduce(A[k, :mk], b[k, :mk])
+            assert int(res["flags"][k]) == o["flags"], (m, d, k, int(res["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k, :mk], o["keep"]), (m, d, k, np.nonzero(masks[k, :mk] != o["keep"]))
+            assert not masks[k, mk:].any()
+            assert abs(res["r"][k] - o["r"]) <= TOL
+            assert int(res["nlp"][k]) == o["nlp"], (m, d, k, int(res["nlp"][k]), o["nlp"])
+        # device-resident call: same bits
+        import torch
+        rd = pa.reduce_batch(torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda(), m=torch.as_tensor(mrows).cuda())
+        assert np.array_equal(rd["keep"].cpu().numpy().view(np.uint64), res["keep"])
+        assert np.array_equal(rd["nlp"].cpu().numpy(), res["nlp"])
+    # a polytope that does not fit the LDS of a CU: PLP_EUNSUPPORTED -> ValueError, never a wrong answer
+    A, b = random_hpolytopes(1, 1200, 16, seed=1, bounded=True)
+    with pytest.raises(ValueError):
+        pa.reduce_batch(A, b)
+
+
 def _pyramids(B, m, d, rng):
     """Polytopes with a highly degenerate vertex: m - d - 1 facets through one apex, a simplex-like base
     below it and duplicated / nearly parallel facets: the redundancy LPs pivot degenerately at the apex

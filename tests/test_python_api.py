@@ -735,3 +735,26 @@ def test_bounding_box_where_the_one_deviating_status_shows(pc):
         assert np.allclose(hi[fin], hi_s[fin], atol=TOL, rtol=0)
         fin = np.isfinite(lo_s) & rest
         assert np.allclose(lo[fin], lo_s[fin], atol=TOL, rtol=0)
+
+
+def test_intersect_and_reduce_beyond_64_rows(pc, monkeypatch):
+    """g14: Polytope.intersect stacks m1 + m2 rows (ref :268-275) and `reduce` takes any number (ref :1053-1163).  Same
+    rows in the same order as the reference on both backends; on 'hip' the whole call is ONE fused launch
+    (reduce_lds_kernel) -- the LP loop over single launches must not be reached."""
+    from polytope_amd import solvers
+    g = load_golden("g14_wide_reduce.npz")
+    if solvers.default_solver == "hip":
+        def boom(*a, **k):
+            raise AssertionError("_reduce_lp_loop reached on the 'hip' backend")
+        monkeypatch.setattr(pc, "_reduce_lp_loop", boom)
+    for k in range(int(g["n"])):
+        P = pc.Polytope(g["c%d_PA" % k], g["c%d_Pb" % k], normalize=False)
+        if int(g["c%d_has_Q" % k]):
+            Q = pc.Polytope(g["c%d_QA" % k], g["c%d_Qb" % k], normalize=False)
+            R = P.intersect(Q)
+        else:
+            R = pc.reduce(P)
+        assert R.A.shape == g["c%d_A" % k].shape, (k, R.A.shape)
+        assert np.allclose(R.A, g["c%d_A" % k], atol=1e-9, rtol=0) and np.allclose(R.b, g["c%d_b" % k], atol=1e-9, rtol=0)
+        assert bool(R.minrep) == bool(g["c%d_minrep" % k])
+        assert abs(float(pc.cheby_ball(R)[0]) - float(g["c%d_r" % k])) <= TOL
