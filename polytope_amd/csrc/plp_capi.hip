@@ -56,6 +56,14 @@ struct plp_ctx {
     size_t mf_bytes = 0;
     hipEvent_t mf_ev = nullptr;  // recorded after every launch that uses mf_buf: the next user (any stream) waits on it
     bool mf_used = false;
+    // device / pinned buffers of the last quickhull session that ended (plp_hull_destroy parks them here, plp_hull_create
+    // takes them when they are large enough): hipMalloc / hipFree of five buffers cost more than a 100 000-point hull
+    struct HullSpare {
+        double* X = nullptr; int32_t* owner = nullptr; double* dist = nullptr; uint8_t* dead = nullptr;
+        char* io = nullptr; char* pin = nullptr;
+        size_t X_bytes = 0, owner_bytes = 0, dist_bytes = 0, dead_cap = 0, io_bytes = 0;
+        bool full = false;
+    } hull_spare;
     // large host-pointer batches (plp_stage.hpp): staging threads, pinned staging buffer, copy stream, one event per chunk
     plp::StagePool* pool = nullptr;
     char* stage = nullptr;
@@ -396,6 +404,12 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
+    if (ctx->hull_spare.full) {
+        (void)hipFree(ctx->hull_spare.X); (void)hipFree(ctx->hull_spare.owner); (void)hipFree(ctx->hull_spare.dist);
+        if (ctx->hull_spare.dead) (void)hipFree(ctx->hull_spare.dead);
+        if (ctx->hull_spare.io) (void)hipFree(ctx->hull_spare.io);
+        if (ctx->hull_spare.pin) (void)hipHostFree(ctx->hull_spare.pin);
+    }
     delete ctx->pool;
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     for (int i = 0; i < ctx->stage_nev; ++i) (void)hipEventDestroy(ctx->stage_ev[i]);
@@ -903,6 +917,7 @@ struct plp_hull {
     double* X;
     int32_t* owner;
     double* dist;
+    size_t X_bytes, owner_bytes, dist_bytes;   // capacities (buffers may come from the context's spare set)
     uint8_t* dead;     // one byte per facet id handed out so far (grow-only)
     size_t dead_cap;
     int next_id;       // next facet id to hand out
@@ -957,6 +972,15 @@ int plp_hull_destroy(plp_hull* h) {
     if (!h) return PLP_OK;
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
+    plp_ctx::HullSpare& sp = h->ctx->hull_spare;
+    if (!sp.full && h->X && h->owner && h->dist) {   // park the buffers for the next session of this context
+        sp.X = h->X; sp.owner = h->owner; sp.dist = h->dist; sp.dead = h->dead; sp.io = h->io; sp.pin = h->pin;
+        sp.X_bytes = h->X_bytes; sp.owner_bytes = h->owner_bytes; sp.dist_bytes = h->dist_bytes;
+        sp.dead_cap = h->dead_cap; sp.io_bytes = h->io_bytes;
+        sp.full = true;
+        delete h;
+        return PLP_OK;
+    }
     if (h->X) (void)hipFree(h->X);
     if (h->owner) (void)hipFree(h->owner);
     if (h->dist) (void)hipFree(h->dist);
@@ -981,9 +1005,20 @@ int plp_hull_create(plp_ctx* ctx, int64_t N, int d, const double* X, plp_hull** 
     h->d = d;
     h->next_id = 1;  // id 0: the virtual facet owning every point (owner[] is zero-filled)
     const size_t n1 = N > 0 ? (size_t)N : 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->X), n1 * d * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->owner), n1 * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->dist), n1 * 8);
+    hipError_t e = hipSuccess;
+    plp_ctx::HullSpare& sp = ctx->hull_spare;
+    if (sp.full && sp.X_bytes >= n1 * d * 8 && sp.owner_bytes >= n1 * 4 && sp.dist_bytes >= n1 * 8) {
+        h->X = sp.X; h->owner = sp.owner; h->dist = sp.dist; h->dead = sp.dead; h->io = sp.io; h->pin = sp.pin;
+        h->X_bytes = sp.X_bytes; h->owner_bytes = sp.owner_bytes; h->dist_bytes = sp.dist_bytes;
+        h->dead_cap = sp.dead_cap; h->io_bytes = sp.io_bytes;
+        sp = plp_ctx::HullSpare();
+        if (h->dead) e = hipMemsetAsync(h->dead, 0, h->dead_cap, ctx->stream);   // no facet id is dead yet
+    } else {
+        h->X_bytes = n1 * d * 8; h->owner_bytes = n1 * 4; h->dist_bytes = n1 * 8;
+        e = hipMalloc(reinterpret_cast<void**>(&h->X), h->X_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->owner), h->owner_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->dist), h->dist_bytes);
+    }
     if (e == hipSuccess) e = hipMemsetAsync(h->owner, 0, n1 * 4, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->dist, 0, n1 * 8, ctx->stream);
     if (e == hipSuccess && N > 0) e = hipMemcpyAsync(h->X, X, (size_t)N * d * 8, hipMemcpyHostToDevice, ctx->stream);

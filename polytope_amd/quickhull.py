@@ -120,7 +120,36 @@ def _rank(M, tol):
     return int(np.sum(np.linalg.svd(M, compute_uv=False) > tol))
 
 
+_BLAS_CTL = None
+
+
+def _blas_single_thread():
+    """Context manager: numpy's BLAS on the calling thread only, for the duration of one hull.
+    The rank check (an SVD) and the start simplex (matrix-vector products) wake OpenBLAS's worker pool, whose threads
+    then spin for tens of milliseconds; measured on the 256-core host of the GPU box they stall the native main loop
+    that follows for 60-90 ms somewhere inside a 40 ms hull (N = 100 000, d = 5).  These calls are far too small to
+    gain from threads.  No-op when threadpoolctl is not importable."""
+    global _BLAS_CTL
+    if _BLAS_CTL is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _BLAS_CTL = ThreadpoolController()
+        except Exception:  # pragma: no cover
+            _BLAS_CTL = False
+    if _BLAS_CTL:
+        return _BLAS_CTL.limit(limits=1, user_api="blas")
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
+    """Compute the convex hull of a set of points (see `_quickhull`; numpy's BLAS is kept on the calling thread
+    meanwhile, `_blas_single_thread`)."""
+    with _blas_single_thread():
+        return _quickhull(POINTS, abs_tol, session_factory)
+
+
+def _quickhull(POINTS, abs_tol=1e-7, session_factory=None):
     """Compute the convex hull of a set of points.
 
     @param POINTS: a n*d np array where each row denotes a point

@@ -273,3 +273,46 @@ def test_config1_randplot_plumbing(backend):
     r, xc = pc.cheby_ball(P2)
     assert abs(r - g["randplot_cheb"][0]) <= 1e-9
     assert np.max(P2.A @ xc + r - P2.b) <= 1e-9   # the centre is feasible (it need not be unique)
+
+
+@pytest.mark.gpu
+def test_hull_device_iterated_loop_in_reference_order(monkeypatch):
+    """PLP_QH_HOST_TAIL=0: every iteration of every g8 hull is ONE plp_hull_reassign on the device (the default hands
+    hulls with fewer than 32 768 outside points to host lists after the first assignment, so without this the
+    device-iterated loop is never compared with the reference's ORDER of rows).  Same facets, same order, same bits."""
+    from polytope_amd import solvers
+    from polytope_amd.quickhull import quickhull
+    monkeypatch.setattr(solvers, "default_solver", "hip")
+    monkeypatch.setenv("PLP_QH_HOST_TAIL", "0")
+    g = load_golden("g8_hull.npz")
+    for k in range(int(g["hull_ncases"])):
+        np.random.seed(int(g[f"hull{k}_seed"]))
+        A, b, V = quickhull(g[f"hull{k}_P"])
+        assert A.shape == g[f"hull{k}_A"].shape, k
+        assert np.array_equal(A, g[f"hull{k}_A"]), k
+        assert np.allclose(b, g[f"hull{k}_b"], rtol=0, atol=1e-12), k
+        assert np.allclose(V, g[f"hull{k}_V"], rtol=0, atol=1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d", [(200000, 4), (60000, 5)])
+def test_hull_host_tail_and_device_loop_agree_bitwise(monkeypatch, N, d):
+    """The default (device while many points are outside, host lists for the long tail), the device-only loop
+    (PLP_QH_HOST_TAIL=0), the host-only loop (a huge threshold) and one / several host threads for the hyperplanes of
+    big iterations all return the same rows, bit for bit, in the same order."""
+    from polytope_amd import solvers
+    from polytope_amd.quickhull import quickhull
+    monkeypatch.setattr(solvers, "default_solver", "hip")
+    P = np.random.default_rng(N + d).standard_normal((N, d))
+    outs = []
+    for env in ({}, {"PLP_QH_HOST_TAIL": "0"}, {"PLP_QH_HOST_TAIL": "1000000000"}, {"PLP_QH_THREADS": "1"}):
+        for key in ("PLP_QH_HOST_TAIL", "PLP_QH_THREADS"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        np.random.seed(3)
+        outs.append(quickhull(P))
+    A0, b0, V0 = outs[0]
+    assert A0.shape[0] > 1000
+    for A, b, V in outs[1:]:
+        assert np.array_equal(A, A0) and np.array_equal(b, b0) and np.array_equal(V, V0)
