@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
+    ap.add_argument("--verify-exchange", action="store_true", help="N > 1, after the timed region: every rank recomputes "
+                    "every rank's results of the last group of batches and compares them with what the all-gather "
+                    "delivered (keep / flags / nlp / r bits); the line gets `exchange_verified`")
     args = ap.parse_args()
 
     import torch
@@ -359,6 +362,36 @@ def main():
         lps_timed = int(t.item())
         assert gathered.numel() == world * G * nb
     nlp_total = lps_timed / args.steps
+    verified = None
+    if multi and args.verify_exchange:
+        # the last gathered group holds the slots of the steps of the (possibly partly filled) last group; rank q's part
+        # must be what a reduce of rank q's batch of that step returns -- recomputed here, on this rank's GPU
+        gcpu = gathered.cpu()
+        first = (args.steps - 1) // G * G
+        ok, nslots = True, 0
+        for kstep in range(first, args.steps):
+            s_ = kstep - first
+            for q in range(world):
+                if strong:
+                    Aq, bq = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=kstep % NB, stream=0)
+                    loq, hiq = shard_bounds(B_PER_GPU, q, world)
+                    Aq, bq = Aq[loq:hiq], bq[loq:hiq]
+                else:
+                    Aq, bq = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=kstep % NB, stream=q)
+                want = pa.reduce_batch(torch.as_tensor(Aq).to(dev), torch.as_tensor(bq).to(dev))
+                got = ex.slot_views(gcpu, q, s_)
+                for key in ("keep", "flags", "nlp"):
+                    ok = ok and bool(torch.equal(got[key].cpu(), want[key].cpu()))
+                ok = ok and bool(torch.equal(got["r"].cpu().view(torch.int64), want["r"].cpu().view(torch.int64)))
+                nslots += 1
+            if strong:   # the reassembled global batch, in batch order
+                Ag, bg_ = random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=kstep % NB, stream=0)
+                wantg = pa.reduce_batch(torch.as_tensor(Ag).to(dev), torch.as_tensor(bg_).to(dev))
+                gv = ex.global_views(gcpu, s_)
+                ok = ok and bool(torch.equal(gv["keep"].cpu(), wantg["keep"].cpu())) and bool(torch.equal(gv["nlp"].cpu(), wantg["nlp"].cpu()))
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        verified = {"ranks": world, "ok": bool(t.item() == 1), "slots_checked": nslots}
 
     if rank == 0:
         alg_bytes = B_LOCAL * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
@@ -400,6 +433,8 @@ def main():
                          "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
                              nlp_local / (kern_ms * 1e-3))},
         }
+        if verified is not None:
+            line["exchange_verified"] = verified
         if valu:  # measured PMC counters of the same kernel (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE)
             line["roofline"].update({k: v for k, v in valu.items() if k != "source"})
             line["roofline"]["counters_source"] = valu.get("source")

@@ -284,9 +284,7 @@ def assign_sharded(X, normals, offsets, abs_tol=1e-7, assign_fn=None, device=Non
     if world > 1:
         pack = torch.stack([mxv.contiguous().view(torch.int64), gidx], dim=1).contiguous()   # [F, 2]
         F = pack.shape[0]
-        allp = torch.empty((world * F, 2), dtype=torch.int64, device=pack.device)
-        dist.all_gather_into_tensor(allp, pack)
-        allp = allp.reshape(world, F, 2)
+        allp = allgather_packed(torch, dist, pack, [F] * world).reshape(world, F, 2)
         dd = allp[:, :, 0].contiguous().view(torch.float64)            # [world, F]
         ii = allp[:, :, 1]
         best = dd.max(dim=0).values
