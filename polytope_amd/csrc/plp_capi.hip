@@ -51,7 +51,7 @@ struct plp_ctx {
     double* rd_tab = nullptr;    // the constraint table A | b (device)
     size_t rd_tab_bytes = 0;
     unsigned long long rd_seq = 0;
-    // containment on the matrix cores: packed operand tiles (plp_contains_mfma.hip)
+    // containment: per-row thresholds of the comparison form (plp_points.hip), a grow-only buffer
     void* mf_buf = nullptr;
     size_t mf_bytes = 0;
     hipEvent_t mf_ev = nullptr;  // recorded after every launch that uses mf_buf: the next user (any stream) waits on it
@@ -771,10 +771,10 @@ int plp_contains_dev(plp_ctx* ctx, void* stream, int P, int m_max, int d, const 
     if (!X || !out || ((!A || !b) && P > 0 && m_max > 0)) return fail(PLP_EINVAL, "NULL pointer");
     if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
-    // operand tiles for the matrix-core path: a grow-only buffer of the context, handed from stream to stream in order
+    // per-row thresholds: a grow-only buffer of the context, handed from stream to stream in order
     void* scratch = nullptr;
     if (P > 0 && m_max > 0) {
-        const size_t need = plp::contains_mfma_scratch_bytes(P, m_max, d);
+        const size_t need = plp::contains_scratch_bytes(P, m_max);
         if (!ctx->mf_ev && hipEventCreateWithFlags(&ctx->mf_ev, hipEventDisableTiming) != hipSuccess) {
             ctx->mf_ev = nullptr;
             (void)hipGetLastError();

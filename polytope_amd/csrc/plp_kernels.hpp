@@ -82,13 +82,11 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st);
 
-// `scratch` (contains_mfma_scratch_bytes(P, m_max, d) bytes of device memory, or nullptr): with it the dot products
-// run on the matrix cores (plp_contains_mfma.hip), near-threshold values redone in the reference's operation order
+// `scratch` (contains_scratch_bytes(P, m_max) bytes of device memory, or nullptr): the per-row thresholds of the
+// comparison form (plp_points.hip); without it the subtraction stays in the kernel
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
                     const double* X, double abs_tol, int mode, unsigned char* out, void* scratch, hipStream_t st);
-size_t contains_mfma_scratch_bytes(int P, int m_max, int d);
-int launch_contains_mfma(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
-                         const double* X, double abs_tol, int mode, unsigned char* out, void* scratch, hipStream_t st);
+size_t contains_scratch_bytes(int P, int m_max);
 
 int launch_assign(long long N, int d, const double* X, int F, const double* normals, const double* offsets,
                   double abs_tol, int* facet_of_point, double* dist, long long* argmax, double* maxd,

@@ -149,19 +149,15 @@ static void launch_contains_d(int P, int m_max, const double* A, const double* b
 
 #define PLP_CASE_C(K) case K: launch_contains_d<K>(P, m_max, A, b, mrows, N, X, abs_tol, mode, out, thr, st); break;
 
+size_t contains_scratch_bytes(int P, int m_max) { return ((size_t)P * (size_t)m_max * 8 + 255) & ~(size_t)255; }
+
 int launch_contains(int P, int m_max, int d, const double* A, const double* b, const int* mrows, long long N,
                     const double* X, double abs_tol, int mode, unsigned char* out, void* scratch, hipStream_t st) {
     if (d < 1 || d > MAX_D || m_max < 0 || P < 0 || N < 0) return 2;
     if (N == 0) return 0;
-    // PLP_CONTAINS_MFMA=1: dot products by v_mfma_f64_16x16x4_f64 (plp_contains_mfma.hip), verdicts bit-identical.
-    // Off by default: measured on MI355X the f64 matrix pipe peaks where the vector FMA pipe does (75.6 vs 58 TFLOP/s in
-    // scripts/microbench/mfma_f64_rate.hip, 78.6 nominal for both) and the contraction must pad k = d + 1 to a multiple
-    // of 4 (C3: 7 -> 8), so the matrix form of C3 cannot finish before 34 ms while this kernel needs 35 ms; the first
-    // matrix-core version takes 78 ms (one accumulator, operand loads not double-buffered).
-    const char* mf = getenv("PLP_CONTAINS_MFMA");
-    if (scratch && mf && mf[0] == '1' &&
-        launch_contains_mfma(P, m_max, d, A, b, mrows, N, X, abs_tol, mode, out, scratch, st) == 0)
-        return 0;
+    // (No matrix-core form: the exact v_mfma_f64_16x16x4_f64 path of round 2 took 78 ms against 35 ms here and was
+    // removed in round 3 -- scripts/microbench/mfma_valu_coissue.hip shows that the f64 matrix and vector pipes of gfx950
+    // do not add up: wavefronts of both kinds on every SIMD reach 41-56 TFLOP/s, the vector kind alone 60.6)
     // thresholds live in the context's scratch buffer (P * m_max doubles; PLP_CONTAINS_THR=0: the subtraction stays in
     // the kernel, for A/B runs)
     const char* th = getenv("PLP_CONTAINS_THR");

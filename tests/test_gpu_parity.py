@@ -1254,49 +1254,3 @@ def test_wide_engine_one_lp_per_wavefront(pa, oracle, monkeypatch):
     assert np.array_equal(dflt["r"], forced["r"], equal_nan=True) and np.array_equal(dflt["status"], forced["status"])
 
 
-def test_contains_matrix_core_path_bit_identical(pa, monkeypatch):
-    """PLP_CONTAINS_MFMA=1: the dot products of contains run on v_mfma_f64_16x16x4_f64 and every value within the
-    error bound of the tolerance is redone in the reference's operation order, so the booleans must be those of the
-    vector kernel bit for bit -- on random batches (ragged rows, several d, both modes), on lattice points that sit
-    exactly on facets, and on the reference's own fixture g4 (4 tolerances, boundary points)."""
-    from polytope_amd import synth
-    rng = np.random.default_rng(8)
-
-    def both(A, b, X, tol, m=None, region=True):
-        monkeypatch.setenv("PLP_CONTAINS_MFMA", "0")
-        v = pa.contains_batch(A, b, X, tol, m=m, region=region)
-        monkeypatch.setenv("PLP_CONTAINS_MFMA", "1")
-        w = pa.contains_batch(A, b, X, tol, m=m, region=region)
-        monkeypatch.delenv("PLP_CONTAINS_MFMA")
-        return np.asarray(v), np.asarray(w)
-
-    total = 0
-    for (P, m, d, N) in [(8, 16, 6, 4096), (5, 16, 3, 1000), (7, 40, 7, 3000), (3, 10, 2, 257), (4, 64, 16, 2000),
-                         (6, 20, 11, 1500), (64, 16, 6, 200000)]:
-        A, b, X = synth.containment_workload(P, N, d=d, m=max(m, 2 * d), seed=3)
-        A, b = np.ascontiguousarray(A[:, :m]), np.ascontiguousarray(b[:, :m])
-        ms = rng.integers(max(1, m - 5), m + 1, P).astype(np.int32)
-        for region in (True, False):
-            v, w = both(A, b, X, 1e-7, m=ms, region=region)
-            assert np.array_equal(v, w), (P, m, d, N, region)
-            total += P * N
-    # points exactly on facets of boxes (a.x - b == 0, tol 0 excludes them: polytope.py:217 is a strict "<")
-    P, d = 16, 3
-    A = np.tile(np.vstack([np.eye(d), -np.eye(d)]), (P, 1, 1))
-    b = np.full((P, 2 * d), 0.5)
-    X = rng.integers(-2, 3, (d, 5000)).astype(float) * 0.5     # coordinates -1, -0.5, 0, 0.5, 1: many on the faces
-    counts = []
-    for tol in (0.0, 1e-7, 0.01):
-        v, w = both(A, b, X, tol, region=False)
-        assert np.array_equal(v, w) and v.any() and not v.all()
-        counts.append(int(v.sum()))
-    assert counts[0] < counts[1] == counts[2]                   # tol = 0 excludes the boundary
-    g = load_golden("g4_contains.npz")
-    for t, tol in enumerate(g["tols"]):
-        monkeypatch.setenv("PLP_CONTAINS_MFMA", "1")
-        got = pa.contains_batch(g["A"], g["b"], g["X"], float(tol), region=False)
-        reg = pa.contains_batch(g["A"], g["b"], g["X"], float(tol), region=True)
-        monkeypatch.delenv("PLP_CONTAINS_MFMA")
-        assert np.array_equal(np.asarray(got).astype(bool), g["res"][t].astype(bool))
-        assert np.array_equal(np.asarray(reg).astype(bool), g["reg"][t].astype(bool))
-    assert total > 1e7
