@@ -84,6 +84,10 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
 #define PLP_R_ASYNC 1  // F2: every lane group walks its own LP list inside one pivot loop (0: lock-step, for A/B runs)
 #endif
 
+#ifndef PLP_R_POOL
+#define PLP_R_POOL 1  // F2: the LPs the presolve left form one list per tile, any lane group takes the next (0: every group its own rows)
+#endif
+
 #ifndef PLP_R_FAST
 #define PLP_R_FAST 1  // F2/F3 on SimplexR::run_fast (0: the general step(), for A/B runs)
 #endif
@@ -763,6 +767,137 @@ __device__ __forceinline__ void reduce_r_tile(
             bool busy = false;
             int kr = 0, e = -1, chi = 0;
             double cxc = 0.0, best = 0.0;
+#if PLP_R_POOL
+            if constexpr (rows <= 32 && PLP_R_PRESOLVE) {
+                // ---- pooled: the LPs the presolve left are few (2.1 per polytope at C2) and unevenly spread -- with every
+                // group on its own list the wavefront waits for the group with most left (15.9 iterations for a mean of
+                // 6.6 pivots).  Here the LPs of all polytopes of the tile form ONE list (polytope order, then row order)
+                // and any lane group takes the next one: the rows are in LDS anyway, and the LPs of a polytope are
+                // independent once the in-place h[k] +- 0.1 round trip (:1149-1151) is written as a rule (an unsettled
+                // row that had its turn before row k carries (b + 0.1) - 0.1, row k itself b + 0.1; settled rows carry the
+                // round trip in LDS already, see f2_presolve) -- the rule reduce_split_kernel uses.  Verdicts travel back
+                // as a bit per list position, OR-ed over the groups at the end.
+                const unsigned todo32 = (unsigned)todo, live32 = (unsigned)live;
+                const unsigned cert32 = live32 & ~todo32 & ((stage == 2) ? ~0u : 0u);
+                const int n_g = __popc(todo32);
+                int off_g = 0, total = 0, nmax = 0;
+                for (int p = 0; p < NGRP; ++p) {
+                    const int np = __builtin_amdgcn_readlane(n_g, p * GS);
+                    off_g = (grp == p) ? total : off_g;
+                    total += np;
+                    nmax = np > nmax ? np : nmax;
+                }
+                const int lane = g.lane;
+                uint64_t verdict = 0ull;   // of my polytope's rows (owner group), filled round by round
+                bool pool_retry = false;
+                for (int rb = 0; rb < total; rb += 64) {
+                    const int rend = total < rb + 64 ? total : rb + 64;
+                    // position t = rb + lane of the list -> (polytope, row)
+                    int ent = -1;
+                    {
+                        const int t = rb + lane;
+                        int tp = 0, toff = 0, run = 0;
+                        unsigned ttd = 0u;
+                        for (int p = 0; p < NGRP; ++p) {
+                            const int np = __builtin_amdgcn_readlane(n_g, p * GS);
+                            const unsigned tdp = (unsigned)__builtin_amdgcn_readlane((int)todo32, p * GS);
+                            const bool at = t >= run;
+                            tp = at ? p : tp;
+                            ttd = at ? tdp : ttd;
+                            toff = at ? run : toff;
+                            run += np;
+                        }
+                        const int rank = t - toff;
+                        for (int i = 0; i < nmax; ++i) ttd = (i < rank) ? (ttd & (ttd - 1u)) : ttd;
+                        ent = (t < total) ? ((tp << 8) | (__ffs((int)ttd) - 1)) : -1;
+                    }
+                    int next = rb;             // wave-uniform
+                    uint64_t res = 0ull;       // bit (t - rb): the LP at position t says "keep" (every lane of the group that solved it)
+                    int cur_t = 0;
+                    const double* pA = myA;    // rows of the polytope whose LP my group is solving
+                    const double* pb = myb;
+                    const double* pan = myan;
+                    for (;;) {
+                        const bool fin = busy & (S.mode == M_DONE);
+                        const bool want = fin | !busy;
+                        const uint64_t wb = __ballot(want & (g.gl == 0));
+                        const int tsk = next + __popcll(wb & ((1ull << g.gbase) - 1ull));
+                        const bool start = want & (tsk < rend);
+                        {
+                            const int adv = next + __popcll(wb);
+                            next = adv < rend ? adv : rend;
+                        }
+                        if (__any(fin | start)) {   // (wave-uniform: every lane is active for the cross-lane reads below)
+                            const int entv = __builtin_amdgcn_ds_bpermute((tsk & 63) << 2, ent);
+                            const int tp = start ? (entv >> 8) : grp;
+                            const unsigned lv = (unsigned)__builtin_amdgcn_ds_bpermute((tp * GS) << 2, (int)live32);
+                            const unsigned ct = (unsigned)__builtin_amdgcn_ds_bpermute((tp * GS) << 2, (int)cert32);
+                            if (fin) {
+                                pool_retry = pool_retry | (S.status == ST_RETRY);
+                                const double fun = cxc - S.negz;               // c.xc + zeta, zeta = -negz
+                                const double hk = (pb[kr] + 0.1) - 0.1;        // h[k] after its round trip (:1149-1151)
+                                const double obj = -fun - hk;                  // (:1156)
+                                const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
+                                res |= keepk ? (1ull << (cur_t - rb)) : 0ull;
+                                busy = false;
+                            }
+                            if (start) {
+                                cur_t = tsk;
+                                kr = entv & 255;
+                                pA = sA + (size_t)tp * rows * D;
+                                pb = sb + (size_t)tp * rows;
+                                pan = san + (size_t)tp * rows;
+                                S.reset(D, __popc(lv), row0);
+#pragma unroll
+                                for (int kk = 0; kk < D; ++kk) S.cost[kk] = -pA[kr * D + kk];  // f = -A[k,:]  (:1145)
+                                cxc = -pan[kr];   // c.xc = -(a_k.xc): the mirror image of the FMA chain that made s_k
+                                const unsigned unsettled = (lv & ~ct) >> row0;
+#pragma unroll
+                                for (int k = 0; k < R; ++k) {
+#pragma unroll
+                                    for (int kk = 0; kk < D; ++kk) S.T[k][kk] = pA[(row0 + k) * D + kk];
+                                    const int rw = row0 + k;
+                                    const double h0 = pb[rw];
+                                    const double hp = h0 + 0.1;
+                                    const bool un = ((unsettled >> k) & 1u) != 0u;
+                                    const double hh = (un & (rw < kr)) ? hp - 0.1 : ((rw == kr) ? hp : h0);
+                                    S.beta[k] = fmax(hh - pan[rw], 0.0);  // 0 for the zeroed rows
+                                }
+                                S.ract = (lv >> row0) & RMASK;
+                                S.mode = M_P2;
+                                S.status = -1;
+                                S.scan_enter(e, best, chi);
+                                if (e < 0) { S.status = ST_OPT; S.mode = M_DONE; }
+                                busy = true;
+                            }
+                        }
+                        if (!__any(busy)) break;
+                        if ((S.mode != M_DONE) & (S.ndeg >= BLAND_AFTER)) { S.status = ST_RETRY; S.mode = M_DONE; }
+                        S.template pivot_core<GS, 0>(g, e, best, chi, nullptr, 0u);
+                    }
+                    // verdicts of this round to every lane, then each owner picks those of its rows
+                    {
+                        unsigned rlo = (unsigned)res, rhi = (unsigned)(res >> 32);
+#pragma unroll
+                        for (int o = GS; o < 64; o <<= 1) {
+                            rlo |= (unsigned)__shfl_xor((int)rlo, o, 64);
+                            rhi |= (unsigned)__shfl_xor((int)rhi, o, 64);
+                        }
+                        const uint64_t all = ((uint64_t)rhi << 32) | rlo;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const int rw = row0 + k;
+                            const int t = off_g + __popc(todo32 & ((1u << rw) - 1u)) - rb;
+                            const bool mine = (((todo32 >> rw) & 1u) != 0u) & (t >= 0) & (t < 64);
+                            const bool kept = mine & (((all >> (t & 63)) & 1ull) != 0ull);
+                            verdict |= spread_rows<R, GS>(grp_ballot(kept, g)) << k;
+                        }
+                    }
+                }
+                keep |= verdict;
+                retry = retry | (__any(pool_retry) != 0);   // (rare: the whole tile is redone by the general kernel)
+            } else
+#endif
             for (;;) {
                 const bool fin = busy & (S.mode == M_DONE);
                 const bool start = (fin | !busy) & (todo != 0ull);

@@ -1058,6 +1058,7 @@ def test_adjacent_pairs_range_and_sharded_single(pa):
     """Slices of the pair space (what one rank computes when the O(n^2) loop is split across GPUs)
     agree with the full matrix; the sharded wrappers with world size 1 agree with the plain calls."""
     import itertools
+    import os
     from polytope_amd import batch, dist as pdist
     from polytope_amd.quickhull import quickhull
     from polytope_amd import solvers
@@ -1083,7 +1084,19 @@ def test_adjacent_pairs_range_and_sharded_single(pa):
         A2, b2, V2 = pdist.quickhull_sharded(P)
     finally:
         solvers.default_solver = old
-    assert np.array_equal(A1, A2) and np.array_equal(b1, b2) and np.array_equal(V1, V2)
+    # (the library's main loop solves the hyperplane systems of inputs of 4096+ points with its own LU, the host facet
+    # graph of the sharded path with numpy.linalg.solve: same rows in the same order, to rounding)
+    assert A1.shape == A2.shape and np.allclose(A1, A2, rtol=0, atol=1e-12) and np.allclose(b1, b2, rtol=0, atol=1e-12)
+    assert np.array_equal(V1, V2)
+    os.environ["PLP_QH_LAPACK_BELOW"] = "1000000000"   # dgesv for every size: bit-identical to the host facet graph
+    try:
+        solvers.default_solver = "hip"
+        np.random.seed(4)
+        A3, b3, V3 = quickhull(P)
+    finally:
+        solvers.default_solver = old
+        del os.environ["PLP_QH_LAPACK_BELOW"]
+    assert np.array_equal(A3, A2) and np.array_equal(b3, b2) and np.array_equal(V3, V2)
 
 
 def test_contains_full_config(pa, oracle):
