@@ -1267,3 +1267,32 @@ def test_wide_engine_one_lp_per_wavefront(pa, oracle, monkeypatch):
     assert np.array_equal(dflt["r"], forced["r"], equal_nan=True) and np.array_equal(dflt["status"], forced["status"])
 
 
+
+
+def test_bench_kernel_full_size_repeatable_and_exact(pa, oracle):
+    """BASELINE config 2 at full size (100 000 polytopes, m = 16, d = 3): eight launches in flight on two streams (every
+    SIMD holding its four wavefronts, tails overlapping heads) return the bits of the first one, and a 3000-polytope
+    sample of it equals the oracle in keep / flags / nlp.  (An instrumented build of round 3 that spilled 76 B per lane
+    returned garbage for ~9 % of the tiles whenever more than one wavefront shared a SIMD; the shipped kernel is pinned
+    here against that failure mode.)"""
+    import torch
+    from polytope_amd.synth import random_hpolytopes
+    A, b = random_hpolytopes(100000, 16, 3, seed=2, stream=1)
+    At, bt = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
+    ref = pa.reduce_batch(At, bt)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for rep in range(8):
+        with torch.cuda.stream(streams[rep & 1]):
+            outs.append(pa.reduce_batch(At, bt))
+    torch.cuda.synchronize()
+    for r in outs:
+        for k in ("keep", "flags", "nlp"):
+            assert torch.equal(r[k], ref[k]), k
+        assert torch.equal(r["r"].view(torch.int64), ref["r"].view(torch.int64))
+    keep = pa.keep_to_bool(ref["keep"].cpu().numpy(), 16)
+    nlp, fl = ref["nlp"].cpu().numpy(), ref["flags"].cpu().numpy()
+    for k in list(range(0, 1500)) + list(range(98500, 100000)):   # full tiles at the front, half-size tiles at the end
+        o = oracle.reduce(A[k], b[k])
+        assert np.array_equal(keep[k], o["keep"]) and int(nlp[k]) == o["nlp"] and int(fl[k]) == o["flags"], k
