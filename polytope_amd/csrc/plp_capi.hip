@@ -348,7 +348,7 @@ bool is_gfx950(int dev) {
 
 extern "C" {
 
-int plp_version(void) { return 210; }  // 200: round 2 (LPs beyond 64 rows, plp_region_diff_search, plp_quickhull_run); 210: plp_ctx_set_check_finite, plp_bbox_batch for d <= 16
+int plp_version(void) { return 300; }  // 200: round 2 (LPs beyond 64 rows, plp_region_diff_search, plp_quickhull_run); 210: plp_ctx_set_check_finite, plp_bbox_batch for d <= 16; 300: round 3 (plp_reduce_wide_batch, F2 presolve)
 
 int plp_device_count(void) {
     int n = 0;

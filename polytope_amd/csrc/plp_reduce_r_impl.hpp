@@ -440,6 +440,12 @@ __device__ __forceinline__ void reduce_r_tile(
             ball = ok & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
             fulldim = ball & (rr > abs_tol);
         }
+        // the Chebyshev ball is final: r and xc go out now (eight registers less to carry through the LP stages)
+        if (valid & (g.gl == 0) & (!SPLIT || grp == 0)) {
+            r_out[tile + gib] = ball ? rr : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xc_out[(tile + gib) * D + k] = ball ? xc[k] : qnan;
+        }
         __syncthreads();  // 1/||a|| of every row is in LDS
         // ---------------------------------------------------------------- dedupe (:1094-1110)
         // (rows are re-read from LDS: the register file limits the occupancy of this kernel, LDS is idle)
@@ -522,6 +528,15 @@ __device__ __forceinline__ void reduce_r_tile(
             for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
             bool lpfail = false;
             double lbk = 0.0;
+            // (batch form, R > 1) the box of coordinate kx waits in lane kx % GS of the group, slot kx / GS, and the
+            // prefilter sums are formed after the last LP: 2R running sums per lane carried through the LP loops were
+            // what the register allocator spilled around this stage (11 dwords per lane, 19 MB of scratch traffic per
+            // C2 launch); same operations in the same order, so the sums are bitwise what they were
+            constexpr int NSLOT = (D + GS - 1) / GS;
+            double blo[NSLOT], bhi[NSLOT];
+#pragma unroll
+            for (int q = 0; q < NSLOT; ++q) { blo[q] = 0.0; bhi[q] = 0.0; }
+            constexpr bool BOX_IN_LANES = !SPLIT && !LAZY && R > 1;
             if constexpr (SPLIT) {
                 for (int round = 0; round * NGRP < 2 * D; ++round) {  // group g: LP g, g + NGRP, ...
                     const int itq = round * NGRP + grp;
@@ -623,6 +638,14 @@ __device__ __forceinline__ void reduce_r_tile(
                 else { val = qnan; lpfail = lpfail | go; }
                 if (!up) {
                     lbk = val;
+                } else if constexpr (BOX_IN_LANES) {
+                    const bool mine = g.gl == (kx % GS);
+#pragma unroll
+                    for (int q = 0; q < NSLOT; ++q) {
+                        const bool here = mine & (q == kx / GS);
+                        blo[q] = here ? lbk : blo[q];
+                        bhi[q] = here ? val : bhi[q];
+                    }
                 } else {  // prefilter sums, accumulated in k order (:1131-1134)
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
@@ -630,6 +653,20 @@ __device__ __forceinline__ void reduce_r_tile(
                         const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
                         s1[k] = s1[k] + pa * (val - lbk);
                         s2[k] = s2[k] + aik * lbk;
+                    }
+                }
+            }
+            if constexpr (BOX_IN_LANES) {
+#pragma unroll
+                for (int kx = 0; kx < D; ++kx) {  // prefilter sums, accumulated in k order (:1131-1134)
+                    const double lo = bcast(blo[kx / GS], g.gbase + kx % GS);
+                    const double hi = bcast(bhi[kx / GS], g.gbase + kx % GS);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const double aik = myA[(row0 + k) * D + kx];
+                        const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                        s1[k] = s1[k] + pa * (hi - lo);
+                        s2[k] = s2[k] + aik * lo;
                     }
                 }
             }
@@ -777,18 +814,18 @@ __device__ __forceinline__ void reduce_r_tile(
                 // row that had its turn before row k carries (b + 0.1) - 0.1, row k itself b + 0.1; settled rows carry the
                 // round trip in LDS already, see f2_presolve) -- the rule reduce_split_kernel uses.  Verdicts travel back
                 // as a bit per list position, OR-ed over the groups at the end.
-                const unsigned todo32 = (unsigned)todo, live32 = (unsigned)live;
-                const unsigned cert32 = live32 & ~todo32 & ((stage == 2) ? ~0u : 0u);
+                // (registers are what this kernel runs out of: the masks are kept as 32-bit words, whatever can be
+                // recomputed from them at the end of a round is, and nlp / flags go out before the loop)
+                const unsigned todo32 = (unsigned)todo;                       // unsettled live rows of MY polytope
+                const unsigned live32 = (stage == 2) ? (unsigned)live : 0u;   // (the settled ones: live32 & ~todo32)
                 const int n_g = __popc(todo32);
-                int off_g = 0, total = 0, nmax = 0;
+                int total = 0, nmax = 0;
                 for (int p = 0; p < NGRP; ++p) {
                     const int np = __builtin_amdgcn_readlane(n_g, p * GS);
-                    off_g = (grp == p) ? total : off_g;
                     total += np;
                     nmax = np > nmax ? np : nmax;
                 }
                 const int lane = g.lane;
-                uint64_t verdict = 0ull;   // of my polytope's rows (owner group), filled round by round
                 bool pool_retry = false;
                 for (int rb = 0; rb < total; rb += 64) {
                     const int rend = total < rb + 64 ? total : rb + 64;
@@ -814,9 +851,7 @@ __device__ __forceinline__ void reduce_r_tile(
                     int next = rb;             // wave-uniform
                     uint64_t res = 0ull;       // bit (t - rb): the LP at position t says "keep" (every lane of the group that solved it)
                     int cur_t = 0;
-                    const double* pA = myA;    // rows of the polytope whose LP my group is solving
-                    const double* pb = myb;
-                    const double* pan = myan;
+                    int cur_p = gib;           // the polytope whose LP my group is solving
                     for (;;) {
                         const bool fin = busy & (S.mode == M_DONE);
                         const bool want = fin | !busy;
@@ -831,11 +866,11 @@ __device__ __forceinline__ void reduce_r_tile(
                             const int entv = __builtin_amdgcn_ds_bpermute((tsk & 63) << 2, ent);
                             const int tp = start ? (entv >> 8) : grp;
                             const unsigned lv = (unsigned)__builtin_amdgcn_ds_bpermute((tp * GS) << 2, (int)live32);
-                            const unsigned ct = (unsigned)__builtin_amdgcn_ds_bpermute((tp * GS) << 2, (int)cert32);
+                            const unsigned ct = lv & ~(unsigned)__builtin_amdgcn_ds_bpermute((tp * GS) << 2, (int)todo32);
                             if (fin) {
                                 pool_retry = pool_retry | (S.status == ST_RETRY);
                                 const double fun = cxc - S.negz;               // c.xc + zeta, zeta = -negz
-                                const double hk = (pb[kr] + 0.1) - 0.1;        // h[k] after its round trip (:1149-1151)
+                                const double hk = (sb[cur_p * rows + kr] + 0.1) - 0.1;   // h[k] after its round trip (:1149-1151)
                                 const double obj = -fun - hk;                  // (:1156)
                                 const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
                                 res |= keepk ? (1ull << (cur_t - rb)) : 0ull;
@@ -844,9 +879,10 @@ __device__ __forceinline__ void reduce_r_tile(
                             if (start) {
                                 cur_t = tsk;
                                 kr = entv & 255;
-                                pA = sA + (size_t)tp * rows * D;
-                                pb = sb + (size_t)tp * rows;
-                                pan = san + (size_t)tp * rows;
+                                cur_p = tp;
+                                const double* pA = sA + tp * rows * D;
+                                const double* pb = sb + tp * rows;
+                                const double* pan = san + tp * rows;
                                 S.reset(D, __popc(lv), row0);
 #pragma unroll
                                 for (int kk = 0; kk < D; ++kk) S.cost[kk] = -pA[kr * D + kk];  // f = -A[k,:]  (:1145)
@@ -884,17 +920,21 @@ __device__ __forceinline__ void reduce_r_tile(
                             rhi |= (unsigned)__shfl_xor((int)rhi, o, 64);
                         }
                         const uint64_t all = ((uint64_t)rhi << 32) | rlo;
+                        int off_g = 0;   // position of my polytope's first LP in the list
+                        for (int p = 0, run = 0; p < NGRP; ++p) {
+                            off_g = (grp == p) ? run : off_g;
+                            run += __builtin_amdgcn_readlane(n_g, p * GS);
+                        }
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
                             const int rw = row0 + k;
                             const int t = off_g + __popc(todo32 & ((1u << rw) - 1u)) - rb;
                             const bool mine = (((todo32 >> rw) & 1u) != 0u) & (t >= 0) & (t < 64);
                             const bool kept = mine & (((all >> (t & 63)) & 1ull) != 0ull);
-                            verdict |= spread_rows<R, GS>(grp_ballot(kept, g)) << k;
+                            keep |= spread_rows<R, GS>(grp_ballot(kept, g)) << k;
                         }
                     }
                 }
-                keep |= verdict;
                 retry = retry | (__any(pool_retry) != 0);   // (rare: the whole tile is redone by the general kernel)
             } else
 #endif
@@ -928,13 +968,9 @@ __device__ __forceinline__ void reduce_r_tile(
                         kr = __ffsll((long long)todo) - 1;
                         todo &= todo - 1ull;
                         S.reset(D, __popcll(live), row0);
-                        cxc = 0.0;
 #pragma unroll
-                        for (int kk = 0; kk < D; ++kk) {
-                            const double ck = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
-                            S.cost[kk] = ck;
-                            cxc = fma(ck, xc[kk], cxc);
-                        }
+                        for (int kk = 0; kk < D; ++kk) S.cost[kk] = -myA[kr * D + kk];  // f = -A[k,:]  (:1145)
+                        cxc = -myan[kr];   // c.xc = -(a_k.xc): the mirror image of the FMA chain that made s_k
                         if ((kr >> RSH) == g.gl) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149)
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
@@ -1012,9 +1048,6 @@ __device__ __forceinline__ void reduce_r_tile(
             keep_out[pg] = keep;
             flags_out[pg] = retry ? (int)RF_RETRY : flags;
             nlp_out[pg] = nlp;
-            r_out[pg] = ball ? rr : 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
         }
     }
 }
