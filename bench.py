@@ -450,6 +450,9 @@ def main():
                                    "batches resident in HBM, one per step in rotation (%.0f MB > 256 MiB Infinity Cache)"
                                    % (B_PER_GPU, DIM, M_ROWS, NB, NB * B_PER_GPU * 8 * M_ROWS * (DIM + 1) / 1e6),
                        "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_LOCAL, "streams": args.streams,
+                       "lp_accounting": "LPs the reference issues on these polytopes (kernel output nlp, checked against the "
+                                        "oracle's count); the redundancy LPs whose verdict the two-witness presolve settles "
+                                        "(81 % of them at this workload, DESIGN.md 4.2) are counted like the ones the simplex solves",
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
