@@ -74,6 +74,7 @@ print("region_diff: %d inputs (%d compared piece by piece, %d IndexError on both
 rng = np.random.default_rng(77)
 nb = 0
 near = 0
+own_diff = 0
 worst_viol = 0.0
 for trial in range(TR):
     d = int(rng.integers(2, 6))
@@ -85,18 +86,39 @@ for trial in range(TR):
         P = np.round(P * 4) / 4                     # lattice: many coplanar points
     res = {}
     err = {}
-    for native in (True, False):
-        Q._NATIVE_LOOP = native
+    # three runs: the native loop with LAPACK's solves for every size (the Python graph's arithmetic: rows must agree
+    # bitwise), the Python graph, and the native loop as shipped ("own": its own LU from 4096 points on, which may differ
+    # from LAPACK's in the last bits of a facet)
+    for native in (True, False, "own"):
+        Q._NATIVE_LOOP = bool(native)
+        if native is True:
+            os.environ["PLP_QH_LAPACK_BELOW"] = str(1 << 60)
+        else:
+            os.environ.pop("PLP_QH_LAPACK_BELOW", None)
         np.random.seed(trial)
         try:
             res[native] = Q.quickhull(P)
-        except Exception as e:  # degenerate input: both must fail alike
+        except Exception as e:  # degenerate input: all must fail alike
             err[native] = type(e).__name__
     if err:
-        if err.get(True) != err.get(False):
+        if not (err.get(True) == err.get(False) == err.get("own")):
             nb += 1
             print("quickhull error mismatch", trial, err, flush=True)
         continue
+    A3, b3, V3 = res["own"]
+    if not (A3.shape == res[False][0].shape and np.array_equal(A3, res[False][0]) and np.array_equal(b3, res[False][1])):
+        # last-bit differences may flip a tie: then the two hulls must still be the same body
+        own_diff += 1
+        A2_, b2_, V2_ = res[False]
+        if A3.size and A2_.size:
+            same = (set(map(tuple, np.unique(V3, axis=0))) == set(map(tuple, np.unique(V2_, axis=0)))
+                    or (float(np.max(A3 @ V2_.T - b3[:, None])) < 1e-6 and float(np.max(A2_ @ V3.T - b2_[:, None])) < 1e-6))
+        else:
+            same = A3.size == A2_.size
+        if not same:
+            nb += 1
+            print("quickhull OWN-LU MISMATCH", trial, d, N, flush=True)
+            continue
     (A1, b1, V1), (A2, b2, V2) = res[True], res[False]
     if A1.size == 0 or A2.size == 0:
         ok = A1.size == A2.size
@@ -123,7 +145,7 @@ for trial in range(TR):
         print("quickhull MISMATCH", trial, d, N, flush=True)
 Q._NATIVE_LOOP = True
 bad += nb
-print("quickhull: %d inputs, mismatches %d (vertex sets that differ from qhull's by points within 5e-7 of either hull: %d; largest point-facet violation %.1e), %.0f s" % (TR, nb, near, worst_viol, time.time() - t0), flush=True)
+print("quickhull: %d inputs, mismatches %d (vertex sets that differ from qhull's by points within 5e-7 of either hull: %d; largest point-facet violation %.1e; hulls where the shipped LU differs from LAPACK in some bit: %d, all the same body), %.0f s" % (TR, nb, near, worst_viol, own_diff, time.time() - t0), flush=True)
 
 # ---------------------------------------------------------------- LP engines
 from degenerate_cases import degenerate_lps  # noqa: E402
