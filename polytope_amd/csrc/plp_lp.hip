@@ -14,11 +14,20 @@
 
 namespace plp {
 
+// Chebyshev batches on the one-LP-per-wavefront engine (plp_wide.hip): d >= PLP_WIDE_MIN_D and either more than
+// PLP_WIDE_MIN_M rows (the lane groups then hold one or two LPs per wavefront anyway and pay select chains for the
+// entering column) or at most PLP_WIDE_SMALL_B LPs (every LP gets a wavefront slot at once: what counts is the latency
+// of one LP, and a wave-uniform pivot is the shortest).  Measured with scripts/debug/wide_grid.py (round 3, after the
+// pivot loop lost its register copies): (33..64 rows, d = 5..10) 15-40 % faster than the lane groups at B = 20 000,
+// every shape with d >= 5 at B = 2 000; (<= 32 rows, B = 20 000) the lane groups stay 10-45 % ahead.
 #ifndef PLP_WIDE_MIN_D
-#define PLP_WIDE_MIN_D 9    // Chebyshev batches with d >= this and more than PLP_WIDE_MIN_M rows: one LP per wavefront
+#define PLP_WIDE_MIN_D 5
 #endif
 #ifndef PLP_WIDE_MIN_M
 #define PLP_WIDE_MIN_M 32
+#endif
+#ifndef PLP_WIDE_SMALL_B
+#define PLP_WIDE_SMALL_B 4096
 #endif
 
 template <int N>
@@ -280,7 +289,7 @@ int launch_cheby(long long B, int m_max, int d, const double* A, const double* b
     // large shapes: one LP per wavefront with a wave-uniform pivot column (plp_wide.hip); PLP_CHEBY_WIDE=0 keeps the
     // lane-group kernels, PLP_CHEBY_WIDE=1 sends every shape it supports (d >= 5) there: A/B, tests
     const char* wide = getenv("PLP_CHEBY_WIDE");
-    const bool wide_on = wide ? wide[0] == '1' : (d >= PLP_WIDE_MIN_D && m_max > PLP_WIDE_MIN_M);
+    const bool wide_on = wide ? wide[0] == '1' : (d >= PLP_WIDE_MIN_D && (m_max > PLP_WIDE_MIN_M || B <= PLP_WIDE_SMALL_B));
     if (wide_on && !(wide && wide[0] == '0') && launch_cheby_w(B, m_max, d, A, b, mrows, r, xc, status, st) == 0) return 0;
     // d <= 8: four rows per lane (PLP_CHEBY_1ROW=1 keeps the one-row-per-lane kernel: A/B, tests)
     const char* one = getenv("PLP_CHEBY_1ROW");

@@ -96,7 +96,7 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
     const int maxit = 50 * (m + nfree) + 100;
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     int status = -1;
-    for (;;) {
+    auto pivot = [&]() __attribute__((always_inline)) -> bool {
         const bool bland = ndeg >= BLAND_AFTER;
         int e;
         double ce;       // reduced cost of the entering column as stored
@@ -109,8 +109,8 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             const double c = lane < NC ? sh.cost[lane] : 0.0;
             const bool elig = (lane < NC) & (fabs(c) > TOL_D) & ((((cfree >> (lane & 31)) & 1u) != 0u) | (c < 0.0));
             const uint64_t eb = __ballot(elig);
-            if (eb == 0) { status = ST_OPT; break; }
-            if (iters >= maxit) { status = ST_ITER; break; }
+            if (eb == 0) { status = ST_OPT; return false; }
+            if (iters >= maxit) { status = ST_ITER; return false; }
             if (!bland) {  // largest |c|: its bit pattern orders like an unsigned integer
                 const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
                 const unsigned mh = wave_max_u32(kh);
@@ -152,7 +152,7 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
         unsigned ml;
         if (hib & (hib - 1ull)) ml = wave_min_u32((kh == mh) ? kl : 0xffffffffu);
         else ml = (unsigned)__builtin_amdgcn_readlane((int)kl, __ffsll((long long)hib) - 1);
-        if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; break; }
+        if (mh >= 0xfff00000u) { status = ((mh == 0xfff00000u) & (ml == 0u)) ? ST_UNBND : ST_NUM; return false; }
         const bool tie = erow & (kh == mh) & (kl == ml);
         const int mhs = (int)(mh ^ 0x80000000u);   // (the minimum is >= 0 in a normal pivot; the forced one ignores ndeg)
         const double qmin = __hiloint2double(mhs >= 0 ? mhs : (int)~mh, mhs >= 0 ? (int)ml : (int)~ml);
@@ -173,8 +173,9 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
         const bool is_r = lane == r;
         if (is_r) {   // (LDS stores and scalars only inside the branch: the row vector itself is updated branch-free below)
 #pragma unroll
-            for (int j = 0; j < NC; ++j) sh.rho[j] = ROW_GET(j) * pinv;
-            sh.rho[NC] = beta * pinv;
+            for (int j = 0; j < NC; ++j) { const double v = ROW_GET(j) * pinv; ROW_SET(j, v); sh.rho[j] = v; }
+            beta = beta * pinv;
+            sh.rho[NC] = beta;
             sh.cv[e] = ((rowvar + 1) << 1) | rowneg;
             rowvar = (vin >> 1) - 1;
             rowneg = (vin & 1) ^ (flip ? 1 : 0);
@@ -186,12 +187,11 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             // (scaling the pivot row in place inside the branch above -- inline asm, so that it stays a branch -- costs
             // a copy of the row vector: 136 VGPRs instead of 102, three waves per SIMD; not kept)
             const double f = is_r ? 0.0 : a;
-            const double sc = is_r ? pinv : 1.0;
             const double rb = sh.rho[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j) * sc));
+            for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j)));
             row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
-            beta = fma(-f, rb, beta * sc);
+            beta = fma(-f, rb, beta);
         }
         // ---- reduced costs (lane j = column j); the entering column is sign-normalised first
         if (lane < NC) {
@@ -206,7 +206,9 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             forced = false;
         }
         __syncthreads();
-    }
+        return true;
+    };
+    while (pivot() && pivot()) {}
     iters_out = iters;
     return status;
 }
