@@ -262,7 +262,10 @@ static void launch_assign_d(long long N, const double* X, int F, const double* n
     // more when the per-point facet scan dominates (VALU bound from F ~ 32 on)
     long long cap = 256ll * 4 * (F <= 16 ? 1 : (F <= 128 ? F / 16 : 8));
     // (requesting the next pass's point before this pass's facet scan was measured: 29.8 us against 27.8 us per launch
-    // at C5 / F = 9 under rocprofv3 -- no gain, not kept; 512 .. 8192 workgroups instead of this cap: equal or slower)
+    // at C5 / F = 9 under rocprofv3 -- no gain, not kept; 512 .. 8192 workgroups instead of this cap: equal or slower;
+    // round 3: the pass's 256 points fetched as one contiguous block, 16 bytes per lane, and transposed through LDS
+    // instead of every lane reading its own row: 39.2 us against 36.1 us per call -- the strided row reads are not
+    // what holds this kernel back, not kept)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     unsigned long long* mb = reinterpret_cast<unsigned long long*>(maxd);
