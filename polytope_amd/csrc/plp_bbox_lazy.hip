@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
     const int m = mrows ? mrows[p] : m_max;
     const bool has = lane < m;
     // ---- F1 (set-up as cheby_w_kernel); my row also goes to LDS for the lazy LPs
-    wide::v16d Tv = (wide::v16d)(0.0);
+    typename wide::RowVec<NC>::type Tv = (typename wide::RowVec<NC>::type)(0.0);
     double T16 = 0.0;
     double nrm2 = 0.0;
     bool finite = true;

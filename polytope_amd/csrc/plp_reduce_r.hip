@@ -1,12 +1,13 @@
 // plp_reduce_r.hip -- dispatch of the fused reduce() on R rows per lane (kernel: plp_reduce_r_impl.hpp).
 //   d <= 8 : four rows per lane, groups of 4 / 8 / 16 lanes (this file); d = 5..8 beyond the latency form's batch sizes:
-//            two rows per lane (plp_reduce_r2c.hip)
+//            two rows per lane (plp_reduce_r2c.hip); d = 5..8 with more than 32 rows: one polytope per wavefront
+//            (reduce_wdense_kernel, plp_reduce_r_impl.hpp)
 //   d >= 9 : two rows per lane, groups of 16 / 32 lanes (plp_reduce_r2a.hip d = 9..12, plp_reduce_r2b.hip d = 13..16;
 //            separate translation units only to keep the build parallel)
 #include "plp_reduce_r_impl.hpp"
 
 #ifndef PLP_REDUCE_LAZY_MID
-#define PLP_REDUCE_LAZY_MID 0  // d = 5..8 with more than 32 rows on reduce_lazy_kernel by default (measured below)
+#define PLP_REDUCE_LAZY_MID 1  // d = 5..8 with more than 32 rows: one polytope per wavefront (reduce_wdense_kernel) by default
 #endif
 
 namespace plp {
@@ -31,7 +32,9 @@ static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, co
             return launch_reduce_r_dg<D, 2, 8>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     }
     if constexpr (D >= 5) {
-        // more than 32 rows: one polytope per wavefront without a stored dictionary (plp_lazy.hpp), as for d >= 9;
+        // more than 32 rows: one polytope per wavefront as for d >= 9 -- with the F3 / F2 LPs on the dense one-LP-per-wavefront
+        // engine (reduce_wdense_kernel; round 3: (64,8) B = 5 000 0.657 -> 0.453 ms, (48,6) B = 20 000 1.08 -> 0.80 ms, ahead
+        // of the two-rows-per-lane kernel AND of the latency form at every batch size, scripts/debug/wdense_ab.py);
         // PLP_REDUCE_LAZY=0 / 1: never / always (A/B)
         const char* lz = getenv("PLP_REDUCE_LAZY");
         if ((lz && lz[0] == '1') || (PLP_REDUCE_LAZY_MID && m_max > 32 && !(lz && lz[0] == '0')))

@@ -245,7 +245,7 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
 // results meet in LDS.  Same engine, same arithmetic per LP: outputs bitwise equal to the batch form; a polytope takes
 // ~12 pivot times instead of ~60 (latency), at ~3x the instruction slots (throughput): for batches that cannot fill
 // the chip anyway.
-template <int D, int GS, int R, bool LAZY = false, bool SPLIT = false>
+template <int D, int GS, int R, bool LAZY = false, bool SPLIT = false, bool WDENSE = false>
 __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -321,7 +321,7 @@ __device__ __forceinline__ void reduce_r_tile(
             const int lane = g.lane;
             const bool h = valid & (lane < m) & (m <= rows);
             has = h ? 1u : 0u;
-            wide::v16d Tv = (wide::v16d)(0.0);
+            typename wide::RowVec<NC>::type Tv = (typename wide::RowVec<NC>::type)(0.0);
             double T16 = 0.0;
             double nrm2 = 0.0;
             bool finite = true;
@@ -597,9 +597,15 @@ __device__ __forceinline__ void reduce_r_tile(
                 if constexpr (LAZY) {
                     S.status = ST_NUM;
                     S.negz = 0.0;
-                    if (__builtin_amdgcn_readfirstlane((int)go))  // (wave-uniform: one polytope per wavefront)
-                        S.status = lazy::solve<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
-                                                  fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, S.negz);
+                    if (__builtin_amdgcn_readfirstlane((int)go)) {  // (wave-uniform: one polytope per wavefront)
+                        if constexpr (WDENSE)
+                            S.status = wide::solve_dense<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                                            fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, S.negz,
+                                                            *reinterpret_cast<wide::WideShared<D>*>(lzrho));
+                        else
+                            S.status = lazy::solve<D>(g.lane, __popcll(live), myA, (g.lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                                      fmax(myb[row0] - myan[row0], 0.0), (lloc & 1u) != 0u, S.negz);
+                    }
                     retry = retry | (go & (S.status == ST_RETRY));
                 }
                 SimplexR<D, R, false, false> S_;
@@ -763,8 +769,13 @@ __device__ __forceinline__ void reduce_r_tile(
                     const bool owner = kr == row0;
                     if (owner) myb[kr] = myb[kr] + 0.1;  // h[k] += 0.1 in place (:1149), undone below (:1151)
                     double negz2 = 0.0;
-                    const int st2 = lazy::solve<D>(g.lane, __popcll(live), myA, ck, fmax(myb[row0] - myan[row0], 0.0),
-                                                   (lloc & 1u) != 0u, negz2);
+                    int st2;
+                    if constexpr (WDENSE)
+                        st2 = wide::solve_dense<D>(g.lane, __popcll(live), myA, ck, fmax(myb[row0] - myan[row0], 0.0),
+                                                   (lloc & 1u) != 0u, negz2, *reinterpret_cast<wide::WideShared<D>*>(lzrho));
+                    else
+                        st2 = lazy::solve<D>(g.lane, __popcll(live), myA, ck, fmax(myb[row0] - myan[row0], 0.0),
+                                             (lloc & 1u) != 0u, negz2);
                     retry = retry | (st2 == ST_RETRY);
                     const double fun = cxc - negz2;  // c.xc + zeta, zeta = -negz
                     double hk_own = 0.0;
@@ -1056,6 +1067,15 @@ __device__ __forceinline__ void reduce_r_tile(
 #ifndef PLP_REDUCE_LAZY_WAVES
 #define PLP_REDUCE_LAZY_WAVES 3
 #endif
+#ifndef PLP_REDUCE_WDENSE_MAXD
+// one polytope per wavefront: F3 / F2 on the dense one-LP-per-wavefront engine up to this d, without a stored dictionary
+// beyond (measured, scripts/debug/wdense_ab.py, 64 rows, B = 20 000, ms dense / lazy: d = 8 1.39 / 2.30, 12 1.66 / 1.90,
+// 13 1.58 / 1.65, 14 1.48 / 1.48, 15 1.48 / 1.38, 16 1.60 / 1.33)
+#define PLP_REDUCE_WDENSE_MAXD 13
+#endif
+#ifndef PLP_REDUCE_WDENSE_WAVES
+#define PLP_REDUCE_WDENSE_WAVES 4
+#endif
 template <int D>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
@@ -1066,14 +1086,32 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_ker
                                   r_out, xc_out, nlp_out);
 }
 
+// The same with the F3 / F2 LPs on the one-LP-per-wavefront DENSE engine (plp_wide.hpp: wide::solve_dense): the
+// dictionary is carried, the pivot column and row are wave-uniform.
+template <int D>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out) {
+    reduce_r_tile<D, 64, 1, true, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                                               flags_out, r_out, xc_out, nlp_out);
+}
+
 template <int D>
 static int launch_reduce_lazy(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
                               unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
     const size_t smem = reduce_r_smem_bytes(64, D, 1) + lazy::lds_bytes<D>();
     if (B > 2147483647ll) return 2;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
-                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+    // PLP_REDUCE_WDENSE=0 / 1: F3 / F2 without / with a stored dictionary (A/B)
+    const char* wd = getenv("PLP_REDUCE_WDENSE");
+    if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD))
+        hipLaunchKernelGGL((reduce_wdense_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+    else
+        hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
     return 0;
 }
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void cheby_w_kernel(long long B, int m_max, con
     if (p >= B) return;
     const int m = mrows ? mrows[p] : m_max;
     const bool has = lane < m;
-    v16d Tv = (v16d)(0.0);
+    typename RowVec<NC>::type Tv = (typename RowVec<NC>::type)(0.0);
     double T16 = 0.0;
     double nrm2 = 0.0;
     bool finite = true;

@@ -57,22 +57,34 @@ __device__ __forceinline__ double rcpn(double a) {
 // T[e] for a wave-uniform e is ONE indexed register move (s_set_gpr_idx / v_movrel: the compiler lowers a dynamic
 // element access with a uniform index that way) instead of a select chain or a branch tree.
 typedef double v16d __attribute__((ext_vector_type(16)));
+typedef double v8d __attribute__((ext_vector_type(8)));
+// (eight doubles are enough up to 8 columns: 16 VGPRs less)
+template <int NC> struct RowVec { typedef v16d type; };
+template <> struct RowVec<1> { typedef v8d type; };
+template <> struct RowVec<2> { typedef v8d type; };
+template <> struct RowVec<3> { typedef v8d type; };
+template <> struct RowVec<4> { typedef v8d type; };
+template <> struct RowVec<5> { typedef v8d type; };
+template <> struct RowVec<6> { typedef v8d type; };
+template <> struct RowVec<7> { typedef v8d type; };
+template <> struct RowVec<8> { typedef v8d type; };
 // (plain local variables, not a struct: the struct form was kept in scratch memory by the compiler)
-#define ROW_GET(j) ((j) < 16 ? Tv[(j) & 15] : T16)
-#define ROW_SET(j, val) do { if ((j) < 16) Tv[(j) & 15] = (val); else T16 = (val); } while (0)
-template <int NC>
-__device__ __forceinline__ double row_at(const v16d& Tv, const double& T16, int e) {  // wave-uniform e
-    if constexpr (NC <= 16) return Tv[e & 15];
-    else return e < 16 ? Tv[e & 15] : T16;
+#define ROW_W ((int)(sizeof(Tv) / sizeof(double)))
+#define ROW_GET(j) ((j) < ROW_W ? Tv[(j) & (ROW_W - 1)] : T16)
+#define ROW_SET(j, val) do { if ((j) < ROW_W) Tv[(j) & (ROW_W - 1)] = (val); else T16 = (val); } while (0)
+template <int NC, class TV>
+__device__ __forceinline__ double row_at(const TV& Tv, const double& T16, int e) {  // wave-uniform e
+    if constexpr (NC <= ROW_W) return Tv[e & (ROW_W - 1)];
+    else return e < ROW_W ? Tv[e & (ROW_W - 1)] : T16;
 }
-template <int NC>
-__device__ __forceinline__ void row_put(v16d& Tv, double& T16, int e, double val) {   // wave-uniform e
-    if constexpr (NC <= 16) {
-        Tv[e & 15] = val;
+template <int NC, class TV>
+__device__ __forceinline__ void row_put(TV& Tv, double& T16, int e, double val) {   // wave-uniform e
+    if constexpr (NC <= ROW_W) {
+        Tv[e & (ROW_W - 1)] = val;
     } else {  // (written as two selects on single elements: a branch here is if-converted into a select of the whole vector)
-        const double old = Tv[e & 15];
-        Tv[e & 15] = e < 16 ? val : old;
-        T16 = e < 16 ? T16 : val;
+        const double old = Tv[e & (ROW_W - 1)];
+        Tv[e & (ROW_W - 1)] = e < ROW_W ? val : old;
+        T16 = e < ROW_W ? T16 : val;
     }
 }
 
@@ -88,9 +100,9 @@ struct WideShared {
 // leaving row is the active one with the smallest signed ratio q0 (F1).  Returns the status; the optimal dictionary
 // stays in T/beta/rowvar/rowneg.
 template <int NC>
-__device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, double& T16, double& beta, int& rowvar,
+__device__ __forceinline__ int wide_run(const int lane, const int m, typename RowVec<NC>::type& Tv, double& T16, double& beta, int& rowvar,
                                         int& rowneg, bool& rowact, WideShared<NC>& sh, const int nfree, bool forced,
-                                        const double q0, int& iters_out) {
+                                        const double q0, int& iters_out, double* negz = nullptr) {
     unsigned cfree = nfree >= 32 ? 0xffffffffu : ((1u << nfree) - 1u);
     int ndeg = 0, iters = 0;
     const int maxit = 50 * (m + nfree) + 100;
@@ -194,6 +206,7 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
             beta = fma(-f, rb, beta);
         }
         // ---- reduced costs (lane j = column j); the entering column is sign-normalised first
+        if (negz) *negz = fma(-(flip ? -ce : ce), sh.rho[NC], *negz);  // objective row: -zeta, as SimplexR carries it
         if (lane < NC) {
             const double fc = flip ? -ce : ce;
             const double cj = sh.cost[lane];
@@ -213,6 +226,29 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, v16d& Tv, d
     return status;
 }
 
+// One LP  min c.y  s.t.  A y <= beta  (y free, beta >= 0: the origin is feasible) of a polytope whose rows sit in LDS, one
+// per lane (dead rows zeroed there): the dense twin of lazy::solve() -- same arguments, same numbers (the dictionary
+// arithmetic is SimplexR's: bitwise the status and -zeta of reduce_r_kernel<D, 64, 1>), Bland's rule inside instead of a
+// retry.  cj: lane j < D holds c_j.  `sh`: this wavefront's LDS block.
+template <int D>
+__device__ __forceinline__ int solve_dense(const int lane, const int nrows, const double* __restrict__ rowsA, const double cj,
+                                           const double beta0, const bool act, double& negz, WideShared<D>& sh) {
+    typename RowVec<D>::type Tv = (typename RowVec<D>::type)(0.0);
+    double T16 = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < D; ++kk) ROW_SET(kk, rowsA[lane * D + kk]);
+    double beta = beta0;
+    int rowvar = D + lane, rowneg = 0, iters = 0;
+    bool rowact = act;
+    __syncthreads();  // (the last LP's reads of the block are done)
+    if (lane <= D) {
+        sh.cost[lane] = lane < D ? cj : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    __syncthreads();
+    negz = 0.0;
+    return wide_run<D>(lane, nrows, Tv, T16, beta, rowvar, rowneg, rowact, sh, D, false, 0.0, iters, &negz);
+}
 
 }  // namespace wide
 }  // namespace plp

@@ -776,25 +776,41 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
     the polytope's rows and the pivots so far with the operations, in the order, the dense engine applies to its stored
     dictionary: every output must be bit-identical to the one-row-per-lane instance of that engine, and to the
     two-rows-per-lane kernel in everything but the last bit of a Chebyshev centre -- ragged, duplicated, infeasible rows; pyramids (degenerate vertices: Bland hand-over); shapes whose LPs run past
-    the four pivots kept in registers into the private-array steps; a sample against the oracle."""
+    the four pivots kept in registers into the private-array steps; a sample against the oracle.  reduce_wdense_kernel (the
+    same kernel with the F3 / F2 LPs on the dense one-LP-per-wavefront engine, wide::solve_dense -- the default for more
+    than 32 rows up to d = 13) must agree with it in every bit as well, d = 5..16, Bland's rule inside the LP included."""
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(5)
 
-    def three(A, b, m=None):
+    def four(A, b, m=None):
         out = []
-        for env in ({"PLP_REDUCE_LAZY": "0"}, {"PLP_REDUCE_LAZY": "0", "PLP_REDUCE_R1": "1"}, {"PLP_REDUCE_LAZY": "1"}):
-            for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1"):
+        for env in ({"PLP_REDUCE_LAZY": "0"}, {"PLP_REDUCE_LAZY": "0", "PLP_REDUCE_R1": "1"},
+                    {"PLP_REDUCE_LAZY": "1", "PLP_REDUCE_WDENSE": "0"}, {"PLP_REDUCE_LAZY": "1", "PLP_REDUCE_WDENSE": "1"}):
+            for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1", "PLP_REDUCE_WDENSE"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             out.append(pa.reduce_batch(A, b, m=m))
-        for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1"):
+        for k in ("PLP_REDUCE_LAZY", "PLP_REDUCE_R1", "PLP_REDUCE_WDENSE"):
             monkeypatch.delenv(k, raising=False)
         return out
 
+    def compare(dense, one_row, lazy, wdense, d, tag):
+        for key in dense:
+            # the two one-polytope-per-wavefront kernels: every output, every bit
+            assert np.array_equal(wdense[key].view(np.uint8), lazy[key].view(np.uint8)), (tag, key)
+            if d > 8:  # (PLP_REDUCE_R1 exists from d = 9 on)
+                assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), (tag, key)
+            if key != "xc":
+                assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), (tag, key)
+        # (two rows per lane compare the two ratios of a lane by cross-multiplication, one row per lane by quotient:
+        # a near-tie can send F1 through another vertex order -- seen once in 130 000 polytopes, centre off by one ulp)
+        assert np.allclose(dense["xc"], lazy["xc"], rtol=0, atol=1e-12, equal_nan=True), tag
+
     steps_seen = 0
     for (B, m, d) in [(600, 64, 16), (600, 64, 12), (600, 48, 9), (500, 33, 9), (400, 36, 14), (300, 64, 13), (300, 40, 10),
-                      (300, 20, 12), (200, 64, 11), (200, 57, 15)]:
+                      (300, 20, 12), (200, 64, 11), (200, 57, 15), (5000, 64, 8), (400, 64, 8), (400, 40, 6), (6000, 33, 5),
+                      (300, 64, 5), (300, 48, 7), (200, 30, 6)]:
         A, b = random_hpolytopes(B, m, d, seed=7 * m + d, stream=0)
         for k in range(0, B, 5):
             j = rng.integers(m)
@@ -804,27 +820,19 @@ def test_reduce_without_stored_dictionary_bitwise(pa, oracle, monkeypatch):
             b[k, 0] = -4.0
         rows = rng.integers(max(d + 2, m - 9), m + 1, B).astype(np.int32)
         for mr in (None, rows):
-            dense, one_row, lazy = three(A, b, mr)
-            for key in dense:
-                assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
-                if key != "xc":
-                    assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), (B, m, d, key)
-            # (two rows per lane compare the two ratios of a lane by cross-multiplication, one row per lane by quotient:
-            # a near-tie can send F1 through another vertex order -- seen once in 130 000 polytopes, centre off by one ulp)
-            assert np.allclose(dense["xc"], lazy["xc"], rtol=0, atol=1e-12, equal_nan=True), (B, m, d)
-        masks = pa.keep_to_bool(lazy["keep"], m)
-        for k in range(0, B, 37):
+            dense, one_row, lazy, wdense = four(A, b, mr)
+            compare(dense, one_row, lazy, wdense, d, (B, m, d))
+        masks = pa.keep_to_bool(wdense["keep"], m)
+        for k in range(0, B, 37 if B < 1000 else 211):
             o = oracle.reduce(A[k, :rows[k]], b[k, :rows[k]])
-            assert int(lazy["flags"][k]) == o["flags"] and np.array_equal(masks[k, :rows[k]], o["keep"]), (m, d, k)
-            assert abs(lazy["r"][k] - o["r"]) <= TOL and int(lazy["nlp"][k]) == o["nlp"]
+            assert int(wdense["flags"][k]) == o["flags"] and np.array_equal(masks[k, :rows[k]], o["keep"]), (m, d, k)
+            assert abs(wdense["r"][k] - o["r"]) <= TOL and int(wdense["nlp"][k]) == o["nlp"]
         steps_seen += int((lazy["nlp"] > 1).sum())
     assert steps_seen > 0
-    A, b = _pyramids(40, 40, 9, rng)
-    dense, one_row, lazy = three(A, b)
-    for key in dense:
-        assert np.array_equal(one_row[key].view(np.uint8), lazy[key].view(np.uint8)), key
-        if key != "xc":
-            assert np.array_equal(dense[key].view(np.uint8), lazy[key].view(np.uint8)), key
+    for (n, m, d) in [(40, 40, 9), (40, 40, 6), (30, 64, 8)]:
+        A, b = _pyramids(n, m, d, rng)
+        dense, one_row, lazy, wdense = four(A, b)
+        compare(dense, one_row, lazy, wdense, d, ("pyramids", m, d))
 
 
 def test_bbox_latency_form_bitwise(pa, monkeypatch):
