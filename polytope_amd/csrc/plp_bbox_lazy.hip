@@ -1,6 +1,9 @@
-// plp_bbox_lazy.hip -- fused bounding boxes for d = 9..16 (polytope/polytope.py:1314-1411): one polytope of up to 64
-// rows per wavefront, the Chebyshev LP on the one-LP-per-wavefront engine (plp_wide.hpp), then the 2d LPs
-// min / max x_k from its centre WITHOUT a stored dictionary (plp_lazy.hpp).  Same contract as bbox_r_kernel
+// plp_bbox_lazy.hip -- fused bounding boxes, one polytope of up to 64 rows per wavefront (polytope/polytope.py:1314-1411):
+// the Chebyshev LP on the one-LP-per-wavefront engine (plp_wide.hpp), then the 2d LPs min / max x_k from its centre
+//   WDENSE (d = 5..13): on the same dense engine (wide::solve_dense: wave-uniform pivots, Bland's rule inside),
+//   otherwise (d = 14..16): WITHOUT a stored dictionary (plp_lazy.hpp).
+// d = 9..16 always come here, d = 5..8 with more than 32 rows (the lane-group kernel bbox_r_kernel holds one or two such
+// polytopes per wavefront and pays select chains for the pivot column).  Same contract as bbox_r_kernel
 // (plp_cheby_r_impl.hpp, d <= 8): status 0 = lb / ub hold the box (+-inf where an LP is unbounded, :1376 / :1398),
 // status 1 = not handled here (empty / flat / unbounded-ball polytopes, LPs that ask for Bland's rule or run past the
 // step limit): the caller solves the generic LPs for those.
@@ -16,7 +19,7 @@ namespace {
 constexpr double BBOX_LAZY_MIN_R = 1e-6;  // (bbox_r_kernel's BBOX_MIN_R)
 }
 
-template <int D>
+template <int D, bool WDENSE>
 __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max, const double* __restrict__ A,
                                                           const double* __restrict__ b, const int* __restrict__ mrows,
                                                           double* __restrict__ lb, double* __restrict__ ub,
@@ -86,7 +89,12 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
         double val = qnan;
         if (__builtin_amdgcn_readfirstlane((int)ok)) {
             double negz = 0.0;
-            const int s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
+            int s2;
+            if constexpr (WDENSE)
+                s2 = wide::solve_dense<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz,
+                                          *reinterpret_cast<wide::WideShared<D>*>(&sh));
+            else
+                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
             // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
             if (s2 == ST_OPT) val = up ? (xck + negz) : (xck - negz);
             else if (s2 == ST_UNBND) val = up ? pinf : -pinf;
@@ -97,22 +105,32 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
     if (lane == 0) status[p] = handed ? 1 : 0;
 }
 
+#ifndef PLP_BBOX_WDENSE_MAXD
+#define PLP_BBOX_WDENSE_MAXD 13  // (as PLP_REDUCE_WDENSE_MAXD: beyond, the LPs are too short to pay for a dictionary reload)
+#endif
+
 template <int D>
 static int launch_bbox_lazy_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
                               double* ub, int* status, hipStream_t st) {
     if (B > 2147483647ll) return 1;
-    hipLaunchKernelGGL((bbox_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows, lb, ub,
-                       status);
+    const char* wd = getenv("PLP_BBOX_WDENSE");  // 0 / 1: never / always the dense engine for the 2d LPs (A/B)
+    if (wd ? wd[0] == '1' : (D <= PLP_BBOX_WDENSE_MAXD))
+        hipLaunchKernelGGL((bbox_lazy_kernel<D, true>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows,
+                           lb, ub, status);
+    else
+        hipLaunchKernelGGL((bbox_lazy_kernel<D, false>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows,
+                           lb, ub, status);
     return 0;
 }
 
 #define PLP_CASE_BL(K) case K: return launch_bbox_lazy_d<K>(B, m_max, A, b, mrows, lb, ub, status, st);
 
-// d = 9..16, m_max <= 64; returns 1 when it does not apply
+// d = 5..16, m_max <= 64; returns 1 when it does not apply
 int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
                      double* ub, int* status, hipStream_t st) {
     if (m_max < 1 || m_max > 64 || B < 1) return 1;
     switch (d) {
+        PLP_CASE_BL(5) PLP_CASE_BL(6) PLP_CASE_BL(7) PLP_CASE_BL(8)
         PLP_CASE_BL(9) PLP_CASE_BL(10) PLP_CASE_BL(11) PLP_CASE_BL(12)
         PLP_CASE_BL(13) PLP_CASE_BL(14) PLP_CASE_BL(15) PLP_CASE_BL(16)
         default: return 1;

@@ -37,6 +37,15 @@ static int launch_bbox_r_d(long long B, int m_max, const double* A, const double
 int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
                 double* ub, int* status, hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || B < 1) return 1;
+    // d = 5..8 with more than 32 rows, beyond the latency form's batch sizes: one polytope per wavefront, wave-uniform
+    // pivots (plp_bbox_lazy.hip).  Measured (scripts/debug/bbox_wide_ab.py, ms): (64,8) B = 5 000 0.523 -> 0.262, B = 20 000
+    // 1.31 -> 0.82, (48,6) 0.52 -> 0.45, (33,5) 0.32 -> 0.30; the latency form keeps B <= 1024 ((64,8) B = 1000: 0.103
+    // against 0.157: its 2d LPs run side by side), the lane groups 32 rows and fewer ((32,6) 0.313 against 0.339).
+    // PLP_BBOX_WIDE=0 / 1: never / every shape with d >= 5 (A/B)
+    const char* bw = getenv("PLP_BBOX_WIDE");
+    if (d >= 5 && d <= 8 && (bw ? bw[0] == '1' : (m_max > 32 && B > 1024)) &&
+        launch_bbox_lazy(B, m_max, d, A, b, mrows, lb, ub, status, st) == 0)
+        return 0;
     switch (d) {
         PLP_CASE_BB(1) PLP_CASE_BB(2) PLP_CASE_BB(3) PLP_CASE_BB(4)
         PLP_CASE_BB(5) PLP_CASE_BB(6) PLP_CASE_BB(7) PLP_CASE_BB(8)

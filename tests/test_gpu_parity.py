@@ -263,16 +263,16 @@ def test_lp_edge_inputs(pa):
 
 
 # ------------------------------------------------------------------------------ bounding box
-@pytest.mark.parametrize("variant", [None, "PLP_CHEBY_RETRY_ALL"])
+@pytest.mark.parametrize("variant", [None, "PLP_CHEBY_RETRY_ALL", "PLP_BBOX_WIDE"])
 def test_bbox_vs_oracle(pa, oracle, variant, monkeypatch):
     """Fused bounding-box kernel (Chebyshev LP, then 2d LPs from its centre) against the oracle's 2d generic LPs
     (bounding_box, polytope.py:1367-1409): boxes within 1e-9, +-inf in the same places; polytopes the kernel hands
     back (status 1) are exactly those without a usable centre."""
     from polytope_amd.synth import random_hpolytopes
-    if variant:
+    if variant:  # (PLP_BBOX_WIDE=1: d >= 5 on the one-polytope-per-wavefront kernel whatever the batch size)
         monkeypatch.setenv(variant, "1")
     rng = np.random.default_rng(41)
-    for (m, d, B) in [(16, 3, 300), (10, 2, 200), (32, 6, 60), (64, 8, 24), (6, 4, 80), (12, 1, 50), (20, 5, 60)]:
+    for (m, d, B) in [(16, 3, 300), (10, 2, 200), (32, 6, 60), (64, 8, 24), (6, 4, 80), (12, 1, 50), (20, 5, 60), (48, 7, 40)]:
         A, b = random_hpolytopes(B, m, d, seed=5 * m + d, bounded=(m >= 2 * d))
         cen = rng.standard_normal((B, d))                     # move them off the origin (generic LPs: phase 1)
         b = b + np.einsum("bij,bj->bi", A, cen)
@@ -856,13 +856,18 @@ def test_bbox_latency_form_bitwise(pa, monkeypatch):
                     assert np.array_equal(ref[key].view(np.uint8), got[key].view(np.uint8)), (m, d, B, key)
 
 
-def test_bbox_large_dimensions(pa, oracle):
-    """Fused bounding boxes for d = 9..16 (bbox_lazy_kernel: Chebyshev LP on the one-LP-per-wavefront engine, the 2d LPs
-    from its centre without a stored dictionary): boxes of bounded polytopes against the oracle's generic LPs (1e-9),
-    +-inf on the unbounded sides of half-open polytopes, status 1 (handed back, NaN) for empty ones; ragged rows."""
+@pytest.mark.parametrize("dense", ["0", "1", None])
+def test_bbox_large_dimensions(pa, oracle, dense, monkeypatch):
+    """Fused bounding boxes, one polytope per wavefront (bbox_lazy_kernel: Chebyshev LP on the one-LP-per-wavefront engine,
+    the 2d LPs from its centre on the same dense engine -- PLP_BBOX_WDENSE=1, the default up to d = 13 -- or without a
+    stored dictionary -- =0, the default beyond): d = 9..16, and d = 5..8 with more than 32 rows at batch sizes beyond the
+    latency form's; boxes of bounded polytopes against the oracle's generic LPs (1e-9), +-inf on the unbounded sides of
+    half-open polytopes, status 1 (handed back, NaN) for empty ones; ragged rows."""
     from polytope_amd.synth import random_hpolytopes
+    if dense is not None:
+        monkeypatch.setenv("PLP_BBOX_WDENSE", dense)
     rng = np.random.default_rng(31)
-    for (B, m, d) in [(40, 64, 16), (40, 40, 9), (30, 33, 12), (30, 20, 10), (20, 57, 13)]:
+    for (B, m, d) in [(40, 64, 16), (40, 40, 9), (30, 33, 12), (30, 20, 10), (20, 57, 13), (1100, 64, 8), (1100, 40, 6), (1100, 33, 5)]:
         A, b = random_hpolytopes(B, m, d, seed=m + d, stream=0)
         A[:, :2 * d] = np.vstack([np.eye(d), -np.eye(d)])[None] if m >= 2 * d else A[:, :2 * d]
         if m >= 2 * d:
@@ -873,7 +878,7 @@ def test_bbox_large_dimensions(pa, oracle):
         rows = rng.integers(max(2 * d if m >= 2 * d else d + 2, m - 5), m + 1, B).astype(np.int32)
         res = pa.bbox_batch(A, b, m=rows)
         nok = 0
-        for k in range(B):
+        for k in (range(B) if B < 100 else range(0, B, 17)):
             lo, hi, bad = oracle.bounding_box(A[k, :rows[k]], b[k, :rows[k]])
             if res["status"][k] == 0:
                 nok += 1
@@ -882,7 +887,7 @@ def test_bbox_large_dimensions(pa, oracle):
                     m, d, k, res["lb"][k], lo, res["ub"][k], hi)
             else:
                 assert np.isnan(res["lb"][k]).all() and np.isnan(res["ub"][k]).all()
-        assert nok >= B // 2, (m, d, nok)
+        assert nok >= (B if B < 100 else len(range(0, B, 17))) // 2, (m, d, nok)
         assert (res["status"][3::9] == 1).all()
 
 
