@@ -47,6 +47,10 @@ int launch_reduce_lds(long long B, int m_max, int d, const double* A, const doub
 int launch_cheby_w(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
                    double* xc, int* status, hipStream_t st);
 
+// generic LPs, one per wavefront, both phases (n = 5..16, m_max <= 64, plp_lp_wide.hip); returns 1 when it does not apply
+int launch_lp_w(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                double* x, double* fun, int* status, int* iters, hipStream_t st);
+
 // generic LPs, four rows per lane, origin-feasible ones only (n <= 8, plp_cheby_r.hip): the others get
 // status ST_RETRY for the general kernel; returns 1 when it does not apply
 int launch_lp_r(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,

@@ -30,6 +30,22 @@ namespace plp {
 #define PLP_WIDE_SMALL_B 4096
 #endif
 
+// Generic LP batches on the one-LP-per-wavefront engine (plp_lp_wide.hip): every batch with n = 5..16.  Measured against
+// the lane-group kernels (scripts/debug/lp_wide_ab.py, 20 000 LPs, ms; x / status / iterations bitwise equal on every
+// input): LPs that need phase 1 (64,16) 1.74 -> 0.34, (64,8) 0.59 -> 0.17, (32,12) 0.48 -> 0.17, (32,6) 0.21 -> 0.09,
+// (16,5) 0.092 -> 0.063; origin-feasible ones (64,16) 0.43 -> 0.25, (32,6) a tie, (16,5) / (24,5) / (32,8) 10-30 % behind
+// (four rows per lane pack several of those per wavefront) -- the mix of a batch is not known to the host, and the
+// reference's LPs are posed in original coordinates, where the origin is rarely feasible.
+// PLP_LP_WIDE=0 / 1: never / always (A/B, tests)
+static bool lp_wide_on(long long B, int m_max, int n) {
+    if (n < 5 || n > MAX_D || m_max > MAX_M || B > 2147483647ll) return false;  // (what launch_lp_w takes)
+    const char* w = getenv("PLP_LP_WIDE");
+    if (w) return w[0] == '1';
+    const char* one = getenv("PLP_LP_1ROW");
+    if (one && one[0] == '1') return false;
+    return true;
+}
+
 template <int N>
 __global__ __launch_bounds__(BLOCK) void lp_kernel(long long B, int m_max, int gs,
                                                    const double* __restrict__ c,
@@ -242,6 +258,10 @@ int launch_lp_phase(long long B, int m_max, int n, const double* c, const double
     }
     const int gs = group_size_for(m_max);
     if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
+    if (lp_wide_on(B, m_max, n)) {  // both phases in one kernel: nothing is handed over
+        if (phase == 2) return 0;
+        if (launch_lp_w(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st) == 0) return 0;
+    }
     const char* one = getenv("PLP_LP_1ROW");
     int retry = 0;
     if (phase == 2) retry = 1;
@@ -265,6 +285,7 @@ int launch_lp(long long B, int m_max, int n, const double* c, const double* G, c
     if (m_max > MAX_M || (lds && lds[0] == '1')) return launch_lp_lds(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st);
     const int gs = group_size_for(m_max);
     if (gs < 0 || n < 1 || n > MAX_D + 1) return 2;
+    if (lp_wide_on(B, m_max, n) && launch_lp_w(B, m_max, n, c, G, h, mrows, x, fun, status, iters, st) == 0) return 0;
     // n <= 8: LPs whose origin is feasible (no phase 1) are solved by the four-rows-per-lane fast path
     // (plp_cheby_r.hip); it marks the others ST_RETRY and the launch below redoes exactly those
     // (PLP_LP_1ROW=1 keeps everything on this file's kernel: A/B, tests).

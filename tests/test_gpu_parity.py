@@ -203,9 +203,10 @@ def test_lp_vs_oracle_and_scipy(pa, oracle):
 
 
 def test_lp_kernel_variants(pa, oracle, monkeypatch):
-    """lpsolve batches take two kernels: origin-feasible LPs the fast path (four rows per lane for n <= 8, two
-    for n = 9..17), the rest (phase 1 needed beyond n = 4, Bland cases) the two-phase kernel in a second launch.  A mixed batch
-    must agree LP by LP with the oracle and with the two-phase kernel alone (PLP_LP_1ROW=1)."""
+    """lpsolve batches: n = 5..16 go to the one-LP-per-wavefront kernel (lp_w_kernel, both phases); the lane-group route
+    (n <= 4, n = 17, PLP_LP_WIDE=0) takes two kernels -- origin-feasible LPs the fast path (four rows per lane for n <= 8,
+    two for n = 9..17), the rest (phase 1 needed beyond n = 4, Bland cases) the two-phase kernel in a second launch.  A mixed
+    batch must agree LP by LP with the oracle and with the two-phase kernel alone (PLP_LP_1ROW=1) on either route."""
     rng = np.random.default_rng(12)
     for (m, n, B) in [(16, 3, 600), (12, 2, 200), (30, 5, 150), (64, 8, 60), (5, 4, 100), (30, 9, 80), (64, 12, 40),
                       (64, 17, 30), (24, 11, 60)]:
@@ -219,14 +220,20 @@ def test_lp_kernel_variants(pa, oracle, monkeypatch):
         G[1::7, 0] = 0.0                                      # zero rows (kept feasible)
         c = rng.standard_normal((B, n))
         mrows = rng.integers(max(1, m - 3), m + 1, B).astype(np.int32)
-        res = pa.lpsolve_batch(c, G, h, m=mrows)
+        res = pa.lpsolve_batch(c, G, h, m=mrows)   # (n = 5..16: one LP per wavefront, both phases in one kernel)
+        monkeypatch.setenv("PLP_LP_WIDE", "0")     # the lane-group kernels for every n
+        res_lg = pa.lpsolve_batch(c, G, h, m=mrows)
+        monkeypatch.delenv("PLP_LP_WIDE")
         monkeypatch.setenv("PLP_LP_1ROW", "1")
         ref = pa.lpsolve_batch(c, G, h, m=mrows)
         monkeypatch.delenv("PLP_LP_1ROW")
-        assert np.array_equal(res["status"], ref["status"]) and set(np.unique(res["status"])) <= {0, 2, 3}
-        assert np.array_equal(res["iters"], ref["iters"])     # the same vertex path
         ok = ref["status"] == 0
-        assert np.allclose(res["fun"][ok], ref["fun"][ok], rtol=0, atol=1e-12)
+        for got in (res, res_lg):
+            assert np.array_equal(got["status"], ref["status"]) and set(np.unique(got["status"])) <= {0, 2, 3}
+            assert np.array_equal(got["iters"], ref["iters"])     # the same vertex path
+            assert np.allclose(got["fun"][ok], ref["fun"][ok], rtol=0, atol=1e-12)
+        if 5 <= n <= 16:  # same dictionary arithmetic: the one-LP-per-wavefront engine returns the general kernel's bits
+            assert np.array_equal(res["x"][ok].view(np.uint64), ref["x"][ok].view(np.uint64)), (m, n)
         for k in range(0, B, 5):
             so, xo, fo, _ = oracle.lp_solve(c[k], G[k, :mrows[k]], h[k, :mrows[k]])
             assert res["status"][k] == so, (m, n, k)
