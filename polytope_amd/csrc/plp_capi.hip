@@ -1462,19 +1462,28 @@ struct RadiusOracle {
             int32_t* rows = sel + n;
             const int32_t base0 = poff[done];
             memcpy(rows, prow.data() + base0, nr * 4);
-            int cnt[4] = {0, 0, 0, 0};
+            int cnt[5] = {0, 0, 0, 0, 0};
             int max_len = 0;
             for (size_t k = 0; k <= n; ++k) off[k] = poff[done + k] - base0;
-            auto cls_of = [&](int len) { return (d > 8 || len > 64) ? 3 : (len > 32 ? 2 : (len > 16 ? 1 : 0)); };
+            // size classes: 0 / 1 / 2 = lists of up to 16 / 32 / 64 rows on the lane-group kernels (d <= 4), 3 = beyond 64 rows
+            // (LDS engine), 4 = d >= 5, up to 64 rows: one LP per wavefront (cheby_gather_w_kernel; PLP_RDIFF_WIDE=0: d = 5..8
+            // on the lane groups, d >= 9 on the LDS engine, as before round 3)
+            const char* rw_env = getenv("PLP_RDIFF_WIDE");
+            const bool rdiff_wide = !(rw_env && rw_env[0] == '0');
+            auto cls_of = [&](int len) {
+                if (len > 64) return 3;
+                if (d >= 5 && rdiff_wide) return 4;
+                return d > 8 ? 3 : (len > 32 ? 2 : (len > 16 ? 1 : 0));
+            };
             for (size_t k = 0; k < n; ++k) {
                 const int len = off[k + 1] - off[k];
                 max_len = len > max_len ? len : max_len;
                 cnt[cls_of(len)]++;
             }
-            size_t start[4], fill[4];
+            size_t start[5], fill[5];
             start[0] = 0;
-            for (int c = 1; c < 4; ++c) start[c] = start[c - 1] + cnt[c - 1];
-            for (int c = 0; c < 4; ++c) fill[c] = start[c];
+            for (int c = 1; c < 5; ++c) start[c] = start[c - 1] + cnt[c - 1];
+            for (int c = 0; c < 5; ++c) fill[c] = start[c];
             for (size_t k = 0; k < n; ++k) sel[fill[cls_of(off[k + 1] - off[k])]++] = (int32_t)k;
             hipStream_t st = ctx->stream;
             const auto tp0 = std::chrono::steady_clock::now();
@@ -1486,6 +1495,8 @@ struct RadiusOracle {
                 return fail(PLP_EUNSUPPORTED, "region_diff: gather kernel does not apply (d=%d)", d);
             if (cnt[3] && plp::launch_cheby_gather_lds(d, max_len, cnt[3], d_off, d_rows, d_sel + start[3], dA, dB, dOut, st))
                 return fail(PLP_EUNSUPPORTED, "region_diff: a stack of %d rows does not fit the LDS engine", max_len);
+            if (cnt[4] && plp::launch_cheby_gather_w(d, cnt[4], d_off, d_rows, d_sel + start[4], dA, dB, dOut, st))
+                return fail(PLP_EUNSUPPORTED, "region_diff: gather kernel does not apply (d=%d)", d);
             double* out = reinterpret_cast<double*>(pin + (2 * cap_lp + 1 + cap_rows) * 4);
             double* out_dev = reinterpret_cast<double*>(pin_dev + (2 * cap_lp + 1 + cap_rows) * 4);
             ++seq;

@@ -35,6 +35,9 @@ int launch_cheby_gather_r(int d, long long n0, long long n1, long long n2, const
                           const double* A, const double* b, double* out, hipStream_t st);
 void launch_rdiff_publish(long long n, const double* src, double* host_out, unsigned long long* host_flag,
                           unsigned long long seq, hipStream_t st);
+// lists of at most 64 rows, d = 5..16: one LP per wavefront (plp_wide.hip); returns 1 when it does not apply
+int launch_cheby_gather_w(int d, long long nlp, const int* off, const int* rows, const int* sel, const double* A,
+                          const double* b, double* out, hipStream_t st);
 int launch_cheby_gather_lds(int d, int m_cap, long long nlp, const int* off, const int* rows, const int* sel,
                             const double* A, const double* b, double* out, hipStream_t st);
 

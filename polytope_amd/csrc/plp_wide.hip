@@ -82,6 +82,81 @@ __global__ __launch_bounds__(64) void cheby_w_kernel(long long B, int m_max, con
     if (lane == 0) status[p] = st;
 }
 
+// The same LP on a ROW SUBSET of one resident table (region_diff's search, plp_rdiff.hip): LP q of the class is list
+// sel[q] of the batch, its rows rows[off[p] .. off[p + 1]) (at most 64).  out[p] as cheby_gather_r_kernel writes it: the
+// radius if the LP is optimal with r >= 0, 0 if optimal with r < 0, NaN for any other status.
+template <int D>
+__global__ __launch_bounds__(64) void cheby_gather_w_kernel(long long nlp, const int* __restrict__ off,
+                                                            const int* __restrict__ rows, const int* __restrict__ sel,
+                                                            const double* __restrict__ A, const double* __restrict__ b,
+                                                            double* __restrict__ out) {
+    constexpr int NC = D + 1;
+    __shared__ WideShared<NC> sh;
+    const int lane = threadIdx.x;
+    const long long q = blockIdx.x;
+    if (q >= nlp) return;
+    const int p = sel[q];
+    const int o = off[p];
+    const int m = off[p + 1] - o;
+    const bool has = lane < m;
+    const long long row = has ? rows[o + lane] : 0;
+    typename RowVec<NC>::type Tv = (typename RowVec<NC>::type)(0.0);
+    double T16 = 0.0;
+    double nrm2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = has ? A[row * D + k] : 0.0;
+        ROW_SET(k, v);
+        nrm2 = nrm2 + v * v;
+        finite = finite & isfinite(v);
+    }
+    const double bi = has ? b[row] : 0.0;
+    finite = finite & isfinite(bi);
+    const double nrm = sqrt(nrm2);
+    const bool zero = !(nrm > 0.0);
+    bool rowact = has & !zero;
+    ROW_SET(D, rowact ? nrm : 0.0);
+    double beta = rowact ? bi : 0.0;
+    int rowvar = NC + lane, rowneg = 0;
+    if (lane <= NC) {
+        sh.cost[lane] = lane == D ? -1.0 : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+    const bool bad = (__ballot(!finite) != 0) | (m > 64);
+    __syncthreads();
+    int st, iters = 0;
+    if (bad) st = ST_NUM;
+    else if (infeasible0) st = ST_INFEAS;
+    else st = wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+    const double mine = rowneg ? -beta : beta;
+    const uint64_t ob = __ballot(rowvar == D);
+    const double r = ob ? uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+    if (lane == 0) out[p] = st != ST_OPT ? __builtin_nan("") : (r >= 0.0 ? r : 0.0);
+}
+
+template <int D>
+static int launch_cheby_gather_w_d(long long nlp, const int* off, const int* rows, const int* sel, const double* A,
+                                   const double* b, double* out, hipStream_t st) {
+    if (nlp > 2147483647ll) return 2;
+    if (nlp < 1) return 0;
+    hipLaunchKernelGGL((cheby_gather_w_kernel<D>), dim3((unsigned)nlp), dim3(64), 0, st, nlp, off, rows, sel, A, b, out);
+    return 0;
+}
+
+#define PLP_CASE_GW(K) case K: return launch_cheby_gather_w_d<K>(nlp, off, rows, sel, A, b, out, st);
+
+// lists of at most 64 rows, d = 5..16; returns 1 when it does not apply
+int launch_cheby_gather_w(int d, long long nlp, const int* off, const int* rows, const int* sel, const double* A,
+                          const double* b, double* out, hipStream_t st) {
+    switch (d) {
+        PLP_CASE_GW(5) PLP_CASE_GW(6) PLP_CASE_GW(7) PLP_CASE_GW(8) PLP_CASE_GW(9) PLP_CASE_GW(10)
+        PLP_CASE_GW(11) PLP_CASE_GW(12) PLP_CASE_GW(13) PLP_CASE_GW(14) PLP_CASE_GW(15) PLP_CASE_GW(16)
+        default: return 1;
+    }
+}
+
 template <int D>
 static int launch_cheby_w_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
                             double* xc, int* status, hipStream_t st) {

@@ -1200,20 +1200,22 @@ def test_bench_force_dist_rccl_path(pa, scaling):
     assert abs(line["config"]["lps_per_step"] - (5 * n[0] + 4 * n[1]) / 9) < 1e-6
 
 
-def test_region_diff_library_search_equals_host_loop(pa):
+def test_region_diff_library_search_equals_host_loop(pa, monkeypatch):
     """region_diff's search runs in the library (plp_region_diff_search: LPs gathered on the device by row index,
     cells an ancestor scan found empty not re-solved, one batch per visited node).  On random overlapping boxes --
     where the reference's INDICES arithmetic takes its odd turns -- it must return exactly the pieces of the host
-    loop over batched calls (which is pinned to the reference by g5 / g11 / g12), or raise IndexError where that does."""
+    loop over batched calls (which is pinned to the reference by g5 / g11 / g12), or raise IndexError where that does.
+    d = 2..4: lane-group gather kernels; d = 5, 6: one LP per wavefront (cheby_gather_w_kernel), and PLP_RDIFF_WIDE=0
+    (lane groups there too) must give the same pieces."""
     import polytope_amd.polytope as pcm
     from polytope_amd import solvers
     old, solvers.default_solver = solvers.default_solver, "hip"
     try:
         rng = np.random.default_rng(77)
         checked = 0
-        for trial in range(24):
-            d = 2 + trial % 3
-            n = int(rng.integers(3, 14))
+        for trial in range(34):
+            d = 2 + trial % 3 if trial < 24 else 5 + trial % 2
+            n = int(rng.integers(3, 14 if d <= 4 else 8))
             cen = rng.random((n, d))
             hw = rng.uniform(0.05, 0.3, (n, d))
             cells = [pcm.box2poly(np.c_[c - w, c + w].tolist()) for c, w in zip(cen, hw)]
@@ -1221,21 +1223,27 @@ def test_region_diff_library_search_equals_host_loop(pa):
             A /= np.linalg.norm(A, axis=1)[:, None]
             P = pcm.Polytope(A, 0.3 * (1 + rng.random(3 * d)) + A @ (0.5 * np.ones(d)))
             out = []
-            for native in (True, False):
-                pcm._RDIFF_NATIVE = native
+            for native in ((True, False) if d <= 4 else (True, False, "lane groups")):
+                pcm._RDIFF_NATIVE = bool(native)
+                if native == "lane groups":
+                    monkeypatch.setenv("PLP_RDIFF_WIDE", "0")
+                else:
+                    monkeypatch.delenv("PLP_RDIFF_WIDE", raising=False)
                 try:
                     D = pcm.region_diff(P.copy(), pcm.Region([c.copy() for c in cells]))
                     ps = list(D.list_poly) if isinstance(D, pcm.Region) else ([] if D.A.size == 0 else [D])
                     out.append([(q.A.copy(), q.b.copy()) for q in ps])
                 except IndexError:
                     out.append("IndexError")
-            assert type(out[0]) is type(out[1]), trial
-            if out[0] != "IndexError":
-                assert len(out[0]) == len(out[1]), (trial, len(out[0]), len(out[1]))
-                for (A0, b0), (A1, b1) in zip(*out):
-                    assert A0.shape == A1.shape and np.allclose(A0, A1, atol=1e-12, rtol=0) and np.allclose(b0, b1, atol=1e-12, rtol=0), trial
-                checked += 1
-        assert checked >= 12
+            monkeypatch.delenv("PLP_RDIFF_WIDE", raising=False)
+            for other in out[1:]:
+                assert type(out[0]) is type(other), trial
+                if out[0] != "IndexError":
+                    assert len(out[0]) == len(other), (trial, d, len(out[0]), len(other))
+                    for (A0, b0), (A1, b1) in zip(out[0], other):
+                        assert A0.shape == A1.shape and np.allclose(A0, A1, atol=1e-12, rtol=0) and np.allclose(b0, b1, atol=1e-12, rtol=0), trial
+            checked += out[0] != "IndexError"
+        assert checked >= 17
     finally:
         pcm._RDIFF_NATIVE = True
         solvers.default_solver = old
