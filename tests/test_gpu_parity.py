@@ -242,6 +242,48 @@ def test_lp_kernel_variants(pa, oracle, monkeypatch):
                 assert np.max(G[k, :mrows[k]] @ res["x"][k] - h[k, :mrows[k]]) <= 1e-7
 
 
+def test_lp_one_per_wavefront_edge_cases(pa, oracle, monkeypatch):
+    """lp_w_kernel (n = 5..16) on the corners of the contract: no rows, zero rows (vacuous and infeasible), zero cost,
+    infeasible and unbounded LPs with and without phase 1, equality-like row pairs (degenerate phase 1: t leaves at 0 or
+    stays basic in a redundant row), ragged row counts -- status / x / iterations as the lane-group kernels and the
+    oracle return them."""
+    rng = np.random.default_rng(8)
+    for n in (5, 8, 11, 16):
+        m = 2 * n + 6
+        B = 12
+        G = np.zeros((B, m, n)); h = np.zeros((B, m)); c = rng.standard_normal((B, n)); rows = np.full(B, m, np.int32)
+        box = np.vstack([np.eye(n), -np.eye(n)])
+        for k in range(B):
+            G[k, :2 * n] = box; h[k, :2 * n] = 1.0 + rng.random(2 * n)
+            G[k, 2 * n:] = rng.standard_normal((6, n)); h[k, 2 * n:] = 3.0 + rng.random(6)
+        rows[0] = 0                                            # no rows: unbounded (status 3) unless c = 0
+        rows[1] = 0; c[1] = 0.0                                # no rows, zero cost: optimal at the origin
+        G[2, 3] = 0.0; h[2, 3] = -1.0                          # 0 <= -1: infeasible
+        G[3, 3] = 0.0; h[3, 3] = 2.0                           # 0 <= 2: vacuous
+        h[4, :n] = -2.0; h[4, n:2 * n] = 1.0                   # x <= -2 and -x <= 1: infeasible, found by phase 1
+        h[5, :n] = -0.5; h[5, n:2 * n] = 1.5                   # -1.5 <= x <= -0.5: origin infeasible, LP feasible
+        G[6, :n] = 0.0; h[6, :n] = 0.0                         # no upper bounds: unbounded for most costs
+        h[7, :n] = -1.0; h[7, n:2 * n] = 1.0                   # x = -1 exactly (pairs of opposite rows): degenerate
+        G[8, 2 * n] = G[8, 0]; h[8, 2 * n] = h[8, 0]           # duplicated row
+        h[9, :2 * n] = 0.0                                      # the box is the single point 0: every pivot degenerate
+        c[10] = 0.0                                             # zero cost on a feasible polytope
+        rows[11] = n + 2                                        # ragged: fewer rows than the box needs -> unbounded
+        got = pa.lpsolve_batch(c, G, h, m=rows)
+        monkeypatch.setenv("PLP_LP_WIDE", "0")
+        ref = pa.lpsolve_batch(c, G, h, m=rows)
+        monkeypatch.delenv("PLP_LP_WIDE")
+        assert np.array_equal(got["status"], ref["status"]), (n, got["status"], ref["status"])
+        assert np.array_equal(got["iters"], ref["iters"]), (n, got["iters"], ref["iters"])
+        ok = ref["status"] == 0
+        assert np.allclose(got["x"][ok], ref["x"][ok], rtol=0, atol=1e-12) and np.isnan(got["x"][~ok]).all()
+        for k in range(B):
+            so, xo, fo, _ = oracle.lp_solve(c[k], G[k, :rows[k]], h[k, :rows[k]])
+            assert got["status"][k] == so, (n, k, got["status"][k], so)
+            if so == 0:
+                assert abs(got["fun"][k] - fo) <= TOL * max(1.0, abs(fo)), (n, k)
+        assert list(got["status"][[0, 1, 2, 4, 5, 10]]) == [3, 0, 2, 2, 0, 0]
+
+
 def test_lp_edge_inputs(pa):
     # known-answer cases of the reference's tests (polytope_test.py:510-548)
     r = pa.lpsolve_batch(np.array([[1.0]]), np.array([[[-1.0]]]), np.array([[1.0]]))
