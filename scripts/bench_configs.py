@@ -118,6 +118,17 @@ def lp():
                           "lp_per_s": B / (ms * 1e-3),
                           "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
                                        "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
+        # generic lpsolve batch in ORIGINAL coordinates (the polytope moved off the origin: phase 1 needed, as for the
+        # reference's own calls), random cost
+        rng = np.random.default_rng(3)
+        h2 = torch.as_tensor(b + np.einsum("bij,bj->bi", A, rng.standard_normal((B, d)) * 3.0)).to(dev)
+        c2 = torch.as_tensor(rng.standard_normal((B, d))).to(dev)
+        res = pa.lpsolve_batch(c2, At, h2)
+        ms = timeit(lambda: pa.lpsolve_batch(c2, At, h2))
+        print(json.dumps({"config": "lpsolve batch (two-phase) B=%d m=%d n=%d" % (B, m, d), "ms": ms,
+                          "lp_per_s": B / (ms * 1e-3), "mean_pivots": float(res["iters"].float().mean()),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK,
+                                       "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
 
 
 def red():
