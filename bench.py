@@ -139,7 +139,7 @@ def end_to_end(torch, pa, A, b, dev, reps=10):
     # chunks on a copy stream, the fused kernel of chunk c starts on the compute stream as soon as chunk c has landed
     # (an event per chunk) and writes into its slice of the result buffer; one D2H copy of the 24 B-per-polytope buffer
     # at the end.  The upload is the critical path; what remains of the kernels is the last chunk's.
-    NCH = 4   # (8 chunks with A and b copied per chunk: 16 copies, 44 GB/s instead of 53, no gain over one copy)
+    NCH = int(os.environ.get("PLP_BENCH_E2E_CHUNKS", "4"))   # (8 chunks with A and b copied per chunk: 16 copies, 44 GB/s instead of 53, no gain over one copy)
     step = ((B + NCH - 1) // NCH + 15) // 16 * 16   # whole tiles of 16 polytopes
     bounds = [(lo, min(B, lo + step)) for lo in range(0, B, step)]
     copy_st = torch.cuda.Stream(device=dev)
