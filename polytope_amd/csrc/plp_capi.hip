@@ -1375,6 +1375,7 @@ struct RadiusOracle {
     std::vector<int32_t> prow, poff;
     std::vector<Key> pkey;
     long long n_lps = 0, n_batches = 0;
+    long long n_lps_long = 0, n_batches_long = 0;  // LPs of more than 64 rows (LDS engine) / batches that hold at least one (stats)
     double t_launch = 0.0, t_wait = 0.0;  // seconds spent enqueueing / waiting for the device (PLP_RDIFF_STATS=1 prints them)
 
     int init(plp_ctx* c, int d_, long long nrows_, const double* A, const double* b) {
@@ -1523,6 +1524,8 @@ struct RadiusOracle {
             for (size_t k = 0; k < n; ++k) memo.put(pkey[done + k], out[k]);
             n_lps += (long long)n;
             n_batches += 1;
+            n_lps_long += cnt[3];
+            n_batches_long += cnt[3] ? 1 : 0;
             done += n;
         }
         pkey.clear();
@@ -1835,8 +1838,9 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     res->n_lps = R.n_lps;
     res->n_batches = R.n_batches;
     if (getenv("PLP_RDIFF_STATS"))
-        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms\n",
-                R.n_lps, R.n_batches, res->n_scan_miss, res->n_node_miss, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3);
+        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms; beyond 64 rows: %lld LPs in %lld batches\n",
+                R.n_lps, R.n_batches, res->n_scan_miss, res->n_node_miss, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3,
+                R.n_lps_long, R.n_batches_long);
     R.release();
     if (rc == PLP_OK && bad_index) rc = fail(PLP_EINVAL, "region_diff: row index out of range (the reference raises IndexError here)");
     if (rc) { delete res; return rc; }
