@@ -1471,9 +1471,11 @@ struct RadiusOracle {
             // on the lane groups, d >= 9 on the LDS engine, as before round 3)
             const char* rw_env = getenv("PLP_RDIFF_WIDE");
             const bool rdiff_wide = !(rw_env && rw_env[0] == '0');
+            const char* rwm_env = getenv("PLP_RDIFF_WIDE_MIND");  // (A/B: smallest d that takes the one-LP-per-wavefront kernel)
+            const int rdiff_wide_mind = rwm_env ? atoi(rwm_env) : 5;
             auto cls_of = [&](int len) {
                 if (len > 64) return 3;
-                if (d >= 5 && rdiff_wide) return 4;
+                if (d >= rdiff_wide_mind && rdiff_wide) return 4;
                 return d > 8 ? 3 : (len > 32 ? 2 : (len > 16 ? 1 : 0));
             };
             for (size_t k = 0; k < n; ++k) {

@@ -151,6 +151,7 @@ static int launch_cheby_gather_w_d(long long nlp, const int* off, const int* row
 int launch_cheby_gather_w(int d, long long nlp, const int* off, const int* rows, const int* sel, const double* A,
                           const double* b, double* out, hipStream_t st) {
     switch (d) {
+        PLP_CASE_GW(2) PLP_CASE_GW(3) PLP_CASE_GW(4)
         PLP_CASE_GW(5) PLP_CASE_GW(6) PLP_CASE_GW(7) PLP_CASE_GW(8) PLP_CASE_GW(9) PLP_CASE_GW(10)
         PLP_CASE_GW(11) PLP_CASE_GW(12) PLP_CASE_GW(13) PLP_CASE_GW(14) PLP_CASE_GW(15) PLP_CASE_GW(16)
         default: return 1;
