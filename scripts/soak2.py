@@ -188,6 +188,11 @@ for kind, c, G, h in degenerate_lps(seed=9, reps=20):
     if got["status"][0] != ref["status"][0] or not np.array_equal(got["fun"], ref["fun"], equal_nan=True):
         ne += 1
         print("degenerate LP MISMATCH", kind, flush=True)
+    dflt = pa.lpsolve_batch(c[None], G[None], h[None])   # (n = 5..16: lp_w_kernel, Bland's rule inside the loop)
+    if dflt["status"][0] != ref["status"][0] or not np.allclose(dflt["fun"], ref["fun"], rtol=0, atol=1e-11, equal_nan=True) \
+            or (5 <= G.shape[1] <= 16 and not np.array_equal(dflt["iters"], ref["iters"])):
+        ne += 1
+        print("degenerate LP MISMATCH (default route)", kind, G.shape, dflt["status"], ref["status"], flush=True)
     if kind.endswith("F1") and G.shape[1] >= 6:
         A = np.ascontiguousarray(G[None, :, :-1]); 
         os.environ["PLP_CHEBY_WIDE"] = "0"; r0 = pa.cheby_ball_batch(A, h[None])
