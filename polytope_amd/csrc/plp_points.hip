@@ -125,7 +125,15 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
 template <int D>
 static void launch_contains_d(int P, int m_max, const double* A, const double* b, const int* mrows, long long N,
                               const double* X, double tol, int mode, unsigned char* out, double* thr, hipStream_t st) {
-    constexpr int PPL = (D <= 8) ? 4 : 2;
+#ifdef PLP_CONTAINS_PPL
+    constexpr int PPL = PLP_CONTAINS_PPL;  // (A/B builds)
+#else
+    // points per lane: every row fetched through the scalar cache feeds PPL FMA chains.  Measured (1M points x 2000
+    // polytopes of 16 rows, ms per call, PPL = 2 / 4 / 6 / 8): d = 2 6.1 / 4.1 / 3.5 / 3.4, d = 3 6.9 / 4.9 / 4.6 / 4.3,
+    // d = 4 6.9 / 5.6 / 5.3 / 5.3, d = 6 9.4 / 7.3 / 7.2 / 7.3, d = 8 11.2 / 9.1 / 8.8 / 9.4 (C3 itself: 35.7 ms with 4,
+    // 33.9 with 6, 34.1 with 8)
+    constexpr int PPL = (D <= 3) ? 8 : ((D <= 8) ? 6 : 2);
+#endif
     long long blocks = (N + (long long)BLOCK * PPL - 1) / ((long long)BLOCK * PPL);
     if (blocks > 256ll * 32) blocks = 256ll * 32;
     if (blocks < 1) blocks = 1;
