@@ -84,6 +84,9 @@ __global__ __launch_bounds__(BLOCK) void contains_kernel(int P, int m_max, const
             unsigned long long ok_m[PPL];
 #pragma unroll
             for (int t = 0; t < PPL; ++t) ok_m[t] = ~0ull;
+            // (requesting row i + 1 before row i's FMA chains -- wait, request, compute: scalar loads return out of order, so
+            // the only wait is "all of them" -- was built in round 3 and measured: 34.7 ms against 33.8 at C3, the copies of
+            // the staged row cost more than the wait the other four or five wavefronts of the SIMD already cover; not kept)
             for (int i = 0; i < m; ++i) {  // rows are wave-uniform: scalar loads, SGPR operands
                 double ar[D];
 #pragma unroll
