@@ -861,7 +861,43 @@ def gen_g14():
     np.savez_compressed(os.path.join(HERE, "g14_wide_reduce.npz"), **out)
 
 
+def gen_g15():
+    """reduce() of the reference on the mid shapes that run one polytope per wavefront in the HIP build (more than 32 rows,
+    d = 5..13; polytope.py:1053-1163): same record layout as g2.  Every eighth polytope is half-open."""
+    rng = np.random.default_rng(1515)
+    recs = []
+    for (m, d, cnt) in [(40, 6, 8), (64, 8, 8), (33, 5, 8), (64, 5, 6), (48, 10, 6), (57, 13, 4), (64, 12, 4), (36, 7, 6)]:
+        for t in range(cnt):
+            A, b = rand_hpoly(rng, m, d, bounded=(t % 8 != 7))
+            if t % 4 == 1:   # a duplicated and a slightly shifted row (the dedupe step, :1094-1110)
+                A[1], b[1] = A[0], b[0]
+                A[3], b[3] = A[2], b[2] + 0.05
+            p = pc.Polytope(A.copy(), b.copy())
+            An, bn = p.A.copy(), p.b.copy()
+            q = pc.reduce(p)
+            kept = [] if q.A.size == 0 else match_rows(An, bn, q.A, q.b)
+            mask = np.zeros(64, bool)
+            mask[kept] = True
+            recs.append(dict(m=m, d=d, A=An, b=bn, mask=mask, empty=(q.A.size == 0), minrep=bool(q.minrep),
+                             r=float(p._chebR), Aout=q.A, bout=q.b))
+    out = dict(
+        m=np.array([r["m"] for r in recs], np.int32),
+        d=np.array([r["d"] for r in recs], np.int32),
+        A=pad([r["A"].ravel() for r in recs], 64 * 16),
+        b=pad([r["b"] for r in recs], 64),
+        mask=np.array([r["mask"] for r in recs]),
+        empty=np.array([r["empty"] for r in recs]),
+        minrep=np.array([r["minrep"] for r in recs]),
+        r=np.array([r["r"] for r in recs]),
+        Aout=pad([r["Aout"].ravel() for r in recs], 64 * 16),
+        bout=pad([r["bout"] for r in recs], 64),
+    )
+    np.savez_compressed(os.path.join(HERE, "g15_reduce_mid.npz"), **out)
+    print("g15:", len(recs), "polytopes; empty", int(out["empty"].sum()), "minrep", int(out["minrep"].sum()),
+          "mean kept", out["mask"].sum(1).mean())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()["gen_" + w]()

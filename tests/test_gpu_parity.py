@@ -447,9 +447,12 @@ def test_cheby_kernel_variants(pa, oracle, variant, monkeypatch):
 
 
 # ------------------------------------------------------------------------------ reduce
-def test_reduce_golden(pa):
+@pytest.mark.parametrize("fixture", ["g2_reduce.npz", "g15_reduce_mid.npz"])
+def test_reduce_golden(pa, fixture):
+    """reduce() of the reference: g2 (224 polytopes, d = 2..16) and g15 (50 polytopes of 33..64 rows, d = 5..13: the shapes
+    that run one polytope per wavefront, reduce_wdense_kernel)."""
     from polytope_amd import _lib
-    g = load_golden("g2_reduce.npz")
+    g = load_golden(fixture)
     for i in range(len(g["m"])):
         m, d = int(g["m"][i]), int(g["d"][i])
         A = g["A"][i, :m * d].reshape(1, m, d)
@@ -785,10 +788,11 @@ def test_reduce_latency_form_bitwise(pa, monkeypatch):
     both(A, b)
     A, b = _pyramids(30, 40, 6, rng)
     both(A, b)
-    g = load_golden("g2_reduce.npz")
-    for i in range(len(g["m"])):
-        m, d = int(g["m"][i]), int(g["d"][i])
-        both(g["A"][i, :m * d].reshape(1, m, d), g["b"][i, :m].reshape(1, m))
+    for fixture in ("g2_reduce.npz", "g15_reduce_mid.npz"):
+        g = load_golden(fixture)
+        for i in range(len(g["m"])):
+            m, d = int(g["m"][i]), int(g["d"][i])
+            both(g["A"][i, :m * d].reshape(1, m, d), g["b"][i, :m].reshape(1, m))
     A, b = random_hpolytopes(9000, 16, 3, seed=78, stream=0)   # medium batches: half-size tiles only
     monkeypatch.setenv("PLP_REDUCE_SPLIT", "0")
     monkeypatch.setenv("PLP_REDUCE_HALF", "0")

@@ -182,7 +182,23 @@ def test_contains_semantics(pc):
         assert np.array_equal(polys[3].contains(g4["X"], abs_tol=float(tol)), g4["res"][ti, 3])
 
 
-# ------------------------------------------------------------------ reduce (g2)
+# ------------------------------------------------------------------ reduce (g2, g15)
+def test_reduce_golden_mid_shapes(pc):
+    """g15: the reference's reduce() on 33..64 rows, d = 5..13 (the shapes the HIP build runs one polytope per wavefront)."""
+    g = load_golden("g15_reduce_mid.npz")
+    for i in range(0, len(g["m"]), 2):
+        m, d = int(g["m"][i]), int(g["d"][i])
+        A, b = unpad(g["A"][i], g["b"][i], m, d)
+        p = pc.Polytope(A, b, normalize=False)
+        q = pc.reduce(p)
+        assert (q.A.size == 0) == bool(g["empty"][i]), i
+        k = q.A.shape[0]
+        Aout, bout = unpad(g["Aout"][i], g["bout"][i], k, d)
+        assert k == int(g["mask"][i].sum()), (i, m, d, k, int(g["mask"][i].sum()))
+        assert np.allclose(q.A, Aout, atol=1e-12, rtol=0) and np.allclose(q.b, bout, atol=1e-12, rtol=0), i
+        assert bool(q.minrep) == bool(g["minrep"][i]) and abs(p.chebR - g["r"][i]) <= TOL, i
+
+
 def test_reduce_golden(pc):
     g = load_golden("g2_reduce.npz")
     for i in range(len(g["m"])):
