@@ -363,9 +363,14 @@ def test_bbox_vs_oracle(pa, oracle, variant, monkeypatch):
         solvers.default_solver = old
 
 
-def test_bbox_golden(pa):
+@pytest.mark.parametrize("wide", [None, "dense", "lazy"])
+def test_bbox_golden(pa, wide, monkeypatch):
     """The reference's own bounding_box outputs (g10: origin outside, unbounded, empty): the fused kernel where it
-    answers, and the Python layer (kernel + generic LPs for what it hands back) for every case."""
+    answers, and the Python layer (kernel + generic LPs for what it hands back) for every case.  `wide`: the d >= 5
+    cases on the one-polytope-per-wavefront kernel (PLP_BBOX_WIDE=1), its 2d LPs with / without a stored dictionary."""
+    if wide:
+        monkeypatch.setenv("PLP_BBOX_WIDE", "1")
+        monkeypatch.setenv("PLP_BBOX_WDENSE", "1" if wide == "dense" else "0")
     import polytope_amd.polytope as pc
     from polytope_amd import solvers
     g = load_golden("g10_bbox.npz")
