@@ -143,13 +143,17 @@ def _g1_groups():
     return g, groups
 
 
-def test_lp_golden(pa):
-    """g1: 1152 LPs solved by the reference (scipy.optimize.linprog / HiGHS).  KNOWN DEVIATION, asserted rather than
+@pytest.mark.parametrize("route", ["default", "lane groups"])
+def test_lp_golden(pa, route, monkeypatch):
+    """(`route`: n = 5..16 on the one-LP-per-wavefront kernel -- the default -- or everything on the lane-group kernels.)
+    g1: 1152 LPs solved by the reference (scipy.optimize.linprog / HiGHS).  KNOWN DEVIATION, asserted rather than
     hidden: on ONE of them (form F3 at (5,3)) the reference returns status 2 ("infeasible") for an LP that is feasible and unbounded --
     HiGHS's presolve cannot tell the two apart and reports "infeasible"; with presolve off it says 3, which is what a
     simplex finds and what this engine returns.  Every other status is the reference's own.  (Callers: cheby_ball
     treats 2 and 3 alike, reduce's F2 can be neither; bounding_box of an UNBOUNDED polytope is where it shows: the
     reference writes l = 0, u = l on 2 and -inf/+inf on 3, polytope.py:1378-1402.)"""
+    if route == "lane groups":
+        monkeypatch.setenv("PLP_LP_WIDE", "0")
     g, groups = _g1_groups()
     worst = 0.0
     deviating = np.nonzero(g["status"] != g["status_nopresolve"])[0]
