@@ -98,8 +98,9 @@ int plp_cheby_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d,
 
 /*
  * Bounding boxes of a batch of polytopes (1 <= d <= 16, m_max <= 64): per polytope the Chebyshev LP and then the 2d LPs
- * min +-e_i.x (form F3) started from its centre -- one launch instead of 2d generic LPs per polytope (d > 8: one
- * polytope per wavefront, the 2d LPs without a stored dictionary).
+ * min +-e_i.x (form F3) started from its centre -- one launch instead of 2d generic LPs per polytope (d > 8, and
+ * d = 5..8 with more than 32 rows in batches beyond 1024 polytopes: one polytope per wavefront, every LP with a
+ * wave-uniform pivot; d >= 14: the 2d LPs without a stored dictionary).
  * Replaces: the LP loops of bounding_box (polytope/polytope.py:1367-1409).
  * Out: lb[B][d], ub[B][d] (-inf / +inf where the LP is unbounded, :1376 / :1398) and status[B]:
  *      0 = lb/ub hold the box,
