@@ -215,7 +215,7 @@ int plp_hull_reassign_dev(plp_ctx *ctx, void *stream, int64_t N, int d, const do
  * Replaces: the O(n^2) loop of find_adjacent_regions (polytope/prop2partition.py:46-63) over
  *           is_adjacent(a, b, overlap=True) (polytope/polytope.py:1843-1866): one Chebyshev LP per
  *           pair on the stacked rows [A_i; A_j], [b_i + abs_tol; b_j + abs_tol].
- * A[n][m_max][d], b[n][m_max], m[n] or NULL; 2*m_max <= 64, d <= 8.  Out: adj[n][n] (symmetric,
+ * A[n][m_max][d], b[n][m_max], m[n] or NULL; 2*m_max <= 64, d <= 16 (d >= 9: one pair per wavefront).  Out: adj[n][n] (symmetric,
  * ones on the diagonal).  The n(n-1)/2 pair LPs are formed on the device from the resident cells.
  */
 int plp_adjacent_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, const double *b,

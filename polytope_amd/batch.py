@@ -387,7 +387,7 @@ def hull_reassign_dev(X, owner, dist, dead, new_id0, normals, offsets, abs_tol=1
 
 def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
     """Adjacency matrix of n single-polytope cells (prop2partition.py:46-63 over polytope.py:1843-1866):
-    uint8[n, n], symmetric, ones on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 8.
+    uint8[n, n], symmetric, ones on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 16.
     The n(n-1)/2 stacked, abs_tol-inflated pair LPs are formed on the device."""
     lib = _lib.load()
     if _is_torch(A):
@@ -414,7 +414,7 @@ def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
 def overlap_pairs(A, b, m=None, abs_tol=1e-7):
     """uint8[n, n]: 1 where the intersection of cells i and j is full-dimensional (Chebyshev radius of the
     stacked rows > abs_tol) -- the pair test of Partition.are_disjoint (prop2partition.py:146-149); ones
-    on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 8."""
+    on the diagonal.  A[n, m_max, d], b[n, m_max]; 2*m_max <= 64, d <= 16."""
     lib = _lib.load()
     if _is_torch(A):
         torch, ctx, stream = _torch_stream_ctx(A)

@@ -1148,8 +1148,8 @@ int plp_adjacent_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, 
     if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
     if (n == 0) return PLP_OK;
     if (!A || !b || !adj) return fail(PLP_EINVAL, "NULL pointer");
-    if (2 * m_max > plp::MAX_M || d > 8)
-        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
+    if (2 * m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=16)", m_max, d);
     if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, abs_tol / 10, adj, 0, 0, nullptr, (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
     return check_launch("adjacent_r_kernel");
@@ -1161,8 +1161,8 @@ int plp_overlap_pairs_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, c
     if (n < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
     if (n == 0) return PLP_OK;
     if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
-    if (2 * m_max > plp::MAX_M || d > 8)
-        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
+    if (2 * m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=16)", m_max, d);
     if (plp::launch_adjacent(n, m_max, d, A, b, m, 0.0, abs_tol, out, 0, 0, nullptr, (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
     return check_launch("adjacent_r_kernel");
@@ -1205,8 +1205,8 @@ int plp_adjacent_pairs_range_dev(plp_ctx* ctx, void* stream, int n, int m_max, i
                     (long long)npairs);
     if (pair_lo == pair_hi) return PLP_OK;
     if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
-    if (2 * m_max > plp::MAX_M || d > 8)
-        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=8)", m_max, d);
+    if (2 * m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=16)", m_max, d);
     if (plp::launch_adjacent(n, m_max, d, A, b, m, abs_tol, abs_tol / 10, nullptr, pair_lo, pair_hi, out,
                              (hipStream_t)stream))
         return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");

@@ -77,11 +77,20 @@ static int launch_adjacent_d(int n, int m_max, const double* A, const double* b,
 int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
                     double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                     hipStream_t st) {
-    if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > 8) return 2;
+    if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > MAX_D) return 2;
     const long long npairs = (long long)n * (n - 1) / 2;
     if (!compact) { p_lo = 0; p_hi = npairs; }
     if (p_lo < 0 || p_hi > npairs || p_lo > p_hi) return 2;
     if (n == 0 || (compact && p_lo == p_hi)) return 0;
+    // d >= 9 (no lane-group kernel), and d = 5..8 when the stacked pair has more than 32 rows or the pairs are few: one
+    // pair per wavefront (plp_wide.hip), the rule of the Chebyshev batches (plp_lp.hip).  PLP_ADJ_WIDE=0 / 1: A/B, tests
+    {
+        const char* aw = getenv("PLP_ADJ_WIDE");
+        const bool wide = d > 8 || (aw ? aw[0] == '1' : (d >= 5 && (2 * m_max > 32 || p_hi - p_lo <= 4096)));
+        if (wide && !(aw && aw[0] == '0' && d <= 8) &&
+            launch_adjacent_w(n, m_max, d, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st) == 0)
+            return 0;
+    }
     switch (d) {
         PLP_CASE_ADJ(1) PLP_CASE_ADJ(2) PLP_CASE_ADJ(3) PLP_CASE_ADJ(4)
         PLP_CASE_ADJ(5) PLP_CASE_ADJ(6) PLP_CASE_ADJ(7) PLP_CASE_ADJ(8)

@@ -78,6 +78,11 @@ int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, c
                     double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                     hipStream_t st);
 
+// the same, one pair per wavefront (d = 5..16, plp_wide.hip); returns 1 when it does not apply
+int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
+                      double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                      hipStream_t st);
+
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                   hipStream_t st);

@@ -158,6 +158,106 @@ int launch_cheby_gather_w(int d, long long nlp, const int* off, const int* rows,
     }
 }
 
+// Pair LPs of find_adjacent_regions / is_adjacent(overlap = True) (polytope/polytope.py:1843-1866 under the pair loop of
+// prop2partition.py:57-61), one pair per wavefront: the rows of cell i and of cell j stacked (at most 64), every b
+// inflated, adjacent iff the Chebyshev radius exceeds `thresh` -- the contract of adjacent_r_kernel (plp_cheby_r_impl.hpp),
+// for d = 5..16 (the lane-group kernel stops at d = 8 and holds one or two such LPs per wavefront from 33 rows on).
+template <int D>
+__global__ __launch_bounds__(64) void adjacent_w_kernel(int n, int m_max, const double* __restrict__ A,
+                                                        const double* __restrict__ b, const int* __restrict__ mrows,
+                                                        double inflate, double thresh, unsigned char* __restrict__ adj,
+                                                        long long p_lo, long long p_hi, unsigned char* __restrict__ compact) {
+    constexpr int NC = D + 1;
+    __shared__ WideShared<NC> sh;
+    const int lane = threadIdx.x;
+    if (!compact) {  // diagonal
+        const long long t = (long long)blockIdx.x * 64 + lane;
+        if (t < n) adj[t * n + t] = 1;
+    }
+    const long long p = p_lo + (long long)blockIdx.x;
+    if (p >= p_hi) return;
+    // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
+    long long i = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+    while (i * (i - 1) / 2 > p) --i;
+    while ((i + 1) * i / 2 <= p) ++i;
+    const long long j = p - i * (i - 1) / 2;
+    const int mi = mrows ? mrows[i] : m_max;
+    const int mj = mrows ? mrows[j] : m_max;
+    const int m = mi + mj;
+    const bool has = lane < m;
+    const long long row = has ? ((lane < mi) ? i * m_max + lane : j * m_max + (lane - mi)) : 0;
+    typename RowVec<NC>::type Tv = (typename RowVec<NC>::type)(0.0);
+    double T16 = 0.0;
+    double nrm2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = has ? A[row * D + k] : 0.0;
+        ROW_SET(k, v);
+        nrm2 = nrm2 + v * v;
+        finite = finite & isfinite(v);
+    }
+    const double bi = has ? b[row] + inflate : 0.0;  // b1 += abs_tol; b2 += abs_tol
+    finite = finite & isfinite(bi);
+    const double nrm = sqrt(nrm2);
+    const bool zero = !(nrm > 0.0);
+    bool rowact = has & !zero;
+    ROW_SET(D, rowact ? nrm : 0.0);
+    double beta = rowact ? bi : 0.0;
+    int rowvar = NC + lane, rowneg = 0;
+    if (lane <= NC) {
+        sh.cost[lane] = lane == D ? -1.0 : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+    const bool bad = (__ballot(!finite) != 0) | (m > 64);
+    __syncthreads();
+    int st, iters = 0;
+    if (bad) st = ST_NUM;
+    else if (infeasible0) st = ST_INFEAS;
+    else st = wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+    const double mine = rowneg ? -beta : beta;
+    const uint64_t ob = __ballot(rowvar == D);
+    const double r = ob ? uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+    const bool yes = (st == ST_OPT) & (r > thresh);
+    if (lane == 0) {
+        if (compact) {
+            compact[p - p_lo] = yes ? 1 : 0;
+        } else {
+            adj[i * n + j] = yes ? 1 : 0;
+            adj[j * n + i] = yes ? 1 : 0;
+        }
+    }
+}
+
+template <int D>
+static int launch_adjacent_w_d(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
+                               double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                               hipStream_t st) {
+    long long blocks = p_hi - p_lo;
+    const long long bdiag = compact ? 0 : ((long long)n + 63) / 64;
+    if (blocks < bdiag) blocks = bdiag;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2147483647ll) return 2;
+    hipLaunchKernelGGL((adjacent_w_kernel<D>), dim3((unsigned)blocks), dim3(64), 0, st, n, m_max, A, b, mrows, inflate, thresh,
+                       adj, p_lo, p_hi, compact);
+    return 0;
+}
+
+#define PLP_CASE_AW(K) \
+    case K: return launch_adjacent_w_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+
+// pairs [p_lo, p_hi) of n cells, 2 * m_max <= 64, d = 5..16; returns 1 when it does not apply
+int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
+                      double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
+                      hipStream_t st) {
+    switch (d) {
+        PLP_CASE_AW(5) PLP_CASE_AW(6) PLP_CASE_AW(7) PLP_CASE_AW(8) PLP_CASE_AW(9) PLP_CASE_AW(10)
+        PLP_CASE_AW(11) PLP_CASE_AW(12) PLP_CASE_AW(13) PLP_CASE_AW(14) PLP_CASE_AW(15) PLP_CASE_AW(16)
+        default: return 1;
+    }
+}
+
 template <int D>
 static int launch_cheby_w_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* r,
                             double* xc, int* status, hipStream_t st) {

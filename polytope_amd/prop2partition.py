@@ -37,7 +37,7 @@ def _uniform_single_cells(regions):
     if len(shapes) != 1:
         return None
     m, d = next(iter(shapes))
-    if 2 * m > 64 or d > 8 or m < 1:
+    if 2 * m > 64 or d > 16 or m < 1:
         return None
     return cells
 

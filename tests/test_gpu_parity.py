@@ -1129,6 +1129,75 @@ def test_degenerate_lps(pa, oracle):
             assert res["iters"][j] <= 50 * (m + n) + 100
 
 
+def test_adjacent_pairs_one_pair_per_wavefront(pa, monkeypatch):
+    """Pair LPs at d = 5..16 (adjacent_w_kernel: one stacked, inflated pair per wavefront; the only device kernel for
+    d >= 9): grids of boxes (adjacent iff neighbours in the grid, faces and corners), random cells with ragged rows against
+    the Chebyshev batch of the host-stacked pairs (r > abs_tol / 10 on b + abs_tol, polytope.py:1843-1866), the lane-group
+    kernel (d <= 8, PLP_ADJ_WIDE=0), pair ranges and the overlap matrix."""
+    import itertools
+    from polytope_amd import batch
+    rng = np.random.default_rng(44)
+    tol = 1e-7
+
+    def by_cheby(A, b, ms, inflate, thresh):
+        n, m_max, d = A.shape
+        ii, jj = np.tril_indices(n, -1)
+        SA = np.zeros((len(ii), 2 * m_max, d)); Sb = np.zeros((len(ii), 2 * m_max)); sm = np.zeros(len(ii), np.int32)
+        for k, (i, j) in enumerate(zip(ii, jj)):
+            mi, mj = ms[i], ms[j]
+            SA[k, :mi] = A[i, :mi]; SA[k, mi:mi + mj] = A[j, :mj]
+            Sb[k, :mi] = b[i, :mi] + inflate; Sb[k, mi:mi + mj] = b[j, :mj] + inflate
+            sm[k] = mi + mj
+        res = pa.cheby_ball_batch(SA, Sb, m=sm)
+        yes = (res["status"] == 0) & (res["r"] > thresh)
+        out = np.eye(n, dtype=np.uint8)
+        out[ii, jj] = yes; out[jj, ii] = yes
+        return out
+
+    for shape in [(3, 2, 2, 2, 2), (2, 2, 2, 2, 2, 2), (3, 2, 2, 1, 1, 1, 1, 1, 2), (2, 2, 1, 1, 3, 1, 1, 1, 1, 1, 1, 2)]:
+        d = len(shape)
+        lo = np.array(list(itertools.product(*[range(k) for k in shape])), dtype=float)
+        n = lo.shape[0]
+        A = np.tile(np.vstack([np.eye(d), -np.eye(d)]), (n, 1, 1))
+        b = np.concatenate([lo + 1.0, -lo], axis=1)
+        adj = pa.adjacent_pairs(A, b)
+        want = (np.abs(lo[:, None, :] - lo[None, :, :]).max(axis=2) <= 1).astype(np.uint8)
+        assert np.array_equal(adj, want), shape
+        if d <= 8:
+            monkeypatch.setenv("PLP_ADJ_WIDE", "0")
+            assert np.array_equal(pa.adjacent_pairs(A, b), want), shape
+            monkeypatch.setenv("PLP_ADJ_WIDE", "1")
+            assert np.array_equal(pa.adjacent_pairs(A, b), want), shape
+            monkeypatch.delenv("PLP_ADJ_WIDE")
+        ii, jj = np.tril_indices(n, -1)
+        for (p0, p1) in [(0, len(ii)), (5, 77), (len(ii) - 3, len(ii))]:
+            assert np.array_equal(batch.adjacent_pairs_range(A, b, p0, p1), want[ii[p0:p1], jj[p0:p1]])
+        ov = pa.overlap_pairs(A, b) if hasattr(pa, "overlap_pairs") else batch.overlap_pairs(A, b)
+        assert np.array_equal(ov, np.eye(n, dtype=np.uint8)), shape      # boxes of a grid only touch
+    n_adj = n_apart = 0
+    for (n, m, d) in [(40, 20, 6), (30, 32, 8), (24, 24, 10), (16, 32, 16), (20, 12, 5)]:
+        # boxes with random centres and widths (overlapping, touching nowhere, apart) cut by a few more random half-spaces
+        cen = rng.uniform(0.0, 2.0, (n, d)); hw = rng.uniform(0.3, 0.9, (n, d))
+        A = np.zeros((n, m, d)); b = np.zeros((n, m))
+        A[:, :d] = np.eye(d); A[:, d:2 * d] = -np.eye(d)
+        b[:, :d] = cen + hw; b[:, d:2 * d] = -(cen - hw)
+        extra = rng.standard_normal((n, m - 2 * d, d)); extra /= np.linalg.norm(extra, axis=2, keepdims=True)
+        A[:, 2 * d:] = extra
+        b[:, 2 * d:] = np.einsum("nij,nj->ni", extra, cen) + rng.uniform(0.2, 1.5, (n, m - 2 * d))
+        ms = rng.integers(max(2 * d, m - 4), m + 1, n).astype(np.int32)
+        adj = pa.adjacent_pairs(A, b, m=ms)
+        assert np.array_equal(adj, by_cheby(A, b, ms, tol, tol / 10)), (n, m, d)
+        n_adj += int(adj.sum()) - n
+        n_apart += n * n - int(adj.sum())
+        if d <= 8:
+            monkeypatch.setenv("PLP_ADJ_WIDE", "0")
+            assert np.array_equal(pa.adjacent_pairs(A, b, m=ms), adj), (n, m, d)
+            monkeypatch.delenv("PLP_ADJ_WIDE")
+        ov = batch.overlap_pairs(A, b, m=ms)
+        assert np.array_equal(ov, by_cheby(A, b, ms, 0.0, tol)), (n, m, d)
+    assert n_adj > 50 and n_apart > 50, (n_adj, n_apart)
+
+
 def test_adjacent_pairs_range_and_sharded_single(pa):
     """Slices of the pair space (what one rank computes when the O(n^2) loop is split across GPUs)
     agree with the full matrix; the sharded wrappers with world size 1 agree with the plain calls."""
