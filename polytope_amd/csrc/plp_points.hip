@@ -135,7 +135,9 @@ static void launch_contains_d(int P, int m_max, const double* A, const double* b
     // polytopes of 16 rows, ms per call, PPL = 2 / 4 / 6 / 8): d = 2 6.1 / 4.1 / 3.5 / 3.4, d = 3 6.9 / 4.9 / 4.6 / 4.3,
     // d = 4 6.9 / 5.6 / 5.3 / 5.3, d = 6 9.4 / 7.3 / 7.2 / 7.3, d = 8 11.2 / 9.1 / 8.8 / 9.4 (C3 itself: 35.7 ms with 4,
     // 33.9 with 6, 34.1 with 8)
-    constexpr int PPL = (D <= 3) ? 8 : ((D <= 8) ? 6 : 2);
+    // (d > 8, 40-row polytopes, PPL = 2 / 3 / 4: d = 9 19.8 / 16.2 / 15.8, d = 10 22.3 / 18.7 / 19.9, d = 12 26.8 / 26.0 / 25.4,
+    // d = 16 39.9 / 41.6 / 43.7)
+    constexpr int PPL = (D <= 3) ? 8 : ((D <= 8) ? 6 : (D == 9 ? 4 : (D <= 12 ? 3 : 2)));
 #endif
     long long blocks = (N + (long long)BLOCK * PPL - 1) / ((long long)BLOCK * PPL);
     if (blocks > 256ll * 32) blocks = 256ll * 32;

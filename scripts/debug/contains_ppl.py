@@ -5,8 +5,8 @@ import numpy as np, torch
 import polytope_amd as pa
 from polytope_amd import synth
 out = []
-for d in (2, 3, 4, 5, 6, 7, 8):
-    A, b, X = synth.containment_workload(2000, 1000000, d=d, m=16, seed=0)
+for d in (tuple(int(v) for v in os.environ["PPL_DIMS"].split(",")) if os.environ.get("PPL_DIMS") else (2, 3, 4, 5, 6, 7, 8)):
+    A, b, X = synth.containment_workload(2000, 1000000, d=d, m=max(16, 2 * d + 8), seed=0)
     At, bt, Xt = (torch.as_tensor(v).cuda() for v in (A, b, X))
     pa.contains_batch(At, bt, Xt, 1e-7); torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -744,7 +744,7 @@ def test_contains_golden(pa):
 
 def test_contains_vs_oracle(pa, oracle):
     from polytope_amd.synth import containment_workload
-    for (P, N, d, m) in [(64, 20000, 6, 16), (7, 1000, 2, 5), (33, 4099, 9, 20), (5, 513, 16, 40), (20, 3000, 1, 2)]:
+    for (P, N, d, m) in [(64, 20000, 6, 16), (7, 1000, 2, 5), (33, 4099, 9, 20), (5, 513, 16, 40), (20, 3000, 1, 2), (9, 2049, 11, 30), (12, 1500, 4, 10)]:
         A, b, X = containment_workload(P, N, d=d, m=m, seed=d)
         mrows = np.random.default_rng(d).integers(max(1, m - 3), m + 1, P).astype(np.int32)
         for tol in (1e-7, 0.0):
