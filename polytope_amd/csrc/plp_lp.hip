@@ -36,6 +36,9 @@ namespace plp {
 // (16,5) 0.092 -> 0.063; origin-feasible ones (64,16) 0.43 -> 0.25, (32,6) a tie, (16,5) / (24,5) / (32,8) 10-30 % behind
 // (four rows per lane pack several of those per wavefront) -- the mix of a batch is not known to the host, and the
 // reference's LPs are posed in original coordinates, where the origin is rarely feasible.
+// (A two-pass route for large batches of LPs with 32 rows and fewer -- lp_r_kernel for the origin-feasible ones, then this
+// engine on what it hands over -- was measured: the feasible batches win their 15-27 % back, the two-phase ones lose
+// 20-30 % to the extra pass ((32,6): 0.097 -> 0.116 ms); not kept.)
 // PLP_LP_WIDE=0 / 1: never / always (A/B, tests)
 static bool lp_wide_on(long long B, int m_max, int n) {
     if (n < 5 || n > MAX_D || m_max > MAX_M || B > 2147483647ll) return false;  // (what launch_lp_w takes)
