@@ -361,6 +361,20 @@ def test_find_adjacent_regions(pc, name):
     assert adj2[0, 1] == want01 == adj2[1, 0] and adj2[2, 2] == 1
 
 
+def test_find_adjacent_regions_high_dimension(pc):
+    """The same in 9 dimensions (a 3 x 2 x 2 x 1^5 x 2 grid of boxes; on the HIP backend the pair LPs of d >= 9 run one pair
+    per wavefront, adjacent_w_kernel): neighbours in the grid -- faces, edges, corners -- and nothing else; disjoint."""
+    import itertools
+    from polytope_amd import prop2partition as p2p
+    shape = (3, 2, 2, 1, 1, 1, 1, 1, 2)
+    lo = np.array(list(itertools.product(*[range(k) for k in shape])), dtype=float)
+    cells = [pc.box2poly(np.c_[l, l + 1.0].tolist()) for l in lo]
+    adj = p2p.find_adjacent_regions([pc.Region([c]) for c in cells]).toarray()
+    want = (np.abs(lo[:, None, :] - lo[None, :, :]).max(axis=2) <= 1).astype(np.int8)
+    assert np.array_equal(adj, want)
+    assert p2p.are_disjoint(cells)
+
+
 # ------------------------------------------------------------------ Partition.are_disjoint / compute_adj
 @pytest.mark.parametrize("name", ["grid2", "grid3", "rand2", "rand3"])
 def test_overlap_and_compute_adj(pc, name):
