@@ -513,7 +513,9 @@ __global__ __launch_bounds__(64) void cheby_gather_lds_kernel(long long nlp, int
 // in the loop, no hand-over pass).  keep is W = ceil(m_max / 64) words per polytope.
 namespace {
 
-constexpr int ROW_DEAD = 0, ROW_LIVE = 1, ROW_SETTLED = 2;  // ROW_SETTLED: live and settled as "keep" by the presolve
+// ROW_SETTLED: live and settled as "keep" by the presolve.  ROW_DROPPED: found redundant by its F2 LP -- still a row of
+// every later LP (the reference solves all of them over G = A_arr, every row, :1142-1160; only the keep mask loses it).
+constexpr int ROW_DEAD = 0, ROW_LIVE = 1, ROW_SETTLED = 2, ROW_DROPPED = 3;
 
 struct RedRows {
     double* A;    // [m][d]
@@ -579,6 +581,12 @@ __global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, 
     R.state = reinterpret_cast<int*>(R.xc + 16);
     for (long long p = blockIdx.x; p < B; p += gridDim.x) {
         const int m = mrows ? mrows[p] : m_max;
+        if (m < 0 || m > m_max) {   // a row count the carved LDS does not hold (caller's device array): no verdict
+            for (int w = lane; w < W; w += 64) keep_out[p * W + w] = 0ull;
+            if (lane == 0) { flags_out[p] = RF_EMPTY | RF_LPFAIL; nlp_out[p] = 0; r_out[p] = 0.0; }
+            if (lane < d) xc_out[p * d + lane] = qnan;
+            continue;
+        }
         const LdsDict D = lds_carve(smem_raw, m_max, ld);
         __syncthreads();
         // ---------------------------------------------------------------- rows -> LDS; F1 (as cheby_lds_kernel)
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, 
                 if (lane == 0) R.b[kr] = hk;
                 const double obj = -fun - hk;     // (:1156)
                 const bool keepk = ((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND);
-                if (!keepk && lane == 0) R.state[kr] = ROW_DEAD;   // (state now means: kept)
+                if (!keepk && lane == 0) R.state[kr] = ROW_DROPPED;
                 __syncthreads();
             }
             flags |= RF_MINREP;
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, 
         __syncthreads();
         for (int w = 0; w < W; ++w) {
             const int i = w * 64 + lane;
-            const bool kept = (flags & (RF_EARLY | RF_MINREP)) && i < m && R.state[i] != ROW_DEAD;
+            const bool kept = (flags & (RF_EARLY | RF_MINREP)) && i < m && R.state[i] != ROW_DEAD && R.state[i] != ROW_DROPPED;
             const unsigned long long word = __ballot(kept);
             if (lane == 0) keep_out[p * W + w] = word;
         }

@@ -41,7 +41,7 @@ namespace plp {
 // 20-30 % to the extra pass ((32,6): 0.097 -> 0.116 ms); not kept.)
 // PLP_LP_WIDE=0 / 1: never / always (A/B, tests)
 static bool lp_wide_on(long long B, int m_max, int n) {
-    if (n < 5 || n > MAX_D || m_max > MAX_M || B > 2147483647ll) return false;  // (what launch_lp_w takes)
+    if (n < 5 || n > MAX_D || m_max < 1 || m_max > MAX_M || B > 2147483647ll) return false;  // (what launch_lp_w takes)
     const char* w = getenv("PLP_LP_WIDE");
     if (w) return w[0] == '1';
     const char* one = getenv("PLP_LP_1ROW");

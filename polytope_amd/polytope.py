@@ -387,16 +387,25 @@ class Region(object):
 
 # ====================================================================================== helpers
 def _pack(polys):
-    """[Polytope] -> A[B, m_max, d], b[B, m_max], m[B] (rows zero-padded)."""
+    """[Polytope] -> A[B, m_max, d], b[B, m_max], m[B] (rows zero-padded).  No per-polytope Python work beyond
+    collecting the array references: one concatenate and one scatter."""
     B = len(polys)
     d = polys[0].A.shape[1]
-    ms = np.array([p.A.shape[0] for p in polys], dtype=np.int32)
+    ms = np.fromiter((p.A.shape[0] for p in polys), dtype=np.int32, count=B)
     m_max = max(int(ms.max()), 1)
+    if int(ms.min()) == m_max:   # same row count everywhere: the padded layout is the concatenation itself
+        A = np.concatenate([p.A for p in polys]).reshape(B, m_max, d)
+        b = np.concatenate([p.b for p in polys]).reshape(B, m_max)
+        return np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64), ms
     A = np.zeros((B, m_max, d))
     b = np.zeros((B, m_max))
-    for k, p in enumerate(polys):
-        A[k, :ms[k]] = p.A
-        b[k, :ms[k]] = p.b
+    total = int(ms.sum())
+    if total:
+        first = np.cumsum(ms) - ms
+        owner = np.repeat(np.arange(B), ms)
+        row = np.arange(total) - np.repeat(first, ms)
+        A[owner, row] = np.concatenate([p.A for p in polys if p.A.shape[0]])
+        b[owner, row] = np.concatenate([p.b for p in polys if p.A.shape[0]])
     return A, b, ms
 
 

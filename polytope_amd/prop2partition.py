@@ -1,16 +1,30 @@
-"""Adjacency of the regions of a partition -- mirror of the O(n^2) pair loop of the reference
-(polytope/prop2partition.py:46-63, `find_adjacent_regions`), which calls `is_adjacent` on every
-pair (i, j < i) and therefore issues one Chebyshev LP per pair of member polytopes
-(polytope/polytope.py:1843-1866).  Here all pair LPs go to the device as ONE batch.
+"""Partitions of a polytopic set -- mirror of polytope/prop2partition.py of the reference: `find_adjacent_regions`
+(:46-63), `Partition` (:68-228: container protocol, `is_partition`, `is_cover`, `are_disjoint`, `refines`,
+`preserves`) and `MetricPartition` (:231-306: `compute_adj`).  Same names, constructor, attributes (`set`, and the
+`regions` / `domain` / `adj` / `_elements` attributes the reference expects its subclasses to provide) and return values.
 
-Also the other two O(n^2) pair loops of that module: `Partition.are_disjoint` (:123-192, one
-intersect + is_fulldim per pair) and `MetricPartition.compute_adj` (:244-306, is_adjacent on every ordered
-pair plus a comparison with the previous matrix), as functions over a list of regions.
+What differs is where the O(n^2) pair loops go.  The reference calls `is_adjacent` / `intersect` / `<=` on one
+pair at a time, each a handful of LPs issued from Python (polytope/polytope.py:1843-1866, :815-830, :1032-1050).
+Here every pair loop is ONE batch on the 'hip' backend:
 
-Only these pair computations are rebuilt; the `Partition` / `MetricPartition` containers of the
-reference are plain Python bookkeeping around them.
+    find_adjacent_regions, compute_adj   n(n-1)/2 stacked, abs_tol-inflated Chebyshev LPs formed on the device
+    are_disjoint                         n(n-1)/2 stacked Chebyshev LPs (radius of the pairwise intersections)
+    refines                              |self| x |other| stacked Chebyshev LPs screen the candidate supersets, then
+                                         one region_diff search per candidate pair
+    is_cover                             one region_diff batch of the domain against all member polytopes
+
+Three places where the reference as written cannot run are given their evident meaning instead of its exception
+(checked against the reference in tests/golden/make_golden.py, g16):
+  * `is_cover` on a set that is not covered calls `logger.Error` (:110, an AttributeError): here the message is
+    logged with `logger.error`, the warning is issued and False is returned;
+  * `preserves` builds `set(other)` (:218) of Regions, which the reference's Region (it defines __eq__ without
+    __hash__) does not allow: the Regions of this package hash by identity, so the difference is by identity;
+  * `are_disjoint(fname=...)` saves figures through `Region.plot`; plotting is out of scope
+    and the argument raises NotImplementedError.
 """
 import logging
+import warnings
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -24,22 +38,51 @@ def _regions_of(partition):
     return partition.regions if hasattr(partition, "regions") else list(partition)
 
 
-def _uniform_single_cells(regions):
-    """All regions are single polytopes (or 1-member Regions) with identical (m, d)?"""
-    cells = []
+def _members_of(regions):
+    """Member polytopes of a list of Polytopes / Regions, flattened -> (members, first[n + 1]): region k owns
+    members[first[k]:first[k + 1]] (none for an empty Region or an empty Polytope)."""
+    members, first = [], [0]
     for r in regions:
         if isinstance(r, pc.Region):
-            if len(r) != 1:
-                return None
-            r = r.list_poly[0]
-        cells.append(r)
-    shapes = {c.A.shape for c in cells}
-    if len(shapes) != 1:
+            members += [p for p in r.list_poly if p.A.size]
+        elif r.A.size:
+            members.append(r)
+        first.append(len(members))
+    return members, np.asarray(first)
+
+
+def _device_pairs_ok(members):
+    """Can the pair kernels (csrc/plp_capi.hip: plp_adjacent_pairs / plp_overlap_pairs) take these polytopes?
+    They stack two members per LP in registers: 2 * m_max <= 64 rows, one dimension d <= 16."""
+    if solvers.default_solver != "hip" or len(members) < 2:
+        return False
+    d = members[0].A.shape[1]
+    return 1 <= d <= 16 and all(p.A.shape[1] == d and 1 <= p.A.shape[0] <= 32 for p in members)
+
+
+def _fold_members(M, first):
+    """Member-pair matrix -> region-pair matrix: region (i, j) is set iff some member pair is (the `any` over member
+    polytopes of is_adjacent, ref polytope.py:1843-1853, and of Region.intersect, :815-830)."""
+    n = len(first) - 1
+    have = np.nonzero(first[1:] > first[:-1])[0]
+    out = np.zeros((n, n), dtype=bool)
+    if have.size:
+        starts = first[have]
+        R = np.maximum.reduceat(np.maximum.reduceat(M != 0, starts, axis=0), starts, axis=1)
+        out[np.ix_(have, have)] = R
+    return out
+
+
+def _pair_matrix_device(regions, kind, abs_tol):
+    """All member pairs of all regions as one batch of stacked Chebyshev LPs formed on the device, folded to the
+    regions; None when the pair kernels do not take the shapes (the callers then go pair by pair)."""
+    members, first = _members_of(regions)
+    if not _device_pairs_ok(members):
         return None
-    m, d = next(iter(shapes))
-    if 2 * m > 64 or d > 16 or m < 1:
-        return None
-    return cells
+    from . import batch
+    A, b, ms = pc._pack(members)
+    fn = batch.adjacent_pairs if kind == "adjacent" else batch.overlap_pairs
+    return _fold_members(fn(A, b, m=ms, abs_tol=abs_tol), first)
 
 
 def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL):
@@ -48,14 +91,12 @@ def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL):
     adj = np.eye(n, dtype=np.int8)
     if n < 2:
         return adj
+    got = _pair_matrix_device(regions, "adjacent", abs_tol)
+    if got is not None:
+        # the stacked, abs_tol-inflated pair LPs (polytope.py:1860-1866) are formed on the device
+        adj |= got.astype(np.int8)
+        return adj
     ii, jj = np.tril_indices(n, -1)
-    cells = _uniform_single_cells(regions) if solvers.default_solver == "hip" else None
-    if cells is not None:
-        # the n(n-1)/2 stacked, abs_tol-inflated pair LPs (polytope.py:1860-1866) are formed on the device
-        from .batch import adjacent_pairs
-        A = np.stack([c.A for c in cells])
-        b = np.stack([c.b for c in cells])
-        return adjacent_pairs(A, b, abs_tol=abs_tol).astype(np.int8)
     flags = pc.is_adjacent_pairs([(regions[i], regions[j]) for i, j in zip(ii, jj)], abs_tol=abs_tol)
     adj[ii[flags], jj[flags]] = 1
     adj[jj[flags], ii[flags]] = 1
@@ -72,10 +113,9 @@ def overlap_matrix_dense(regions, abs_tol=pc.ABS_TOL):
     over = np.eye(n, dtype=bool)
     if n < 2:
         return over
-    cells = _uniform_single_cells(regions) if solvers.default_solver == "hip" else None
-    if cells is not None:
-        from .batch import overlap_pairs
-        return overlap_pairs(np.stack([c.A for c in cells]), np.stack([c.b for c in cells]), abs_tol=abs_tol).astype(bool)
+    got = _pair_matrix_device(regions, "overlap", abs_tol)
+    if got is not None:
+        return over | got
     stacks, owner = [], []
     for i in range(n):
         li = regions[i].list_poly if isinstance(regions[i], pc.Region) else [regions[i]]
@@ -92,6 +132,17 @@ def overlap_matrix_dense(regions, abs_tol=pc.ABS_TOL):
             if r > abs_tol:
                 over[i, j] = over[j, i] = True
     return over
+
+
+def touch_matrix(smalls, bigs, abs_tol=pc.ABS_TOL):
+    """len(smalls) x len(bigs) bool: does some member of smalls[i] meet some member of bigs[j] in a set of Chebyshev
+    radius > abs_tol -- the scan region_diff opens with (ref polytope.py:2148-2158), for every pair at once; None when
+    the device pair kernels do not take the shapes."""
+    both = list(smalls) + list(bigs)
+    got = _pair_matrix_device(both, "overlap", abs_tol)
+    if got is None:
+        return None
+    return got[:len(smalls), len(smalls):]
 
 
 def are_disjoint(partition, check_all=False):
@@ -137,3 +188,166 @@ def find_adjacent_regions(partition):
     """
     regions = _regions_of(partition)
     return sp.lil_matrix(adjacency_matrix_dense(regions))
+
+
+################################
+
+
+def _all_polytopic(items):
+    return all(isinstance(x, (pc.Polytope, pc.Region)) for x in items)
+
+
+class Partition(object):
+    """Partition of a set (ref :68-228).
+
+    An iterable container of sets over `Partition.set`; the members (`self.regions`) implement union / `__add__`,
+    difference, intersection and `__le__`, so the builtin `set` can be used for discrete sets and Polytope / Region
+    for polytopic ones.  As in the reference the constructor stores only `set`; `regions` (and `domain` for
+    `is_cover`, `_elements` for `preserves`) are provided by the user or the subclass.
+    """
+
+    def __init__(self, domain=None):
+        # `domain` rather than `set` to avoid shadowing the builtin (ref :85-91)
+        self.set = domain
+
+    def __len__(self):
+        return len(self.regions)
+
+    def __iter__(self):
+        return iter(self.regions)
+
+    def __getitem__(self, key):
+        return self.regions[key]
+
+    def is_partition(self):
+        """Return True if Regions are pairwise disjoint and cover domain (ref :102-105)."""
+        return self.is_cover() and self.are_disjoint()
+
+    def is_cover(self):
+        """Return True if Regions cover domain (ref :107-121): `domain <= union of the regions`.
+
+        The reference accumulates the union with `+=`, i.e. union(check_convex=True), which merges members into convex
+        pieces at O(n^2) envelope tests; that changes how the union is written, not the set.  For polytopic members the
+        union is taken as the list of all member polytopes and the subset test (one region_diff search of each member
+        of the domain against that list, then the volume of what is left: polytope.py:1032-1050) decides."""
+        regions = list(self.regions)
+        if _all_polytopic(regions) and isinstance(self.domain, (pc.Polytope, pc.Region)):
+            members, _ = _members_of(regions)
+            union = pc.Region(members)
+        else:
+            union = pc.Region()
+            for region in regions:
+                union += region
+        if not self.domain <= union:
+            msg = "partition does not cover domain."
+            logger.error(msg)
+            warnings.warn(msg)
+            return False
+        return True
+
+    def are_disjoint(self, check_all=False, fname=None):
+        """Return True if all Regions are disjoint (ref :123-192).
+
+        For every offending pair the reference's report is logged: the two regions, the volume of their intersection
+        and of their difference as a percentage of their mean volume.  Without `check_all` the scan of region i
+        stops at its first offender (the reference's `break` leaves the inner loop only).
+
+        @param check_all: report every offending pair
+        @param fname: path prefix for the reference's debugging figures; plotting is out of scope here
+        """
+        logger.info("checking if PPP is a partition.")
+        if fname:
+            raise NotImplementedError("are_disjoint(fname=...): the figures need Region.plot, which is out of scope")
+        regions = list(self.regions)
+        over = overlap_matrix_dense(regions)
+        ok = True
+        for i, region in enumerate(regions):
+            for j in np.nonzero(over[i, :i])[0].tolist():
+                other = regions[j]
+                isect = region.intersect(other)
+                diff = region.diff(other)
+                mean_volume = (region.volume + other.volume) / 2.0
+                overlap = 100 * isect.volume / mean_volume
+                non_overlap = 100 * diff.volume / mean_volume
+                msg = "PPP is not a partition, regions: " + str(i) + " and: " + str(j) + " intersect each other.\n"
+                msg += "Offending regions are:\n" + 10 * "-" + "\n"
+                msg += str(region) + 10 * "-" + "\n" + str(other) + 10 * "-" + "\n"
+                msg += "|cap| = " + str(overlap) + " %\n" + "|diff| = " + str(non_overlap) + "\n"
+                logger.error(msg)
+                ok = False
+                if not check_all:
+                    break
+        return ok
+
+    def refines(self, other):
+        """Return True if each element is a subset of some element of `other` (ref :194-207).
+
+        For polytopic elements on the 'hip' backend one batch of stacked Chebyshev LPs finds, for every element, the
+        elements of `other` it meets at all; `small <= big` runs only for those.  An element that does not meet `big`
+        is left whole by the difference (region_diff returns its minuend, polytope.py:2154-2158), so there
+        `small <= big` is `small.volume < ABS_TOL`."""
+        smalls, bigs = list(self), list(other)
+        touch = None
+        if smalls and bigs and _all_polytopic(smalls) and _all_polytopic(bigs):
+            touch = touch_matrix(smalls, bigs)
+        for i, small in enumerate(smalls):
+            found_superset = False
+            for j, big in enumerate(bigs):
+                if touch is not None and not touch[i, j]:
+                    inside = bool(small.volume < pc.ABS_TOL)
+                else:
+                    inside = small <= big
+                if inside:
+                    found_superset = True
+                    break
+            if not found_superset:
+                return False
+        return True
+
+    def preserves(self, other):
+        """Return True if it refines the closure of `other` under complement (ref :209-228): every element lies in
+        each of its annotated `supersets` and meets no other element of `other`."""
+        for item in self._elements:
+            # item subset of these sets
+            for superset in item.supersets:
+                if not item <= superset:
+                    return False
+            # item subset of the complements of these sets
+            for other_set in set(other).difference(item.supersets):
+                if item.intersect(other_set):
+                    return False
+        return True
+
+
+class MetricPartition(Partition):
+    """Partition of a metric space, with the adjacency of its regions (ref :231-306).
+
+    Two subsets are adjacent if the intersection of their closures is non-empty."""
+
+    def compute_adj(self):
+        """Update the adjacency matrix `self.adj` by checking all region pairs (polytope.is_adjacent on each, as one
+        batch) and compare it with the previous one, if any.  -> True if the previous matrix was right (ref :244-306).
+        """
+        regions = list(self.regions)
+        logger.info("computing adjacency from scratch...")
+        adj = sp.lil_matrix(adjacency_matrix_dense(regions).astype(float))
+        logger.info("...done computing adjacency.")
+        ok = True
+        if self.adj is not None:
+            logger.info("checking previous adjacency...")
+            new, old = adj.toarray(), sp.lil_matrix(self.adj).toarray()
+            for i, j in zip(*np.nonzero(new)):
+                if new[i, j] != old[i, j]:
+                    ok = False
+                    logger.error("PPP adjacency matrix is incomplete, missing: (" + str(i) + ", " + str(j) + ")")
+            for i, j in zip(*np.nonzero(old)):
+                if new[i, j] != old[i, j]:
+                    ok = False
+                    logger.error("PPP adjacency matrix is incorrect, has 1 at: (" + str(i) + ", " + str(j) + ")")
+            if not ok:
+                logger.error("PPP had incorrect adjacency matrix.")
+            logger.info("done checking previous adjacency.")
+        else:
+            logger.info("no previous adjacency found: skip verification.")
+        self.adj = adj
+        return ok

@@ -124,7 +124,9 @@ _BLAS_CTL = None
 
 
 def _blas_single_thread():
-    """Context manager: numpy's BLAS on the calling thread only, for the duration of one hull.
+    """Context manager: numpy's BLAS limited to one thread for the duration of one hull.  The limit is the BLAS
+    library's own thread count, i.e. PROCESS-WIDE: BLAS calls made by other Python threads meanwhile also run
+    single-threaded (tens of milliseconds per hull).
     The rank check (an SVD) and the start simplex (matrix-vector products) wake OpenBLAS's worker pool, whose threads
     then spin for tens of milliseconds; measured on the 256-core host of the GPU box they stall the native main loop
     that follows for 60-90 ms somewhere inside a 40 ms hull (N = 100 000, d = 5).  These calls are far too small to
@@ -143,8 +145,8 @@ def _blas_single_thread():
 
 
 def quickhull(POINTS, abs_tol=1e-7, session_factory=None):
-    """Compute the convex hull of a set of points (see `_quickhull`; numpy's BLAS is kept on the calling thread
-    meanwhile, `_blas_single_thread`)."""
+    """Compute the convex hull of a set of points (see `_quickhull`; numpy's BLAS is limited to one thread, process-wide,
+    meanwhile: `_blas_single_thread`)."""
     with _blas_single_thread():
         return _quickhull(POINTS, abs_tol, session_factory)
 

@@ -31,6 +31,9 @@ Sets:
                    region_diff + an adjacency sample on the full 1000-cell 10x10x5x2 grid  (polytope.py:2117-2282)
   g13_volume_subset.npz  seeded volume(), is_subset, == / <= / >= on polytopes and Regions (polytope.py:1529-1594, :1032-1050)
   g14_wide_reduce.npz  reduce() / Polytope.intersect() on inputs of more than 64 rows    (polytope.py:1053-1163, :255-275)
+  g16_partition.npz  Partition.is_cover / are_disjoint / refines / preserves, MetricPartition.compute_adj on box grids,
+                   triangles, multi-member regions, a non-cover and overlapping sets  (prop2partition.py:46-306)
+  g17_structured.npz  reduce() keep masks on structured (16,3) polytopes: ties, duplicates, tangent rows, corner cuts (:1053-1163)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -897,7 +900,212 @@ def gen_g15():
           "mean kept", out["mask"].sum(1).mean())
 
 
+# ----------------------------------------------------------------------------- G16
+def _g16_sets():
+    """Cell sets for the Partition / MetricPartition classes: name -> (domain, [region, ...]); a region is a list of
+    member polytopes.  Boxes, triangles, multi-member regions, a set that does not cover, sets that overlap."""
+    import itertools
+    box = pc.box2poly
+    sets = {}
+    g2 = [[box([[i, i + 1], [j, j + 1]])] for i in range(4) for j in range(3)]
+    sets["grid2"] = ([box([[0, 4], [0, 3]])], g2)
+    sets["grid2_hole"] = ([box([[0, 4], [0, 3]])], g2[:5] + g2[6:11])               # two cells missing: no cover
+    sets["grid2_coarse"] = ([box([[0, 4], [0, 3]])],                                   # L-shaped / multi-member regions
+                            [[g2[0][0], g2[1][0], g2[3][0]], [g2[2][0], g2[5][0], g2[4][0]],
+                             [box([[2, 4], [0, 3]])]])
+    sets["grid2_cols"] = ([box([[0, 4], [0, 3]])], [[box([[i, i + 1], [0, 3]])] for i in range(4)])
+    g3 = [[box([[i, i + 1], [j, j + 1], [k, k + 1]])] for i, j, k in itertools.product(range(3), range(2), range(2))]
+    sets["grid3"] = ([box([[0, 3], [0, 2], [0, 2]])], g3)
+    sets["grid3_slabs"] = ([box([[0, 3], [0, 2], [0, 2]])], [[box([[i, i + 1], [0, 2], [0, 2]])] for i in range(3)])
+    rng = np.random.default_rng(16)
+    lo = np.round(rng.random((10, 2)) * 3, 1)
+    sets["rand2"] = ([box([[0, 4], [0, 4]])], [[box([[a, a + 1.2], [c, c + 0.9]])] for a, c in lo])   # overlaps, no cover
+    # triangles: every unit square of a 3 x 2 grid cut along its diagonal (non-box rows, m = 3)
+    tri = []
+    for i in range(3):
+        for j in range(2):
+            p00, p10, p11, p01 = [i, j], [i + 1, j], [i + 1, j + 1], [i, j + 1]
+            tri.append([alg.qhull(np.array([p00, p10, p11], dtype=float))])
+            tri.append([alg.qhull(np.array([p00, p11, p01], dtype=float))])
+    sets["tri2"] = ([box([[0, 3], [0, 2]])], tri)
+    sets["tri2_squares"] = ([box([[0, 3], [0, 2]])], [[box([[i, i + 1], [j, j + 1]])] for i in range(3) for j in range(2)])
+    # covers a two-member domain, with overlap between the covering regions
+    sets["overlap_cover"] = ([box([[0, 2], [0, 1]]), box([[2, 3], [0, 1]])],
+                             [[box([[0, 1.5], [0, 1]])], [box([[1, 3], [0, 1]])]])
+    # 4-D slabs of the unit cube (d = 4, the dimension of BASELINE config 4)
+    sets["slab4"] = ([box([[0, 1]] * 4)], [[box([[k / 5, (k + 1) / 5]] + [[0, 1]] * 3)] for k in range(5)])
+    return sets
+
+
+def _g16_partition(cls, domain, regions):
+    from polytope.prop2partition import Partition, MetricPartition
+    dom = domain[0] if len(domain) == 1 else pc.Region(domain)
+    part = dict(Partition=Partition, MetricPartition=MetricPartition)[cls](dom)
+    part.domain = dom
+    part.regions = [pc.Region(list(r)) for r in regions]
+    part.adj = None
+    return part
+
+
+def gen_g16():
+    """Class-level outputs of polytope/prop2partition.py: Partition.is_cover / are_disjoint / is_partition / refines /
+    preserves (:68-228) and MetricPartition.compute_adj (:231-306), find_adjacent_regions (:46-63)."""
+    import logging
+    logging.disable(logging.CRITICAL)
+    sets = _g16_sets()
+    out = {"names": np.array(list(sets))}
+    for name, (domain, regions) in sets.items():
+        d = domain[0].A.shape[1]
+        members = [p for r in regions for p in r]
+        owner = np.array([k for k, r in enumerate(regions) for _ in r], np.int32)
+        mmax = max(p.A.shape[0] for p in members + domain)
+        out[name + "_d"] = np.int32(d)
+        out[name + "_owner"] = owner
+        out[name + "_m"] = np.array([p.A.shape[0] for p in members], np.int32)
+        out[name + "_Ab"] = pad([np.c_[p.A, p.b].ravel() for p in members], mmax * (d + 1))
+        out[name + "_dom_m"] = np.array([p.A.shape[0] for p in domain], np.int32)
+        out[name + "_dom_Ab"] = pad([np.c_[p.A, p.b].ravel() for p in domain], mmax * (d + 1))
+        part = _g16_partition("MetricPartition", domain, regions)
+        raised = False
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cover = bool(part.is_cover())
+        except AttributeError as e:
+            # :110 `logger.Error(msg)`: the branch of a set that is not covered
+            assert "Error" in str(e), e
+            cover, raised = False, True
+        disjoint = bool(part.are_disjoint())
+        assert disjoint == bool(part.are_disjoint(check_all=True))
+        first_ok = bool(part.compute_adj())
+        adj = part.adj.toarray()
+        assert bool(part.compute_adj())                     # the matrix agrees with itself
+        n = len(regions)
+        wrong = part.adj.copy()
+        wrong[0, n - 1] = 0.0 if wrong[0, n - 1] else 1.0
+        part.adj = wrong
+        wrong_ok = bool(part.compute_adj())
+        far = pc.find_adjacent_regions(part).toarray()
+        out[name + "_cover"] = np.bool_(cover)
+        out[name + "_cover_raised"] = np.bool_(raised)
+        out[name + "_disjoint"] = np.bool_(disjoint)
+        out[name + "_adj"] = adj
+        out[name + "_adj_ok"] = np.array([first_ok, wrong_ok])
+        out[name + "_far"] = far
+        print("g16", name, "n", n, "cover", cover, "(raised)" if raised else "", "disjoint", disjoint,
+              "adjacent pairs", int((adj != 0).sum() - n) // 2, "compute_adj", first_ok, wrong_ok)
+    # refines (:194-207): every ordered pair of sets over the same domain
+    groups = [["grid2", "grid2_hole", "grid2_coarse", "grid2_cols"], ["grid3", "grid3_slabs"], ["tri2", "tri2_squares"]]
+    pairs, verdict = [], []
+    for grp in groups:
+        for a in grp:
+            for b in grp:
+                pa = _g16_partition("Partition", *sets[a])
+                pb = _g16_partition("Partition", *sets[b])
+                pairs.append(a + ">" + b)
+                verdict.append(bool(pa.refines(pb)))
+    out["refines_pairs"] = np.array(pairs)
+    out["refines"] = np.array(verdict)
+    print("g16 refines:", dict(zip(pairs, verdict)))
+    # preserves (:209-228).  The reference builds set(other) of Regions, which its Region does not allow (__eq__
+    # without __hash__: TypeError); the expected values are the loop of :219-227 over the reference's own `<=` and
+    # `intersect`, with the difference taken by identity.
+    def preserves(elements, other):
+        for item in elements:
+            for superset in item.supersets:
+                if not item <= superset:
+                    return False
+            for other_set in [o for o in other if not any(o is s_ for s_ in item.supersets)]:
+                if item.intersect(other_set):
+                    return False
+        return True
+    try:
+        set([pc.Region([pc.box2poly([[0, 1], [0, 1]])])])
+        out["preserves_ref_hashable"] = np.bool_(True)
+    except TypeError:
+        out["preserves_ref_hashable"] = np.bool_(False)
+    pres = []
+    for fine, coarse, shift in [("grid2", "grid2_cols", 0), ("grid2", "grid2_cols", 1), ("tri2", "tri2_squares", 0),
+                                ("grid2_coarse", "grid2_cols", 0)]:
+        pf = _g16_partition("Partition", *sets[fine])
+        pcoarse = _g16_partition("Partition", *sets[coarse])
+        nc = len(pcoarse.regions)
+        for item in pf.regions:
+            # annotate with the coarse element holding the item's Chebyshev centre (shifted by `shift` for a wrong one)
+            xc = item.list_poly[0].chebXc
+            k = [t for t, big in enumerate(pcoarse.regions) if xc in big][0]
+            item.supersets = [pcoarse.regions[(k + shift) % nc]]
+        pres.append((fine + ">" + coarse + "+" + str(shift), preserves(pf.regions, pcoarse.regions)))
+    out["preserves_cases"] = np.array([c for c, _ in pres])
+    out["preserves"] = np.array([v for _, v in pres])
+    print("g16 preserves:", pres, "reference Regions hashable:", bool(out["preserves_ref_hashable"]))
+    logging.disable(logging.NOTSET)
+    np.savez_compressed(os.path.join(HERE, "g16_partition.npz"), **out)
+
+
+# ----------------------------------------------------------------------------- G17
+def gen_g17():
+    """reduce() (polytope.py:1053-1163) on STRUCTURED (16, 3) polytopes (tests/structured_cases.py: duplicated and
+    shifted-parallel rows, vertex fans, tangent rows, slacks within a few abs_tol of the threshold, mutually redundant
+    corner cuts, lattice normals, one-ulp twins): which input rows the reference keeps."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from structured_cases import structured_polytopes, family_names
+    A, b, fam = structured_polytopes(960, seed=17)
+    def run(tight):
+        """reduce() over the set -> (keep, empty, minrep, r); tight: HiGHS with feasibility tolerances of 1e-10."""
+        keep = np.zeros((len(A), 16), bool)
+        empty = np.zeros(len(A), bool)
+        minrep = np.zeros(len(A), bool)
+        rad = np.zeros(len(A))
+        saved = alg.lpsolve
+        if tight:
+            def lp_tight(c, G, h, solver=None):
+                sol = linprog(c, G, np.transpose(h), None, None, bounds=(None, None),
+                              options={"primal_feasibility_tolerance": 1e-10, "dual_feasibility_tolerance": 1e-10})
+                return dict(status=sol.status, x=sol.x, fun=sol.fun)
+            alg.lpsolve = lp_tight
+        try:
+            for k in range(len(A)):
+                p = pc.Polytope(A[k], b[k], normalize=False)
+                q = pc.reduce(p)
+                empty[k] = q.A.size == 0
+                minrep[k] = bool(q.minrep)
+                rad[k] = float(p._chebR) if p._chebR is not None else np.nan
+                if empty[k]:
+                    continue
+                # Rows come back renormalised by the constructor (A * (1 / norm), :130-138), b after the in-place 0.1
+                # round trip (:1149-1151).  Input rows on one plane (twins one ulp apart, exact duplicates) cannot be
+                # told apart by value: of such a class the dedupe (:1097-1109) leaves the row of smallest normalised b,
+                # the LAST of equals.
+                scale = 1 / np.sqrt(np.sum(A[k] * A[k], axis=1))
+                An, bn = A[k] * scale[:, None], b[k] * scale
+                used = []
+                for a, bb in zip(q.A, q.b):
+                    cand = np.nonzero((An == a).all(1) & (np.abs(bn - bb) < 1e-12))[0]
+                    assert cand.size, (k, a, bb)
+                    best = [c for c in cand if bn[c] == bn[cand].min()][-1]
+                    assert best not in used
+                    used.append(best)
+                keep[k, used] = True
+        finally:
+            alg.lpsolve = saved
+        return keep, empty, minrep, rad
+
+    keep, empty, minrep, rad = run(False)
+    keep_t, empty_t, minrep_t, rad_t = run(True)
+    # HiGHS stops at points that violate rows by up to 1e-7 (its default primal feasibility tolerance), which moves an F2
+    # objective by about as much: a row whose exact slack lies that close to abs_tol is kept or dropped by the tolerance
+    # setting, not by the polytope.  `pinned`: the reference's answer is the same with the tolerances at 1e-10.
+    pinned = (keep == keep_t).all(1) & (empty == empty_t) & (minrep == minrep_t)
+    print("g17: verdicts that depend on HiGHS's feasibility tolerance:", int((~pinned).sum()), "of", len(A),
+          "by family", np.bincount(fam[~pinned], minlength=len(family_names())))
+    np.savez_compressed(os.path.join(HERE, "g17_structured.npz"), seed=np.int64(17), keep=keep, empty=empty, minrep=minrep,
+                        r=rad, r_tight=rad_t, pinned=pinned, fam=fam.astype(np.int32), names=np.array(family_names()),
+                        A_sum=np.float64(A.sum()), b_sum=np.float64(b.sum()))
+    print("g17:", len(A), "structured polytopes; empty", int(empty.sum()), "mean kept", keep.sum(1).mean())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()["gen_" + w]()

@@ -545,6 +545,82 @@ def test_reduce_beyond_64_rows_vs_oracle(pa, oracle):
         pa.reduce_batch(A, b)
 
 
+def _corner_cuts(A, b, rng, ncut=3, depth=1.5e-7, tilt=1e-3):
+    """Overwrite the last `ncut` rows of every polytope (whose first 2d rows are the box |x_i| <= 3) with planes that
+    cut the corner (3, ..., 3) `depth` deep (> abs_tol: each alone is irredundant), tilted against each other by
+    `tilt` rad (1 - cos > abs_tol: the dedupe lets them pass).  With the others present each cuts less than abs_tol: the
+    reference's F2 LPs, which all run over ALL rows (polytope.py:1142-1160), drop every one of them."""
+    B, m, d = A.shape
+    v = np.full(d, 3.0)
+    for k in range(B):
+        for t in range(ncut):
+            n = np.ones(d) / np.sqrt(d) + tilt * rng.standard_normal(d)
+            n /= np.linalg.norm(n)
+            A[k, m - 1 - t] = n
+            b[k, m - 1 - t] = n @ v - depth
+
+
+def test_reduce_mutually_redundant_rows(pa, oracle):
+    """Rows that are redundant only because of each other: every F2 LP sees every live row, also the rows an earlier F2
+    LP found redundant (ref :1142-1160 solves over G = A_arr throughout) -- on the register kernels (<= 64 rows) and on
+    reduce_lds_kernel (> 64 rows), exactly the oracle's masks."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(23)
+    dropped_all = 0
+    for (m, d, B) in [(16, 3, 64), (24, 4, 32), (40, 6, 16), (70, 3, 24), (90, 4, 16), (130, 5, 8)]:
+        A, b = random_hpolytopes(B, m, d, seed=500 + m, bounded=True)
+        b[:, 2 * d:] += 2.5   # the random rows stay clear of the corner (3, ..., 3)
+        _corner_cuts(A, b, rng)
+        res = pa.reduce_batch(A, b)
+        masks = pa.keep_to_bool(res["keep"], m)
+        for k in range(B):
+            o = oracle.reduce(A[k], b[k])
+            assert int(res["flags"][k]) == o["flags"], (m, d, k)
+            assert np.array_equal(masks[k], o["keep"]), (m, d, k, np.nonzero(masks[k] != o["keep"]))
+            assert int(res["nlp"][k]) == o["nlp"], (m, d, k)
+            dropped_all += int(not o["keep"][m - 3:].any())
+    assert dropped_all > 0   # the case is there: somewhere all three cuts go
+
+
+def test_reduce_structured_ties_golden_and_bench_shape(pa, oracle):
+    """Structured (16, 3) polytopes (tests/structured_cases.py): ties in the ratio tests, duplicated / shifted-parallel
+    rows, vertex fans, tangent rows, slacks a few abs_tol from the threshold, mutually redundant corner cuts, lattice
+    normals, one-ulp twins.  (i) g17: the reference's masks where its verdict does not hang on HiGHS's tolerance;
+    (ii) 24 576 of them as ONE batch -- the bench kernel's launch shape, every tile full, the F2 presolve and its early
+    `h[k] +- 0.1` round trip (ref :1149-1151) on non-random data -- mask, flags, LP count and b round trip exactly the
+    oracle's."""
+    from test_oracle_golden import structured_golden
+    from structured_cases import structured_polytopes
+    from polytope_amd import _lib
+    g, A, b = structured_golden()
+    res = pa.reduce_batch(A, b)
+    masks = pa.keep_to_bool(res["keep"], 16)
+    for k in np.nonzero(g["pinned"])[0]:
+        assert bool(int(res["flags"][k]) & _lib.RF_EMPTY) == bool(g["empty"][k]), k
+        if not g["empty"][k]:
+            assert np.array_equal(masks[k], g["keep"][k]), (k, masks[k], g["keep"][k])
+            assert bool(int(res["flags"][k]) & _lib.RF_MINREP) == bool(g["minrep"][k]), k
+            assert abs(res["r"][k] - g["r_tight"][k]) <= TOL, k
+    B = 24576
+    A, b, fam = structured_polytopes(B, seed=29)
+    res = pa.reduce_batch(A, b)
+    masks = pa.keep_to_bool(res["keep"], 16)
+    bad = []
+    for k in range(B):
+        o = oracle.reduce(A[k], b[k])
+        if not (int(res["flags"][k]) == o["flags"] and np.array_equal(masks[k], o["keep"])
+                and int(res["nlp"][k]) == o["nlp"] and abs(res["r"][k] - o["r"]) <= TOL):
+            bad.append((k, int(fam[k]), int(res["flags"][k]), o["flags"], int(res["nlp"][k]), o["nlp"]))
+    assert not bad, (len(bad), bad[:8])
+    # the same batch on the device-resident path, twice: bit-repeatable
+    import torch
+    Ad, bd = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
+    r1, r2 = pa.reduce_batch(Ad, bd), pa.reduce_batch(Ad, bd)
+    for key in ("keep", "flags", "nlp", "r"):
+        assert torch.equal(r1[key], r2[key]), key
+    assert np.array_equal(r1["keep"].cpu().numpy().view(np.uint64).ravel(), res["keep"].ravel())
+
+
 def _pyramids(B, m, d, rng):
     """Polytopes with a highly degenerate vertex: m - d - 1 facets through one apex, a simplex-like base
     below it and duplicated / nearly parallel facets: the redundancy LPs pivot degenerately at the apex
