@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 B_PER_GPU, M_ROWS, DIM = 100000, 16, 3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMD_CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 
 
 def cpu_baseline(A, b, nlp_gpu):
@@ -85,6 +86,9 @@ def cpu_baseline(A, b, nlp_gpu):
     gpu_lps = int(nlp_gpu[:n].sum())
     assert gpu_lps == lps, "LP count of the GPU (%d) != oracle (%d) on the first %d polytopes" % (gpu_lps, lps, n)
     out["port_1core_lp_per_s"] = lps / t_or
+    out["port_presolve"] = False
+    out["port_note"] = ("the C port solves EVERY LP the reference issues with its simplex (no presolve): its LP/s compare with "
+                        "`value` as work disposed of, and with config.value_simplex_only as simplex runs")
     out["nlp_checked"] = "GPU nlp[:%d].sum() == oracle count == %d" % (n, lps)
     out["sample"] += "; port: oracle/plp_oracle.c reduce() on the first %d polytopes (%d LPs, %.1f s)" % (n, lps, t_or)
     try:  # the same C port on every host core: what a competent CPU code does with the box
@@ -337,12 +341,20 @@ def main():
     # oracle in tests/ and, for batch 0, in the cpu_baseline leg below)
     nlp_batches = [pa.reduce_batch(At_, bt_)["nlp"] for At_, bt_ in dev_batches]
     nlp_of = [int(v.sum().item()) for v in nlp_batches]
+    # In-run accounting (include/plp.h: plp_reduce_counters): from the first call on the fused reduce kernels add the
+    # number of LPs that ran the simplex to a device word (one atomic per tile); reset right before the timed region and
+    # read right after it, so the line can say what was SOLVED beside what was disposed of.  PLP_BENCH_NO_COUNT=1: off.
+    counting = os.environ.get("PLP_BENCH_NO_COUNT", "0") != "1"
+    if counting:
+        pa.batch.reduce_simplex_runs(dev_index, reset=True)
     for _ in range(args.warmup):
         step()
     nissued[0] = 0
     if ex is not None:
         drain()
     torch.cuda.synchronize()
+    if counting:
+        pa.batch.reduce_simplex_runs(dev_index, reset=True)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -371,6 +383,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    simplex_timed_local = pa.batch.reduce_simplex_runs(dev_index) if counting else None   # of the K timed steps, this rank
     if multi:
         rdev = dev if args.backend == "nccl" else torch.device("cpu")
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -387,6 +400,43 @@ def main():
         lps_timed = int(t.item())
         assert gathered.numel() == world * G * nb
     nlp_total = lps_timed / args.steps
+    simplex_timed = simplex_timed_local
+    ranks_seen, exchange_ms = None, None
+    if multi:
+        if counting:
+            t = torch.tensor([simplex_timed_local], dtype=torch.int64, device=rdev)
+            dist.all_reduce(t)
+            simplex_timed = int(t.item())
+        # self-check of the collective layer: how many ranks answer, and what ONE exchange of a group costs on its own
+        # (all-gather of G x 24 B x polytopes per rank, nothing overlapping it)
+        t = torch.ones(1, dtype=torch.int64, device=rdev)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+        src = ex.big[0]
+        dst = torch.empty((world * src.numel(),), dtype=torch.uint8, device=src.device)
+        for _ in range(3):
+            dist.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        dist.barrier()
+        te = time.perf_counter()
+        nrep = 10
+        for _ in range(nrep):
+            dist.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        te = torch.tensor([(time.perf_counter() - te) / nrep * 1e3], dtype=torch.float64, device=rdev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        exchange_ms = float(te.item())
+    shard_alone_ms = None
+    if strong:   # the floor of strong scaling: one rank's shard as a launch of its own (no exchange), event-timed
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            pa.reduce_batch(*dev_batches[0])
+        e0.record()
+        for k in range(50):
+            pa.reduce_batch(*dev_batches[k % NB])
+        e1.record()
+        torch.cuda.synchronize()
+        shard_alone_ms = e0.elapsed_time(e1) / 50
     verified = None
     if multi and args.verify_exchange:
         # the last gathered group holds the slots of the steps of the (possibly partly filled) last group; rank q's part
@@ -450,9 +500,13 @@ def main():
                                    "batches resident in HBM, one per step in rotation (%.0f MB > 256 MiB Infinity Cache)"
                                    % (B_PER_GPU, DIM, M_ROWS, NB, NB * B_PER_GPU * 8 * M_ROWS * (DIM + 1) / 1e6),
                        "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_LOCAL, "streams": args.streams,
-                       "lp_accounting": "LPs the reference issues on these polytopes (kernel output nlp, checked against the "
-                                        "oracle's count); the redundancy LPs whose verdict the two-witness presolve settles "
-                                        "(81 % of them at this workload, DESIGN.md 4.2) are counted like the ones the simplex solves",
+                       "lp_accounting": "`value` counts the LPs the reference issues on these polytopes (kernel output nlp, checked "
+                                        "against the oracle's count); `lps_simplex_per_step` of them ran the simplex in the timed "
+                                        "steps (device counter, plp_reduce_counters), the others are redundancy LPs whose verdict the "
+                                        "two-witness presolve settled (DESIGN.md 4.2): `presolved_frac` of all LPs",
+                       "lps_simplex_per_step": None if simplex_timed is None else simplex_timed / args.steps,
+                       "presolved_frac": None if simplex_timed is None else 1.0 - simplex_timed / lps_timed,
+                       "value_simplex_only": None if simplex_timed is None else simplex_timed / elapsed,
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -461,11 +515,28 @@ def main():
                          "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
                              nlp_local / (kern_ms * 1e-3))},
         }
+        if multi:
+            line["config"]["rccl_ranks_seen"] = ranks_seen
+            line["config"]["exchange_ms_per_group"] = exchange_ms
+            line["config"]["exchange_bytes_per_rank_per_group"] = G * nb
+        if strong:
+            line["config"]["strong_floor"] = {
+                "shard_polytopes": B_LOCAL, "shard_kernel_ms_alone": shard_alone_ms,
+                "note": "one rank's shard as a launch of its own: a launch of a few thousand tiles cannot fill 4096 wavefront "
+                        "slots for long enough to amortise its ramp and drain (12 500 polytopes: ~81 us against 203/8 = 25 us "
+                        "ideal), so strong scaling at this batch size is bounded by this figure, not by the exchange"}
         if verified is not None:
             line["exchange_verified"] = verified
         if valu:  # measured PMC counters of the same kernel (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE)
             line["roofline"].update({k: v for k, v in valu.items() if k != "source"})
             line["roofline"]["counters_source"] = valu.get("source")
+            if "valu_insts_per_launch" in valu:
+                # the bound that matters: a VALU instruction of a wavefront occupies its SIMD for 4 cycles; 256 CUs x 4
+                # SIMDs at 2.4 GHz (MI355X_MICROARCH.md).  Counter from the committed PMC pass, time from THIS run.
+                line["roofline"]["valu_issue_frac"] = valu["valu_insts_per_launch"] * 4.0 / (
+                    1024 * SIMD_CLOCK_HZ * kern_ms * 1e-3) * (B_LOCAL / B_PER_GPU)
+                line["roofline"]["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed PMC pass) x 4 cycles / (1024 SIMDs x "
+                                                       "2.4 GHz x kernel_ms of this run)")
         if args.pipelined and not multi and args.streams == 1:
             # Not `value`: the same K steps again with two independent batches in flight (two HIP streams).  100 000
             # polytopes are 6250 wavefronts for 4096 resident slots, so the last round of a launch runs half empty;

@@ -131,6 +131,18 @@ int plp_reduce_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d
                          int32_t *flags, double *r, double *xc, int32_t *nlp);
 
 /*
+ * In-run accounting of plp_reduce_batch[_dev]: nlp[] counts the LPs the REFERENCE issues for a polytope
+ * (polytope/polytope.py:1081, :1119, :1142-1151: 1 + 2d + one per row that reaches the redundancy loop).  Not all of them
+ * run the simplex here: a redundancy LP whose verdict "keep" a feasible witness point proves (the presolve)
+ * is answered without one.  This call returns the number of LPs that DID run the simplex in the fused reduce launches
+ * issued through `ctx` since the counter was last reset (all streams; the first call of a context switches the counting
+ * on and returns 0).  It enqueues a copy on `stream` and blocks until it has landed, so it sees every launch enqueued on
+ * that stream before it.  reset != 0: the counter restarts at zero.  The second pass that redoes polytopes flagged for
+ * Bland's rule and the kernels for more than 64 rows do not count.
+ */
+int plp_reduce_counters(plp_ctx *ctx, void *stream, uint64_t *simplex_runs, int reset);
+
+/*
  * The same for polytopes of ANY row count whose rows and dictionary fit the LDS of a CU (about 500 rows at d = 16,
  * 2000 at d = 3): `reduce` has no row limit in the reference (polytope/polytope.py:1053-1163), Polytope.intersect
  * stacks m1 + m2 rows (:268-275) and region_diff's leaves as many as the search collected (:2276).

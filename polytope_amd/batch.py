@@ -231,6 +231,25 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
 
 
+def reduce_simplex_runs(device=None, reset=False, stream=None):
+    """Number of LPs that ran the simplex in the fused reduce launches of this process's context for `device` since the
+    counter was last reset (include/plp.h: plp_reduce_counters) -- `nlp` counts the LPs the reference issues, of which
+    the presolve settles a part without a simplex run.  The first call switches the counting on and returns 0.
+    `stream`: a torch stream (default: torch's current stream when torch is loaded with a GPU, else the HIP default)."""
+    lib = _lib.load()
+    ctx = _lib.context(device)
+    if stream is None:
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(ctx.device)
+    sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+    out = C.c_uint64(0)
+    _lib.check(lib.plp_reduce_counters(ctx.handle, sp, C.cast(C.byref(out), C.c_void_p), 1 if reset else 0),
+               "plp_reduce_counters")
+    return int(out.value)
+
+
 def keep_to_bool(keep, m_max):
     """uint64 keep masks (one word per polytope, or [B, W] words for more than 64 rows) -> bool[B, m_max]."""
     keep = np.asarray(keep).astype(np.uint64)

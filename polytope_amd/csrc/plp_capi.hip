@@ -75,6 +75,9 @@ struct plp_ctx {
     hipEvent_t stage_ev[16] = {};
     int stage_nev = 0;
     bool check_finite = false;  // plp_ctx_set_check_finite
+    // plp_reduce_counters: device word the fused reduce kernels add their simplex-run count to (lazily allocated; the
+    // kernels get nullptr until the first plp_reduce_counters call of the context, and then it costs one atomic per tile)
+    unsigned long long* reduce_ctr = nullptr;
 };
 
 namespace {
@@ -406,6 +409,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_out) (void)hipFree(ctx->rd_out);
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
+    if (ctx->reduce_ctr) (void)hipFree(ctx->reduce_ctr);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
     if (ctx->qh_block) (void)hipFree(ctx->qh_block);
     if (ctx->hull_spare.full) {
@@ -638,10 +642,31 @@ int plp_reduce_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d
     if (m_max > plp::MAX_M || d > plp::MAX_D)
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
-    if (plp::launch_reduce(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r, xc,
-                           nlp, st))
-        return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
+    plp::t_reduce_ctr = ctx->reduce_ctr;
+    const int lrc = plp::launch_reduce(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r,
+                                       xc, nlp, st);
+    plp::t_reduce_ctr = nullptr;
+    if (lrc) return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
     return check_launch("reduce_kernel");
+}
+
+int plp_reduce_counters(plp_ctx* ctx, void* stream, uint64_t* simplex_runs, int reset) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t CTR_BYTES = (size_t)plp::PLP_CTR_SLOTS * 64;
+    if (!ctx->reduce_ctr) {   // first call: from now on the kernels launched through this context count
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->reduce_ctr), CTR_BYTES));
+        HIP_TRY(hipMemsetAsync(ctx->reduce_ctr, 0, CTR_BYTES, st));
+    }
+    std::vector<unsigned long long> host(CTR_BYTES / 8);
+    HIP_TRY(hipMemcpyAsync(host.data(), ctx->reduce_ctr, CTR_BYTES, hipMemcpyDeviceToHost, st));
+    if (reset) HIP_TRY(hipMemsetAsync(ctx->reduce_ctr, 0, CTR_BYTES, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long v = 0ull;   // (two's-complement partial sums: the total is what counts)
+    for (int k = 0; k < plp::PLP_CTR_SLOTS; ++k) v += host[(size_t)k * 8];
+    if (simplex_runs) *simplex_runs = (uint64_t)v;
+    return PLP_OK;
 }
 
 int plp_reduce_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b,

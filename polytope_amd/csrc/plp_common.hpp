@@ -33,6 +33,9 @@ constexpr int MAX_D = 16;  // space dimension
 constexpr int WAVE = 64;   // CDNA wavefront
 constexpr int BLOCK = 256; // 4 waves per workgroup
 
+// plp_reduce_counters: the device counter is this many 8-byte words, 64 B apart (a power of two)
+constexpr int PLP_CTR_SLOTS = 1024;
+
 // ids of variables: 0..n-1 structural free x_j ; n+i slack of row i ; -1 phase-1 artificial
 constexpr int ID_T = -1;
 

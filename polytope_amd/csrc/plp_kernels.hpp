@@ -83,6 +83,10 @@ int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b,
                       double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
                       hipStream_t st);
 
+// Device counter (or nullptr) the fused reduce kernels of the calling thread add their simplex-run count to: set by
+// plp_reduce_batch_dev from the context around the launch (plp_reduce_counters reads it back)
+extern thread_local unsigned long long* t_reduce_ctr;
+
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                   hipStream_t st);

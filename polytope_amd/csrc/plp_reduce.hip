@@ -30,6 +30,8 @@
 
 namespace plp {
 
+thread_local unsigned long long* t_reduce_ctr = nullptr;
+
 static inline size_t reduce_smem_bytes(int gs, int D) {
     const int NG = BLOCK / gs;
     return ((size_t)NG * gs * (D + 1) * 8 + 15) & ~(size_t)15;

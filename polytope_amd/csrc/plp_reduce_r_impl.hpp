@@ -68,6 +68,22 @@ __device__ __forceinline__ uint64_t spread_rows(uint64_t x) {
     return out;
 }
 
+
+// In-run count of the LPs that ran the simplex (plp_reduce_counters): the tile's sum of `v` over its lane-group leaders
+// goes to the device counter with one atomic (ctr is a kernel argument: the branch is wave-uniform).  Two's-complement
+// adds: negative contributions (the LPs the presolve settles, subtracted from the reference count) wrap as they should.
+__device__ __forceinline__ void ctr_add(unsigned long long* ctr, int v, bool leader) {
+    if (ctr) {
+        int s = leader ? v : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        // one of PLP_CTR_SLOTS words, 64 B apart, picked by the workgroup: a single word took every tile of a launch
+        // through one L2 atomic unit (measured: +17 % on the bench kernel); the reader sums the slots
+        if ((threadIdx.x & 63) == 0)
+            atomicAdd(ctr + (size_t)(blockIdx.x & (PLP_CTR_SLOTS - 1)) * 8, (unsigned long long)(long long)s);
+    }
+}
+
 #ifndef PLP_REDUCE_R_WAVES
 // Waves per SIMD the register allocator must leave room for.  Measured at d=3 (100k polytopes, m=16)
 // with the fast pivot path (no general engine in this kernel: 132 VGPRs unconstrained):
@@ -250,7 +266,7 @@ __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int RSH = R == 8 ? 3 : (R == 4 ? 2 : (R == 2 ? 1 : 0));  // log2(R)
     static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows per lane");
@@ -757,6 +773,7 @@ __device__ __forceinline__ void reduce_r_tile(
                 {   // rows the presolve settles as "keep" need no LP (lane i = row i: the ballot is the row mask)
                     const uint64_t cert = __ballot((f2_presolve<D, 1>(myA, myb, myan, row0, m_max, lloc & 1u, abs_tol) & 1u) != 0u);
                     keep |= cert;
+                    ctr_add(ctr, -__popcll(cert), g.gl == 0);
                     todo &= ~(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(cert >> 32)) << 32) |
                               (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cert));
                 }
@@ -806,6 +823,7 @@ __device__ __forceinline__ void reduce_r_tile(
                 for (int k = 0; k < R; ++k) cert |= spread_rows<R, GS>(grp_ballot(((okb >> k) & 1u) != 0u, g)) << k;
                 keep |= cert;
                 todo &= ~cert;
+                ctr_add(ctr, -__popcll(cert), g.gl == 0);
             }
 #endif
             SimplexR<D, R, false, false> S;
@@ -1060,6 +1078,7 @@ __device__ __forceinline__ void reduce_r_tile(
             flags_out[pg] = retry ? (int)RF_RETRY : flags;
             nlp_out[pg] = nlp;
         }
+        ctr_add(ctr, nlp, valid & (g.gl == 0) & (!SPLIT || grp == 0));   // every LP the reference issues, less the presolved ones
     }
 }
 
@@ -1081,9 +1100,9 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_ker
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     reduce_r_tile<D, 64, 1, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
-                                  r_out, xc_out, nlp_out);
+                                  r_out, xc_out, nlp_out, ctr);
 }
 
 // The same with the F3 / F2 LPs on the one-LP-per-wavefront DENSE engine (plp_wide.hpp: wide::solve_dense): the
@@ -1093,9 +1112,9 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     reduce_r_tile<D, 64, 1, true, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                                               flags_out, r_out, xc_out, nlp_out);
+                                               flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
 template <int D>
@@ -1108,10 +1127,10 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     const char* wd = getenv("PLP_REDUCE_WDENSE");
     if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD))
         hipLaunchKernelGGL((reduce_wdense_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
-                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
     else
         hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
-                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
     return 0;
 }
 
@@ -1121,9 +1140,9 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_split_ke
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     reduce_r_tile<D, GS, R, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                                         flags_out, r_out, xc_out, nlp_out);
+                                         flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
 // Batches up to this size take the latency form.  Measured (device time per call, batch form -> latency form): (16,3)
@@ -1142,9 +1161,9 @@ __global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : (R == 2 && 
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     reduce_r_tile<D, GS, R>((long long)blockIdx.x * (RBLOCK / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                            flags_out, r_out, xc_out, nlp_out);
+                            flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
 // Polytopes of up to 16 rows: the first `nbig` workgroups take tiles of 16 polytopes (4 lanes x 4 rows each), the rest
@@ -1156,13 +1175,13 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_mix_ke
     int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
     if ((int)blockIdx.x < nbig)
         reduce_r_tile<D, 4, 4>((long long)blockIdx.x * (RBLOCK / 4), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                               flags_out, r_out, xc_out, nlp_out);
+                               flags_out, r_out, xc_out, nlp_out, ctr);
     else
         reduce_r_tile<D, 8, 2>((long long)nbig * (RBLOCK / 4) + (long long)((int)blockIdx.x - nbig) * (RBLOCK / 8), B, m_max,
-                               Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out);
+                               Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
 template <int D, int GS, int R = RR>
@@ -1184,7 +1203,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
         if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= PLP_REDUCE_SPLIT_MAXB(D, GS))) {
             const size_t sm1 = (((size_t)GS * R * (D + 2) + 2 * D + 2) * 8 + 15) & ~(size_t)15;
             hipLaunchKernelGGL((reduce_split_kernel<D, GS, R>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), sm1, st, B, m_max,
-                               A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                               A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
             return 0;
         }
     }
@@ -1204,7 +1223,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
             const long long nsmall = (B + NG / 2 - 1) / (NG / 2);
             const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
             hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)nsmall), dim3(RBLOCK), smem > smem2 ? smem : smem2, st,
-                               0, B, m_max, A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                               0, B, m_max, A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
             return 0;
         }
         if (tail_tiles > 0 && tail_tiles < blocks && blocks > 4096) {
@@ -1214,12 +1233,12 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
             const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
             hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
                                smem > smem2 ? smem : smem2, st, (int)nbig, B, m_max, A, b, mrows, abs_tol,
-                               (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                               (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
             return 0;
         }
     }
     hipLaunchKernelGGL((reduce_r_kernel<D, GS, R>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
-                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp);
+                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
     return 0;
 }
 

@@ -621,6 +621,35 @@ def test_reduce_structured_ties_golden_and_bench_shape(pa, oracle):
     assert np.array_equal(r1["keep"].cpu().numpy().view(np.uint64).ravel(), res["keep"].ravel())
 
 
+def test_reduce_simplex_run_counter(pa):
+    """plp_reduce_counters: LPs that ran the simplex in the fused reduce launches since the last reset.  Between B (F1 of
+    every polytope) and nlp.sum() (what the reference issues); repeatable; equal to nlp.sum() where no presolve runs
+    (the latency form of small batches solves every LP); the host-pointer and the device-pointer calls count alike."""
+    import torch
+    from polytope_amd import batch
+    from polytope_amd.synth import random_hpolytopes
+    batch.reduce_simplex_runs(reset=True)      # (the first call of the context switches the counting on)
+    for (m, d, B) in [(16, 3, 20000), (32, 6, 6000), (64, 8, 3000), (64, 12, 2500)]:
+        A, b = random_hpolytopes(B, m, d, seed=700 + m, bounded=True)
+        Ad, bd = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
+        batch.reduce_simplex_runs(reset=True)
+        res = pa.reduce_batch(Ad, bd)
+        n1 = batch.reduce_simplex_runs(reset=True)
+        nlp = int(res["nlp"].sum().item())
+        assert B <= n1 < nlp, (m, d, B, n1, nlp)          # random polytopes: the presolve settles most F2 LPs
+        pa.reduce_batch(Ad, bd)
+        assert batch.reduce_simplex_runs(reset=True) == n1
+        pa.reduce_batch(A, b)                              # host path (chunked upload): same launches, same count
+        assert batch.reduce_simplex_runs(reset=True) == n1
+        small = pa.reduce_batch(Ad[:200], bd[:200])
+        ns = batch.reduce_simplex_runs(reset=True)
+        if m <= 32:   # latency form (reduce_split_kernel): every LP on the simplex, no presolve
+            assert ns == int(small["nlp"].sum().item())
+        else:         # one polytope per wavefront with the presolve, as in the large batch
+            assert 200 <= ns < int(small["nlp"].sum().item())
+    assert batch.reduce_simplex_runs() == 0
+
+
 def _pyramids(B, m, d, rng):
     """Polytopes with a highly degenerate vertex: m - d - 1 facets through one apex, a simplex-like base
     below it and duplicated / nearly parallel facets: the redundancy LPs pivot degenerately at the apex
