@@ -78,6 +78,11 @@ struct plp_ctx {
     // plp_reduce_counters: device word the fused reduce kernels add their simplex-run count to (lazily allocated; the
     // kernels get nullptr until the first plp_reduce_counters call of the context, and then it costs one atomic per tile)
     unsigned long long* reduce_ctr = nullptr;
+    // plp_assign_dev (few facets): the workgroups' (max, index) partials, one grow-only buffer PER STREAM -- calls on
+    // different streams never share one, so nothing has to order them (a handful of streams per context in practice;
+    // beyond 16 the table is emptied after a device synchronisation)
+    struct StreamBuf { void* p = nullptr; size_t bytes = 0; };
+    std::unordered_map<void*, StreamBuf> as_scratch;
 };
 
 namespace {
@@ -410,6 +415,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
     if (ctx->reduce_ctr) (void)hipFree(ctx->reduce_ctr);
+    for (auto& kv : ctx->as_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
     if (ctx->qh_block) (void)hipFree(ctx->qh_block);
     if (ctx->hull_spare.full) {
@@ -878,8 +884,26 @@ int plp_assign_dev(plp_ctx* ctx, void* stream, int64_t N, int d, const double* X
         return fail(PLP_EINVAL, "NULL pointer");
     if (d > plp::MAX_D) return fail(PLP_EUNSUPPORTED, "d=%d > 16", d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
+    void* scratch = nullptr;
+    const size_t need = plp::assign_scratch_bytes(N, F);
+    if (need) {
+        if (ctx->as_scratch.size() >= 16 && !ctx->as_scratch.count(stream)) {
+            (void)hipDeviceSynchronize();
+            for (auto& kv : ctx->as_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+            ctx->as_scratch.clear();
+        }
+        plp_ctx::StreamBuf& sb = ctx->as_scratch[stream];
+        if (need > sb.bytes) {
+            if (sb.p) { (void)hipStreamSynchronize(st); (void)hipFree(sb.p); }   // (its last user ran on this stream)
+            sb.p = nullptr;
+            sb.bytes = 0;
+            if (hipMalloc(&sb.p, need + need / 2) == hipSuccess) sb.bytes = need + need / 2;
+            else (void)hipGetLastError();   // no scratch: the general kernel takes the call
+        }
+        scratch = sb.p;
+    }
     if (plp::launch_assign(N, d, X, F, normals, offsets, abs_tol, fop, dist, reinterpret_cast<long long*>(argmax),
-                           maxd, nullptr, 0, st))
+                           maxd, scratch, scratch ? ctx->as_scratch[stream].bytes : 0, st))
         return fail(PLP_EUNSUPPORTED, "assign kernel: unsupported size");
     return check_launch("assign_kernel");
 }

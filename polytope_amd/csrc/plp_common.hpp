@@ -36,6 +36,35 @@ constexpr int BLOCK = 256; // 4 waves per workgroup
 // plp_reduce_counters: the device counter is this many 8-byte words, 64 B apart (a power of two)
 constexpr int PLP_CTR_SLOTS = 1024;
 
+// np.sum(n * p) as numpy evaluates it on a contiguous vector of D doubles (the reference's quickhull distance,
+// polytope/quickhull.py:121): the products first, then add.reduce's pairwise_sum -- below 8 elements one running sum in
+// index order; from 8 on eight running sums r[j] over the blocks of eight, combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the D % 8 left-over elements one by one (oracle: np_sum_prod, pinned bit
+// for bit by tests/golden g18).  No fma: the kernels are built with -ffp-contract=off.
+template <int D>
+__host__ __device__ __forceinline__ double np_dot(const double* __restrict__ n, const double* __restrict__ x) {
+    if constexpr (D < 8) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = s + n[k] * x[k];
+        return s;
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = n[j] * x[j];
+        constexpr int BLK = D - D % 8;
+#pragma unroll
+        for (int i = 8; i < BLK; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + n[i + j] * x[i + j];
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = BLK; i < D; ++i) res = res + n[i] * x[i];
+        return res;
+    }
+}
+
 // ids of variables: 0..n-1 structural free x_j ; n+i slack of row i ; -1 phase-1 artificial
 constexpr int ID_T = -1;
 

@@ -68,10 +68,7 @@ __global__ __launch_bounds__(BLOCK) void hull_reassign_kernel(
             }
             if (__any(pooled && slot < 0)) {
                 for (int f = 0; f < fc; ++f) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) s = s + sn[f * D + k] * x[k];  // sum(n*p)  (quickhull.py:121)
-                    const double dv = s - so[f];
+                    const double dv = np_dot<D>(sn + f * D, x) - so[f];  // sum(n*p) - d  (quickhull.py:121), numpy's order
                     if (pooled && slot < 0 && dv > tol) { slot = f0 + f; dd = dv; }
                 }
             }

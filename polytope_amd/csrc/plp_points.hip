@@ -227,10 +227,7 @@ __global__ __launch_bounds__(BLOCK) void assign_kernel(long long N, const double
             }
             if (!__all(fop >= 0 || !inb)) {
                 for (int f = 0; f < fc; ++f) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) s = s + sn[f * D + k] * x[k];  // sum(n*p)  (quickhull.py:121)
-                    const double dist = s - so[f];
+                    const double dist = np_dot<D>(sn + f * D, x) - so[f];  // sum(n*p) - d  (quickhull.py:121), numpy's order
                     if (inb && fop < 0 && dist > tol) { fop = f0 + f; dd = dist; }
                 }
             }
@@ -265,11 +262,144 @@ __global__ void assign_init_kernel(int F, unsigned long long* maxbits, unsigned 
     if (f < F) { maxbits[f] = 0ull; argmax[f] = ~0ull; }
 }
 
-size_t assign_scratch_bytes(long long, int) { return 0; }
+// ---- few facets (F <= ASSIGN_SMALL_F): HBM-bound.  The kernel above ends every workgroup with one global u64 max per
+// facet -- a thousand workgroups on nine addresses, which the L2 atomic units take one at a time -- and needs a second
+// pass over all points for "first maximum wins".  Here a workgroup settles both in LDS (max of the distance bits, then
+// the lowest point index among its points that attain it) and writes ONE (max, index) pair per facet to a partials table;
+// a tiny second kernel folds the table.  No global atomics, no initialisation launch, no arg-max pass over N.
+// Measured at C5 (1 M points, d = 8, F = 9; device time per call, 50 calls back to back): general kernel 31.9 us ->
+// 21.5 us with two points per lane (one: 23.3, four: 21.7).  Also built and measured, not kept: every lane fetching one
+// quarter of four consecutive points (a quad reads 64 contiguous bytes per load instead of four 16-byte pieces 64 bytes
+// apart) with a 4 x 4 transpose over the quad by DPP quad_perm moves -- 24.0 us: as in round 3 (LDS transpose), the
+// strided row reads are not what holds the kernel back.
+constexpr int ASSIGN_SMALL_F = 64;
+
+template <int D, int PPT>
+__global__ __launch_bounds__(BLOCK) void assign_small_kernel(long long N, const double* __restrict__ X, int F,
+                                                             const double* __restrict__ normals,
+                                                             const double* __restrict__ offsets, double tol,
+                                                             int* __restrict__ fop_out, double* __restrict__ dist_out,
+                                                             unsigned long long* __restrict__ part, long long nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* sn = reinterpret_cast<double*>(smem_raw);                    // [F][D]
+    double* so = sn + (size_t)F * D;                                     // [F]
+    unsigned long long* smax = reinterpret_cast<unsigned long long*>(so + F);  // [F]
+    unsigned long long* sarg = smax + F;                                 // [F]
+    for (int idx = threadIdx.x; idx < F * D; idx += BLOCK) sn[idx] = normals[idx];
+    for (int idx = threadIdx.x; idx < F; idx += BLOCK) { so[idx] = offsets[idx]; smax[idx] = 0ull; sarg[idx] = ~0ull; }
+    const long long base = (long long)blockIdx.x * (BLOCK * PPT);
+    double x[PPT][D];
+    long long q[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        q[p] = base + (long long)p * BLOCK + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[p][k] = q[p] < N ? X[q[p] * D + k] : 0.0;
+    }
+    __syncthreads();
+    int fop[PPT];
+    double dd[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) { fop[p] = -1; dd[p] = 0.0; }
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const double dist = np_dot<D>(sn + f * D, x[p]) - so[f];   // sum(n*p) - d  (quickhull.py:121), numpy's order
+            const bool take = (q[p] < N) & (fop[p] < 0) & (dist > tol);  // the FIRST facet in list order (:224-245)
+            fop[p] = take ? f : fop[p];
+            dd[p] = take ? dist : dd[p];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        if (q[p] < N) { fop_out[q[p]] = fop[p]; dist_out[q[p]] = dd[p]; }
+        if (fop[p] >= 0) atomicMax(&smax[fop[p]], (unsigned long long)__double_as_longlong(dd[p]));  // dd > tol >= 0
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PPT; ++p)   // get_furthest keeps the first maximum (strict '<', :97-100): the lowest index
+        if (fop[p] >= 0 && (unsigned long long)__double_as_longlong(dd[p]) == smax[fop[p]])
+            atomicMin(&sarg[fop[p]], (unsigned long long)q[p]);
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += BLOCK) {
+        part[((size_t)f * nblk + blockIdx.x) * 2] = smax[f];
+        part[((size_t)f * nblk + blockIdx.x) * 2 + 1] = sarg[f];
+    }
+}
+
+// one workgroup per facet folds the workgroups' (max bits, lowest index) pairs: larger distance wins, then lower index
+__global__ __launch_bounds__(BLOCK) void assign_finish_kernel(long long nblk, const unsigned long long* __restrict__ part,
+                                                              unsigned long long* __restrict__ maxbits,
+                                                              unsigned long long* __restrict__ argmax) {
+    __shared__ unsigned long long sbits[BLOCK / 64], sidx[BLOCK / 64];
+    const int f = blockIdx.x;
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(part) + (size_t)f * nblk;
+    unsigned long long bits = 0ull, idx = ~0ull;
+    for (long long b = threadIdx.x; b < nblk; b += BLOCK) {
+        const ulonglong2 v = src[b];
+        const bool better = (v.x > bits) | ((v.x == bits) & (v.y < idx));
+        bits = better ? v.x : bits;
+        idx = better ? v.y : idx;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long v = __shfl_xor(bits, o, 64), i = __shfl_xor(idx, o, 64);
+        const bool better = (v > bits) | ((v == bits) & (i < idx));
+        bits = better ? v : bits;
+        idx = better ? i : idx;
+    }
+    if ((threadIdx.x & 63) == 0) { sbits[threadIdx.x >> 6] = bits; sidx[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < BLOCK / 64; ++w) {
+            const bool better = (sbits[w] > bits) | ((sbits[w] == bits) & (sidx[w] < idx));
+            bits = better ? sbits[w] : bits;
+            idx = better ? sidx[w] : idx;
+        }
+        maxbits[f] = bits;               // 0.0 and -1 for "no point"
+        argmax[f] = bits ? idx : ~0ull;
+    }
+}
+
+size_t assign_scratch_bytes(long long N, int F) {
+    if (F > ASSIGN_SMALL_F || N < 1) return 0;
+    const long long nblk = (N + BLOCK - 1) / BLOCK;   // (the PPT = 1 grid: the largest)
+    return (size_t)F * nblk * 16;
+}
+
+template <int D, int PPT>
+static void launch_assign_small(long long N, const double* X, int F, const double* normals, const double* offsets,
+                                double tol, int* fop, double* dist, long long* argmax, double* maxd, void* scratch,
+                                hipStream_t st) {
+    const long long nblk = (N + (long long)BLOCK * PPT - 1) / ((long long)BLOCK * PPT);
+    const size_t smem = ((size_t)F * (D + 1) + 2 * (size_t)F) * 8;
+    unsigned long long* part = static_cast<unsigned long long*>(scratch);
+    hipLaunchKernelGGL((assign_small_kernel<D, PPT>), dim3((unsigned)nblk), dim3(BLOCK), smem, st, N, X, F, normals,
+                       offsets, tol, fop, dist, part, nblk);
+    hipLaunchKernelGGL(assign_finish_kernel, dim3((unsigned)F), dim3(BLOCK), 0, st, nblk, part,
+                       reinterpret_cast<unsigned long long*>(maxd), reinterpret_cast<unsigned long long*>(argmax));
+}
 
 template <int D>
 static void launch_assign_d(long long N, const double* X, int F, const double* normals, const double* offsets,
-                            double tol, int* fop, double* dist, long long* argmax, double* maxd, hipStream_t st) {
+                            double tol, int* fop, double* dist, long long* argmax, double* maxd, void* scratch,
+                            size_t scratch_bytes, hipStream_t st) {
+    // PLP_ASSIGN_SMALL=0: the general kernel for every F (A/B, tests); PLP_ASSIGN_PPT=1|2|4: points per lane
+    const char* sm = getenv("PLP_ASSIGN_SMALL");
+    if (!(sm && sm[0] == '0') && F <= ASSIGN_SMALL_F && N >= 1 && scratch && scratch_bytes >= assign_scratch_bytes(N, F)) {
+        const char* pp = getenv("PLP_ASSIGN_PPT");
+        const int ppt = pp ? atoi(pp) : (N >= 262144 ? 2 : 1);
+        if constexpr (D <= 8) {
+            if (ppt >= 4) {
+                launch_assign_small<D, 4>(N, X, F, normals, offsets, tol, fop, dist, argmax, maxd, scratch, st);
+                return;
+            }
+        }
+        if (ppt >= 2) launch_assign_small<D, 2>(N, X, F, normals, offsets, tol, fop, dist, argmax, maxd, scratch, st);
+        else launch_assign_small<D, 1>(N, X, F, normals, offsets, tol, fop, dist, argmax, maxd, scratch, st);
+        return;
+    }
     long long blocks = (N + BLOCK - 1) / BLOCK;
     // few blocks when there are few facets (HBM/atomic bound: one global atomic per (block, facet));
     // more when the per-point facet scan dominates (VALU bound from F ~ 32 on)
@@ -293,11 +423,11 @@ static void launch_assign_d(long long N, const double* X, int F, const double* n
     hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)blocks2), dim3(BLOCK), 0, st, N, fop, dist, mb, am);
 }
 
-#define PLP_CASE_A(K) case K: launch_assign_d<K>(N, X, F, normals, offsets, abs_tol, fop, dist, argmax, maxd, st); break;
+#define PLP_CASE_A(K) case K: launch_assign_d<K>(N, X, F, normals, offsets, abs_tol, fop, dist, argmax, maxd, scratch, scratch_bytes, st); break;
 
 int launch_assign(long long N, int d, const double* X, int F, const double* normals, const double* offsets,
-                  double abs_tol, int* fop, double* dist, long long* argmax, double* maxd, void*, size_t,
-                  hipStream_t st) {
+                  double abs_tol, int* fop, double* dist, long long* argmax, double* maxd, void* scratch,
+                  size_t scratch_bytes, hipStream_t st) {
     if (d < 1 || d > MAX_D || F < 1 || N < 0 || !(abs_tol >= 0.0)) return 2;
     switch (d) {
         PLP_CASE_A(1) PLP_CASE_A(2) PLP_CASE_A(3) PLP_CASE_A(4) PLP_CASE_A(5) PLP_CASE_A(6)

@@ -34,6 +34,7 @@ Sets:
   g16_partition.npz  Partition.is_cover / are_disjoint / refines / preserves, MetricPartition.compute_adj on box grids,
                    triangles, multi-member regions, a non-cover and overlapping sets  (prop2partition.py:46-306)
   g17_structured.npz  reduce() keep masks on structured (16,3) polytopes: ties, duplicates, tangent rows, corner cuts (:1053-1163)
+  g18_distance_order.npz  quickhull distance() at d = 7..16, bitwise: numpy's sum keeps 8 partial sums from 8 elements on (quickhull.py:117-121)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -1105,7 +1106,44 @@ def gen_g17():
     print("g17:", len(A), "structured polytopes; empty", int(empty.sum()), "mean kept", keep.sum(1).mean())
 
 
+# ----------------------------------------------------------------------------- G18
+def gen_g18():
+    """distance() (quickhull.py:117-121) where numpy's sum changes its order of additions: below 8 elements np.sum
+    adds in index order, from 8 on it keeps eight partial sums (pairwise_sum).  Distances of 4096 points to the d + 1
+    facets of a start simplex at d = 7, 8, 9, 12, 16, to be matched BIT FOR BIT; first-facet assignment (:224-245) and
+    furthest point (:87-102) with them."""
+    rng = np.random.default_rng(18)
+    out = {}
+    for d in (7, 8, 9, 12, 16):
+        S = rng.standard_normal((d + 1, d))
+        xc = S.mean(axis=0)
+        S0 = S - xc
+        facets = [qh.Facet(S0[np.setdiff1d(np.arange(d + 1), [i]), :]) for i in range(d + 1)]
+        normals = np.array([np.asarray(f.normal).ravel() for f in facets])
+        offsets = np.array([float(np.asarray(f.distance).ravel()[0]) for f in facets])
+        N = 4096
+        X = rng.standard_normal((N, d)) * 1.5 - xc
+        dist_all = np.array([[float(qh.distance(X[q], f)) for f in facets] for q in range(N)])
+        fop = np.full(N, -1, np.int32)
+        dist = np.zeros(N)
+        for q in range(N):
+            hit = np.nonzero(dist_all[q] > 1e-7)[0]
+            if hit.size:
+                fop[q], dist[q] = hit[0], dist_all[q, hit[0]]
+        argmax = np.full(d + 1, -1, np.int64)
+        for fi, f in enumerate(facets):
+            idx = [q for q in range(N) if fop[q] == fi]
+            f.outside = [qh.Outside_point(X[q], dist[q]) for q in idx]
+            if idx:
+                pfar = f.get_furthest()
+                argmax[fi] = [q for q in idx if np.array_equal(X[q], pfar.coordinates)][0]
+        out.update({f"d{d}_normals": normals, f"d{d}_offsets": offsets, f"d{d}_X": X, f"d{d}_distall": dist_all,
+                    f"d{d}_fop": fop, f"d{d}_dist": dist, f"d{d}_argmax": argmax})
+    np.savez_compressed(os.path.join(HERE, "g18_distance_order.npz"), **out)
+    print("g18: distances at d = 7, 8, 9, 12, 16 (numpy's pairwise order from 8 elements on)")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     for w in which:
         globals()["gen_" + w]()

@@ -1193,13 +1193,35 @@ def test_assign_golden(pa, d):
     g = load_golden("g6_quickhull.npz")
     res = pa.assign_batch(g[f"d{d}_X"], g[f"d{d}_normals"], g[f"d{d}_offsets"], 1e-7)
     assert np.array_equal(res["facet"], g[f"d{d}_fop"])
-    assert np.allclose(res["dist"], g[f"d{d}_dist"], atol=1e-13, rtol=0)
+    assert np.array_equal(res["dist"], g[f"d{d}_dist"])   # bit for bit (numpy's order of additions at d = 8)
     assert np.array_equal(res["argmax"], g[f"d{d}_argmax"])
+
+
+@pytest.mark.parametrize("d", [7, 8, 9, 12, 16])
+def test_assign_distance_order_golden(pa, d, monkeypatch):
+    """g18: the reference's distances (np.sum(n * p) - d0, quickhull.py:117-121) BIT FOR BIT where numpy's sum changes its
+    order of additions (eight partial sums from 8 elements on), first-facet assignment and furthest point -- on the
+    few-facets kernel with one, two and four points per lane and on the general kernel."""
+    g = load_golden("g18_distance_order.npz")
+    X, nrm, off = g[f"d{d}_X"], g[f"d{d}_normals"], g[f"d{d}_offsets"]
+    for env in ({}, {"PLP_ASSIGN_PPT": "1"}, {"PLP_ASSIGN_PPT": "2"}, {"PLP_ASSIGN_PPT": "4"}, {"PLP_ASSIGN_SMALL": "0"}):
+        for k in ("PLP_ASSIGN_PPT", "PLP_ASSIGN_SMALL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        import torch
+        for res in (pa.assign_batch(X, nrm, off, 1e-7),
+                    {k: v.cpu().numpy() for k, v in pa.assign_batch(torch.as_tensor(X).cuda(), torch.as_tensor(nrm).cuda(),
+                                                                    torch.as_tensor(off).cuda(), 1e-7).items()}):
+            assert np.array_equal(res["facet"], g[f"d{d}_fop"]), env
+            assert np.array_equal(res["dist"], g[f"d{d}_dist"]), env
+            assert np.array_equal(res["argmax"], g[f"d{d}_argmax"]), env
 
 
 def test_assign_vs_oracle(pa, oracle):
     from polytope_amd.synth import quickhull_workload
-    for (N, d, F) in [(100000, 8, 9), (5000, 3, 4), (30000, 8, 64), (20000, 4, 600), (1000, 16, 17)]:
+    for (N, d, F) in [(100000, 8, 9), (5000, 3, 4), (30000, 8, 64), (20000, 4, 600), (1000, 16, 17), (300001, 8, 9),
+                      (70001, 8, 33), (65, 8, 9), (1, 8, 2), (40000, 12, 13), (40000, 9, 65)]:
         X, nrm, off = quickhull_workload(N, d=d, F=F, seed=F)
         X[N // 2] = X[N // 3]  # exact tie of distances: the first maximum must win
         fo, do_, am, mx = oracle.assign(X, nrm, off, 1e-7)
