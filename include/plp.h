@@ -244,6 +244,19 @@ int plp_overlap_pairs(plp_ctx *ctx, int n, int m_max, int d, const double *A, co
 int plp_overlap_pairs_dev(plp_ctx *ctx, void *stream, int n, int m_max, int d, const double *A,
                           const double *b, const int32_t *m, double abs_tol, uint8_t *out);
 /*
+ * Cross pairs of TWO lists of cells held in one table (the first n1 cells, then n2 cells; A[n1+n2][m_max][d] ...):
+ * out[a * n2 + c] = 1 iff the stack [cell a of the first list; cell c of the second] has a Chebyshev radius > thresh
+ * (status 0), else 0.  Replaces: the scan region_diff opens with, one Chebyshev LP per cell of the subtrahend
+ * (polytope/polytope.py:2148-2158), repeated by mldivide for every member of the minuend (:1484-1496) and by
+ * Partition.refines for every pair of elements (prop2partition.py:194-207) -- here all n1 * n2 LPs in one launch, the
+ * stacked rows formed on the device from the resident table.  2 * m_max <= 64, d <= 16.
+ */
+int plp_overlap_cross(plp_ctx *ctx, int n1, int n2, int m_max, int d, const double *A, const double *b,
+                      const int32_t *m, double thresh, uint8_t *out);
+int plp_overlap_cross_dev(plp_ctx *ctx, void *stream, int n1, int n2, int m_max, int d, const double *A,
+                          const double *b, const int32_t *m, double thresh, uint8_t *out);
+
+/*
  * plp_adjacent_pairs for a slice of the pair space (one rank's shard when the O(n^2) loop is split across
  * GPUs): pairs pair_lo <= p < pair_hi in the order p = i (i - 1) / 2 + j, j < i; out[p - pair_lo].
  */

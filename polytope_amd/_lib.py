@@ -57,6 +57,8 @@ SIGNATURES = {
     "plp_adjacent_pairs_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "plp_overlap_pairs": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "plp_overlap_pairs_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
+    "plp_overlap_cross": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
+    "plp_overlap_cross_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp]),
     "plp_adjacent_pairs_range": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, C.c_int64,
                                            C.c_int64, _vp]),
     "plp_adjacent_pairs_range_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double,

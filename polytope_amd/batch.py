@@ -39,6 +39,18 @@ def _finite_or_raise(what, *arrays):
             raise ValueError("%s: input must not contain values inf, nan, or None" % what)
 
 
+# Debug counter: bytes the host-pointer entry points of this module handed to the library for upload (and the bytes
+# polytope_amd.polytope moved to the device when it made a packed table resident).  Device-pointer calls add nothing.
+h2d_bytes = 0
+
+
+def _count_h2d(*arrays):
+    global h2d_bytes
+    for a in arrays:
+        if a is not None:
+            h2d_bytes += int(a.nbytes)
+
+
 def _torch_stream_ctx(t):
     import torch
     dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
@@ -89,6 +101,7 @@ def lpsolve_batch(c, G, h, m=None):
     fun = np.empty(B)
     status = np.empty(B, np.int32)
     iters = np.empty(B, np.int32)
+    _count_h2d(c, G, h, mm)
     _lib.check(lib.plp_lp_solve_batch(_lib.context().handle, B, m_max, n, _ptr(c), _ptr(G), _ptr(h), _ptr(mm),
                                       _ptr(x), _ptr(fun), _ptr(status), _ptr(iters)), "plp_lp_solve_batch")
     return dict(status=status, x=x, fun=fun, iters=iters)
@@ -123,6 +136,7 @@ def cheby_ball_batch(A, b, m=None):
     r = np.empty(B)
     xc = np.empty((B, d))
     status = np.empty(B, np.int32)
+    _count_h2d(A, b, mm)
     _lib.check(lib.plp_cheby_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), _ptr(r),
                                    _ptr(xc), _ptr(status)), "plp_cheby_batch")
     return dict(r=r, xc=xc, status=status)
@@ -158,6 +172,7 @@ def bbox_batch(A, b, m=None):
     lb = np.empty((B, d))
     ub = np.empty((B, d))
     status = np.empty(B, np.int32)
+    _count_h2d(A, b, mm)
     _lib.check(lib.plp_bbox_batch(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), _ptr(lb),
                                   _ptr(ub), _ptr(status)), "plp_bbox_batch")
     return dict(lb=lb, ub=ub, status=status)
@@ -226,6 +241,7 @@ def reduce_batch(A, b, m=None, abs_tol=1e-7, out=None):
     xc = np.empty((B, d))
     nlp = np.empty(B, np.int32)
     fn, name = (lib.plp_reduce_wide_batch, "plp_reduce_wide_batch") if wide else (lib.plp_reduce_batch, "plp_reduce_batch")
+    _count_h2d(A, b, mm)
     _lib.check(fn(_lib.context().handle, B, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
                   _ptr(keep), _ptr(flags), _ptr(r), _ptr(xc), _ptr(nlp)), name)
     return dict(keep=keep, flags=flags, r=r, xc=xc, nlp=nlp)
@@ -291,6 +307,7 @@ def contains_batch(A, b, X, abs_tol=1e-7, m=None, region=True):
     N = X.shape[1]
     mm = None if m is None else _np(m, np.int32).reshape(P)
     out = np.zeros((N,) if region else (P, N), np.uint8)
+    _count_h2d(A, b, mm, X)
     _lib.check(lib.plp_contains(_lib.context().handle, P, m_max, d, _ptr(A), _ptr(b), _ptr(mm), N, _ptr(X),
                                 float(abs_tol), mode, _ptr(out)), "plp_contains")
     return out
@@ -326,6 +343,7 @@ def assign_batch(X, normals, offsets, abs_tol=1e-7):
     dist = np.empty(N)
     am = np.empty(F, np.int64)
     mx = np.empty(F)
+    _count_h2d(X, normals, offsets)
     _lib.check(lib.plp_assign(_lib.context().handle, N, d, _ptr(X), F, _ptr(normals), _ptr(offsets), float(abs_tol),
                               _ptr(fop), _ptr(dist), _ptr(am), _ptr(mx)), "plp_assign")
     return dict(facet=fop, dist=dist, argmax=am, maxd=mx)
@@ -425,6 +443,7 @@ def adjacent_pairs(A, b, m=None, abs_tol=1e-7):
     mm = None if m is None else _np(m, np.int32).reshape(n)
     _finite_or_raise("adjacent_pairs", A, b)
     adj = np.zeros((n, n), np.uint8)
+    _count_h2d(A, b, mm)
     _lib.check(lib.plp_adjacent_pairs(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
                                       _ptr(adj)), "plp_adjacent_pairs")
     return adj
@@ -451,8 +470,37 @@ def overlap_pairs(A, b, m=None, abs_tol=1e-7):
     mm = None if m is None else _np(m, np.int32).reshape(n)
     _finite_or_raise("overlap_pairs", A, b)
     out = np.zeros((n, n), np.uint8)
+    _count_h2d(A, b, mm)
     _lib.check(lib.plp_overlap_pairs(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(abs_tol),
                                      _ptr(out)), "plp_overlap_pairs")
+    return out
+
+
+def overlap_cross(A, b, n1, m=None, thresh=1e-7):
+    """uint8[n1, n - n1]: 1 where the stack [cell a; cell c] of cell a < n1 of the table and cell c >= n1 has a Chebyshev
+    radius > thresh -- the opening scan of region_diff (polytope.py:2148-2158) for every (minuend member, subtrahend
+    cell) pair at once.  A[n, m_max, d], b[n, m_max]; 2 * m_max <= 64, d <= 16."""
+    lib = _lib.load()
+    n1 = int(n1)
+    if _is_torch(A):
+        torch, ctx, stream = _torch_stream_ctx(A)
+        A = _tprep(torch, A, torch.float64)
+        b = _tprep(torch, b, torch.float64)
+        m = _tprep(torch, m, torch.int32)
+        n, m_max, d = A.shape
+        out = torch.empty((n1, n - n1), dtype=torch.uint8, device=A.device)
+        _lib.check(lib.plp_overlap_cross_dev(ctx.handle, stream, n1, n - n1, m_max, d, _ptr(A), _ptr(b), _ptr(m),
+                                             float(thresh), _ptr(out)), "plp_overlap_cross_dev")
+        return out
+    A = _np(A)
+    n, m_max, d = A.shape
+    b = _np(b).reshape(n, m_max)
+    mm = None if m is None else _np(m, np.int32).reshape(n)
+    _finite_or_raise("overlap_cross", A, b)
+    out = np.zeros((n1, n - n1), np.uint8)
+    _count_h2d(A, b, mm)
+    _lib.check(lib.plp_overlap_cross(_lib.context().handle, n1, n - n1, m_max, d, _ptr(A), _ptr(b), _ptr(mm), float(thresh),
+                                     _ptr(out)), "plp_overlap_cross")
     return out
 
 
@@ -477,6 +525,7 @@ def adjacent_pairs_range(A, b, pair_lo, pair_hi, m=None, abs_tol=1e-7):
     mm = None if m is None else _np(m, np.int32).reshape(n)
     _finite_or_raise("adjacent_pairs_range", A, b)
     out = np.zeros(max(hi - lo, 0), np.uint8)
+    _count_h2d(A, b, mm)
     _lib.check(lib.plp_adjacent_pairs_range(_lib.context().handle, n, m_max, d, _ptr(A), _ptr(b), _ptr(mm),
                                             float(abs_tol), lo, hi, _ptr(out)), "plp_adjacent_pairs_range")
     return out
@@ -507,6 +556,7 @@ def region_diff_search(A, b, m, mi, abs_tol=1e-7):
         raise ValueError("region_diff_search: table must have m + 2 * sum(mi) rows")
     _finite_or_raise("region_diff_search", A, b)
     h = C.c_void_p()
+    _count_h2d(A, b)
     _lib.check(lib.plp_region_diff_search(_lib.context().handle, d, int(m), int(mi.size), _ptr(mi), _ptr(A), _ptr(b),
                                           float(abs_tol), C.byref(h)), "plp_region_diff_search")
     try:

@@ -1243,6 +1243,48 @@ int plp_overlap_pairs(plp_ctx* ctx, int n, int m_max, int d, const double* A, co
     return PLP_OK;
 }
 
+int plp_overlap_cross_dev(plp_ctx* ctx, void* stream, int n1, int n2, int m_max, int d, const double* A, const double* b,
+                          const int32_t* m, double thresh, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n1 < 0 || n2 < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (n1 == 0 || n2 == 0) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    if (2 * m_max > plp::MAX_M || d > plp::MAX_D)
+        return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (2*m_max<=64, d<=16)", m_max, d);
+    if ((long long)n1 + n2 > 2147483647ll) return fail(PLP_EUNSUPPORTED, "too many cells");
+    if (plp::launch_adjacent(n1 + n2, m_max, d, A, b, m, 0.0, thresh, nullptr, 0, (long long)n1 * n2, out,
+                             (hipStream_t)stream, n1))
+        return fail(PLP_EUNSUPPORTED, "adjacent kernel: unsupported size");
+    return check_launch("adjacent_r_kernel");
+}
+
+int plp_overlap_cross(plp_ctx* ctx, int n1, int n2, int m_max, int d, const double* A, const double* b, const int32_t* m,
+                      double thresh, uint8_t* out) {
+    if (!ctx) return fail(PLP_EINVAL, "ctx is NULL");
+    if (n1 < 0 || n2 < 0 || m_max < 1 || d < 1) return fail(PLP_EINVAL, "bad sizes");
+    if (n1 == 0 || n2 == 0) return PLP_OK;
+    if (!A || !b || !out) return fail(PLP_EINVAL, "NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n1 + n2;
+    const size_t nA = n * m_max * d, nb = n * m_max, nout = (size_t)n1 * n2;
+    int rc = ensure_arena(ctx, pad(nA * 8) + pad(nb * 8) + pad(n * 4) + pad(nout) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    double* dA = a.take<double>(nA);
+    double* db = a.take<double>(nb);
+    int32_t* dm = a.take<int32_t>(n);
+    uint8_t* dout = a.take<uint8_t>(nout);
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(db, b, nb * 8, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(hipMemcpyAsync(dm, m, n * 4, hipMemcpyHostToDevice, st));
+    rc = plp_overlap_cross_dev(ctx, st, n1, n2, m_max, d, dA, db, m ? dm : nullptr, thresh, dout);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PLP_OK;
+}
+
 int plp_adjacent_pairs_range_dev(plp_ctx* ctx, void* stream, int n, int m_max, int d, const double* A,
                                  const double* b, const int32_t* m, double abs_tol, int64_t pair_lo,
                                  int64_t pair_hi, uint8_t* out) {

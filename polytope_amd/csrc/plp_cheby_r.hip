@@ -49,7 +49,7 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 template <int D, int GS>
 static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
                               double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                              hipStream_t st) {
+                              int cross_n1, hipStream_t st) {
     constexpr long long gpb = RBLK / GS;
     long long blocks = (p_hi - p_lo + gpb - 1) / gpb;
     const long long bdiag = compact ? 0 : ((long long)n + RBLK - 1) / RBLK;
@@ -57,28 +57,29 @@ static int launch_adjacent_dg(int n, int m_max, const double* A, const double* b
     if (blocks < 1) blocks = 1;
     if (blocks > 2147483647ll) return 2;
     hipLaunchKernelGGL((adjacent_r_kernel<D, GS>), dim3((unsigned)blocks), dim3(RBLK), 0, st, n, m_max, A, b, mrows,
-                       inflate, thresh, adj, p_lo, p_hi, compact, force_retry_env());
+                       inflate, thresh, adj, p_lo, p_hi, compact, force_retry_env(), cross_n1);
     return 0;
 }
 
 template <int D>
 static int launch_adjacent_d(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
                              double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                             hipStream_t st) {
+                             int cross_n1, hipStream_t st) {
     const int rows = 2 * m_max;
     PLP_DISPATCH_GS(RowsPerLane<D>::value, rows,
-                    (launch_adjacent_dg<D, GSV>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st)));
+                    (launch_adjacent_dg<D, GSV>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, cross_n1, st)));
 }
 
 #define PLP_CASE_ADJ(K) \
-    case K: return launch_adjacent_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+    case K: return launch_adjacent_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, cross_n1, st);
 
 // compact == nullptr: all pairs into the n x n matrix adj; else pairs [p_lo, p_hi) into compact[p - p_lo]
 int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
                     double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                    hipStream_t st) {
+                    hipStream_t st, int cross_n1) {
     if (n < 0 || m_max < 1 || 2 * m_max > MAX_M || d < 1 || d > MAX_D) return 2;
-    const long long npairs = (long long)n * (n - 1) / 2;
+    if (cross_n1 < 0 || cross_n1 > n || (cross_n1 > 0 && !compact)) return 2;
+    const long long npairs = cross_n1 > 0 ? (long long)cross_n1 * (n - cross_n1) : (long long)n * (n - 1) / 2;
     if (!compact) { p_lo = 0; p_hi = npairs; }
     if (p_lo < 0 || p_hi > npairs || p_lo > p_hi) return 2;
     if (n == 0 || (compact && p_lo == p_hi)) return 0;
@@ -88,7 +89,7 @@ int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, c
         const char* aw = getenv("PLP_ADJ_WIDE");
         const bool wide = d > 8 || (aw ? aw[0] == '1' : (d >= 5 && (2 * m_max > 32 || p_hi - p_lo <= 4096)));
         if (wide && !(aw && aw[0] == '0' && d <= 8) &&
-            launch_adjacent_w(n, m_max, d, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st) == 0)
+            launch_adjacent_w(n, m_max, d, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st, cross_n1) == 0)
             return 0;
     }
     switch (d) {

@@ -312,7 +312,7 @@ template <int D, int GS>
 __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     int n, int m_max, const double* __restrict__ A, const double* __restrict__ b, const int* __restrict__ mrows,
     double inflate, double thresh, unsigned char* __restrict__ adj, long long p_lo, long long p_hi,
-    unsigned char* __restrict__ compact, int force_retry) {
+    unsigned char* __restrict__ compact, int force_retry, int cross_n1) {
     const Grp g(GS);
     constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
@@ -320,11 +320,17 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void adjacent_r_kernel(
     const int row0 = g.gl * R;
     const long long p = p_lo + (long long)blockIdx.x * gpb + gib;
     const bool valid = p < p_hi;
-    // p -> (i, j) with j < i, p = i (i - 1) / 2 + j
+    // p -> (i, j) with j < i, p = i (i - 1) / 2 + j;  cross pairs (cross_n1 > 0, compact only): the table holds two lists,
+    // n1 cells then n - n1 cells, and p = a (n - n1) + c pairs cell a of the first with cell c of the second
     long long i = valid ? (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5) : 1;
     while (i * (i - 1) / 2 > p) --i;
     while ((i + 1) * i / 2 <= p) ++i;
-    const long long j = valid ? p - i * (i - 1) / 2 : 0;
+    long long j = valid ? p - i * (i - 1) / 2 : 0;
+    if (cross_n1 > 0) {
+        const long long n2 = n - cross_n1;
+        i = valid ? p / n2 : 0;
+        j = valid ? cross_n1 + (p - i * n2) : 0;
+    }
     const int mi = valid ? (mrows ? mrows[i] : m_max) : 0;
     const int mj = valid ? (mrows ? mrows[j] : m_max) : 0;
     double x[D + 1];

@@ -74,14 +74,16 @@ int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const doubl
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8) into the n x n matrix adj (compact == nullptr),
 // or of the pairs p_lo <= p < p_hi, p = i (i - 1) / 2 + j, j < i, into compact[p - p_lo]
 // a pair counts iff the Chebyshev radius of the two stacked cells, each b inflated by `inflate`, exceeds `thresh`
+// cross_n1 > 0 (compact only): the table holds two lists, n1 cells then n - n1 cells, and pair p = a (n - n1) + c is cell a
+// of the first list stacked on cell c of the second (p_lo <= p < p_hi within [0, n1 (n - n1)))
 int launch_adjacent(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
                     double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                    hipStream_t st);
+                    hipStream_t st, int cross_n1 = 0);
 
 // the same, one pair per wavefront (d = 5..16, plp_wide.hip); returns 1 when it does not apply
 int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
                       double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                      hipStream_t st);
+                      hipStream_t st, int cross_n1 = 0);
 
 // Device counter (or nullptr) the fused reduce kernels of the calling thread add their simplex-run count to: set by
 // plp_reduce_batch_dev from the context around the launch (plp_reduce_counters reads it back)

@@ -166,7 +166,8 @@ template <int D>
 __global__ __launch_bounds__(64) void adjacent_w_kernel(int n, int m_max, const double* __restrict__ A,
                                                         const double* __restrict__ b, const int* __restrict__ mrows,
                                                         double inflate, double thresh, unsigned char* __restrict__ adj,
-                                                        long long p_lo, long long p_hi, unsigned char* __restrict__ compact) {
+                                                        long long p_lo, long long p_hi, unsigned char* __restrict__ compact,
+                                                        int cross_n1) {
     constexpr int NC = D + 1;
     __shared__ WideShared<NC> sh;
     const int lane = threadIdx.x;
@@ -180,7 +181,12 @@ __global__ __launch_bounds__(64) void adjacent_w_kernel(int n, int m_max, const 
     long long i = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
     while (i * (i - 1) / 2 > p) --i;
     while ((i + 1) * i / 2 <= p) ++i;
-    const long long j = p - i * (i - 1) / 2;
+    long long j = p - i * (i - 1) / 2;
+    if (cross_n1 > 0) {   // two lists in one table (see adjacent_r_kernel): cell i of the first with cell j of the second
+        const long long n2 = n - cross_n1;
+        i = p / n2;
+        j = cross_n1 + (p - i * n2);
+    }
     const int mi = mrows ? mrows[i] : m_max;
     const int mj = mrows ? mrows[j] : m_max;
     const int m = mi + mj;
@@ -233,24 +239,24 @@ __global__ __launch_bounds__(64) void adjacent_w_kernel(int n, int m_max, const 
 template <int D>
 static int launch_adjacent_w_d(int n, int m_max, const double* A, const double* b, const int* mrows, double inflate,
                                double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                               hipStream_t st) {
+                               int cross_n1, hipStream_t st) {
     long long blocks = p_hi - p_lo;
     const long long bdiag = compact ? 0 : ((long long)n + 63) / 64;
     if (blocks < bdiag) blocks = bdiag;
     if (blocks < 1) blocks = 1;
     if (blocks > 2147483647ll) return 2;
     hipLaunchKernelGGL((adjacent_w_kernel<D>), dim3((unsigned)blocks), dim3(64), 0, st, n, m_max, A, b, mrows, inflate, thresh,
-                       adj, p_lo, p_hi, compact);
+                       adj, p_lo, p_hi, compact, cross_n1);
     return 0;
 }
 
 #define PLP_CASE_AW(K) \
-    case K: return launch_adjacent_w_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, st);
+    case K: return launch_adjacent_w_d<K>(n, m_max, A, b, mrows, inflate, thresh, adj, p_lo, p_hi, compact, cross_n1, st);
 
 // pairs [p_lo, p_hi) of n cells, 2 * m_max <= 64, d = 5..16; returns 1 when it does not apply
 int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b, const int* mrows, double inflate,
                       double thresh, unsigned char* adj, long long p_lo, long long p_hi, unsigned char* compact,
-                      hipStream_t st) {
+                      hipStream_t st, int cross_n1) {
     switch (d) {
         PLP_CASE_AW(5) PLP_CASE_AW(6) PLP_CASE_AW(7) PLP_CASE_AW(8) PLP_CASE_AW(9) PLP_CASE_AW(10)
         PLP_CASE_AW(11) PLP_CASE_AW(12) PLP_CASE_AW(13) PLP_CASE_AW(14) PLP_CASE_AW(15) PLP_CASE_AW(16)

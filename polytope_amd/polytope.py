@@ -290,7 +290,7 @@ class Region(object):
             points = np.array(points)
         if points.shape[0] != self.dim:
             raise ValueError("points should be column vectors")
-        return _contains_many(self.list_poly, points, abs_tol, region=True)
+        return _contains_many(self.list_poly, points, abs_tol, region=True, owner=self)
 
     def __eq__(self, other):
         return self <= other and other <= self
@@ -409,7 +409,56 @@ def _pack(polys):
     return A, b, ms
 
 
-def _contains_many(polys, points, abs_tol, region=True):
+class _PackedTable(object):
+    """(A, b, m) of a list of polytopes packed once, and -- on the 'hip' backend -- resident on the device from the first
+    call that needs it there: `dev()` returns the torch CUDA tensors the `*_batch` entry points take as they are (device
+    pointers on torch's stream: nothing is packed or uploaded again).  polytope_amd.batch.h2d_bytes counts the upload."""
+    __slots__ = ("A", "b", "ms", "_dev", "_refs")
+
+    def __init__(self, polys):
+        self.A, self.b, self.ms = _pack(polys)
+        self._dev = None
+        self._refs = [(p.A, p.b) for p in polys]   # the key's arrays stay alive: their ids cannot be handed out again
+
+    def dev(self):
+        if self._dev is None:
+            import torch
+            from . import batch, _lib
+            dev = torch.device("cuda", _lib.context().device)
+            batch._count_h2d(self.A, self.b, self.ms)
+            self._dev = tuple(torch.as_tensor(v).to(dev) for v in (self.A, self.b, self.ms))
+        return self._dev
+
+
+_tables = {}          # key (identity of the members' arrays) -> _PackedTable, most recently used last
+_TABLES_MAX = 8
+
+
+def _table_of(polys, owner=None):
+    """Packed table of a list of non-empty polytopes of one dimension.  Kept on `owner` (a Region: `_packed`) or in a small
+    most-recently-used cache, keyed by the IDENTITY of the members' A / b arrays: a list that changes (members added,
+    removed, replaced, arrays reassigned) gets a new table; arrays edited in place are not noticed -- the same rule as the
+    reference's own caches (bbox, chebR, fulldim: ref :139-147, never invalidated)."""
+    key = tuple((id(p.A), id(p.b)) for p in polys)
+    if owner is not None:
+        hit = getattr(owner, "_packed", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    tab = _tables.pop(key, None)
+    if tab is None:
+        tab = _PackedTable(polys)
+        while len(_tables) >= _TABLES_MAX:
+            _tables.pop(next(iter(_tables)))
+    _tables[key] = tab
+    if owner is not None:
+        try:
+            owner._packed = (key, tab)
+        except AttributeError:  # pragma: no cover
+            pass
+    return tab
+
+
+def _contains_many(polys, points, abs_tol, region=True, owner=None):
     points = np.asarray(points, dtype=float)
     if _use_hip():
         solvers._require("hip")
@@ -421,6 +470,15 @@ def _contains_many(polys, points, abs_tol, region=True):
         if polys[0].A.shape[1] > _MAX_DIM:
             raise ValueError("the 'hip' backend handles dimension <= %d, got %d" % (_MAX_DIM, polys[0].A.shape[1]))
         from .batch import contains_batch
+        if owner is not None and len(polys) >= 8:
+            # a Region asked again and again (volume(), point-in-region queries): its rows stay on the device
+            import torch
+            At, bt, mt = _table_of(polys, owner).dev()
+            pts = np.ascontiguousarray(points)
+            from . import batch as _b
+            _b._count_h2d(pts)
+            Xt = torch.as_tensor(pts).to(At.device)
+            return contains_batch(At, bt, Xt, abs_tol, m=mt, region=True).cpu().numpy().astype(bool)
         A, b, ms = _pack(polys)
         return contains_batch(A, b, np.ascontiguousarray(points), abs_tol, m=ms, region=True).astype(bool)
     # explicitly selected non-'hip' backend: the reference's own numpy expression (ref :217-218)
@@ -835,6 +893,8 @@ def _members(s):
 # for convexity again and again.  The verdict is a pure function of the members' (A, b), so it is kept.
 _convex_memo = {}
 _CONVEX_MEMO_MAX = 50000
+_hull_memo = {}          # ordered group of members (content) -> the merged convex piece of union(check_convex=True)
+_HULL_MEMO_MAX = 20000
 
 
 def _content_key(p):
@@ -893,9 +953,19 @@ def union(polyreg1, polyreg2, check_convex=False):
             if not convex:
                 group.pop()
         lst = [p for p in lst if not any(p is q for q in group)]
-        hull = reduce(envelope(Region(group)))
-        if not is_empty(hull):
-            final.append(reduce(hull))
+        # The merged piece is a pure function of the group's members (envelope + reduce of their rows), and the repeated
+        # union of Region.intersect / mldivide (ref :815-830, :1484-1496) meets the same groups at every step: kept like
+        # the convexity verdicts above (Region(1000 cells).intersect(P): 656 envelopes and 844 reduce calls without).
+        hkey = tuple(_content_key(m) for m in group)
+        piece = _hull_memo.get(hkey)
+        if piece is None:
+            hull = reduce(envelope(Region(group)))
+            piece = reduce(hull) if not is_empty(hull) else hull
+            if len(_hull_memo) >= _HULL_MEMO_MAX:
+                _hull_memo.clear()
+            _hull_memo[hkey] = piece
+        if not is_empty(piece):
+            final.append(piece)
     return Region(final)
 
 
@@ -1005,22 +1075,29 @@ def mldivide(a, b, save=False):
     if isinstance(a, Region):
         out = Region()
         subs = b.list_poly
-        # the subtrahends' rows, packed once for the per-minuend screening batches below (stacking 1000 small arrays
-        # per minuend was a third of is_subset(200 cells, 1000 cells))
+        # Which subtrahends touch which member of the minuend at all?  A subtrahend whose intersection with `poly` has
+        # radius < ABS_TOL leaves `poly` -- and every piece cut from it later -- unchanged (region_diff returns its
+        # minuend when nothing intersects, ref :2154-2158), so the chain below skips it.  On the 'hip' backend the
+        # Chebyshev LPs of ALL (member, subtrahend) stacks are one launch over the resident rows of both regions
+        # (plp_overlap_cross); shapes the pair kernels do not take are screened member by member (one batch each).
         live_all = [c for c in subs if c.A.size]
+        mine = [p for p in a if not is_empty(p)]
+        touch = None
         packed = None
-        if _use_hip() and len(live_all) > 1 and len({c.A.shape for c in live_all}) == 1:
-            packed = (np.stack([c.A for c in live_all]), np.stack([c.b for c in live_all]))
+        if _use_hip() and len(subs) > 1 and mine:
+            touch = _cross_touch(mine, live_all, a, b)
+            if touch is None and len(live_all) > 1 and len({c.A.shape for c in live_all}) == 1:
+                packed = (np.stack([c.A for c in live_all]), np.stack([c.b for c in live_all]))
+        row = 0
         for poly in a:
-            # Which subtrahends touch this polytope at all?  One batch of Chebyshev LPs on the stacked rows
-            # instead of one region_diff call per subtrahend: a subtrahend whose intersection with `poly` has
-            # radius < ABS_TOL leaves `poly` -- and every piece cut from it later -- unchanged (region_diff
-            # returns its minuend when nothing intersects, ref :2154-2158), so the chain below skips it.
             touching = subs
             if _use_hip() and len(subs) > 1 and not is_empty(poly):
-                live = live_all
-                keep = iter(_radii_stacked(poly, live, packed))
-                touching = [c for c in subs if not c.A.size or next(keep) >= ABS_TOL]
+                if touch is not None:
+                    keep = iter(touch[row])
+                    row += 1
+                else:
+                    keep = iter(r >= ABS_TOL for r in _radii_stacked(poly, live_all, packed))
+                touching = [c for c in subs if not c.A.size or next(keep)]
             rest = poly
             for sub in touching:
                 rest = mldivide(rest, sub, save=save)
@@ -1029,6 +1106,34 @@ def mldivide(a, b, save=False):
     if isinstance(a, Polytope):
         return region_diff(a, b)
     raise Exception("a neither Region nor Polytope")
+
+
+def _cross_touch(firsts, seconds, owner1=None, owner2=None):
+    """bool[len(firsts), len(seconds)]: does the stack [first; second] have a Chebyshev radius >= ABS_TOL -- the opening scan
+    of region_diff (ref :2148-2158) for every pair, one launch over the two lists' resident rows; None when the pair
+    kernels do not take the shapes (more than 32 rows in a member, differing dimensions, too many pairs for one matrix)."""
+    if not firsts or not seconds:
+        return np.zeros((len(firsts), len(seconds)), dtype=bool)
+    d = firsts[0].A.shape[1]
+    if not (1 <= d <= _MAX_DIM) or any(p.A.shape[1] != d or not 1 <= p.A.shape[0] <= 32 for p in firsts + seconds):
+        return None
+    if len(firsts) * len(seconds) > (1 << 28):
+        return None
+    import torch
+    from .batch import overlap_cross
+    A1, b1, m1 = _table_of(firsts, owner1).dev()
+    A2, b2, m2 = _table_of(seconds, owner2).dev()
+    mm = max(A1.shape[1], A2.shape[1])
+
+    def widen(A, b):
+        if A.shape[1] == mm:
+            return A, b
+        return (torch.nn.functional.pad(A, (0, 0, 0, mm - A.shape[1])), torch.nn.functional.pad(b, (0, mm - b.shape[1])))
+    A1, b1 = widen(A1, b1)
+    A2, b2 = widen(A2, b2)
+    got = overlap_cross(torch.cat([A1, A2]), torch.cat([b1, b2]), len(firsts), m=torch.cat([m1, m2]),
+                        thresh=float(np.nextafter(ABS_TOL, 0.0)))   # r > pred(ABS_TOL)  <=>  r >= ABS_TOL
+    return got.cpu().numpy().astype(bool)
 
 
 def _radii_stacked(poly, others, packed=None):

@@ -60,29 +60,50 @@ def _device_pairs_ok(members):
     return 1 <= d <= 16 and all(p.A.shape[1] == d and 1 <= p.A.shape[0] <= 32 for p in members)
 
 
-def _fold_members(M, first):
-    """Member-pair matrix -> region-pair matrix: region (i, j) is set iff some member pair is (the `any` over member
-    polytopes of is_adjacent, ref polytope.py:1843-1853, and of Region.intersect, :815-830)."""
-    n = len(first) - 1
-    have = np.nonzero(first[1:] > first[:-1])[0]
-    out = np.zeros((n, n), dtype=bool)
-    if have.size:
-        starts = first[have]
-        R = np.maximum.reduceat(np.maximum.reduceat(M != 0, starts, axis=0), starts, axis=1)
-        out[np.ix_(have, have)] = R
-    return out
-
-
-def _pair_matrix_device(regions, kind, abs_tol):
-    """All member pairs of all regions as one batch of stacked Chebyshev LPs formed on the device, folded to the
-    regions; None when the pair kernels do not take the shapes (the callers then go pair by pair)."""
+def _pair_list_device(regions, kind, abs_tol):
+    """All member pairs of all regions as one batch of stacked Chebyshev LPs formed on the device, folded to the regions:
+    (rows, cols) of the region pairs (i != j, both orders, sorted by row then column) for which SOME member pair is set
+    (the `any` over member polytopes of is_adjacent, ref polytope.py:1843-1853, and of Region.intersect, :815-830);
+    None when the pair kernels do not take the shapes (the callers then go pair by pair).  The members' rows are
+    packed and uploaded once (polytope._table_of): a second call on the same regions -- the adjacency after the
+    disjointness check, compute_adj against a previous matrix -- moves no input bytes; the n x n result stays on the
+    device and only the indices of its nonzeros come back."""
     members, first = _members_of(regions)
     if not _device_pairs_ok(members):
         return None
+    import torch
     from . import batch
-    A, b, ms = pc._pack(members)
+    At, bt, mt = pc._table_of(members).dev()
     fn = batch.adjacent_pairs if kind == "adjacent" else batch.overlap_pairs
-    return _fold_members(fn(A, b, m=ms, abs_tol=abs_tol), first)
+    nz = torch.nonzero(fn(At, bt, m=mt, abs_tol=abs_tol)).cpu().numpy()     # member pairs, row-major order
+    r, c = nz[:, 0], nz[:, 1]
+    if len(members) != len(regions) or np.any(np.diff(first) != 1):
+        owner = np.repeat(np.arange(len(regions)), np.diff(first))
+        r, c = owner[r], owner[c]
+        code = np.unique(r * len(regions) + c)
+        r, c = code // len(regions), code % len(regions)
+    off = r != c
+    return r[off], c[off]
+
+
+def _lil_from_pairs(n, r, c, dtype, diagonal=True):
+    """lil_matrix with ones at (r, c) (sorted by row, then column) and on the diagonal, built from its row lists (the
+    constructor from a dense array walks all n^2 entries)."""
+    if diagonal:
+        code = np.unique(np.concatenate([r * n + c, np.arange(n) * (n + 1)]))
+        r, c = code // n, code % n
+    L = sp.lil_matrix((n, n), dtype=dtype)
+    ends = np.cumsum(np.bincount(r, minlength=n)).tolist()
+    cols = c.tolist()
+    one = np.dtype(dtype).type(1).item()
+    rows, data = np.empty(n, dtype=object), np.empty(n, dtype=object)
+    start = 0
+    for k, e in enumerate(ends):
+        rows[k] = cols[start:e]
+        data[k] = [one] * (e - start)
+        start = e
+    L.rows, L.data = rows, data
+    return L
 
 
 def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL):
@@ -91,10 +112,10 @@ def adjacency_matrix_dense(regions, abs_tol=pc.ABS_TOL):
     adj = np.eye(n, dtype=np.int8)
     if n < 2:
         return adj
-    got = _pair_matrix_device(regions, "adjacent", abs_tol)
+    got = _pair_list_device(regions, "adjacent", abs_tol)
     if got is not None:
         # the stacked, abs_tol-inflated pair LPs (polytope.py:1860-1866) are formed on the device
-        adj |= got.astype(np.int8)
+        adj[got[0], got[1]] = 1
         return adj
     ii, jj = np.tril_indices(n, -1)
     flags = pc.is_adjacent_pairs([(regions[i], regions[j]) for i, j in zip(ii, jj)], abs_tol=abs_tol)
@@ -113,9 +134,10 @@ def overlap_matrix_dense(regions, abs_tol=pc.ABS_TOL):
     over = np.eye(n, dtype=bool)
     if n < 2:
         return over
-    got = _pair_matrix_device(regions, "overlap", abs_tol)
+    got = _pair_list_device(regions, "overlap", abs_tol)
     if got is not None:
-        return over | got
+        over[got[0], got[1]] = True
+        return over
     stacks, owner = [], []
     for i in range(n):
         li = regions[i].list_poly if isinstance(regions[i], pc.Region) else [regions[i]]
@@ -138,11 +160,23 @@ def touch_matrix(smalls, bigs, abs_tol=pc.ABS_TOL):
     """len(smalls) x len(bigs) bool: does some member of smalls[i] meet some member of bigs[j] in a set of Chebyshev
     radius > abs_tol -- the scan region_diff opens with (ref polytope.py:2148-2158), for every pair at once; None when
     the device pair kernels do not take the shapes."""
-    both = list(smalls) + list(bigs)
-    got = _pair_matrix_device(both, "overlap", abs_tol)
+    if solvers.default_solver != "hip":
+        return None
+    m1, f1 = _members_of(smalls)
+    m2, f2 = _members_of(bigs)
+    if abs_tol != pc.ABS_TOL:
+        return None
+    got = pc._cross_touch(m1, m2)
     if got is None:
         return None
-    return got[:len(smalls), len(smalls):]
+    # fold the member pairs to the elements (any member pair)
+    n1, n2 = len(f1) - 1, len(f2) - 1
+    out = np.zeros((n1, n2), dtype=bool)
+    h1 = np.nonzero(f1[1:] > f1[:-1])[0]
+    h2 = np.nonzero(f2[1:] > f2[:-1])[0]
+    if h1.size and h2.size:
+        out[np.ix_(h1, h2)] = np.maximum.reduceat(np.maximum.reduceat(got, f1[h1], axis=0), f2[h2], axis=1)
+    return out
 
 
 def are_disjoint(partition, check_all=False):
@@ -165,7 +199,7 @@ def compute_adj(partition, previous=None):
     """Adjacency matrix from scratch and its comparison with a previous one, as
     MetricPartition.compute_adj does (ref :244-306) -> (adj lil_matrix, ok)."""
     regions = _regions_of(partition)
-    adj = sp.lil_matrix(adjacency_matrix_dense(regions).astype(float))
+    adj = _adjacency_lil(regions, float)
     ok = True
     if previous is not None:
         new, old = adj.toarray() != 0, sp.lil_matrix(previous).toarray() != 0
@@ -180,14 +214,21 @@ def compute_adj(partition, previous=None):
     return adj, ok
 
 
+def _adjacency_lil(regions, dtype):
+    n = len(regions)
+    got = _pair_list_device(regions, "adjacent", pc.ABS_TOL) if n >= 2 else None
+    if got is not None:
+        return _lil_from_pairs(n, got[0], got[1], dtype)
+    return sp.lil_matrix(adjacency_matrix_dense(regions).astype(dtype))
+
+
 def find_adjacent_regions(partition):
     """Return region pairs that are spatially adjacent, as the reference does.
 
     @type partition: iterable container of L{Region} (anything with `.regions`, or a list)
     @rtype: scipy.sparse.lil_matrix (n x n, int8, ones on the diagonal)
     """
-    regions = _regions_of(partition)
-    return sp.lil_matrix(adjacency_matrix_dense(regions))
+    return _adjacency_lil(_regions_of(partition), np.int8)
 
 
 ################################
@@ -330,7 +371,7 @@ class MetricPartition(Partition):
         """
         regions = list(self.regions)
         logger.info("computing adjacency from scratch...")
-        adj = sp.lil_matrix(adjacency_matrix_dense(regions).astype(float))
+        adj = _adjacency_lil(regions, float)
         logger.info("...done computing adjacency.")
         ok = True
         if self.adj is not None:

@@ -788,3 +788,59 @@ def test_intersect_and_reduce_beyond_64_rows(pc, monkeypatch):
         assert np.allclose(R.A, g["c%d_A" % k], atol=1e-9, rtol=0) and np.allclose(R.b, g["c%d_b" % k], atol=1e-9, rtol=0)
         assert bool(R.minrep) == bool(g["c%d_minrep" % k])
         assert abs(float(pc.cheby_ball(R)[0]) - float(g["c%d_r" % k])) <= TOL
+
+
+# ------------------------------------------------------------------ resident tables, cross pairs (hip only)
+@pytest.mark.gpu
+def test_cross_pairs_and_resident_tables():
+    """plp_overlap_cross against the one-batch-per-member scan it replaces (the opening scan of region_diff, ref
+    :2148-2158, for every (member, cell) pair), on boxes and random polytopes with ragged row counts, d = 2..9; then the
+    packed tables: a Region's rows go to the device once (batch.h2d_bytes stands still on the second call)."""
+    import itertools
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers, batch, prop2partition as p2p
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    try:
+        rng = np.random.default_rng(5)
+        for d, n1, n2 in [(2, 7, 40), (4, 30, 200), (6, 5, 33), (9, 4, 21)]:
+            def rand_cell():
+                lo = rng.random(d) * (2 if d <= 4 else 0.6)
+                w = 0.3 + rng.random(d)
+                box = pc.box2poly([[a, a + ww] for a, ww in zip(lo, w)])
+                k = int(rng.integers(0, 4))
+                if k == 0:
+                    return box
+                R = rng.standard_normal((k, d))
+                R /= np.linalg.norm(R, axis=1)[:, None]
+                c = lo + w / 2
+                return pc.Polytope(np.vstack([box.A, R]), np.hstack([box.b, R @ c + 0.2 * rng.random(k)]))
+            firsts = [rand_cell() for _ in range(n1)]
+            seconds = [rand_cell() for _ in range(n2)]
+            got = pc._cross_touch(firsts, seconds)
+            want = np.array([[r >= pc.ABS_TOL for r in pc._radii_stacked(p, seconds)] for p in firsts])
+            assert got.shape == (n1, n2) and np.array_equal(got, want), (d, np.argwhere(got != want)[:5])
+            assert got.sum() < got.size and (d > 4 or got.sum() > 0)
+        # mldivide / is_subset over the screening: the 4-D grid, 60 cells against all 200
+        shape = (5, 5, 4, 2)
+        cells = [pc.box2poly([[i[k] / shape[k], (i[k] + 1) / shape[k]] for k in range(4)])
+                 for i in itertools.product(*[range(n) for n in shape])]
+        big = pc.Region(cells)
+        assert pc.is_subset(pc.Region(cells[:60]), big)
+        shifted = pc.Region([c.translation(np.array([0.9, 0.0, 0.0, 0.0])) for c in cells[:20]])
+        assert not pc.is_subset(shifted, big)
+        # resident rows: the second query uploads the points only; adjacency twice uploads nothing the second time
+        pts = rng.random((4, 5000))
+        inside = big.contains(pts)
+        h0 = batch.h2d_bytes
+        assert np.array_equal(big.contains(pts), inside) and inside.all()
+        assert batch.h2d_bytes - h0 == pts.nbytes
+        regs = [pc.Region([c]) for c in cells]
+        adj = p2p.adjacency_matrix_dense(regs)
+        h0 = batch.h2d_bytes
+        assert np.array_equal(p2p.adjacency_matrix_dense(regs), adj)
+        assert batch.h2d_bytes == h0
+        regs[3] = pc.Region([cells[3].copy()])          # a member replaced: a new table
+        assert np.array_equal(p2p.adjacency_matrix_dense(regs), adj) and batch.h2d_bytes > h0
+    finally:
+        solvers.default_solver = old
