@@ -51,6 +51,14 @@ struct plp_ctx {
     double* rd_tab = nullptr;    // the constraint table A | b (device)
     size_t rd_tab_bytes = 0;
     unsigned long long rd_seq = 0;
+    // the search's resident LP server (plp_rdiff.hip: rdiff_server_kernel): host-mapped mailbox / records / results block,
+    // its device view, the device-side state words, the sequence number of the last batch
+    char* rd_srv = nullptr;
+    char* rd_srv_dev = nullptr;
+    unsigned long long* rd_srv_state = nullptr;
+    unsigned long long rd_srv_seq = 0;    // batches issued so far
+    unsigned long long rd_srv_word = 0;   // mailbox word of the last batch that was answered
+    unsigned long long rd_srv_init[4] = {0, 0, 0, 0};
     // containment: per-row thresholds of the comparison form (plp_points.hip), a grow-only buffer
     void* mf_buf = nullptr;
     size_t mf_bytes = 0;
@@ -411,6 +419,8 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->rd_pin) (void)hipHostFree(ctx->rd_pin);
+    if (ctx->rd_srv) (void)hipHostFree(ctx->rd_srv);
+    if (ctx->rd_srv_state) (void)hipFree(ctx->rd_srv_state);
     if (ctx->rd_out) (void)hipFree(ctx->rd_out);
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
@@ -1468,6 +1478,71 @@ struct RadiusOracle {
     long long n_lps = 0, n_batches = 0;
     long long n_lps_long = 0, n_batches_long = 0;  // LPs of more than 64 rows (LDS engine) / batches that hold at least one (stats)
     double t_launch = 0.0, t_wait = 0.0;  // seconds spent enqueueing / waiting for the device (PLP_RDIFF_STATS=1 prints them)
+    // ---- resident LP server (d <= 4; PLP_RDIFF_SERVER=0: every batch a launch, as in round 3)
+    static constexpr size_t SRV_MAXLP = 2048, SRV_OUT = 128, SRV_REC = SRV_OUT + SRV_MAXLP * 16;
+    static constexpr size_t SRV_BYTES = SRV_REC + SRV_MAXLP * 66 * 4;
+    static constexpr unsigned long long SRV_EXIT = ~0ull;
+    bool srv_on = false, srv_running = false;
+    long long n_srv_batches = 0, n_srv_starts = 0;
+    volatile unsigned long long* srv_mail() { return reinterpret_cast<volatile unsigned long long*>(ctx->rd_srv); }
+    volatile unsigned long long* srv_done() { return reinterpret_cast<volatile unsigned long long*>(ctx->rd_srv + 64); }
+    int srv_init() {
+        const char* e = getenv("PLP_RDIFF_SERVER");
+        if ((e && e[0] == '0') || d > 4) return PLP_OK;
+        if (!ctx->rd_srv) {
+            char *hp = nullptr, *hp_dev = nullptr;
+            unsigned long long* st8 = nullptr;
+            hipError_t err = hipHostMalloc(reinterpret_cast<void**>(&hp), SRV_BYTES, hipHostMallocMapped | hipHostMallocCoherent);
+            if (err == hipSuccess) err = hipHostGetDevicePointer(reinterpret_cast<void**>(&hp_dev), hp, 0);
+            if (err == hipSuccess) err = hipMalloc(reinterpret_cast<void**>(&st8), 64);
+            if (err != hipSuccess) {
+                if (hp) (void)hipHostFree(hp);
+                (void)hipGetLastError();
+                return PLP_OK;   // no server: the launch path serves the search
+            }
+            memset(hp, 0, 128);
+            ctx->rd_srv = hp;
+            ctx->rd_srv_dev = hp_dev;
+            ctx->rd_srv_state = st8;
+            ctx->rd_srv_seq = 0;
+            ctx->rd_srv_word = 0;
+        }
+        srv_on = true;
+        return PLP_OK;
+    }
+    // last: the sequence number of the last batch that was answered.  pending: batch last + 1 is in the mailbox already
+    // (the server retired while it was on its way) -- the new server finds it there; else the mailbox says "nothing new".
+    int srv_start(unsigned long long last, bool pending) {
+        if (!pending) __atomic_store_n(srv_mail(), last, __ATOMIC_RELEASE);
+        __atomic_store_n(srv_done() + 1, 1ull, __ATOMIC_RELEASE);
+        ctx->rd_srv_init[0] = ctx->rd_srv_init[2] = ctx->rd_srv_init[3] = 0ull;   // word 0: "retire" flag
+        ctx->rd_srv_init[1] = last;                                                // word 1: the mailbox as the device republishes it
+        HIP_TRY(hipMemcpyAsync(ctx->rd_srv_state, ctx->rd_srv_init, 32, hipMemcpyHostToDevice, ctx->stream));
+        const char* ip = getenv("PLP_RDIFF_SERVER_IDLE");
+        const unsigned idle = ip ? (unsigned)atoi(ip) : 1500u;   // empty mailbox polls (~2 us each) before it retires
+        const char* wg = getenv("PLP_RDIFF_SERVER_WGS");
+        // workgroups (one wavefront each: 4 / 2 / 1 lists per round).  Measured at config 4 (751 batches, ~120 lists each, a
+        // few of up to 2048): waiting for the device 22.4 / 16.6 / 14.1 / 12.7 / 12.3 ms with 32 / 64 / 128 / 256 / 1024
+        // (the launch path: 4.3 ms of launches + 11.3 ms of waiting)
+        const int nwg = wg ? atoi(wg) : 256;
+        if (plp::launch_rdiff_server(d, nwg < 1 ? 1 : nwg, reinterpret_cast<const unsigned long long*>(ctx->rd_srv_dev),
+                                     reinterpret_cast<const int*>(ctx->rd_srv_dev + SRV_REC),
+                                     ctx->rd_srv_dev + SRV_OUT,
+                                     reinterpret_cast<unsigned long long*>(ctx->rd_srv_dev + 64 + 8), ctx->rd_srv_state, dA, dB,
+                                     last, idle, ctx->stream))
+            return fail(PLP_EUNSUPPORTED, "region_diff: no LP server for d=%d", d);
+        int rc = check_launch("rdiff_server");
+        if (rc) return rc;
+        srv_running = true;
+        ++n_srv_starts;
+        return PLP_OK;
+    }
+    void srv_stop() {
+        if (!srv_running) return;
+        __atomic_store_n(srv_mail(), SRV_EXIT, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(ctx->stream);
+        srv_running = false;
+    }
 
     int init(plp_ctx* c, int d_, long long nrows_, const double* A, const double* b) {
         ctx = c; d = d_; nrows = nrows_;
@@ -1516,10 +1591,10 @@ struct RadiusOracle {
         HIP_TRY(hipMemcpyAsync(dA, A, (size_t)nrows * d * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dB, b, (size_t)nrows * 8, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        return PLP_OK;
+        return srv_init();
     }
     void release() {
-        if (ctx) { (void)hipStreamSynchronize(ctx->stream); ctx->rd_seq = seq; }
+        if (ctx) { srv_stop(); (void)hipStreamSynchronize(ctx->stream); ctx->rd_seq = seq; }
     }
     // queue the list base[0..nb) + suf[0..ns) (key given) for the next batch unless known or queued already
     // `required`: the search cannot continue without this radius; only speculative lists are subject to the bound
@@ -1574,6 +1649,62 @@ struct RadiusOracle {
                 max_len = len > max_len ? len : max_len;
                 cnt[cls_of(len)]++;
             }
+            if (srv_on && n <= SRV_MAXLP && !cnt[3] && !cnt[4]) {
+                // ---- the resident server takes the batch: records by size class, header, sequence word; spin on done_seq
+                const auto tp0 = std::chrono::steady_clock::now();
+                int32_t* rec = reinterpret_cast<int32_t*>(ctx->rd_srv + SRV_REC);
+                int32_t* rc_[3] = {rec, rec + (size_t)cnt[0] * 18, rec + (size_t)cnt[0] * 18 + (size_t)cnt[1] * 34};
+                static const int cap_[3] = {16, 32, 64};
+                for (size_t k = 0; k < n; ++k) {
+                    const int len = off[k + 1] - off[k];
+                    const int c = cls_of(len);
+                    int32_t* r = rc_[c];
+                    r[0] = (int32_t)k;
+                    r[1] = len;
+                    memcpy(r + 2, prow.data() + base0 + off[k], (size_t)len * 4);
+                    rc_[c] = r + cap_[c] + 2;
+                }
+                if (!srv_running || __atomic_load_n(srv_done() + 1, __ATOMIC_ACQUIRE) == 0ull) {
+                    if (srv_running) { (void)hipStreamSynchronize(ctx->stream); srv_running = false; }   // it retired (idle)
+                    int rc = srv_start(ctx->rd_srv_word, false);
+                    if (rc) return rc;
+                }
+                // one word: [batch number : 28 | n2 : 12 | n1 : 12 | n0 : 12] (never 0, never all ones)
+                const unsigned long long last_word = ctx->rd_srv_word;
+                ctx->rd_srv_seq = (ctx->rd_srv_seq % 0xffffff0ull) + 1ull;
+                const unsigned long long sq = (ctx->rd_srv_seq << 36) | ((unsigned long long)cnt[2] << 24) |
+                                              ((unsigned long long)cnt[1] << 12) | (unsigned long long)cnt[0];
+                __atomic_store_n(srv_mail(), sq, __ATOMIC_RELEASE);
+                const auto tp1 = std::chrono::steady_clock::now();
+                // every radius arrives beside the batch's word (one 16-byte store of the lane group that solved it)
+                const volatile unsigned long long* sres = reinterpret_cast<const volatile unsigned long long*>(ctx->rd_srv + SRV_OUT);
+                unsigned long long spins = 0;
+                for (size_t k = 0; k < n;) {
+                    if (__atomic_load_n(&sres[2 * k + 1], __ATOMIC_ACQUIRE) == sq) { ++k; continue; }
+                    if ((++spins & 0x3fffull) == 0ull) {
+                        if (__atomic_load_n(srv_done() + 1, __ATOMIC_ACQUIRE) == 0ull) {
+                            // the server retired while the batch was on its way (or part of it did the batch and part did
+                            // not): start it again, it finds the batch in the mailbox and solves it (again)
+                            (void)hipStreamSynchronize(ctx->stream);
+                            int rc = srv_start(last_word, true);
+                            if (rc) return rc;
+                        }
+                        if (spins > 4000000000ull) return fail(PLP_EHIP, "region_diff: the LP server did not answer batch %llu", sq);
+                    }
+                }
+                const auto tp2 = std::chrono::steady_clock::now();
+                t_launch += std::chrono::duration<double>(tp1 - tp0).count();
+                t_wait += std::chrono::duration<double>(tp2 - tp1).count();
+                ctx->rd_srv_word = sq;
+                const double* sout = reinterpret_cast<const double*>(ctx->rd_srv + SRV_OUT);
+                for (size_t k = 0; k < n; ++k) memo.put(pkey[done + k], sout[2 * k]);
+                n_lps += (long long)n;
+                n_batches += 1;
+                n_srv_batches += 1;
+                done += n;
+                continue;
+            }
+            srv_stop();   // (a batch the server does not take: the launches below queue behind it on the same stream)
             size_t start[5], fill[5];
             start[0] = 0;
             for (int c = 1; c < 5; ++c) start[c] = start[c - 1] + cnt[c - 1];
@@ -1931,9 +2062,9 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     res->n_lps = R.n_lps;
     res->n_batches = R.n_batches;
     if (getenv("PLP_RDIFF_STATS"))
-        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms; beyond 64 rows: %lld LPs in %lld batches\n",
+        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms; beyond 64 rows: %lld LPs in %lld batches; resident server: %lld batches, %lld starts\n",
                 R.n_lps, R.n_batches, res->n_scan_miss, res->n_node_miss, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3,
-                R.n_lps_long, R.n_batches_long);
+                R.n_lps_long, R.n_batches_long, R.n_srv_batches, R.n_srv_starts);
     R.release();
     if (rc == PLP_OK && bad_index) rc = fail(PLP_EINVAL, "region_diff: row index out of range (the reference raises IndexError here)");
     if (rc) { delete res; return rc; }

@@ -33,6 +33,10 @@ size_t lds_lp_bytes(int m_max, int nc);  // 0: does not fit
 // of the batch; out[p] = radius as cheby_ball reads it (0 unless optimal with r >= 0).  plp_rdiff.hip / plp_lds.hip
 int launch_cheby_gather_r(int d, long long n0, long long n1, long long n2, const int* off, const int* rows, const int* sel,
                           const double* A, const double* b, double* out, hipStream_t st);
+// the LP server of a region_diff search (plp_rdiff.hip, d <= 4): one resident launch, batches through a host-mapped mailbox
+int launch_rdiff_server(int d, int nwg, const unsigned long long* mail, const int* rec, void* out, unsigned long long* alive,
+                        unsigned long long* dstate, const double* A, const double* b, unsigned long long last_word,
+                        unsigned idle_polls, hipStream_t st);
 void launch_rdiff_publish(long long n, const double* src, double* host_out, unsigned long long* host_flag,
                           unsigned long long seq, hipStream_t st);
 // lists of at most 64 rows, d = 5..16: one LP per wavefront (plp_wide.hip); returns 1 when it does not apply

@@ -128,6 +128,129 @@ int launch_cheby_gather_r(int d, long long n0, long long n1, long long n2, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The LP server of a search (d <= 4): ONE launch stays resident for the whole search and takes batch after batch from a
+// host-mapped mailbox, so a visited node costs neither a kernel launch, nor the dispatch gap to a publish kernel, nor a
+// chain of dependent reads across PCIe, nor a fence -- what remained of a node after round 3 (launches 4 ms + device wait
+// 11 ms of a 23 ms search at config 4: ~15 us of launch, dispatch and index chasing around ~6 us of pivots).
+//   mailbox: ONE 64-bit word  [batch number : 28 | n2 : 12 | n1 : 12 | n0 : 12]  (a single store on the host, a single
+//            load on the device: the list counts cannot be seen apart from the batch they belong to)
+//   records, by size class (<= 16 / 32 / 64 rows), fixed stride:   [position in the batch | length | rows ...]
+//   results: 16 bytes per LP, [radius | mailbox word], stored straight into host memory, the word after the radius was
+//            acknowledged -- the host knows a radius is there when the word beside it is the batch's (no completion
+//            counter, no system-scope fence on the device:
+//            a first version had both and lost to the launches it replaced, 18.5 ms against 15.6 ms of waiting).
+// Every wait is bounded: after `idle_polls` empty polls of the mailbox workgroup 0 retires the server (a device word the
+// others look at between polls; the host relaunches it when the next batch comes), and a host that wants it gone writes
+// RD_EXIT.
+constexpr unsigned long long RD_EXIT = ~0ull;
+
+template <int D, int GS>
+__device__ __forceinline__ void server_slot(int slot, int n, const int* __restrict__ rec, int cap,
+                                            const double* __restrict__ A, const double* __restrict__ b,
+                                            ulonglong2* __restrict__ out_host, unsigned long long word, int force_retry) {
+    const Grp g(GS);
+    constexpr int gpb = 64 / GS;
+    const int q = slot * gpb + (int)threadIdx.x / GS;
+    const bool valid = q < n;
+    const int* r = rec + (size_t)(valid ? q : 0) * (cap + 2);
+    // The record is read with system-scope loads: a plain load may be served from a cache line this resident kernel
+    // fetched for an EARLIER batch (nothing invalidates the caches between batches; a first version read stale rows).
+    // One read across PCIe per lane, all in flight together.
+    int p = 0, m = 0, myrow = 0;
+    if (valid) {
+        p = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        m = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        myrow = __hip_atomic_load(r + 2 + (g.gl < cap ? g.gl : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        myrow = g.gl < m ? myrow : 0;
+    }
+    double x[D + 1];
+    const int st = cheby_r_solve<D, GS, 1>(
+        g, valid, m, g.gl, [&](int, int kk) { return A[(long long)myrow * D + kk]; }, [&](int) { return b[myrow]; }, x,
+        force_retry);
+    if (valid & (g.gl == 0)) {
+        const double rad = st != ST_OPT ? __builtin_nan("") : (x[D] >= 0.0 ? x[D] : 0.0);
+        // Written through to system memory at once (system-scope stores: a plain store to host memory may sit in the L2
+        // until the kernel ends -- and this kernel does not end).  The radius first; the word beside it only after the
+        // radius store has been acknowledged (one 16-byte store arrived torn: new word, old radius).
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(out_host + p);
+        __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(rad), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(dst + 1, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void rdiff_server_kernel(const unsigned long long* __restrict__ mail_host,
+                                                          const int* __restrict__ rec_host,
+                                                          ulonglong2* __restrict__ out_host,
+                                                          unsigned long long* __restrict__ alive_host,
+                                                          unsigned long long* __restrict__ dstate,
+                                                          const double* __restrict__ A, const double* __restrict__ b,
+                                                          unsigned long long last_word, unsigned idle_polls, int force_retry) {
+    const int wg = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
+    unsigned long long seen = last_word;
+    unsigned polls = 0;
+    for (;;) {
+        // Only workgroup 0 polls the mailbox across PCIe and republishes it in device memory, where the others look: with
+        // every workgroup polling the host the reads queue up behind each other (scripts/microbench/mailbox_latency.hip:
+        // a round trip of 1.7 us with up to 16 pollers, 6.5 us with 64 -- and the record reads wait in the same queue).
+        unsigned long long w = 0ull, e = 0ull;
+        if (lane == 0) {
+            if (wg == 0) {
+                w = __hip_atomic_load(mail_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w != seen && w != RD_EXIT) __hip_atomic_store(dstate + 1, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                w = __hip_atomic_load(dstate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                e = __hip_atomic_load(dstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        w = __shfl(w, 0, 64);
+        e = __shfl(e, 0, 64);
+        if (w == RD_EXIT || e == RD_EXIT) break;
+        if (w == seen) {
+            // (workgroup 0 decides for all; the others carry a generous bound of their own so that no wait is unbounded)
+            if (++polls > (wg == 0 ? idle_polls : idle_polls * 64u + 65536u)) break;
+            if (wg != 0) __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        polls = 0;
+        seen = w;
+        const int n0 = (int)(w & 0xfffull), n1 = (int)((w >> 12) & 0xfffull), n2 = (int)((w >> 24) & 0xfffull);
+        // slots: 4 lists of <= 16 rows, 2 of <= 32 or 1 of <= 64 per wavefront
+        const int s0 = (n0 + 3) >> 2, s1 = (n1 + 1) >> 1, s2 = n2;
+        const int total = s0 + s1 + s2;
+        const int* rec0 = rec_host;
+        const int* rec1 = rec0 + (size_t)n0 * 18;
+        const int* rec2 = rec1 + (size_t)n1 * 34;
+        for (int s = wg; s < total; s += G) {
+            if (s < s0) server_slot<D, 16>(s, n0, rec0, 16, A, b, out_host, w, force_retry);
+            else if (s < s0 + s1) server_slot<D, 32>(s - s0, n1, rec1, 32, A, b, out_host, w, force_retry);
+            else server_slot<D, 64>(s - s0 - s1, n2, rec2, 64, A, b, out_host, w, force_retry);
+        }
+    }
+    if (wg == 0 && lane == 0) {
+        __hip_atomic_store(dstate, RD_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // the others follow
+        __hip_atomic_store(alive_host, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);         // retired
+    }
+}
+
+// returns 1 when there is no server for this dimension
+int launch_rdiff_server(int d, int nwg, const unsigned long long* mail, const int* rec, void* out, unsigned long long* alive,
+                        unsigned long long* dstate, const double* A, const double* b, unsigned long long last_word,
+                        unsigned idle_polls, hipStream_t st) {
+#define PLP_SRV(K)                                                                                                      \
+    case K:                                                                                                             \
+        hipLaunchKernelGGL((rdiff_server_kernel<K>), dim3((unsigned)nwg), dim3(64), 0, st, mail, rec,                    \
+                           static_cast<ulonglong2*>(out), alive, dstate, A, b, last_word, idle_polls, force_retry_env()); \
+        return 0;
+    switch (d) {
+        PLP_SRV(1) PLP_SRV(2) PLP_SRV(3) PLP_SRV(4)
+        default: return 1;
+    }
+#undef PLP_SRV
+}
+
 void launch_rdiff_publish(long long n, const double* src, double* host_out, unsigned long long* host_flag,
                           unsigned long long seq, hipStream_t st) {
     hipLaunchKernelGGL(rdiff_publish_kernel, dim3(1), dim3(256), 0, st, n, src, host_out, host_flag, seq);

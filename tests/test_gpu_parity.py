@@ -1451,6 +1451,70 @@ def test_bench_force_dist_rccl_path(pa, scaling):
     assert abs(line["config"]["lps_per_step"] - (5 * n[0] + 4 * n[1]) / 9) < 1e-6
 
 
+def test_region_diff_resident_lp_server(pa, monkeypatch):
+    """The search's LPs on the resident server (one launch per search, batches through a host-mapped mailbox,
+    rdiff_server_kernel) against a launch per batch (PLP_RDIFF_SERVER=0): the same pieces, row for row, on the 81-cell
+    grid of g12 and on random overlapping boxes in d = 2..4 -- also when the server retires between batches (an idle
+    limit of a few polls: every batch finds it gone or going and restarts it), with a single workgroup, and across
+    consecutive searches (the mailbox word carries on)."""
+    import itertools
+    import polytope_amd.polytope as pcm
+    from polytope_amd import solvers, batch
+    old, solvers.default_solver = solvers.default_solver, "hip"
+    try:
+        rng = np.random.default_rng(88)
+        cases = []
+        shape = (3, 3, 3, 3)
+        cells = [pcm.box2poly([[i[k] / 3, (i[k] + 1) / 3] for k in range(4)]) for i in itertools.product(*[range(3)] * 4)]
+        A = rng.standard_normal((10, 4))
+        A /= np.linalg.norm(A, axis=1)[:, None]
+        cases.append((pcm.Polytope(A, 0.35 + A @ (0.5 * np.ones(4))), cells))
+        for trial in range(9):
+            d = 2 + trial % 3
+            n = int(rng.integers(4, 14))
+            cen, hw = rng.random((n, d)), rng.uniform(0.05, 0.3, (n, d))
+            A = rng.standard_normal((3 * d, d))
+            A /= np.linalg.norm(A, axis=1)[:, None]
+            cases.append((pcm.Polytope(A, 0.3 * (1 + rng.random(3 * d)) + A @ (0.5 * np.ones(d))),
+                          [pcm.box2poly(np.c_[c - w, c + w].tolist()) for c, w in zip(cen, hw)]))
+        spy = {}
+        orig = batch.region_diff_search
+
+        def counted(*a, **k):
+            out = orig(*a, **k)
+            spy["batches"] = spy.get("batches", 0) + out[1]["batches"]
+            return out
+        monkeypatch.setattr(batch, "region_diff_search", counted)
+
+        def run(env):
+            for k in ("PLP_RDIFF_SERVER", "PLP_RDIFF_SERVER_IDLE", "PLP_RDIFF_SERVER_WGS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            res = []
+            for P, cs in cases:
+                try:
+                    D = pcm.region_diff(P.copy(), pcm.Region([c.copy() for c in cs]))
+                    ps = list(D.list_poly) if isinstance(D, pcm.Region) else ([] if D.A.size == 0 else [D])
+                    res.append([(q.A.copy(), q.b.copy()) for q in ps])
+                except IndexError:
+                    res.append("IndexError")
+            return res
+        want = run({"PLP_RDIFF_SERVER": "0"})
+        assert spy["batches"] > 50 and any(isinstance(w, list) and len(w) > 3 for w in want)
+        for env in ({}, {"PLP_RDIFF_SERVER_IDLE": "3"}, {"PLP_RDIFF_SERVER_WGS": "1"}, {"PLP_RDIFF_SERVER_WGS": "7",
+                                                                                        "PLP_RDIFF_SERVER_IDLE": "40"}):
+            got = run(env)
+            for k, (g_, w_) in enumerate(zip(got, want)):
+                assert type(g_) is type(w_), (env, k)
+                if w_ != "IndexError":
+                    assert len(g_) == len(w_), (env, k, len(g_), len(w_))
+                    for (A0, b0), (A1, b1) in zip(g_, w_):
+                        assert np.array_equal(A0, A1) and np.array_equal(b0, b1), (env, k)
+    finally:
+        solvers.default_solver = old
+
+
 def test_region_diff_library_search_equals_host_loop(pa, monkeypatch):
     """region_diff's search runs in the library (plp_region_diff_search: LPs gathered on the device by row index,
     cells an ancestor scan found empty not re-solved, one batch per visited node).  On random overlapping boxes --
