@@ -184,60 +184,73 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
     //     x* = xc + t1 a_k + t2 d,   t1 = s_j / (a_j.a_k) (a hair less),   d = a_k - rho a_j,  rho = a_j.a_k / |a_j|^2,
     // with t2 such that a_k.x* = b_k + tau.  Feasible iff  t1 (a_i.a_k) + t2 (a_i.d) = (t1 + t2) (a_i.a_k) - t2 rho (a_i.a_j)
     // <= s_i  for every other live row.  Two candidates at a time (register budget of the bench kernel).
+    // At most H = 2 blocked candidates per lane get the second witness (the first two; a lane rarely has more, and a row
+    // that goes without simply runs the simplex): ONE pass over the rows for both instead of a pass per pair of my rows.
     unsigned ok2 = cand & ~ok;
     constexpr int H = R >= 2 ? 2 : 1;
-#pragma unroll 1
-    for (int h0 = 0; h0 < R; h0 += H) {
-        const unsigned hm = ((1u << H) - 1u) << h0;
-        if (!__any((ok2 & hm) != 0u)) continue;
-        double bk_[H][D], aj[H][D], c1[H], c2[H];
-        int rowk[H];
-#pragma unroll
-        for (int q = 0; q < H; ++q) {
-            const int k = h0 + q;
-            int j = 0;
-            double sk_t = 0.0, gk = 0.0;
-#pragma unroll
-            for (int kq = 0; kq < R; ++kq) {  // (k is a loop variable here: select instead of indexing the register arrays)
-                j = (kq == k) ? jb[kq] : j;
-                sk_t = (kq == k) ? skt[kq] : sk_t;
-                gk = (kq == k) ? gkk[kq] : gk;
-            }
-            rowk[q] = row0 + k;
-            double gjk = 0.0, gjj = 0.0;
-#pragma unroll
-            for (int kk = 0; kk < D; ++kk) {
-                bk_[q][kk] = myA[(row0 + k) * D + kk];
-                aj[q][kk] = myA[j * D + kk];
-                gjk = fma(aj[q][kk], bk_[q][kk], gjk);
-                gjj = fma(aj[q][kk], aj[q][kk], gjj);
-            }
-            const double sj = fmax(myb[j] - myan[j], 0.0);
-            const double rho = gjk / gjj;
-            const double t1 = (sj / gjk) * (1.0 - 0x1p-40);
-            const double akd = fma(-rho, gjk, gk);        // a_k.d = |a_k|^2 - (a_j.a_k)^2 / |a_j|^2 >= 0
-            const double t2 = fma(-t1, gk, sk_t) / akd;   // (s_k + tau - t1 |a_k|^2) / a_k.d
-            c1[q] = t1 + t2;
-            c2[q] = t2 * rho;
-            // (a blocked ray has a_j.a_k > 0 and t1 |a_k|^2 < s_k + tau; anything else -- parallel rows, NaN -- is left to the simplex)
-            if (!((gjk > 0.0) & (akd > 1e-12 * gk) & (t2 >= 0.0) & (t2 < 1e300))) ok2 &= ~(1u << k);
-        }
-        for (int i = 0; i < m_loop; ++i) {
-            double ai[D];
-#pragma unroll
-            for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
-            const double si = fmax(myb[i] - myan[i], 0.0);
+    {
+        int kq[H];
+        {
+            unsigned rem = ok2;
+            unsigned pick = 0u;
 #pragma unroll
             for (int q = 0; q < H; ++q) {
-                double gik = 0.0, gij = 0.0;
+                kq[q] = rem ? __ffs((int)rem) - 1 : (q ? kq[q ? q - 1 : 0] : 0);   // (no candidate left: the previous one again)
+                pick |= rem ? (1u << kq[q]) : 0u;
+                rem &= rem - 1u;
+            }
+            ok2 &= pick;
+        }
+        if (__any(ok2 != 0u)) {
+            double bk_[H][D], aj[H][D], c1[H], c2[H];
+            int rowk[H];
+#pragma unroll
+            for (int q = 0; q < H; ++q) {
+                const int k = kq[q];
+                int j = 0;
+                double sk_t = 0.0, gk = 0.0;
+#pragma unroll
+                for (int kx = 0; kx < R; ++kx) {  // (k is data here: select instead of indexing the register arrays)
+                    j = (kx == k) ? jb[kx] : j;
+                    sk_t = (kx == k) ? skt[kx] : sk_t;
+                    gk = (kx == k) ? gkk[kx] : gk;
+                }
+                rowk[q] = row0 + k;
+                double gjk = 0.0, gjj = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) {
-                    gik = fma(ai[kk], bk_[q][kk], gik);
-                    gij = fma(ai[kk], aj[q][kk], gij);
+                    bk_[q][kk] = myA[(row0 + k) * D + kk];
+                    aj[q][kk] = myA[j * D + kk];
+                    gjk = fma(aj[q][kk], bk_[q][kk], gjk);
+                    gjj = fma(aj[q][kk], aj[q][kk], gjj);
                 }
-                const double lhs = fma(-c2[q], gij, c1[q] * gik);
-                const bool fine = (i == rowk[q]) | (lhs <= si);
-                ok2 = fine ? ok2 : (ok2 & ~(1u << (h0 + q)));
+                const double sj = fmax(myb[j] - myan[j], 0.0);
+                const double rho = gjk / gjj;
+                const double t1 = (sj / gjk) * (1.0 - 0x1p-40);
+                const double akd = fma(-rho, gjk, gk);        // a_k.d = |a_k|^2 - (a_j.a_k)^2 / |a_j|^2 >= 0
+                const double t2 = fma(-t1, gk, sk_t) / akd;   // (s_k + tau - t1 |a_k|^2) / a_k.d
+                c1[q] = t1 + t2;
+                c2[q] = t2 * rho;
+                // (a blocked ray has a_j.a_k > 0 and t1 |a_k|^2 < s_k + tau; anything else -- parallel rows, NaN -- is left to the simplex)
+                if (!((gjk > 0.0) & (akd > 1e-12 * gk) & (t2 >= 0.0) & (t2 < 1e300))) ok2 &= ~(1u << k);
+            }
+            for (int i = 0; i < m_loop; ++i) {
+                double ai[D];
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
+                const double si = fmax(myb[i] - myan[i], 0.0);
+#pragma unroll
+                for (int q = 0; q < H; ++q) {
+                    double gik = 0.0, gij = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) {
+                        gik = fma(ai[kk], bk_[q][kk], gik);
+                        gij = fma(ai[kk], aj[q][kk], gij);
+                    }
+                    const double lhs = fma(-c2[q], gij, c1[q] * gik);
+                    const bool fine = (i == rowk[q]) | (lhs <= si);
+                    ok2 = fine ? ok2 : (ok2 & ~(1u << kq[q]));
+                }
             }
         }
     }

@@ -30,6 +30,9 @@ constexpr int ID_TR = -1;  // id of the phase-1 artificial variable
 // max(a, b) as ONE v_max_f64.  fmax() makes the compiler canonicalise operands it cannot prove to be the result
 // of an arithmetic instruction (values that went through selects or bit operations) with an extra v_max_f64 x, x;
 // the operands here are never signalling NaNs, and v_max_f64 itself returns the non-NaN operand like fmax().
+#ifndef PLP_FOLD_FIXUP
+#define PLP_FOLD_FIXUP 1  // entering column zeroed before the update instead of rewritten after it (0: A/B)
+#endif
 #ifndef PLP_RAW_MAX
 #define PLP_RAW_MAX 1
 #endif
@@ -516,6 +519,41 @@ struct SimplexR {
         const int krow = __builtin_amdgcn_ds_bpermute(raddr, kb);
         // ------------------------------------------------ update
         // the (sign-normalised) reduced cost of the entering column
+#if PLP_FOLD_FIXUP
+        const double fc = act ? (FORCED ? cfe : -best) : 0.0;
+        const double fc2 = (CARRY && act) ? c2e : 0.0;
+        // The entering column will hold the leaving variable: -a_k p in my rows, -c_e p in the cost row.  Zeroed here, with
+        // p in its place in the pivot row, the updates below produce exactly that (fma(-f, p, 0) = -(f p), one rounding
+        // either way) -- the oracle's pivot() does the same -- and the column needs no pass of its own afterwards.
+#pragma unroll
+        for (int j = (KIND == 1) ? NC - 1 : 0; j < NC; ++j) {
+            if (act & (e == j)) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) T[k][j] = 0.0;
+                cost[j] = 0.0;
+                if constexpr (CARRY) cost2[j] = 0.0;
+                rho[j] = p;
+                cv[j] = TRACKX ? (vout >> 1) : vout;
+                if constexpr (TRACKX) cneg = (cneg & ~(1u << j)) | ((unsigned)(vout & 1) << j);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; ++j) cost[j] = fma(-fc, rho[j], cost[j]);
+        negz = fma(-fc, rhob, negz);
+        if constexpr (CARRY) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) cost2[j] = fma(-fc2, rho[j], cost2[j]);
+            negz2 = fma(-fc2, rhob, negz2);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool other = act & !(is_r & (k == krow));
+            const double f = other ? a[k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) T[k][j] = fma(-f, rho[j], T[k][j]);
+            beta[k] = fma(-f, rhob, beta[k]);
+        }
+#else
         const double fc = act ? (FORCED ? cfe : -best) : 0.0;
 #pragma unroll
         for (int j = 0; j < NC; ++j) cost[j] = fma(-fc, rho[j], cost[j]);
@@ -550,6 +588,7 @@ struct SimplexR {
                 if constexpr (TRACKX) cneg = (cneg & ~(1u << j)) | ((unsigned)(vout & 1) << j);
             }
         }
+#endif
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             if (is_r & (k == krow)) {  // the pivot row itself
