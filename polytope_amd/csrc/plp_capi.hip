@@ -86,6 +86,10 @@ struct plp_ctx {
     // plp_reduce_counters: device word the fused reduce kernels add their simplex-run count to (lazily allocated; the
     // kernels get nullptr until the first plp_reduce_counters call of the context, and then it costs one atomic per tile)
     unsigned long long* reduce_ctr = nullptr;
+    // fused reduce: one word per call in flight (a ring of 64) that the fast kernels raise to the call's number when they
+    // hand a polytope to the general kernel, so that its second pass can leave on one load (plp_reduce.hip)
+    unsigned long long* retry_ring = nullptr;
+    unsigned long long reduce_epoch = 0;
     // plp_assign_dev (few facets): the workgroups' (max, index) partials, one grow-only buffer PER STREAM -- calls on
     // different streams never share one, so nothing has to order them (a handful of streams per context in practice;
     // beyond 16 the table is emptied after a device synchronisation)
@@ -425,6 +429,7 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->rd_tab) (void)hipFree(ctx->rd_tab);
     if (ctx->mf_buf) (void)hipFree(ctx->mf_buf);
     if (ctx->reduce_ctr) (void)hipFree(ctx->reduce_ctr);
+    if (ctx->retry_ring) (void)hipFree(ctx->retry_ring);
     for (auto& kv : ctx->as_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
     if (ctx->qh_block) (void)hipFree(ctx->qh_block);
@@ -659,9 +664,21 @@ int plp_reduce_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     plp::t_reduce_ctr = ctx->reduce_ctr;
+    if (!ctx->retry_ring) {
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->retry_ring), 64 * 8) == hipSuccess) {
+            if (hipMemset(ctx->retry_ring, 0, 64 * 8) != hipSuccess) { (void)hipFree(ctx->retry_ring); ctx->retry_ring = nullptr; }
+        } else {
+            ctx->retry_ring = nullptr;
+        }
+        (void)hipGetLastError();
+    }
+    ctx->reduce_epoch += 1;
+    plp::t_reduce_retry = ctx->retry_ring ? ctx->retry_ring + (ctx->reduce_epoch & 63ull) : nullptr;
+    plp::t_reduce_epoch = ctx->reduce_epoch;
     const int lrc = plp::launch_reduce(B, m_max, d, A, b, m, abs_tol, reinterpret_cast<unsigned long long*>(keep), flags, r,
                                        xc, nlp, st);
     plp::t_reduce_ctr = nullptr;
+    plp::t_reduce_retry = nullptr;
     if (lrc) return fail(PLP_EUNSUPPORTED, "reduce kernel: unsupported size");
     return check_launch("reduce_kernel");
 }

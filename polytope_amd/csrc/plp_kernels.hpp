@@ -92,6 +92,10 @@ int launch_adjacent_w(int n, int m_max, int d, const double* A, const double* b,
 // Device counter (or nullptr) the fused reduce kernels of the calling thread add their simplex-run count to: set by
 // plp_reduce_batch_dev from the context around the launch (plp_reduce_counters reads it back)
 extern thread_local unsigned long long* t_reduce_ctr;
+// Device word (or nullptr) and the value the fast kernels raise it to when they hand a polytope to the general kernel
+// (RF_RETRY): the second pass of launch_reduce leaves at once when the word does not hold the call's value
+extern thread_local unsigned long long* t_reduce_retry;
+extern thread_local unsigned long long t_reduce_epoch;
 
 int launch_reduce(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                   double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,

@@ -31,6 +31,8 @@
 namespace plp {
 
 thread_local unsigned long long* t_reduce_ctr = nullptr;
+thread_local unsigned long long* t_reduce_retry = nullptr;
+thread_local unsigned long long t_reduce_epoch = 0ull;
 
 static inline size_t reduce_smem_bytes(int gs, int D) {
     const int NG = BLOCK / gs;
@@ -57,8 +59,12 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
                                                        int* __restrict__ flags_out,
                                                        double* __restrict__ r_out,
                                                        double* __restrict__ xc_out,
-                                                       int* __restrict__ nlp_out) {
+                                                       int* __restrict__ nlp_out,
+                                                       const unsigned long long* __restrict__ retry_word,
+                                                       unsigned long long epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // second pass: the fast kernels raise the call's word when they hand a polytope back; normally they did not
+    if (retry_only && retry_word && *retry_word != epoch) return;
     const Grp g(gs);
     const int NG = BLOCK / gs;
     const int gib = threadIdx.x / gs;
@@ -307,7 +313,7 @@ static int launch_reduce_d(long long B, int m_max, int gs, const double* A, cons
     if (blocks < 1) blocks = 1;
     if (retry_only && blocks > 256 * 8) blocks = 256 * 8;  // mostly flag reads: a grid-stride sweep
     hipLaunchKernelGGL(reduce_kernel<D>, dim3((unsigned)blocks), dim3(BLOCK), smem, st, B, m_max, gs, A, b, mrows,
-                       abs_tol, retry_only, keep, flags, r, xc, nlp);
+                       abs_tol, retry_only, keep, flags, r, xc, nlp, retry_only ? t_reduce_retry : nullptr, t_reduce_epoch);
     return 0;
 }
 

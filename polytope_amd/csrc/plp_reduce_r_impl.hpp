@@ -279,7 +279,8 @@ __device__ __forceinline__ void reduce_r_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int RSH = R == 8 ? 3 : (R == 4 ? 2 : (R == 2 ? 1 : 0));  // log2(R)
     static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows per lane");
@@ -1092,6 +1093,13 @@ __device__ __forceinline__ void reduce_r_tile(
             nlp_out[pg] = nlp;
         }
         ctr_add(ctr, nlp, valid & (g.gl == 0) & (!SPLIT || grp == 0));   // every LP the reference issues, less the presolved ones
+        // a polytope handed to the general kernel: say so in the call's word, so that the second pass -- which normally
+        // finds nothing -- can leave on ONE load instead of sweeping the flags of the whole batch
+        if (retry_word) {
+            if (__any(retry & valid)) {
+                if ((threadIdx.x & 63) == 0) atomicMax(retry_word, epoch);
+            }
+        }
     }
 }
 
@@ -1113,9 +1121,10 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_ker
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     reduce_r_tile<D, 64, 1, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
-                                  r_out, xc_out, nlp_out, ctr);
+                                  r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
 // The same with the F3 / F2 LPs on the one-LP-per-wavefront DENSE engine (plp_wide.hpp: wide::solve_dense): the
@@ -1125,9 +1134,10 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     reduce_r_tile<D, 64, 1, true, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                                               flags_out, r_out, xc_out, nlp_out, ctr);
+                                               flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
 template <int D>
@@ -1140,10 +1150,10 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     const char* wd = getenv("PLP_REDUCE_WDENSE");
     if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD))
         hipLaunchKernelGGL((reduce_wdense_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
-                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
     else
         hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
-                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                           mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
     return 0;
 }
 
@@ -1153,9 +1163,10 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_split_ke
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     reduce_r_tile<D, GS, R, false, true>((long long)blockIdx.x, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                                         flags_out, r_out, xc_out, nlp_out, ctr);
+                                         flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
 // Batches up to this size take the latency form.  Measured (device time per call, batch form -> latency form): (16,3)
@@ -1174,9 +1185,10 @@ __global__ __launch_bounds__(RBLOCK, (R == 8 ? PLP_REDUCE_R8_WAVES : (R == 2 && 
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     reduce_r_tile<D, GS, R>((long long)blockIdx.x * (RBLOCK / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                            flags_out, r_out, xc_out, nlp_out, ctr);
+                            flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
 // Polytopes of up to 16 rows: the first `nbig` workgroups take tiles of 16 polytopes (4 lanes x 4 rows each), the rest
@@ -1188,13 +1200,14 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_R_WAVES(D)) void reduce_r_mix_ke
     int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
-    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
     if ((int)blockIdx.x < nbig)
         reduce_r_tile<D, 4, 4>((long long)blockIdx.x * (RBLOCK / 4), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                               flags_out, r_out, xc_out, nlp_out, ctr);
+                               flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
     else
         reduce_r_tile<D, 8, 2>((long long)nbig * (RBLOCK / 4) + (long long)((int)blockIdx.x - nbig) * (RBLOCK / 8), B, m_max,
-                               Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
+                               Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
 template <int D, int GS, int R = RR>
@@ -1216,7 +1229,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
         if ((sp && sp[0] == '1') || (!(sp && sp[0] == '0') && B <= PLP_REDUCE_SPLIT_MAXB(D, GS))) {
             const size_t sm1 = (((size_t)GS * R * (D + 2) + 2 * D + 2) * 8 + 15) & ~(size_t)15;
             hipLaunchKernelGGL((reduce_split_kernel<D, GS, R>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), sm1, st, B, m_max,
-                               A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                               A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
             return 0;
         }
     }
@@ -1236,7 +1249,7 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
             const long long nsmall = (B + NG / 2 - 1) / (NG / 2);
             const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
             hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)nsmall), dim3(RBLOCK), smem > smem2 ? smem : smem2, st,
-                               0, B, m_max, A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                               0, B, m_max, A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
             return 0;
         }
         if (tail_tiles > 0 && tail_tiles < blocks && blocks > 4096) {
@@ -1246,12 +1259,12 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
             const size_t smem2 = reduce_r_smem_bytes(8, D, 2);
             hipLaunchKernelGGL((reduce_r_mix_kernel<D>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
                                smem > smem2 ? smem : smem2, st, (int)nbig, B, m_max, A, b, mrows, abs_tol,
-                               (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                               (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
             return 0;
         }
     }
     hipLaunchKernelGGL((reduce_r_kernel<D, GS, R>), dim3((unsigned)blocks), dim3(RBLOCK), smem, st, B, m_max, A, b, mrows,
-                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr);
+                       abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
     return 0;
 }
 
