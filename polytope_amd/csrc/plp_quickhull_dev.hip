@@ -104,6 +104,13 @@ __device__ __forceinline__ double np_sum_dev(const double* a, int n) {
     return res;
 }
 
+// np.sum(n * p) for a run-time d <= 16: the products, then numpy's order of additions (np_sum_dev)
+__device__ __forceinline__ double np_dot_dev(const double* n, const double* x, int d) {
+    double prod[16];
+    for (int c = 0; c < d; ++c) prod[c] = n[c] * x[c];
+    return np_sum_dev(prod, d);
+}
+
 // exclusive prefix sum over the workgroup; *total = the sum
 __device__ __forceinline__ int block_scan(int v, int* total, int* sh /* [17] */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -523,9 +530,7 @@ __global__ __launch_bounds__(QT) void qh_tail_kernel(QhDev S) {
                         bool hit = false;
                         if (f < fc) {
                             const double* nn = s_fn + f * d;
-                            double sdot = nn[0] * x[0];
-                            for (int cc = 1; cc < d; ++cc) sdot = sdot + nn[cc] * x[cc];
-                            dist = sdot - s_fo[f];
+                            dist = np_dot_dev(nn, x, d) - s_fo[f];   // sum(n*p) - d  (quickhull.py:121), numpy's order
                             hit = dist > S.tol;
                         }
                         const unsigned long long hb = __ballot(hit);

@@ -342,7 +342,7 @@ int plp_quickhull_run(plp_ctx* ctx, int64_t N, int d, const double* X0, const in
     // ---- the long tail on the host.  Late iterations move a handful of points each; a device round trip (~50 us)
     // per iteration then costs more than the arithmetic.  Once fewer than HOST_TAIL points are outside the hull the
     // owners and distances are downloaded once and the outside sets continue as host lists, with the device
-    // kernel's arithmetic (k-ordered products and sums, first facet with distance > abs_tol, furthest point with
+    // kernel's arithmetic (products summed in numpy's order, first facet with distance > abs_tol, furthest point with
     // the lowest index among equals).
     long long host_tail = 32768;
     if (const char* e = getenv("PLP_QH_HOST_TAIL")) host_tail = atoll(e);
@@ -382,9 +382,9 @@ int plp_quickhull_run(plp_ctx* ctx, int64_t N, int d, const double* X0, const in
             for (int64_t q : outside[f]) {
                 for (int j = 0; j < k; ++j) {
                     const double* nn = &H.FN[(size_t)(f0 + j) * d];
-                    double sdot = nn[0] * X0[q * d];
-                    for (int c = 1; c < d; ++c) sdot = sdot + nn[c] * X0[q * d + c];
-                    const double dist = sdot - H.FO[f0 + j];
+                    double prod[16];
+                    for (int c = 0; c < d; ++c) prod[c] = nn[c] * X0[q * d + c];
+                    const double dist = np_sum(prod, d) - H.FO[f0 + j];   // sum(n*p) - d  (quickhull.py:121), numpy's order
                     if (dist > abs_tol) {
                         outside[f0 + j].push_back(q);
                         dist_of[q] = dist;

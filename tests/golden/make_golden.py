@@ -35,6 +35,7 @@ Sets:
                    triangles, multi-member regions, a non-cover and overlapping sets  (prop2partition.py:46-306)
   g17_structured.npz  reduce() keep masks on structured (16,3) polytopes: ties, duplicates, tangent rows, corner cuts (:1053-1163)
   g18_distance_order.npz  quickhull distance() at d = 7..16, bitwise: numpy's sum keeps 8 partial sums from 8 elements on (quickhull.py:117-121)
+  g19_hull_highdim.npz  quickhull() end to end at d = 8, 9, 12: rows in the reference's order (quickhull.py:141-359)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
                    polytope.py:1597-1695)
@@ -1143,7 +1144,25 @@ def gen_g18():
     print("g18: distances at d = 7, 8, 9, 12, 16 (numpy's pairwise order from 8 elements on)")
 
 
+# ----------------------------------------------------------------------------- G19
+def gen_g19():
+    """quickhull() end to end in dimensions 8, 9 and 12 -- where distance()'s np.sum adds in eight partial sums (g18) --
+    rows in the order the reference returns them under a seeded global RNG (quickhull.py:141-359)."""
+    rng = np.random.default_rng(19)
+    out = {}
+    cases = [(8, 14, 5), (8, 16, 6), (9, 15, 7), (12, 16, 8)]
+    for k, (d, n, seed) in enumerate(cases):
+        P = rng.standard_normal((n, d))
+        np.random.seed(seed)
+        A, b, V = qh.quickhull(P)
+        out[f"hull{k}_P"], out[f"hull{k}_seed"] = P, np.array(seed)
+        out[f"hull{k}_A"], out[f"hull{k}_b"], out[f"hull{k}_V"] = A, b, V
+        print("g19 hull", k, "d", d, "points", n, "facets", A.shape[0])
+    out["hull_ncases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "g19_hull_highdim.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     for w in which:
         globals()["gen_" + w]()

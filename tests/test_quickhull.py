@@ -36,9 +36,11 @@ def planes(A, b):
 
 
 # ------------------------------------------------------------------ end-to-end hulls
-def test_hull_rows_in_reference_order(backend):
+@pytest.mark.parametrize("fixture", ["g8_hull.npz", "g19_hull_highdim.npz"])
+def test_hull_rows_in_reference_order(backend, fixture):
+    """g8: d = 2..5; g19: d = 8, 9, 12, where the reference's distances are numpy's eight partial sums."""
     from polytope_amd.quickhull import quickhull
-    g = load_golden("g8_hull.npz")
+    g = load_golden(fixture)
     for k in range(int(g["hull_ncases"])):
         np.random.seed(int(g[f"hull{k}_seed"]))
         A, b, V = quickhull(g[f"hull{k}_P"])
