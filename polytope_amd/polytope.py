@@ -103,9 +103,22 @@ class Polytope(object):
         self.vertices = vertices
 
     def __str__(self):
-        rows = ["  %s | %s" % (np.array2string(a, precision=5, suppress_small=True), np.format_float_positional(
-            bb, precision=5)) for a, bb in zip(self.A, self.b)]
-        return "Single polytope \n" + "\n".join(rows) + "\n"
+        """The H-representation as the reference prints it (ref :150-176, pinned by its test_polytope_str): numpy's
+        rendering of A and of b as a column, side by side, ' x <= ' on the middle row."""
+        left = str(self.A).split("\n")
+        right = str(self.b.reshape(-1, 1) if self.b.ndim == 1 else self.b).split("\n")
+        n = len(left)
+        at = (n - 1) // 2
+        out = []
+        for k in range(n):
+            if k == at:
+                mid = " x <= "
+            elif k == n - 1:
+                mid = "|    "
+            else:
+                mid = " |    "
+            out.append(left[k] + mid + right[k])
+        return "Single polytope \n  " + "\n  ".join(out) + "\n"
 
     def __len__(self):
         return 0

@@ -1041,6 +1041,13 @@ def gen_g16():
     out["preserves_cases"] = np.array([c for c, _ in pres])
     out["preserves"] = np.array([v for _, v in pres])
     print("g16 preserves:", pres, "reference Regions hashable:", bool(out["preserves_ref_hashable"]))
+    # __str__ of Polytope / Region (polytope.py:150-176, :711-721; pinned by the reference's own test_polytope_str)
+    strs = [str(pc.Polytope(np.array([[1]]), np.array([1])))]
+    for box in ([[0, 1]], [[0, 1], [0, 2]], [[0, 1], [0, 2], [0, 3]]):
+        strs.append(str(pc.box2poly(box)))
+    strs.append(str(pc.Region([pc.box2poly([[0, 1], [0, 2]]), pc.box2poly([[1, 2], [0, 2]])])))
+    strs.append(str(pc.Polytope(np.array([[0.6, -0.8], [-1.0, 0.0], [0.0, 1.0]]), np.array([1.25, 0.5, 3.0]))))
+    out["str_cases"] = np.array(strs)
     logging.disable(logging.NOTSET)
     np.savez_compressed(os.path.join(HERE, "g16_partition.npz"), **out)
 

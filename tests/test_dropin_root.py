@@ -164,3 +164,15 @@ def test_g9_pair_matrices_through_the_classes(pc, name):
     assert part.compute_adj() and np.array_equal(part.adj.toarray() != 0, g[name + "_adj"] != 0)
     assert np.array_equal(pc.find_adjacent_regions(part).toarray(), g[name + "_adj"])
     assert pc.is_adjacent(cells[0], cells[1]) == bool(g[name + "_adj"][0, 1])
+
+
+def test_str_of_polytope_and_region(pc):
+    """`print(p)`: the reference's rendering (polytope.py:150-176, :711-721), which its own test_polytope_str pins."""
+    g = load_golden("g16_partition.npz")
+    got = [str(pc.Polytope(np.array([[1]]), np.array([1])))]
+    for box in ([[0, 1]], [[0, 1], [0, 2]], [[0, 1], [0, 2], [0, 3]]):
+        got.append(str(pc.box2poly(box)))
+    got.append(str(pc.Region([pc.box2poly([[0, 1], [0, 2]]), pc.box2poly([[1, 2], [0, 2]])])))
+    got.append(str(pc.Polytope(np.array([[0.6, -0.8], [-1.0, 0.0], [0.0, 1.0]]), np.array([1.25, 0.5, 3.0]))))
+    assert got == [str(v) for v in g["str_cases"]]
+    assert got[0] == "Single polytope \n  [[1.]] x <= [[1.]]\n"
