@@ -116,6 +116,52 @@ def _hyperplanes(V):
     return n, -dd
 
 
+# ---- the reference's module-level objects (quickhull.py:43-139), for code that imports them.  The hull itself does not
+# go through them: it keeps index arrays on the device (HullSession) instead of a list of point objects per facet.
+class Facet(object):
+    """Facet of an n-dimensional polyhedron that contains the origin (ref :43-102): `vertices` (n x n, one per row),
+    `normal` (unit, pointing out, n x 1), `distance` (of the facet's plane from the origin), `outside` (a list of
+    Outside_point), `neighbors`."""
+
+    def __init__(self, points):
+        points = np.asarray(points, dtype=float)
+        self.outside = []
+        self.vertices = points
+        self.neighbors = []
+        n, off = _hyperplanes(points[None, :, :])
+        self.normal = n[0][:, None]
+        self.distance = np.array([off[0]])
+
+    def get_furthest(self):
+        """Remove and return the outside point furthest from the facet; the first one among equals (ref :87-102)."""
+        best = 0
+        for i in range(1, len(self.outside)):
+            if self.outside[best].distance < self.outside[i].distance:
+                best = i
+        return self.outside.pop(best)
+
+
+class Outside_point(object):
+    """Coordinates of a point and its distance to the facet it is assigned to (ref :105-114)."""
+
+    def __init__(self, coordinates, distance):
+        self.distance = distance
+        self.coordinates = coordinates
+
+
+def distance(p, fac1):
+    """Signed distance of point `p` from the plane of `fac1` (ref :117-121): np.sum(n * p) - d."""
+    return np.sum(np.asarray(fac1.normal).flatten() * np.asarray(p).flatten()) - fac1.distance
+
+
+def is_neighbor(fac1, fac2, abs_tol=1e-7):
+    """True if the two facets share d - 1 vertices (ref :124-139): vertices of fac1 that have a twin in fac2."""
+    v1, v2 = np.asarray(fac1.vertices), np.asarray(fac2.vertices)
+    dim = v1.shape[1]
+    twin = np.all(np.abs(v1[:dim, None, :] - v2[None, :dim, :]) < abs_tol, axis=2)
+    return int(np.count_nonzero(twin.any(axis=1))) == dim - 1
+
+
 def _rank(M, tol):
     return int(np.sum(np.linalg.svd(M, compute_uv=False) > tol))
 

@@ -362,3 +362,22 @@ def test_device_facet_graph_in_reference_order(monkeypatch):
         assert A.shape == g[f"hull{k}_A"].shape, k
         assert np.allclose(A, g[f"hull{k}_A"], rtol=0, atol=1e-12) and np.allclose(b, g[f"hull{k}_b"], rtol=0, atol=1e-12), k
         assert np.allclose(V, g[f"hull{k}_V"], rtol=0, atol=1e-12), k
+
+
+@pytest.mark.parametrize("d", [2, 3, 5, 8])
+def test_reference_module_objects(d):
+    """Facet / Outside_point / distance / is_neighbor (quickhull.py:43-139) as importable names: the reference's Facet
+    normals and offsets of a start simplex (g6), its distances bit for bit, get_furthest's first-maximum rule."""
+    from polytope_amd import quickhull as Q
+    g = load_golden("g6_quickhull.npz")
+    S0, X = g[f"d{d}_simplex"], g[f"d{d}_X"]
+    facets = [Q.Facet(S0[np.setdiff1d(np.arange(d + 1), [i]), :]) for i in range(d + 1)]
+    for i, f in enumerate(facets):
+        assert np.array_equal(np.asarray(f.normal).ravel(), g[f"d{d}_normals"][i])
+        assert float(np.asarray(f.distance).ravel()[0]) == float(g[f"d{d}_offsets"][i])
+        for q in range(0, 64):
+            assert float(Q.distance(X[q], f)) == float(g[f"d{d}_distall"][q, i])
+    assert Q.is_neighbor(facets[0], facets[1]) and not Q.is_neighbor(facets[0], facets[0])
+    f = facets[0]
+    f.outside = [Q.Outside_point(np.array([k]), v) for k, v in enumerate([0.3, 0.9, 0.9, 0.1])]
+    assert f.get_furthest().coordinates[0] == 1 and len(f.outside) == 3   # the FIRST maximum (:97-100)
