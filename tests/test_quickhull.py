@@ -376,7 +376,7 @@ def test_reference_module_objects(d):
         assert np.array_equal(np.asarray(f.normal).ravel(), g[f"d{d}_normals"][i])
         assert float(np.asarray(f.distance).ravel()[0]) == float(g[f"d{d}_offsets"][i])
         for q in range(0, 64):
-            assert float(Q.distance(X[q], f)) == float(g[f"d{d}_distall"][q, i])
+            assert np.asarray(Q.distance(X[q], f)).ravel()[0] == g[f"d{d}_distall"][q, i]
     assert Q.is_neighbor(facets[0], facets[1]) and not Q.is_neighbor(facets[0], facets[0])
     f = facets[0]
     f.outside = [Q.Outside_point(np.array([k]), v) for k, v in enumerate([0.3, 0.9, 0.9, 0.1])]
