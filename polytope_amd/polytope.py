@@ -976,7 +976,9 @@ def union(polyreg1, polyreg2, check_convex=False):
             piece = reduce(hull) if not is_empty(hull) else hull
             if len(_hull_memo) >= _HULL_MEMO_MAX:
                 _hull_memo.clear()
-            _hull_memo[hkey] = piece
+            _hull_memo[hkey] = piece.copy() if not is_empty(piece) else piece   # (private: callers may edit what they get)
+        elif not is_empty(piece):
+            piece = piece.copy()
         if not is_empty(piece):
             final.append(piece)
     return Region(final)

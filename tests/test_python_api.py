@@ -790,6 +790,44 @@ def test_intersect_and_reduce_beyond_64_rows(pc, monkeypatch):
         assert abs(float(pc.cheby_ball(R)[0]) - float(g["c%d_r" % k])) <= TOL
 
 
+def test_union_memos_do_not_change_results(pc):
+    """union(check_convex=True) keeps the convexity verdict and the merged piece of a group by content (the repeated
+    union of Region.intersect meets the same groups at every step): with the memos emptied before the call, filled by
+    an earlier call, or filled by a DIFFERENT region, the pieces are the same, and a memoised piece is not aliased
+    into a caller's edit."""
+    import itertools
+    shape = (4, 3, 2)
+    cells = [pc.box2poly([[i[k] / shape[k], (i[k] + 1) / shape[k]] for k in range(3)])
+             for i in itertools.product(*[range(n) for n in shape])]
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((9, 3))
+    A /= np.linalg.norm(A, axis=1)[:, None]
+    P = pc.Polytope(A, 0.3 + A @ (0.5 * np.ones(3)))
+    Q = pc.Polytope(A, 0.22 + A @ np.array([0.4, 0.6, 0.5]))
+
+    def pieces(X):
+        R = pc.Region([c.copy() for c in cells]).intersect(X.copy())
+        return [(p.A.copy(), p.b.copy()) for p in (R.list_poly if isinstance(R, pc.Region) else [R])]
+
+    def same(u, v):
+        return len(u) == len(v) and all(np.array_equal(a0, a1) and np.array_equal(b0, b1) for (a0, b0), (a1, b1) in zip(u, v))
+    pc._hull_memo.clear(); pc._convex_memo.clear()
+    cold = pieces(P)
+    warm = pieces(P)
+    pieces(Q)                     # other groups in between
+    again = pieces(P)
+    pc._hull_memo.clear(); pc._convex_memo.clear()
+    cold2 = pieces(P)
+    assert len(cold) >= 1 and same(cold, warm) and same(cold, again) and same(cold, cold2)
+    # a caller that edits a returned piece in place does not reach into later results
+    R = pc.Region([c.copy() for c in cells]).intersect(P.copy())
+    first = (R.list_poly if isinstance(R, pc.Region) else [R])[0]
+    keepA = first.A.copy()
+    first.A *= 2.0
+    assert same(pieces(P), cold)
+    first.A[...] = keepA
+
+
 # ------------------------------------------------------------------ resident tables, cross pairs (hip only)
 @pytest.mark.gpu
 def test_cross_pairs_and_resident_tables():
