@@ -1495,6 +1495,7 @@ struct RadiusOracle {
     long long n_lps = 0, n_batches = 0;
     long long n_lps_long = 0, n_batches_long = 0;  // LPs of more than 64 rows (LDS engine) / batches that hold at least one (stats)
     double t_launch = 0.0, t_wait = 0.0;  // seconds spent enqueueing / waiting for the device (PLP_RDIFF_STATS=1 prints them)
+    double t_store = 0.0;                 // ... and putting the radii of a batch into the memo
     // ---- resident LP server (d <= 4; PLP_RDIFF_SERVER=0: every batch a launch, as in round 3)
     static constexpr size_t SRV_MAXLP = 2048, SRV_OUT = 128, SRV_REC = SRV_OUT + SRV_MAXLP * 16;
     static constexpr size_t SRV_BYTES = SRV_REC + SRV_MAXLP * 66 * 4;
@@ -1715,6 +1716,7 @@ struct RadiusOracle {
                 ctx->rd_srv_word = sq;
                 const double* sout = reinterpret_cast<const double*>(ctx->rd_srv + SRV_OUT);
                 for (size_t k = 0; k < n; ++k) memo.put(pkey[done + k], sout[2 * k]);
+                t_store += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp2).count();
                 n_lps += (long long)n;
                 n_batches += 1;
                 n_srv_batches += 1;
@@ -1978,6 +1980,8 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     };
     rc = PLP_OK;
     bool bad_index = false;
+    const auto t_search0 = std::chrono::steady_clock::now();
+    double t_spec = 0.0;   // seconds spent assembling the lists of a batch (PLP_RDIFF_STATS)
     while (level != -1 && rc == PLP_OK) {
         if (counter[at(level)] == 0) {
             // ---- scan: first cell j >= level whose stack with the current rows is full-dimensional
@@ -1996,6 +2000,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                 }
                 if (!miss) { have_all = true; break; }
                 res->n_scan_miss++;
+                const auto ts0 = std::chrono::steady_clock::now();
                 queue_scan(alive, level, kbase, true);
                 {   // the outcome "no cell hits": a piece is emitted, then the node the search re-opens and what follows it
                     std::vector<int> c2 = counter, o2 = open_cells;
@@ -2003,6 +2008,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                     long long l2 = level, s2 = sumc;
                     if (!leaf_on(c2, o2, i2, l2, s2) && want_state(i2)) queue_empty_chain(c2, o2, i2, l2, s2, 6);
                 }
+                t_spec += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
                 rc = R.flush();
                 if (rc) break;
             }
@@ -2056,6 +2062,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
         const Key knode = key_of_list(cur.data(), cur.size());
         if (!R.memo.find(knode)) {
             res->n_node_miss++;
+            const auto ts0 = std::chrono::steady_clock::now();
             R.want(knode, cur.data(), cur.size(), nullptr, 0, true);
             {
                 std::vector<int> c2 = counter, o2 = open_cells;
@@ -2064,6 +2071,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
             }
             // what it needs next when it is NOT empty: its scan and the first child of every cell still alive
             if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode, false);
+            t_spec += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
             rc = R.flush();
             if (rc) break;
         }
@@ -2079,9 +2087,10 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
     res->n_lps = R.n_lps;
     res->n_batches = R.n_batches;
     if (getenv("PLP_RDIFF_STATS"))
-        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms; beyond 64 rows: %lld LPs in %lld batches; resident server: %lld batches, %lld starts\n",
+        fprintf(stderr, "plp_region_diff_search: %lld LPs, %lld batches (%lld scan misses, %lld node misses), %lld requests, launch %.1f ms, device wait %.1f ms; beyond 64 rows: %lld LPs in %lld batches; resident server: %lld batches, %lld starts; search loop %.1f ms of which assembling the batches' lists %.1f ms, storing results %.1f ms\n",
                 R.n_lps, R.n_batches, res->n_scan_miss, res->n_node_miss, res->n_requests, R.t_launch * 1e3, R.t_wait * 1e3,
-                R.n_lps_long, R.n_batches_long, R.n_srv_batches, R.n_srv_starts);
+                R.n_lps_long, R.n_batches_long, R.n_srv_batches, R.n_srv_starts,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_search0).count() * 1e3, t_spec * 1e3, R.t_store * 1e3);
     R.release();
     if (rc == PLP_OK && bad_index) rc = fail(PLP_EINVAL, "region_diff: row index out of range (the reference raises IndexError here)");
     if (rc) { delete res; return rc; }
