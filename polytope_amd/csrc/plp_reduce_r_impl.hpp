@@ -118,6 +118,10 @@ __device__ __forceinline__ void ctr_add(unsigned long long* ctr, int v, bool lea
 #define PLP_REDUCE_R8_WAVES 2
 #endif
 
+#ifndef PLP_R_DEDUPE_HALF
+#define PLP_R_DEDUPE_HALF 1  // 16 rows at four per lane: every pair of rows once (0: every lane all 16 partners of its rows)
+#endif
+
 #ifndef PLP_R_PRESOLVE
 #define PLP_R_PRESOLVE 2  // F2: rows answered by the presolve below skip the simplex (0: every LP on the simplex; 1: first witness only; A/B runs)
 #endif
@@ -479,7 +483,47 @@ __device__ __forceinline__ void reduce_r_tile(
         __syncthreads();  // 1/||a|| of every row is in LDS
         // ---------------------------------------------------------------- dedupe (:1094-1110)
         // (rows are re-read from LDS: the register file limits the occupancy of this kernel, LDS is idle)
-        {
+        if constexpr (!SPLIT && !LAZY && rows == 16 && R == 4 && PLP_R_DEDUPE_HALF) {
+            // Sixteen row slots, four per lane: every unordered pair {i, j} once instead of twice.  Row i meets its partners
+            // j = i + 1 .. i + 8 (mod 16): the 8 cyclic distances cover all 120 pairs (distance 8 twice: harmless), the
+            // dot product is the same number whichever of the two rows' owners forms it (products commute, same order
+            // of additions), and ONE evaluation settles both rows' verdicts; the lanes' 16-bit masks of removed rows are
+            // OR-ed over the group.  32 pairs per lane instead of 64.
+            unsigned remmask = 0u;
+            double ni[R][D], bin_[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double an_i = myan[row0 + k];
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) ni[k][kk] = myA[(row0 + k) * D + kk] * an_i;
+                bin_[k] = myb[row0 + k] * an_i;
+            }
+            for (int t = 1; t <= 8; ++t) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int i = row0 + k;
+                    const int j = (i + t) & 15;
+                    const double an_j = myan[j];
+                    double dot = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) dot = dot + ni[k][kk] * (myA[j * D + kk] * an_j);
+                    const double bjn = myb[j] * an_j;
+                    const bool par = valid & (m <= rows) & (i < m) & (j < m) & (dot > 1.0 - abs_tol);
+                    // the reference's rule for the pair (lo, hi), lo < hi (:1104-1109): b_lo < b_hi removes hi, else lo
+                    const bool i_lo = i < j;
+                    const double blo = i_lo ? bin_[k] : bjn, bhi = i_lo ? bjn : bin_[k];
+                    const int lo = i_lo ? i : j, hi = i_lo ? j : i;
+                    const int gone = (blo < bhi) ? hi : lo;
+                    remmask |= par ? (1u << gone) : 0u;
+                }
+            }
+            remmask |= (unsigned)__shfl_xor((int)remmask, 1, 64);
+            remmask |= (unsigned)__shfl_xor((int)remmask, 2, 64);
+            const unsigned removed = (remmask >> row0) & RMASK;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                live |= spread_rows<R, GS>(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
+        } else {
             unsigned removed = 0u;
             double ni[R][D], bin_[R];
 #pragma unroll
