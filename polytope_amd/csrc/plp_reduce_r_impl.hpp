@@ -498,6 +498,8 @@ __device__ __forceinline__ void reduce_r_tile(
                 for (int kk = 0; kk < D; ++kk) ni[k][kk] = myA[(row0 + k) * D + kk] * an_i;
                 bin_[k] = myb[row0 + k] * an_i;
             }
+            // (unrolled by two: fully unrolled the loop is 0.5 % faster and the kernel spills 56 B per lane instead of 28)
+#pragma unroll 2
             for (int t = 1; t <= 8; ++t) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -1284,7 +1286,8 @@ static int launch_reduce_r_dg(long long B, int m_max, const double* A, const dou
         // A third class of quarter-size tiles (16 lanes x 1 row) behind the half-size ones was measured too: no gain
         // (0.2557-0.2602 ms for the last 2/256 .. 12/256 of the batch), not kept.
         const char* mx = getenv("PLP_REDUCE_MIX");
-        long long tail_tiles = blocks / 16 < 1024 ? blocks / 16 : 1024;
+        // (round 4: 1/32 of the tiles instead of 1/16 -- the optimum is flat between 2/64 and 8/64: 0.1908 / 0.1919 ms)
+        long long tail_tiles = blocks / 32 < 1024 ? blocks / 32 : 1024;
         if (mx) tail_tiles = blocks * atoi(mx) / 64;
         // medium batches (fewer full tiles than half the chip's wavefront slots): half-size tiles only -- twice the
         // wavefronts, each done in about half the time.  PLP_REDUCE_HALF=0 / 1: never / whenever blocks <= 4096 (A/B).
