@@ -43,7 +43,8 @@ struct GenScalars {  // wave-uniform state of one LP
 // downwards, x := -x; a: my entry of the (sign-normalised) entering column, pinv its reciprocal.
 template <int NC, class TV>
 __device__ __forceinline__ void gen_apply(const int lane, TV& Tv, double& T16, double& beta, int& rowvar, int& rowneg,
-                                          bool& rowact, WideSharedC<NC>& sh, GenScalars& S, const bool carry, const int e,
+                                          bool& rowact, WideSharedC<NC>& sh, GenScalars& S, double& cc, double& cc2,
+                                          const bool carry, const int e,
                                           const bool flip, const double ce, const double c2e, const double a, const double pinv,
                                           const int r, const bool clamp) {
     const double p = uniform_lane(pinv, r);
@@ -71,11 +72,23 @@ __device__ __forceinline__ void gen_apply(const int lane, TV& Tv, double& T16, d
     const double fc2 = flip ? -c2e : c2e;
     S.negz = fma(-fc, rb, S.negz);
     if (carry) S.negz2 = fma(-fc2, rb, S.negz2);
+#if PLP_WIDE_CREG
+    {   // both cost rows stay in registers (lane j: column j; 0 beyond the columns), see plp_wide.hpp
+        const double rj = sh.rho[lane < NC ? lane : NC];
+        const double n1 = (lane == e) ? -(fc * p) : fma(-fc, rj, cc);
+        cc = lane < NC ? n1 : 0.0;
+        if (carry) {
+            const double n2 = (lane == e) ? -(fc2 * p) : fma(-fc2, rj, cc2);
+            cc2 = lane < NC ? n2 : 0.0;
+        }
+    }
+#else
     if (lane < NC) {
         const double rj = sh.rho[lane];
         sh.cost[lane] = (lane == e) ? -(fc * p) : fma(-fc, rj, sh.cost[lane]);
         if (carry) sh.cost2[lane] = (lane == e) ? -(fc2 * p) : fma(-fc2, rj, sh.cost2[lane]);
     }
+#endif
     S.cfree &= ~(1u << e);
     S.iters += 1;
     if (clamp & rowact & (beta < 0.0)) beta = 0.0;  // rounding of a forced pivot
@@ -86,22 +99,37 @@ __device__ __forceinline__ void gen_apply(const int lane, TV& Tv, double& T16, d
 // with the smallest q0 leaves" (phase 1's start).  Returns the status.
 template <int NC, class TV>
 __device__ __forceinline__ int gen_run(const int lane, TV& Tv, double& T16, double& beta, int& rowvar, int& rowneg,
-                                       bool& rowact, WideSharedC<NC>& sh, GenScalars& S, const bool carry, bool forced,
-                                       const double q0) {
+                                       bool& rowact, WideSharedC<NC>& sh, GenScalars& S, double& cc, double& cc2,
+                                       const bool carry, bool forced_first, const double q0) {
     int ndeg = 0;
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     int status = -1;
+#if PLP_WIDE_PEEL
+    auto pivot = [&](auto forced_c) __attribute__((always_inline)) -> bool {
+        constexpr bool forced = decltype(forced_c)::value;   // (the forced first pivot is an instance of its own)
+#else
+    bool forced = forced_first;
     auto pivot = [&]() __attribute__((always_inline)) -> bool {
+#endif
         const bool bland = ndeg >= BLAND_AFTER;
         int e;
         double ce, c2e = 0.0;
         bool flip = false;
         if (forced) {
             e = NC - 1;
+#if PLP_WIDE_CREG
+            ce = uniform_lane(cc, NC - 1);
+            if (carry) c2e = uniform_lane(cc2, NC - 1);
+#else
             ce = sh.cost[NC - 1];
             if (carry) c2e = sh.cost2[NC - 1];
+#endif
         } else {
+#if PLP_WIDE_CREG
+            const double c = cc;
+#else
             const double c = lane < NC ? sh.cost[lane] : 0.0;
+#endif
             const bool alive = (lane < NC) & (((S.dead >> (lane & 31)) & 1u) == 0u);
             const bool elig = alive & (fabs(c) > TOL_D) & ((((S.cfree >> (lane & 31)) & 1u) != 0u) | (c < 0.0));
             const uint64_t eb = __ballot(elig);
@@ -124,7 +152,11 @@ __device__ __forceinline__ int gen_run(const int lane, TV& Tv, double& T16, doub
             }
             e = __builtin_amdgcn_readfirstlane(e);
             ce = uniform_lane(c, e);
+#if PLP_WIDE_CREG
+            if (carry) c2e = uniform_lane(cc2, e);
+#else
             if (carry) c2e = uniform_lane(lane < NC ? sh.cost2[lane] : 0.0, e);
+#endif
             flip = ce > 0.0;
         }
         e = __builtin_amdgcn_readfirstlane(e);
@@ -159,11 +191,21 @@ __device__ __forceinline__ int gen_run(const int lane, TV& Tv, double& T16, doub
         }
         r = __builtin_amdgcn_readfirstlane(r);
         if (!forced) ndeg = (qmin <= DEGEN_EPS) ? ndeg + 1 : 0;
-        gen_apply<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, carry, e, flip, ce, c2e, a, pinv, r, forced);
+        gen_apply<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, cc, cc2, carry, e, flip, ce, c2e, a, pinv, r, forced);
+#if !PLP_WIDE_PEEL
         forced = false;
+#endif
         return true;
     };
+#if PLP_WIDE_PEEL
+    {
+        bool go = true;
+        if (forced_first) go = pivot(std::integral_constant<bool, true>{});
+        while (go) go = pivot(std::integral_constant<bool, false>{});
+    }
+#else
     while (pivot() && pivot()) {}
+#endif
     return status;
 }
 
@@ -210,9 +252,17 @@ __global__ __launch_bounds__(64, 4) void lp_w_kernel(long long B, int m_max, con
     S.maxit = 50 * (m + N) + 100;
     S.negz = 0.0;
     S.negz2 = 0.0;
+    double cc = 0.0, cc2 = 0.0;  // (PLP_WIDE_CREG) my column's entries of the two cost rows
     if (lane <= NC) {
+#if PLP_WIDE_CREG
+        if (lane < NC) {
+            cc = need_p1 ? (lane == N ? 1.0 : 0.0) : (lane < N ? cj : 0.0);
+            cc2 = (need_p1 & (lane < N)) ? cj : 0.0;
+        }
+#else
         sh.cost[lane] = need_p1 ? (lane == N ? 1.0 : 0.0) : (lane < N ? cj : 0.0);
         sh.cost2[lane] = (need_p1 & (lane < N)) ? cj : 0.0;
+#endif
         sh.cv[lane] = lane == N ? 0 : ((lane + 1) << 1);  // column N holds t (id -1)
     }
     __syncthreads();
@@ -222,9 +272,9 @@ __global__ __launch_bounds__(64, 4) void lp_w_kernel(long long B, int m_max, con
     } else if (infeasible0) {
         st = ST_INFEAS;
     } else if (!need_p1) {
-        st = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, false, false, 0.0);
+        st = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, cc, cc2, false, false, 0.0);
     } else {
-        const int s1 = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, true, true, beta);
+        const int s1 = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, cc, cc2, true, true, beta);
         if (s1 != ST_OPT) {
             st = (s1 == ST_ITER) ? ST_ITER : ST_NUM;  // (the auxiliary problem is never unbounded)
         } else {
@@ -249,21 +299,29 @@ __global__ __launch_bounds__(64, 4) void lp_w_kernel(long long B, int m_max, con
                     if (ed < 0) {  // row "0 = t": redundant, it takes no further part
                         if (lane == rt) rowact = false;
                     } else {
-                        const double cc1 = lane < NC ? sh.cost[lane] : 0.0;
-                        const double cc2 = lane < NC ? sh.cost2[lane] : 0.0;
+#if PLP_WIDE_CREG
+                        const double cc1_ = cc, cc2_ = cc2;
+#else
+                        const double cc1_ = lane < NC ? sh.cost[lane] : 0.0;
+                        const double cc2_ = lane < NC ? sh.cost2[lane] : 0.0;
+#endif
                         const double a = row_at<NC>(Tv, T16, ed);
-                        gen_apply<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, true, ed, false, uniform_lane(cc1, ed),
-                                      uniform_lane(cc2, ed), a, rcpn(a), rt, true);
+                        gen_apply<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, cc, cc2, true, ed, false,
+                                      uniform_lane(cc1_, ed), uniform_lane(cc2_, ed), a, rcpn(a), rt, true);
                     }
                 }
                 // the column that now holds t is dropped; the carried cost row becomes active
                 const uint64_t tcol = __ballot((lane < NC) && (sh.cv[lane < NC ? lane : 0] >> 1) == 0);
                 S.dead |= (unsigned)tcol;
+#if PLP_WIDE_CREG
+                cc = cc2;
+#else
                 if (lane < NC) sh.cost[lane] = sh.cost2[lane];
+#endif
                 S.negz = S.negz2;
                 if (rowact & (beta < 0.0)) beta = 0.0;
                 __syncthreads();
-                st = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, false, false, 0.0);
+                st = gen_run<NC>(lane, Tv, T16, beta, rowvar, rowneg, rowact, sh, S, cc, cc2, false, false, 0.0);
             }
         }
     }

@@ -4,10 +4,26 @@
 #pragma once
 #include "plp_kernels.hpp"
 #include "plp_wave.hpp"
+#include <type_traits>
 
 namespace plp {
 namespace wide {
 
+#ifndef PLP_WIDE_CREG
+#define PLP_WIDE_CREG 1
+#endif
+#ifndef PLP_WIDE_PEEL
+#define PLP_WIDE_PEEL 2
+#endif
+#ifndef PLP_WIDE_DPP1
+#define PLP_WIDE_DPP1 1
+#endif
+#ifndef PLP_WIDE_SPLITLOAD
+#define PLP_WIDE_SPLITLOAD 0
+#endif
+#ifndef PLP_WIDE_BPERM
+#define PLP_WIDE_BPERM 0
+#endif
 #define PLP_DPP_BCAST15 0x142
 #define PLP_DPP_BCAST31 0x143
 
@@ -29,6 +45,30 @@ __device__ __forceinline__ double uniform_lane(double v, int lane) {  // value o
 // wave-wide min / max of a u32 with the DPP operand folded into the VALU op (one instruction per level; hipcc does
 // not fold v_mov_dpp into the consumer by itself); result wave-uniform (lane 63 holds it after the row_bcast levels)
 #define PLP_W_DPP(OP, v, CTRL, RM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL " row_mask:" RM " bank_mask:0xf" : "+v"(v))
+#if PLP_WIDE_DPP1
+// the six levels and the read-out as ONE asm statement: the hazard nops are written once (a VALU write needs two wait
+// states before a DPP read of the same register); statement by statement the compiler adds its own s_nop in front of
+// every one of them (12 scalar instructions per reduction, two reductions per pivot)
+#define PLP_W_REDUCE(OP, v, res)                                                                     \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"          \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"          \
+                 "s_nop 0\n\tv_readlane_b32 %1, %0, 63"                                              \
+                 : "+v"(v), "=s"(res))
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned res;
+    PLP_W_REDUCE("v_min_u32_dpp", v, res);
+    return res;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    unsigned res;
+    PLP_W_REDUCE("v_max_u32_dpp", v, res);
+    return res;
+}
+#else
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
     PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1]", "0xf");
@@ -47,6 +87,7 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:31", "0xc");
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+#endif
 __device__ __forceinline__ double rcpn(double a) {
     const double x0 = __builtin_amdgcn_rcp(a);
     const double x1 = fma(x0, fma(-a, x0, 1.0), x0);
@@ -108,17 +149,40 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
     const int maxit = 50 * (m + nfree) + 100;
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     int status = -1;
+#if PLP_WIDE_CREG
+    // the reduced costs stay in a register (lane j: column j) from the set-up the caller left in sh.cost: one LDS
+    // store -> fence -> load round trip less on the chain from one pivot to the next pricing
+    double c = lane < NC ? sh.cost[lane < NC ? lane : 0] : 0.0;
+#endif
+#if PLP_WIDE_PEEL
+    // three instances of the pivot -- the forced first one, Dantzig's rule, Bland's rule -- instead of one body that
+    // tests `forced` and `ndeg >= BLAND_AFTER` as data at every step (scalar compares, selects and branches of every pivot)
+    auto pivot = [&](auto forced_c, auto bland_c) __attribute__((always_inline)) -> bool {
+        constexpr bool forced = decltype(forced_c)::value;
+#if PLP_WIDE_PEEL == 2
+        const bool bland = ndeg >= BLAND_AFTER;   // (PEEL == 2: only the forced pivot is an instance of its own)
+#else
+        constexpr bool bland = decltype(bland_c)::value;
+#endif
+#else
     auto pivot = [&]() __attribute__((always_inline)) -> bool {
         const bool bland = ndeg >= BLAND_AFTER;
+#endif
         int e;
         double ce;       // reduced cost of the entering column as stored
         bool flip = false;
         if (forced) {
             e = NC - 1;
+#if PLP_WIDE_CREG
+            ce = uniform_lane(c, NC - 1);
+#else
             ce = sh.cost[NC - 1];
+#endif
         } else {
             // ---- pricing: lane j looks after column j
+#if !PLP_WIDE_CREG
             const double c = lane < NC ? sh.cost[lane] : 0.0;
+#endif
             const bool elig = (lane < NC) & (fabs(c) > TOL_D) & ((((cfree >> (lane & 31)) & 1u) != 0u) | (c < 0.0));
             const uint64_t eb = __ballot(elig);
             if (eb == 0) { status = ST_OPT; return false; }
@@ -193,35 +257,88 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
             rowneg = (vin & 1) ^ (flip ? 1 : 0);
             rowact = !efree;  // a free variable never leaves again
         }
+#if PLP_WIDE_BPERM
+        double rb;
+        {
+            // the scaled pivot row goes from lane r's registers to every lane through the LDS crossbar (ds_bpermute, no
+            // memory): the update does not wait for the store -> load round trip, which only the cost row still needs
+            const int raddr = r << 2;
+            const double f = is_r ? 0.0 : a;
+            rb = bcast_addr(beta, raddr);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, bcast_addr(ROW_GET(j), raddr), ROW_GET(j)));
+            row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
+            beta = fma(-f, rb, beta);
+        }
         __syncthreads();
+#else
+        __syncthreads();
+        const double rb = sh.rho[NC];
         {
             // row r: T * (1/a_r)  (f = 0);  every other row: T - a_i * rho  (scale 1)
             // (scaling the pivot row in place inside the branch above -- inline asm, so that it stays a branch -- costs
             // a copy of the row vector: 136 VGPRs instead of 102, three waves per SIMD; not kept)
             const double f = is_r ? 0.0 : a;
-            const double rb = sh.rho[NC];
+#if PLP_WIDE_SPLITLOAD
+            // the pivot row is fetched in two halves (the scheduler would otherwise hoist all NC loads: 2 NC registers)
+            constexpr int NH = NC > 8 ? (NC + 1) / 2 : NC;
+#pragma unroll
+            for (int j = 0; j < NH; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = NH; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j)));
+#else
 #pragma unroll
             for (int j = 0; j < NC; ++j) ROW_SET(j, fma(-f, sh.rho[j], ROW_GET(j)));
+#endif
             row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
             beta = fma(-f, rb, beta);
         }
+#endif
         // ---- reduced costs (lane j = column j); the entering column is sign-normalised first
-        if (negz) *negz = fma(-(flip ? -ce : ce), sh.rho[NC], *negz);  // objective row: -zeta, as SimplexR carries it
+        if (negz) *negz = fma(-(flip ? -ce : ce), rb, *negz);  // objective row: -zeta, as SimplexR carries it
+#if PLP_WIDE_CREG
+        {
+            const double fc = flip ? -ce : ce;
+            const double cn = (lane == e) ? -(fc * p) : fma(-fc, sh.rho[lane < NC ? lane : NC], c);
+            c = lane < NC ? cn : 0.0;
+        }
+#else
         if (lane < NC) {
             const double fc = flip ? -ce : ce;
             const double cj = sh.cost[lane];
             sh.cost[lane] = (lane == e) ? -(fc * p) : fma(-fc, sh.rho[lane], cj);
         }
+#endif
         cfree &= ~(1u << e);
         iters += 1;
         if (forced) {
             if (rowact & (beta < 0.0)) beta = 0.0;  // rounding of the forced pivot
+#if !PLP_WIDE_PEEL
             forced = false;
+#endif
         }
         __syncthreads();
         return true;
     };
+#if PLP_WIDE_PEEL
+    {
+        using T_ = std::integral_constant<bool, true>;
+        using F_ = std::integral_constant<bool, false>;
+        bool go = true;
+        if (forced) go = pivot(T_{}, F_{});
+#if PLP_WIDE_PEEL == 2
+        while (go) go = pivot(F_{}, F_{});
+#else
+        while (go) {
+            if (ndeg < BLAND_AFTER) go = pivot(F_{}, F_{});
+            else go = pivot(F_{}, T_{});
+        }
+#endif
+    }
+#else
     while (pivot() && pivot()) {}
+#endif
     iters_out = iters;
     return status;
 }
