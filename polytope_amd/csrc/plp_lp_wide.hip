@@ -61,7 +61,7 @@ __device__ __forceinline__ void gen_apply(const int lane, TV& Tv, double& T16, d
         rowneg = (vin & 1) ^ (flip ? 1 : 0);
         rowact = !efree;  // a free variable never leaves again
     }
-    __syncthreads();
+    wave_sync();
     const double f = is_r ? 0.0 : a;
     const double rb = sh.rho[NC];
 #pragma unroll
@@ -92,7 +92,7 @@ __device__ __forceinline__ void gen_apply(const int lane, TV& Tv, double& T16, d
     S.cfree &= ~(1u << e);
     S.iters += 1;
     if (clamp & rowact & (beta < 0.0)) beta = 0.0;  // rounding of a forced pivot
-    __syncthreads();
+    wave_sync();
 }
 
 // Dantzig / Bland loop from a primal-feasible dictionary; `forced`: the first pivot is "column NC-1 enters, the active row

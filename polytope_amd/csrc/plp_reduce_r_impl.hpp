@@ -1186,6 +1186,290 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense
                                                flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
+// ---- the same polytope-per-workgroup pipeline with the INDEPENDENT LPs of a polytope spread over NW wavefronts.
+// At the batch sizes where one wavefront per polytope cannot fill the chip (5 000 polytopes are 4.9 wavefronts per SIMD,
+// all resident from the start: the launch is a drain, 2-3 waves per SIMD on average, profiles/r04/r04e_wide_counters.json)
+// a workgroup of NW wavefronts takes one polytope: wavefront 0 runs F1 (while the others run the dedupe, its partner
+// loop cut into NW - 1 ranges), the prefilter and the presolve (lane = row, as reduce_wdense_kernel), and wavefront w takes every NW-th of the 2d box LPs and of the
+// redundancy LPs the presolve left.  Each LP is
+// wide::solve_dense on the rows in LDS exactly as in reduce_wdense_kernel; the in-place h[k] +- 0.1 round trip
+// (:1149-1151) becomes the rule reduce_split_kernel uses (an unsettled row that had its turn before row k carries
+// (b + 0.1) - 0.1, row k itself b + 0.1), so the outputs are bit for bit those of the one-wavefront form.
+#ifndef PLP_REDUCE_WSPLIT_MAXB
+// Measured (scripts/debug/wsplit_sweep.py, ms with one / two / four wavefronts per polytope):
+//   (64,8)   B = 1  0.192 / 0.116 / 0.085    250  0.230 / 0.142 / 0.100    1 000  0.251 / 0.162 / 0.131    2 000  0.292 / 0.212 / 0.222
+//            5 000  0.444 / 0.417 / 0.432    8 000  0.658 / 0.597 / 0.640    16 000  1.127 / 1.077 / 1.218
+//   (48,6)   250  0.159 / 0.096 / 0.070    5 000  0.301 / 0.253 / 0.254    16 000  0.678 / 0.620 / 0.681
+//   (64,12)  250  0.267 / 0.161 / 0.120    5 000  0.580 / 0.495 / 0.543    16 000  1.336 / 1.319 / 1.591
+// two wavefronts per polytope up to here, four up to PLP_REDUCE_WSPLIT_MAXB4
+#define PLP_REDUCE_WSPLIT_MAXB 16000
+#endif
+#ifndef PLP_REDUCE_WSPLIT_MAXB4
+#define PLP_REDUCE_WSPLIT_MAXB4 1500   // four wavefronts per polytope up to here
+#endif
+template <int D>
+__host__ __device__ constexpr size_t wsplit_block_bytes() { return (sizeof(wide::WideShared<D + 1>) + 15) & ~(size_t)15; }
+template <int D, int NW>
+static inline size_t reduce_wsplit_smem_bytes() {
+    return (size_t)64 * (D + 2) * 8 + (size_t)(D + 2 + 2 * D) * 8 + 8 * 8 + 8 * 4 + 64 * 4 + NW * wsplit_block_bytes<D>();
+}
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void reduce_wsplit_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
+    int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word,
+    unsigned long long epoch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int rows = 64;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long pg = blockIdx.x;
+    double* myA = reinterpret_cast<double*>(smem_raw);   // [64][D]
+    double* myb = myA + rows * D;                         // [64]
+    double* myan = myb + rows;                            // [64]  1/||a_i||, then a_i.xc
+    double* sxc = myan + rows;                            // [D + 2]  xc, r
+    double* sval = sxc + (D + 2);                         // [2 D]    box values
+    unsigned long long* s64 = reinterpret_cast<unsigned long long*>(sval + 2 * D);  // removed, kept, todo, live
+    unsigned* s32 = reinterpret_cast<unsigned*>(s64 + 8);  // flags (1: an LP failed, 2: retry), next box LP, next F2 LP, ball bits
+    int* slist = reinterpret_cast<int*>(s32 + 8);          // [64] the rows whose LP runs, in row order
+    unsigned char* shb = reinterpret_cast<unsigned char*>(slist + 64) + (size_t)w * wsplit_block_bytes<D>();
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    {
+        const int rowsz = m_max * D;
+        const double* src = Ag + pg * rowsz;
+        for (int idx = threadIdx.x; idx < rowsz; idx += 64 * NW) myA[idx] = src[idx];
+        const double* srcb = bg + pg * m_max;
+        for (int idx = threadIdx.x; idx < m_max; idx += 64 * NW) myb[idx] = srcb[idx];
+        if (threadIdx.x < 8) { s64[threadIdx.x] = 0ull; s32[threadIdx.x] = 0u; }
+    }
+    __syncthreads();
+    const int m = mrows ? mrows[pg] : m_max;
+    const bool has = (lane < m) & (m <= rows);
+    bool retry = force_retry != 0;
+    // ---------------------------------------------------------------- F1: Chebyshev ball (wavefront 0) while the others dedupe
+    constexpr int NC1 = D + 1;
+    wide::WideShared<NC1>& sh1 = *reinterpret_cast<wide::WideShared<NC1>*>(shb);
+    typename wide::RowVec<NC1>::type Tv = (typename wide::RowVec<NC1>::type)(0.0);
+    double T16 = 0.0, beta1 = 0.0, q01 = 0.0;
+    int rowvar1 = NC1 + lane, rowneg1 = 0;
+    bool rowact1 = false, infeasible0 = false, bad1 = false;
+    if (w == 0) {
+        double nrm2 = 0.0;
+        bool finite = true;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            const double v = has ? myA[lane * D + kk] : 0.0;
+            ROW_SET(kk, v);
+            nrm2 = nrm2 + v * v;
+            finite = finite & isfinite(v);
+        }
+        const double bk = has ? myb[lane] : 0.0;
+        finite = finite & isfinite(bk);
+        const double nrm = sqrt(nrm2);
+        myan[lane] = 1.0 / nrm;
+        const bool zero = !(nrm > 0.0);
+        rowact1 = has & !zero;
+        ROW_SET(D, rowact1 ? nrm : 0.0);
+        beta1 = rowact1 ? bk : 0.0;
+        q01 = bk / nrm;
+        if (lane <= NC1) {
+            sh1.cost[lane] = lane == D ? -1.0 : 0.0;
+            sh1.cv[lane] = (lane + 1) << 1;
+        }
+        infeasible0 = __ballot(has & zero & (bk < -TOL_FEAS)) != 0;
+        bad1 = (__ballot(!finite) != 0) | (m > rows);
+    }
+    __syncthreads();  // 1/||a|| of every row
+    if (w == 0) {
+        int st1, it1 = 0;
+        if (bad1) st1 = ST_NUM;
+        else if (infeasible0) st1 = ST_INFEAS;
+        else st1 = wide::wide_run<NC1>(lane, m, Tv, T16, beta1, rowvar1, rowneg1, rowact1, sh1, NC1, true, q01, it1);
+        const double mine = rowneg1 ? -beta1 : beta1;
+        double xc1[D], rr1 = 0.0;
+#pragma unroll
+        for (int j = 0; j <= D; ++j) {
+            const uint64_t ob = __ballot(rowvar1 == j);
+            const double xj = ob ? wide::uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+            if (j < D) xc1[j < D ? j : 0] = xj; else rr1 = xj;
+        }
+        const bool ball1 = (st1 == ST_OPT) & (rr1 >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        const bool full1 = ball1 & (rr1 > abs_tol);
+        if (lane == 0) {
+            r_out[pg] = ball1 ? rr1 : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { xc_out[pg * D + k] = ball1 ? xc1[k] : qnan; sxc[k] = xc1[k]; }
+            sxc[D] = rr1;
+            s32[3] = (ball1 ? 1u : 0u) | (full1 ? 2u : 0u);
+        }
+    } else {
+        // ------------------------------------------------------------ dedupe (:1094-1110): the partners j in NW - 1 ranges
+        bool removed = false;
+        double ni[D];
+        const double an_i = myan[lane];
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) ni[kk] = myA[lane * D + kk] * an_i;
+        const double bin_ = myb[lane] * an_i;
+        const int jw = (m_max + NW - 2) / (NW - 1);
+        const int j1 = w * jw < m_max ? w * jw : m_max;
+        for (int j = (w - 1) * jw; j < j1; ++j) {
+            const bool jrow = j < m;
+            const double an_j = myan[j];
+            double dot = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) dot = dot + ni[kk] * (myA[j * D + kk] * an_j);
+            const double bjn = myb[j] * an_j;
+            const bool par = has & jrow & (j != lane) & (dot > 1.0 - abs_tol);
+            const bool rem = par & ((lane < j) ? !(bin_ < bjn) : (bjn < bin_));
+            removed = removed | rem;
+        }
+        const uint64_t rb = __ballot(removed);
+        if ((lane == 0) & (rb != 0ull)) atomicOr(&s64[0], (unsigned long long)rb);
+    }
+    __syncthreads();  // the ball, the removed rows
+    double xc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xc[k] = sxc[k];
+    const bool ball = (s32[3] & 1u) != 0u, fulldim = (s32[3] & 2u) != 0u;
+    uint64_t live = __ballot(has) & ~(uint64_t)s64[0];
+    auto zero_dead = [&](bool alive) {   // (wavefront 0, lane = row) rows that dropped out are zeroed: A, b and s
+        if (!alive) {
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) myA[lane * D + kk] = 0.0;
+            myb[lane] = 0.0;
+            myan[lane] = 0.0;
+        }
+    };
+    if (w == 0) {   // the dictionary translated to the Chebyshev centre: s_i = a_i.xc replaces 1/||a_i||
+        double sk = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) sk = fma(has ? myA[lane * D + kk] : 0.0, ball ? xc[kk] : 0.0, sk);
+        myan[lane] = sk;
+        zero_dead(((live >> lane) & 1ull) != 0ull);
+    }
+    int flags = fulldim ? 0 : RF_EMPTY;
+    int nlp = 1;
+    uint64_t keep = 0ull;
+    int stage = 0;
+    if (fulldim) {
+        const int neq = __popcll(live);
+        if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
+        else stage = (neq > 3 * D) ? 1 : 2;
+    }
+    __syncthreads();
+    wide::WideShared<D>& shd = *reinterpret_cast<wide::WideShared<D>*>(shb);
+    // ---------------------------------------------------------------- F3: bounding box (:1367-1409), any wavefront the next LP
+    if (stage == 1) {
+        const bool act = ((live >> lane) & 1ull) != 0ull;
+        const int nlive = __popcll(live);
+        for (int it = w; it < 2 * D; it += NW) {   // (w is a scalar: the loop stays wave-uniform)
+            const int kx = it >> 1;
+            const bool up = it & 1;
+            double xck = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
+            double negz = 0.0;
+            const int st = wide::solve_dense<D>(lane, nlive, myA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                                fmax(myb[lane] - myan[lane], 0.0), act, negz, shd);
+            double val;
+            unsigned fl = 0u;
+            if (st == ST_OPT) val = up ? (xck + negz) : (xck - negz);
+            else if (st == ST_UNBND) val = up ? pinf : -pinf;
+            else { val = qnan; fl = 1u; }
+            if (st == ST_RETRY) fl |= 2u;
+            if (lane == 0) {
+                sval[it] = val;
+                if (fl) atomicOr(&s32[0], fl);
+            }
+        }
+        __syncthreads();
+        if (w == 0) {   // prefilter sums, accumulated in k order (:1131-1134)
+            double s1 = 0.0, s2 = 0.0;
+            for (int kx = 0; kx < D; ++kx) {
+                const double lo = sval[2 * kx], hi = sval[2 * kx + 1];
+                const double aik = myA[lane * D + kx];
+                const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                s1 = s1 + pa * (hi - lo);
+                s2 = s2 + aik * lo;
+            }
+            const bool out = act & ((s1 - (myb[lane] - s2)) < -1e-4);
+            const uint64_t l2 = live & ~__ballot(out);
+            zero_dead(((l2 >> lane) & 1ull) != 0ull);
+            if (lane == 0) s64[3] = l2;
+        }
+        __syncthreads();
+        live = s64[3];
+        const unsigned fl = s32[0];
+        retry = retry | ((fl & 2u) != 0u);
+        nlp += 2 * D;
+        if (fl & 1u) flags |= RF_LPFAIL;
+        if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
+        else stage = 2;
+    }
+    // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+    if (stage == 2) {
+        const bool act = ((live >> lane) & 1ull) != 0ull;
+        const int nlive = __popcll(live);
+        nlp += nlive;
+        if (w == 0) {
+            uint64_t todo = live;
+#if PLP_R_PRESOLVE
+            {   // rows the presolve settles as "keep" need no LP (lane i = row i: the ballot is the row mask)
+                const uint64_t cert = __ballot((f2_presolve<D, 1>(myA, myb, myan, lane, m_max, act ? 1u : 0u, abs_tol) & 1u) != 0u);
+                todo &= ~cert;
+                ctr_add(ctr, -__popcll(cert), lane == 0);
+                if ((lane == 0) & (cert != 0ull)) atomicOr(&s64[1], (unsigned long long)cert);
+            }
+#endif
+            if ((todo >> lane) & 1ull) slist[__popcll(todo & ((1ull << lane) - 1ull))] = lane;
+            if (lane == 0) s64[2] = todo;
+        }
+        __syncthreads();
+        // (wave-uniform, and said so: the LP loop stays scalar)
+        const uint64_t todo_v = s64[2];
+        const uint64_t todo = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(todo_v >> 32)) << 32) |
+                              (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)todo_v);
+        const int ntodo = __popcll(todo);
+        const double h0 = myb[lane];
+        const double sl = myan[lane];
+        const bool mytodo = ((todo >> lane) & 1ull) != 0ull;
+        for (int idx = w; idx < ntodo; idx += NW) {
+            const int kr = __builtin_amdgcn_readfirstlane(slist[idx]);
+            const double ck = lane < D ? -myA[kr * D + (lane < D ? lane : 0)] : 0.0;  // f = -A[k,:]  (:1145)
+            const double cxc = -myan[kr];
+            // h as the reference holds it when row kr has its turn (:1149-1151)
+            const double hp = h0 + 0.1;
+            const double hh = (mytodo & (lane < kr)) ? hp - 0.1 : ((lane == kr) ? hp : h0);
+            double negz2 = 0.0;
+            const int st2 = wide::solve_dense<D>(lane, nlive, myA, ck, fmax(hh - sl, 0.0), act, negz2, shd);
+            const double fun = cxc - negz2;  // c.xc + zeta, zeta = -negz
+            const double hk = (myb[kr] + 0.1) - 0.1;
+            const double obj = -fun - hk;    // (:1156)
+            const bool keepk = ((st2 == ST_OPT) & (obj > abs_tol)) | (st2 == ST_UNBND);
+            if (lane == 0) {
+                if (keepk) atomicOr(&s64[1], 1ull << kr);
+                if (st2 == ST_RETRY) atomicOr(&s32[0], 2u);
+            }
+        }
+        __syncthreads();
+        keep = s64[1];
+        retry = retry | ((s32[0] & 2u) != 0u);
+        flags |= RF_MINREP;
+    }
+    // ---------------------------------------------------------------- results
+    if (w == 0) {
+        if (lane == 0) {
+            keep_out[pg] = keep;
+            flags_out[pg] = retry ? (int)RF_RETRY : flags;
+            nlp_out[pg] = nlp;
+        }
+        ctr_add(ctr, nlp, lane == 0);
+        if (retry_word && retry && lane == 0) atomicMax(retry_word, epoch);
+    }
+}
+
 template <int D>
 static int launch_reduce_lazy(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
                               unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
@@ -1194,10 +1478,32 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
     // PLP_REDUCE_WDENSE=0 / 1: F3 / F2 without / with a stored dictionary (A/B)
     const char* wd = getenv("PLP_REDUCE_WDENSE");
-    if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD))
+    if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD)) {
+        // batches that leave the chip part empty at one wavefront per polytope: NW wavefronts per polytope
+        // (PLP_REDUCE_WSPLIT=0 / 1: never / always, PLP_REDUCE_WSPLIT_MAXB: the largest batch that takes it)
+        const char* ws = getenv("PLP_REDUCE_WSPLIT");      // 0: never, 2 / 4: always with that many wavefronts per polytope
+        const char* wb = getenv("PLP_REDUCE_WSPLIT_MAXB");
+        const char* wb4 = getenv("PLP_REDUCE_WSPLIT_MAXB4");
+        const long long maxb = wb ? atoll(wb) : PLP_REDUCE_WSPLIT_MAXB;
+        const long long maxb4 = wb4 ? atoll(wb4) : PLP_REDUCE_WSPLIT_MAXB4;
+        const int fi = (fr && fr[0] == '1') ? 1 : 0;
+        if (B >= 1 && !(ws && ws[0] == '0')) {
+            if ((ws && ws[0] == '4') || (!ws && B <= maxb4)) {
+                const size_t smem_ws = reduce_wsplit_smem_bytes<D, 4>();
+                hipLaunchKernelGGL((reduce_wsplit_kernel<D, 4>), dim3((unsigned)B), dim3(256), smem_ws, st, B, m_max, A, b, mrows,
+                                   abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
+                return 0;
+            }
+            if ((ws && ws[0] == '2') || (!ws && B <= maxb)) {
+                const size_t smem_ws = reduce_wsplit_smem_bytes<D, 2>();
+                hipLaunchKernelGGL((reduce_wsplit_kernel<D, 2>), dim3((unsigned)B), dim3(128), smem_ws, st, B, m_max, A, b, mrows,
+                                   abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
+                return 0;
+            }
+        }
         hipLaunchKernelGGL((reduce_wdense_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
                            mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
-    else
+    } else
         hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
                            mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
     return 0;

@@ -27,6 +27,22 @@ namespace wide {
 #define PLP_DPP_BCAST15 0x142
 #define PLP_DPP_BCAST31 0x143
 
+// Ordering point for the wavefront's own LDS block (one wavefront writes and reads it: the LDS unit serves a wavefront's
+// operations in issue order, what is needed is that the compiler keeps them in program order).  PLP_WIDE_WAVESYNC=0: the
+// workgroup barrier -- the same thing in a 64-thread workgroup, and wrong in reduce_wsplit_kernel, whose wavefronts run
+// different LPs.
+#ifndef PLP_WIDE_WAVESYNC
+#define PLP_WIDE_WAVESYNC 1
+#endif
+__device__ __forceinline__ void wave_sync() {
+#if PLP_WIDE_WAVESYNC
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __syncthreads();
+#endif
+}
 __device__ __forceinline__ int wave_min_i32(int v) {
     int t;
     t = __builtin_amdgcn_update_dpp(v, v, PLP_DPP_XOR1, 0xF, 0xF, false); v = t < v ? t : v;
@@ -270,9 +286,9 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
             row_put<NC>(Tv, T16, e, is_r ? pinv : -(f * p));
             beta = fma(-f, rb, beta);
         }
-        __syncthreads();
+        wave_sync();
 #else
-        __syncthreads();
+        wave_sync();
         const double rb = sh.rho[NC];
         {
             // row r: T * (1/a_r)  (f = 0);  every other row: T - a_i * rho  (scale 1)
@@ -318,7 +334,7 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
             forced = false;
 #endif
         }
-        __syncthreads();
+        wave_sync();
         return true;
     };
 #if PLP_WIDE_PEEL
@@ -357,12 +373,12 @@ __device__ __forceinline__ int solve_dense(const int lane, const int nrows, cons
     double beta = beta0;
     int rowvar = D + lane, rowneg = 0, iters = 0;
     bool rowact = act;
-    __syncthreads();  // (the last LP's reads of the block are done)
+    wave_sync();  // (the last LP's reads of the block are done)
     if (lane <= D) {
         sh.cost[lane] = lane < D ? cj : 0.0;
         sh.cv[lane] = (lane + 1) << 1;
     }
-    __syncthreads();
+    wave_sync();
     negz = 0.0;
     return wide_run<D>(lane, nrows, Tv, T16, beta, rowvar, rowneg, rowact, sh, D, false, 0.0, iters, &negz);
 }

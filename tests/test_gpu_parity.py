@@ -728,6 +728,53 @@ def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
         assert abs(res["r"][k] - o["r"]) <= TOL and int(res["nlp"][k]) == o["nlp"]
 
 
+@pytest.mark.gpu
+def test_reduce_wavefronts_per_polytope_bitwise(pa, oracle, monkeypatch):
+    """reduce_wsplit_kernel<D, NW> -- the polytope-per-workgroup pipeline with the independent LPs of a polytope spread over
+    NW = 2 / 4 wavefronts (the default up to 16 000 / 1 500 polytopes where reduce_wdense_kernel used to run: more than 32 rows at
+    d = 5..8, d = 9..13) -- must give every output bit of the one-wavefront form: the h[k] +- 0.1 round trip is a rule there,
+    the box LPs and the redundancy LPs run in another order and on other wavefronts.  Batches of 1 .. 3 000, ragged,
+    duplicated and infeasible rows, pyramids (degenerate vertices: Bland's rule inside the LPs), a sample against the oracle."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(11)
+
+    def three(A, b, m=None):
+        out = []
+        for ws in ("0", "2", "4"):
+            monkeypatch.setenv("PLP_REDUCE_WSPLIT", ws)
+            out.append(pa.reduce_batch(A, b, m=m))
+        monkeypatch.delenv("PLP_REDUCE_WSPLIT", raising=False)
+        out.append(pa.reduce_batch(A, b, m=m))   # the default choice
+        return out
+
+    for (B, m, d) in [(1, 64, 8), (7, 40, 5), (300, 64, 8), (300, 48, 6), (200, 64, 12), (200, 57, 13), (3000, 33, 7),
+                      (2, 64, 13), (150, 64, 9), (100, 35, 10)]:
+        A, b = random_hpolytopes(B, m, d, seed=5 * m + d, stream=0)
+        for k in range(0, B, 5):
+            j = rng.integers(m)
+            A[k, (j + 1) % m] = A[k, j]
+            b[k, (j + 1) % m] = b[k, j] + rng.choice([0.0, 0.05])
+        for k in range(3, B, 11):
+            b[k, 0] = -4.0
+        rows = rng.integers(max(d + 2, m - 9), m + 1, B).astype(np.int32)
+        for mr in (None, rows):
+            one, two, four, default = three(A, b, mr)
+            for key in one:
+                for other in (two, four, default):
+                    assert np.array_equal(one[key].view(np.uint8), other[key].view(np.uint8)), ((B, m, d), key, mr is None)
+        masks = pa.keep_to_bool(two["keep"], m)
+        for k in range(0, B, 41 if B < 1000 else 307):
+            o = oracle.reduce(A[k, :rows[k]], b[k, :rows[k]])
+            assert int(two["flags"][k]) == o["flags"] and np.array_equal(masks[k, :rows[k]], o["keep"]), (m, d, k)
+            assert abs(two["r"][k] - o["r"]) <= TOL and int(two["nlp"][k]) == o["nlp"]
+    for (n, m, d) in [(40, 40, 9), (40, 40, 6), (30, 64, 8)]:
+        A, b = _pyramids(n, m, d, rng)
+        one, two, four, default = three(A, b)
+        for key in one:
+            for other in (two, four, default):
+                assert np.array_equal(one[key].view(np.uint8), other[key].view(np.uint8)), ("pyramids", m, d, key)
+
+
 @pytest.mark.parametrize("variant", ["PLP_REDUCE_1ROW", "PLP_REDUCE_RETRY_ALL", "PLP_REDUCE_SPLIT=0", "PLP_REDUCE_SPLIT=1",
                                      "PLP_REDUCE_SPLIT=0,PLP_REDUCE_RETRY_ALL=1", "PLP_REDUCE_SPLIT=1,PLP_REDUCE_RETRY_ALL=1"])
 def test_reduce_kernel_variants(pa, oracle, variant, monkeypatch):
