@@ -1213,7 +1213,7 @@ template <int D, int NW>
 static inline size_t reduce_wsplit_smem_bytes() {
     return (size_t)64 * (D + 2) * 8 + (size_t)(D + 2 + 2 * D) * 8 + 8 * 8 + 8 * 4 + 64 * 4 + NW * wsplit_block_bytes<D>();
 }
-template <int D, int NW>
+template <int D, int NW, bool WDENSE = true>
 __global__ __launch_bounds__(64 * NW) void reduce_wsplit_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -1371,8 +1371,13 @@ __global__ __launch_bounds__(64 * NW) void reduce_wsplit_kernel(
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
             double negz = 0.0;
-            const int st = wide::solve_dense<D>(lane, nlive, myA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
-                                                fmax(myb[lane] - myan[lane], 0.0), act, negz, shd);
+            int st;
+            if constexpr (WDENSE)
+                st = wide::solve_dense<D>(lane, nlive, myA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                          fmax(myb[lane] - myan[lane], 0.0), act, negz, shd);
+            else   // (d beyond PLP_REDUCE_WDENSE_MAXD: the LPs without a stored dictionary, plp_lazy.hpp)
+                st = lazy::solve<D>(lane, nlive, myA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0,
+                                    fmax(myb[lane] - myan[lane], 0.0), act, negz);
             double val;
             unsigned fl = 0u;
             if (st == ST_OPT) val = up ? (xck + negz) : (xck - negz);
@@ -1443,7 +1448,9 @@ __global__ __launch_bounds__(64 * NW) void reduce_wsplit_kernel(
             const double hp = h0 + 0.1;
             const double hh = (mytodo & (lane < kr)) ? hp - 0.1 : ((lane == kr) ? hp : h0);
             double negz2 = 0.0;
-            const int st2 = wide::solve_dense<D>(lane, nlive, myA, ck, fmax(hh - sl, 0.0), act, negz2, shd);
+            int st2;
+            if constexpr (WDENSE) st2 = wide::solve_dense<D>(lane, nlive, myA, ck, fmax(hh - sl, 0.0), act, negz2, shd);
+            else st2 = lazy::solve<D>(lane, nlive, myA, ck, fmax(hh - sl, 0.0), act, negz2);
             const double fun = cxc - negz2;  // c.xc + zeta, zeta = -negz
             const double hk = (myb[kr] + 0.1) - 0.1;
             const double obj = -fun - hk;    // (:1156)
@@ -1478,32 +1485,43 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
     // PLP_REDUCE_WDENSE=0 / 1: F3 / F2 without / with a stored dictionary (A/B)
     const char* wd = getenv("PLP_REDUCE_WDENSE");
-    if (wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD)) {
+    const bool dense = wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD);
+    {
         // batches that leave the chip part empty at one wavefront per polytope: NW wavefronts per polytope
-        // (PLP_REDUCE_WSPLIT=0 / 1: never / always, PLP_REDUCE_WSPLIT_MAXB: the largest batch that takes it)
-        const char* ws = getenv("PLP_REDUCE_WSPLIT");      // 0: never, 2 / 4: always with that many wavefronts per polytope
+        // (PLP_REDUCE_WSPLIT=0: never, 2 / 4: always with that many; PLP_REDUCE_WSPLIT_MAXB / _MAXB4: the largest batches that take them)
+        const char* ws = getenv("PLP_REDUCE_WSPLIT");
         const char* wb = getenv("PLP_REDUCE_WSPLIT_MAXB");
         const char* wb4 = getenv("PLP_REDUCE_WSPLIT_MAXB4");
-        const long long maxb = wb ? atoll(wb) : PLP_REDUCE_WSPLIT_MAXB;
-        const long long maxb4 = wb4 ? atoll(wb4) : PLP_REDUCE_WSPLIT_MAXB4;
+        // (without a stored dictionary, d = 14..16: (64,16) B = 250 0.228 / 0.143 / 0.112 ms with one / two / four wavefronts,
+        // 1 000 0.248 / 0.170 / 0.201, 3 000 0.355 / 0.346 / 0.437, 8 000 0.704 / 0.703 / 0.951)
+        const long long maxb = wb ? atoll(wb) : (dense ? PLP_REDUCE_WSPLIT_MAXB : 3000);
+        const long long maxb4 = wb4 ? atoll(wb4) : (dense ? PLP_REDUCE_WSPLIT_MAXB4 : 500);
         const int fi = (fr && fr[0] == '1') ? 1 : 0;
+        int nw = 0;
         if (B >= 1 && !(ws && ws[0] == '0')) {
-            if ((ws && ws[0] == '4') || (!ws && B <= maxb4)) {
-                const size_t smem_ws = reduce_wsplit_smem_bytes<D, 4>();
-                hipLaunchKernelGGL((reduce_wsplit_kernel<D, 4>), dim3((unsigned)B), dim3(256), smem_ws, st, B, m_max, A, b, mrows,
-                                   abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
-                return 0;
-            }
-            if ((ws && ws[0] == '2') || (!ws && B <= maxb)) {
-                const size_t smem_ws = reduce_wsplit_smem_bytes<D, 2>();
-                hipLaunchKernelGGL((reduce_wsplit_kernel<D, 2>), dim3((unsigned)B), dim3(128), smem_ws, st, B, m_max, A, b, mrows,
-                                   abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
-                return 0;
-            }
+            if ((ws && ws[0] == '4') || (!ws && B <= maxb4)) nw = 4;
+            else if ((ws && ws[0] == '2') || (!ws && B <= maxb)) nw = 2;
         }
+#define PLP_WSPLIT_LAUNCH(NW_, DENSE_)                                                                                          \
+        {                                                                                                                       \
+            const size_t smem_ws = reduce_wsplit_smem_bytes<D, NW_>();                                                          \
+            hipLaunchKernelGGL((reduce_wsplit_kernel<D, NW_, DENSE_>), dim3((unsigned)B), dim3(64 * NW_), smem_ws, st, B, m_max, A, b, \
+                               mrows, abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);        \
+            return 0;                                                                                                           \
+        }
+        if constexpr (D <= PLP_REDUCE_WDENSE_MAXD) {
+            if (dense && nw == 4) PLP_WSPLIT_LAUNCH(4, true)
+            if (dense && nw == 2) PLP_WSPLIT_LAUNCH(2, true)
+        } else {
+            if (!dense && nw == 4) PLP_WSPLIT_LAUNCH(4, false)
+            if (!dense && nw == 2) PLP_WSPLIT_LAUNCH(2, false)
+        }
+#undef PLP_WSPLIT_LAUNCH
+    }
+    if (dense)
         hipLaunchKernelGGL((reduce_wdense_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
                            mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
-    } else
+    else
         hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
                            mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
     return 0;

@@ -12,6 +12,9 @@ namespace wide {
 #ifndef PLP_WIDE_CREG
 #define PLP_WIDE_CREG 1
 #endif
+#ifndef PLP_WIDE_ROW9_V8
+#define PLP_WIDE_ROW9_V8 1
+#endif
 #ifndef PLP_WIDE_PEEL
 #define PLP_WIDE_PEEL 2
 #endif
@@ -125,6 +128,10 @@ template <> struct RowVec<5> { typedef v8d type; };
 template <> struct RowVec<6> { typedef v8d type; };
 template <> struct RowVec<7> { typedef v8d type; };
 template <> struct RowVec<8> { typedef v8d type; };
+#if PLP_WIDE_ROW9_V8
+// nine columns (d = 8 and its F1 / phase-1 column): eight in the vector, the ninth in the scalar T16, as for 17 columns
+template <> struct RowVec<9> { typedef v8d type; };
+#endif
 // (plain local variables, not a struct: the struct form was kept in scratch memory by the compiler)
 #define ROW_W ((int)(sizeof(Tv) / sizeof(double)))
 #define ROW_GET(j) ((j) < ROW_W ? Tv[(j) & (ROW_W - 1)] : T16)

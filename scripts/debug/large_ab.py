@@ -44,7 +44,7 @@ def digest(res):
 
 
 out = {}
-for (B, m, d) in [(20000, 64, 16), (20000, 64, 12), (20000, 48, 9)]:
+for (B, m, d) in [(20000, 64, 16), (20000, 64, 12), (20000, 48, 9), (20000, 64, 8)]:
     A, b = synth.random_hpolytopes(B, m, d, seed=1)
     At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
     res = pa.cheby_ball_batch(At, bt)
