@@ -137,11 +137,11 @@ __device__ __forceinline__ int gen_run(const int lane, TV& Tv, double& T16, doub
             if (S.iters >= S.maxit) { status = ST_ITER; return false; }
             if (!bland) {
                 const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
-                const unsigned mh = wave_max_u32(kh);
+                const unsigned mh = low_max_u32<NC>(kh);
                 uint64_t top = __ballot(elig & (kh == mh));
                 if (top & (top - 1ull)) {
                     const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
-                    const unsigned ml = wave_max_u32(kl);
+                    const unsigned ml = low_max_u32<NC>(kl);
                     top = __ballot(elig & (kh == mh) & (kl == ml));
                 }
                 e = __ffsll((long long)top) - 1;

@@ -87,6 +87,31 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     PLP_W_REDUCE("v_max_u32_dpp", v, res);
     return res;
 }
+// the same over the first N lanes only (the pricing: lane j = column j, the lanes beyond hold 0): three DPP levels cover
+// 8 lanes, four cover 16, every one of those lanes ends with the maximum and lane 0 is read
+template <int N>
+__device__ __forceinline__ unsigned low_max_u32(unsigned v) {
+    if constexpr (N <= 8) {
+        unsigned res;
+        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 0\n\tv_readlane_b32 %1, %0, 0"
+                     : "+v"(v), "=s"(res));
+        return res;
+    } else if constexpr (N <= 16) {
+        unsigned res;
+        asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 0\n\tv_readlane_b32 %1, %0, 0"
+                     : "+v"(v), "=s"(res));
+        return res;
+    } else {
+        return wave_max_u32(v);
+    }
+}
 #else
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     PLP_W_DPP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2]", "0xf");
@@ -106,6 +131,8 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     PLP_W_DPP("v_max_u32_dpp", v, "row_bcast:31", "0xc");
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+template <int N>
+__device__ __forceinline__ unsigned low_max_u32(unsigned v) { return wave_max_u32(v); }
 #endif
 __device__ __forceinline__ double rcpn(double a) {
     const double x0 = __builtin_amdgcn_rcp(a);
@@ -212,11 +239,11 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
             if (iters >= maxit) { status = ST_ITER; return false; }
             if (!bland) {  // largest |c|: its bit pattern orders like an unsigned integer
                 const unsigned kh = elig ? ((unsigned)__double2hiint(c) & 0x7fffffffu) : 0u;
-                const unsigned mh = wave_max_u32(kh);
+                const unsigned mh = low_max_u32<NC>(kh);
                 uint64_t top = __ballot(elig & (kh == mh));
                 if (top & (top - 1ull)) {  // several columns share the high word (rare): the low words decide
                     const unsigned kl = (elig & (kh == mh)) ? (unsigned)__double2loint(c) : 0u;
-                    const unsigned ml = wave_max_u32(kl);
+                    const unsigned ml = low_max_u32<NC>(kl);
                     top = __ballot(elig & (kh == mh) & (kl == ml));
                 }
                 e = __ffsll((long long)top) - 1;
