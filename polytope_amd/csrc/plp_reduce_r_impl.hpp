@@ -1162,6 +1162,9 @@ __device__ __forceinline__ void reduce_r_tile(
 #ifndef PLP_REDUCE_WDENSE_WAVES
 #define PLP_REDUCE_WDENSE_WAVES 4
 #endif
+#ifndef PLP_REDUCE_WDENSE_WAVES8
+#define PLP_REDUCE_WDENSE_WAVES8 6   // d <= 8 (89 VGPRs at d = 8 unconstrained: the presolve; 78 under the bound, nothing spills)
+#endif
 template <int D>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LAZY_WAVES) void reduce_lazy_ker
 // The same with the F3 / F2 LPs on the one-LP-per-wavefront DENSE engine (plp_wide.hpp: wide::solve_dense): the
 // dictionary is carried, the pivot column and row are wave-uniform.
 template <int D>
-__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense_kernel(
+__global__ __launch_bounds__(RBLOCK, ((D) <= 8 ? PLP_REDUCE_WDENSE_WAVES8 : PLP_REDUCE_WDENSE_WAVES)) void reduce_wdense_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
@@ -1205,7 +1208,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_WDENSE_WAVES) void reduce_wdense
 #define PLP_REDUCE_WSPLIT_MAXB 16000
 #endif
 #ifndef PLP_REDUCE_WSPLIT_MAXB4
-#define PLP_REDUCE_WSPLIT_MAXB4 1500   // four wavefronts per polytope up to here
+#define PLP_REDUCE_WSPLIT_MAXB4 2000   // four wavefronts per polytope up to here
 #endif
 template <int D>
 __host__ __device__ constexpr size_t wsplit_block_bytes() { return (sizeof(wide::WideShared<D + 1>) + 15) & ~(size_t)15; }
@@ -1213,8 +1216,14 @@ template <int D, int NW>
 static inline size_t reduce_wsplit_smem_bytes() {
     return (size_t)64 * (D + 2) * 8 + (size_t)(D + 2 + 2 * D) * 8 + 8 * 8 + 8 * 4 + 64 * 4 + NW * wsplit_block_bytes<D>();
 }
+// (d <= 8: the presolve is the register peak -- 94 VGPRs at d = 8 --; held to 80, six waves per SIMD, nothing spills: 78.
+//  From d = 9 on the same bound sends the 16-wide row vector to scratch: unconstrained there, 92..130)
+#ifndef PLP_REDUCE_WSPLIT_WAVES8
+#define PLP_REDUCE_WSPLIT_WAVES8 6
+#endif
+#define PLP_REDUCE_WSPLIT_WAVES(D) ((D) <= 8 ? PLP_REDUCE_WSPLIT_WAVES8 : 1)
 template <int D, int NW, bool WDENSE = true>
-__global__ __launch_bounds__(64 * NW) void reduce_wsplit_kernel(
+__global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_wsplit_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out,
