@@ -330,10 +330,13 @@ int launch_reduce_phase(long long B, int m_max, int d, const double* A, const do
     const char* one = getenv("PLP_REDUCE_1ROW");
     int retry = 0;
     if (phase == 2) retry = 1;
-    else if (!(one && one[0] == '1') &&
-             launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0) {
-        if (phase == 1) return 0;
-        retry = 1;
+    else if (!(one && one[0] == '1')) {
+        const int rc = launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        if (rc == 3) return 0;   // complete: no polytope can ask for the second pass
+        if (rc == 0) {
+            if (phase == 1) return 0;
+            retry = 1;
+        }
     }
     switch (d) {
         PLP_CASE_R(1) PLP_CASE_R(2) PLP_CASE_R(3) PLP_CASE_R(4) PLP_CASE_R(5) PLP_CASE_R(6)
@@ -352,9 +355,11 @@ int launch_reduce(long long B, int m_max, int d, const double* A, const double* 
     // needs Bland's rule; the second launch below redoes exactly those with this file's kernel.
     const char* one = getenv("PLP_REDUCE_1ROW");
     int retry = 0;
-    if (!(one && one[0] == '1') &&
-        launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st) == 0)
-        retry = 1;
+    if (!(one && one[0] == '1')) {
+        const int rc = launch_reduce_r(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        if (rc == 3) return 0;   // complete (one polytope per workgroup, Bland's rule inside the LPs): no second pass
+        if (rc == 0) retry = 1;
+    }
     switch (d) {
         PLP_CASE_R(1) PLP_CASE_R(2) PLP_CASE_R(3) PLP_CASE_R(4) PLP_CASE_R(5) PLP_CASE_R(6)
         PLP_CASE_R(7) PLP_CASE_R(8) PLP_CASE_R(9) PLP_CASE_R(10) PLP_CASE_R(11) PLP_CASE_R(12)

@@ -1495,6 +1495,9 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     // PLP_REDUCE_WDENSE=0 / 1: F3 / F2 without / with a stored dictionary (A/B)
     const char* wd = getenv("PLP_REDUCE_WDENSE");
     const bool dense = wd ? wd[0] == '1' : (D <= PLP_REDUCE_WDENSE_MAXD);
+    // 3: complete -- the dense LPs carry Bland's rule inside, no polytope is handed to a second pass (the caller then
+    // launches none: at small batches the idle second launch was 5 % of the call)
+    const int done = (dense && !(fr && fr[0] == '1')) ? 3 : 0;
     {
         // batches that leave the chip part empty at one wavefront per polytope: NW wavefronts per polytope
         // (PLP_REDUCE_WSPLIT=0: never, 2 / 4: always with that many; PLP_REDUCE_WSPLIT_MAXB / _MAXB4: the largest batches that take them)
@@ -1516,7 +1519,7 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
             const size_t smem_ws = reduce_wsplit_smem_bytes<D, NW_>();                                                          \
             hipLaunchKernelGGL((reduce_wsplit_kernel<D, NW_, DENSE_>), dim3((unsigned)B), dim3(64 * NW_), smem_ws, st, B, m_max, A, b, \
                                mrows, abs_tol, fi, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);        \
-            return 0;                                                                                                           \
+            return done;                                                                                                        \
         }
         if constexpr (D <= PLP_REDUCE_WDENSE_MAXD) {
             if (dense && nw == 4) PLP_WSPLIT_LAUNCH(4, true)
@@ -1533,7 +1536,7 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
     else
         hipLaunchKernelGGL((reduce_lazy_kernel<D>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(RBLOCK), smem, st, B, m_max, A, b,
                            mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry, t_reduce_epoch);
-    return 0;
+    return done;
 }
 
 // Small batches: one polytope per wavefront, its LPs spread over the lane groups (reduce_r_tile, SPLIT).
