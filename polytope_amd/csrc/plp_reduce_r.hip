@@ -6,6 +6,9 @@
 //            separate translation units only to keep the build parallel)
 #include "plp_reduce_r_impl.hpp"
 
+#ifndef PLP_REDUCE_WG_MAXB
+#define PLP_REDUCE_WG_MAXB 1500   // d >= 5, any row count: one polytope per workgroup up to this many polytopes
+#endif
 #ifndef PLP_REDUCE_LAZY_MID
 #define PLP_REDUCE_LAZY_MID 1  // d = 5..8 with more than 32 rows: one polytope per wavefront (reduce_wdense_kernel) by default
 #endif
@@ -37,7 +40,13 @@ static int launch_reduce_r_d(long long B, int m_max, int gs, const double* A, co
         // of the two-rows-per-lane kernel AND of the latency form at every batch size, scripts/debug/wdense_ab.py);
         // PLP_REDUCE_LAZY=0 / 1: never / always (A/B)
         const char* lz = getenv("PLP_REDUCE_LAZY");
-        if ((lz && lz[0] == '1') || (PLP_REDUCE_LAZY_MID && m_max > 32 && !(lz && lz[0] == '0')))
+        // ... and, round 4, ANY row count while the batch is small: one polytope per workgroup, its LPs on 2 / 4 wavefronts
+        // (reduce_wsplit_kernel), is 1.15x .. 2x ahead of the lane-group kernels up to ~1 000 polytopes at every (m <= 32, d)
+        // measured, level at 2 000 .. 4 000, behind beyond (scripts/debug/mid_wsplit_table.py); the A/B switches of the
+        // lane-group forms keep their meaning
+        const bool small_batch = !lz && B <= PLP_REDUCE_WG_MAXB && !getenv("PLP_REDUCE_SPLIT") && !getenv("PLP_REDUCE_MIDR2") &&
+                                 !getenv("PLP_REDUCE_HALF") && !getenv("PLP_REDUCE_MIX");
+        if ((lz && lz[0] == '1') || (PLP_REDUCE_LAZY_MID && m_max > 32 && !(lz && lz[0] == '0')) || small_batch)
             return launch_reduce_lazy<D>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     }
     if constexpr (D >= 5) {

@@ -2,6 +2,10 @@
 // VGPR file), groups of 16 / 32 lanes for up to 32 / 64 rows.  Same kernel template as d <= 8.
 #include "plp_reduce_r_impl.hpp"
 
+#ifndef PLP_REDUCE_WG_MAXB
+#define PLP_REDUCE_WG_MAXB 1500
+#endif
+
 namespace plp {
 
 template <int D>
@@ -15,7 +19,9 @@ static int launch_r2_d(long long B, int m_max, const double* A, const double* b,
     // (48 rows, d = 9) to 2.1x (36 rows, d = 14) faster than two rows per lane, outputs bitwise equal; with 32 rows and
     // fewer the four-polytopes-per-wavefront form below wins or ties.  PLP_REDUCE_LAZY=0 / 1: never / always (A/B).
     const char* lz = getenv("PLP_REDUCE_LAZY");
-    if ((lz && lz[0] == '1') || (m_max > 32 && !(lz && lz[0] == '0')))
+    // (round 4: and any row count up to PLP_REDUCE_WG_MAXB polytopes, see plp_reduce_r.hip)
+    const bool small_batch = !lz && B <= PLP_REDUCE_WG_MAXB && !(r1 && r1[0]);
+    if ((lz && lz[0] == '1') || (m_max > 32 && !(lz && lz[0] == '0')) || small_batch)
         return launch_reduce_lazy<D>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     if (m_max <= 32) return launch_reduce_r_dg<D, 16, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     return launch_reduce_r_dg<D, 32, 2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);

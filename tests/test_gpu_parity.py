@@ -643,9 +643,9 @@ def test_reduce_simplex_run_counter(pa):
         assert batch.reduce_simplex_runs(reset=True) == n1
         small = pa.reduce_batch(Ad[:200], bd[:200])
         ns = batch.reduce_simplex_runs(reset=True)
-        if m <= 32:   # latency form (reduce_split_kernel): every LP on the simplex, no presolve
+        if d <= 4:    # latency form (reduce_split_kernel): every LP on the simplex, no presolve
             assert ns == int(small["nlp"].sum().item())
-        else:         # one polytope per wavefront with the presolve, as in the large batch
+        else:         # one polytope per workgroup (d >= 5: any row count while the batch is small) with the presolve
             assert 200 <= ns < int(small["nlp"].sum().item())
     assert batch.reduce_simplex_runs() == 0
 
