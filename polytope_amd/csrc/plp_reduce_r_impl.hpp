@@ -1189,6 +1189,103 @@ __global__ __launch_bounds__(RBLOCK, ((D) <= 8 ? PLP_REDUCE_WDENSE_WAVES8 : PLP_
                                                flags_out, r_out, xc_out, nlp_out, ctr, retry_word, epoch);
 }
 
+// f2_presolve<D, 1> with the two passes over the rows cut into NW ranges, one per wavefront of reduce_wsplit_kernel (lane =
+// candidate row in EVERY wavefront): the verdict of a row is the AND of the ranges' verdicts, its blocking row the last one
+// found in row order -- the same bits as the one-wavefront function.  Nothing is written to the rows here (the caller
+// applies the round trip of the settled rows after its next barrier).  smask: 2 NW words, sjb: NW x 64 ints in LDS.
+template <int D, int NW>
+__device__ __forceinline__ bool f2_presolve_ws(const double* myA, const double* myb, const double* myan, const int lane,
+                                               const int m_loop, bool cand, const double abs_tol, const int w,
+                                               unsigned long long* smask, int* sjb) {
+    double ak[D];
+    double g = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < D; ++kk) {
+        ak[kk] = myA[lane * D + kk];
+        g = fma(ak[kk], ak[kk], g);
+    }
+    const double bk = myb[lane];
+    const double sk = fmax(bk - myan[lane], 0.0);
+    const double tau = abs_tol + 1e-9 * (1.0 + fabs(bk) + sk);
+    const double skt = sk + tau;
+    if (!((g > 0.0) & (tau < 0.05))) cand = false;  // (NaN-safe: such a row is never settled)
+    const int iw = (m_loop + NW - 1) / NW;
+    const int i0 = w * iw;
+    const int i1 = i0 + iw < m_loop ? i0 + iw : m_loop;
+    bool ok = cand;
+    int jb = -1;
+    for (int i = i0; i < i1; ++i) {
+        double ai[D];
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
+        const double si = fmax(myb[i] - myan[i], 0.0);
+        double gik = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) gik = fma(ai[kk], ak[kk], gik);
+        const bool fine = (i == lane) | (skt * gik <= si * g);
+        ok = ok & fine;
+        jb = fine ? jb : i;
+    }
+    {
+        const uint64_t okm = __ballot(ok);
+        if (lane == 0) smask[w] = okm;
+        sjb[w * 64 + lane] = jb;
+    }
+    __syncthreads();
+    bool okall = cand;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        okall = okall & (((smask[q] >> lane) & 1ull) != 0ull);
+        const int jq = sjb[q * 64 + lane];
+        j = jq >= 0 ? jq : j;
+    }
+#if PLP_R_PRESOLVE >= 2
+    bool ok2 = cand & !okall;
+    if (__any(ok2)) {   // (the same in every wavefront: the barrier below is met by all or by none)
+        double aj[D];
+        double gjk = 0.0, gjj = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) {
+            aj[kk] = myA[j * D + kk];
+            gjk = fma(aj[kk], ak[kk], gjk);
+            gjj = fma(aj[kk], aj[kk], gjj);
+        }
+        const double sj = fmax(myb[j] - myan[j], 0.0);
+        const double rho = gjk / gjj;
+        const double t1 = (sj / gjk) * (1.0 - 0x1p-40);
+        const double akd = fma(-rho, gjk, g);
+        const double t2 = fma(-t1, g, skt) / akd;
+        const double c1 = t1 + t2;
+        const double c2 = t2 * rho;
+        if (!((gjk > 0.0) & (akd > 1e-12 * g) & (t2 >= 0.0) & (t2 < 1e300))) ok2 = false;
+        for (int i = i0; i < i1; ++i) {
+            double ai[D];
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
+            const double si = fmax(myb[i] - myan[i], 0.0);
+            double gik = 0.0, gij = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                gik = fma(ai[kk], ak[kk], gik);
+                gij = fma(ai[kk], aj[kk], gij);
+            }
+            const double lhs = fma(-c2, gij, c1 * gik);
+            const bool fine = (i == lane) | (lhs <= si);
+            ok2 = ok2 & fine;
+        }
+        const uint64_t m2 = __ballot(ok2);
+        if (lane == 0) smask[NW + w] = m2;
+        __syncthreads();
+        bool all2 = true;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) all2 = all2 & (((smask[NW + q] >> lane) & 1ull) != 0ull);
+        okall = okall | (cand & !okall & all2);
+    }
+#endif
+    return okall;
+}
+
 // ---- the same polytope-per-workgroup pipeline with the INDEPENDENT LPs of a polytope spread over NW wavefronts.
 // At the batch sizes where one wavefront per polytope cannot fill the chip (5 000 polytopes are 4.9 wavefronts per SIMD,
 // all resident from the start: the launch is a drain, 2-3 waves per SIMD on average, profiles/r04/r04e_wide_counters.json)
@@ -1214,7 +1311,8 @@ template <int D>
 __host__ __device__ constexpr size_t wsplit_block_bytes() { return (sizeof(wide::WideShared<D + 1>) + 15) & ~(size_t)15; }
 template <int D, int NW>
 static inline size_t reduce_wsplit_smem_bytes() {
-    return (size_t)64 * (D + 2) * 8 + (size_t)(D + 2 + 2 * D) * 8 + 8 * 8 + 8 * 4 + 64 * 4 + NW * wsplit_block_bytes<D>();
+    return (size_t)64 * (D + 2) * 8 + (size_t)(D + 2 + 2 * D) * 8 + 8 * 8 + 8 * 4 + 64 * 4 + NW * wsplit_block_bytes<D>() +
+           (size_t)2 * NW * 8 + (size_t)NW * 64 * 4;  // + the presolve's masks and blocking rows
 }
 // (d <= 8: the presolve is the register peak -- 94 VGPRs at d = 8 --; held to 80, six waves per SIMD, nothing spills: 78.
 //  From d = 9 on the same bound sends the 16-wide row vector to scratch: unconstrained there, 92..130)
@@ -1243,6 +1341,9 @@ __global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_ws
     unsigned* s32 = reinterpret_cast<unsigned*>(s64 + 8);  // flags (1: an LP failed, 2: retry), next box LP, next F2 LP, ball bits
     int* slist = reinterpret_cast<int*>(s32 + 8);          // [64] the rows whose LP runs, in row order
     unsigned char* shb = reinterpret_cast<unsigned char*>(slist + 64) + (size_t)w * wsplit_block_bytes<D>();
+    unsigned long long* smask = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(slist + 64) +
+                                                                      (size_t)NW * wsplit_block_bytes<D>());  // [2 NW]
+    int* sjb = reinterpret_cast<int*>(smask + 2 * NW);                                                        // [NW][64]
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     {
@@ -1427,24 +1528,20 @@ __global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_ws
         const bool act = ((live >> lane) & 1ull) != 0ull;
         const int nlive = __popcll(live);
         nlp += nlive;
-        if (w == 0) {
-            uint64_t todo = live;
+        uint64_t todo = live;
 #if PLP_R_PRESOLVE
-            {   // rows the presolve settles as "keep" need no LP (lane i = row i: the ballot is the row mask)
-                const uint64_t cert = __ballot((f2_presolve<D, 1>(myA, myb, myan, lane, m_max, act ? 1u : 0u, abs_tol) & 1u) != 0u);
-                todo &= ~cert;
-                ctr_add(ctr, -__popcll(cert), lane == 0);
-                if ((lane == 0) & (cert != 0ull)) atomicOr(&s64[1], (unsigned long long)cert);
-            }
-#endif
-            if ((todo >> lane) & 1ull) slist[__popcll(todo & ((1ull << lane) - 1ull))] = lane;
-            if (lane == 0) s64[2] = todo;
+        // rows the presolve settles as "keep" need no LP: every wavefront takes a range of the rows to test against
+        const bool settled = f2_presolve_ws<D, NW>(myA, myb, myan, lane, m_max, act, abs_tol, w, smask, sjb);
+        const uint64_t cert = __ballot(settled);   // (lane i = row i: the ballot is the row mask, the same in every wavefront)
+        todo &= ~cert;
+        if (w == 0) {
+            ctr_add(ctr, -__popcll(cert), lane == 0);
+            if ((lane == 0) & (cert != 0ull)) atomicOr(&s64[1], (unsigned long long)cert);
+            if (settled) myb[lane] = (myb[lane] + 0.1) - 0.1;  // (:1149-1151), as f2_presolve leaves the settled rows
         }
+#endif
+        if ((w == 0) && ((todo >> lane) & 1ull)) slist[__popcll(todo & ((1ull << lane) - 1ull))] = lane;
         __syncthreads();
-        // (wave-uniform, and said so: the LP loop stays scalar)
-        const uint64_t todo_v = s64[2];
-        const uint64_t todo = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(todo_v >> 32)) << 32) |
-                              (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)todo_v);
         const int ntodo = __popcll(todo);
         const double h0 = myb[lane];
         const double sl = myan[lane];

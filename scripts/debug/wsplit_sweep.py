@@ -15,7 +15,7 @@ def timeit(fn, reps=9):
         ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
 
-for (m, d) in [(64, 8), (48, 6), (64, 5)]:
+for (m, d) in [(64, 8), (32, 6), (64, 12)]:
     for B in [1, 250, 1000, 1500, 2000, 3000, 5000, 8000, 12000, 16000]:
         A, b = synth.random_hpolytopes(B, m, d, seed=2)
         At, bt = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
