@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "plp_cheby_r_impl.hpp"
+#include "plp_wide.hpp"
 
 namespace plp {
 
@@ -180,6 +181,66 @@ __device__ __forceinline__ void server_slot(int slot, int n, const int* __restri
     }
 }
 
+// The same batch entry on the one-LP-per-wavefront engine (plp_wide.hpp: wave-uniform pivot column and row, the body of
+// cheby_gather_w_kernel): a list of any length up to 64 rows takes a wavefront of its own.  Measured on the launch path at
+// d = 4 (PLP_RDIFF_WIDE_MIND=4): 9.7 ms of device time for the 751 batches of config 4 against 10.9 ms on the lane groups.
+template <int D>
+__device__ __forceinline__ void server_slot_w(int q, const int* __restrict__ rec, int cap, const double* __restrict__ A,
+                                              const double* __restrict__ b, ulonglong2* __restrict__ out_host,
+                                              unsigned long long word) {
+    using namespace wide;
+    constexpr int NC = D + 1;
+    __shared__ WideShared<NC> sh;
+    const int lane = threadIdx.x;
+    const int* r = rec + (size_t)q * (cap + 2);
+    const int p = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int m = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int myrow = __hip_atomic_load(r + 2 + (lane < cap ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool has = lane < m;
+    const long long row = has ? myrow : 0;
+    typename RowVec<NC>::type Tv = (typename RowVec<NC>::type)(0.0);
+    double T16 = 0.0;
+    double nrm2 = 0.0;
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = has ? A[row * D + k] : 0.0;
+        ROW_SET(k, v);
+        nrm2 = nrm2 + v * v;
+        finite = finite & isfinite(v);
+    }
+    const double bi = has ? b[row] : 0.0;
+    finite = finite & isfinite(bi);
+    const double nrm = sqrt(nrm2);
+    const bool zero = !(nrm > 0.0);
+    bool rowact = has & !zero;
+    ROW_SET(D, rowact ? nrm : 0.0);
+    double beta = rowact ? bi : 0.0;
+    int rowvar = NC + lane, rowneg = 0;
+    wave_sync();   // (the last LP's reads of the block are done)
+    if (lane <= NC) {
+        sh.cost[lane] = lane == D ? -1.0 : 0.0;
+        sh.cv[lane] = (lane + 1) << 1;
+    }
+    const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+    const bool bad = (__ballot(!finite) != 0) | (m > 64);
+    wave_sync();
+    int st, iters = 0;
+    if (bad) st = ST_NUM;
+    else if (infeasible0) st = ST_INFEAS;
+    else st = wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+    const double mine = rowneg ? -beta : beta;
+    const uint64_t ob = __ballot(rowvar == D);
+    const double rv = ob ? uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+    if (lane == 0) {
+        const double rad = st != ST_OPT ? __builtin_nan("") : (rv >= 0.0 ? rv : 0.0);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(out_host + p);
+        __hip_atomic_store(dst, (unsigned long long)__double_as_longlong(rad), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(dst + 1, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(64) void rdiff_server_kernel(const unsigned long long* __restrict__ mail_host,
                                                           const int* __restrict__ rec_host,
@@ -187,7 +248,7 @@ __global__ __launch_bounds__(64) void rdiff_server_kernel(const unsigned long lo
                                                           unsigned long long* __restrict__ alive_host,
                                                           unsigned long long* __restrict__ dstate,
                                                           const double* __restrict__ A, const double* __restrict__ b,
-                                                          unsigned long long last_word, unsigned idle_polls, int force_retry) {
+                                                          unsigned long long last_word, unsigned idle_polls, int force_retry, int wide_engine) {
     const int wg = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
     unsigned long long seen = last_word;
     unsigned polls = 0;
@@ -223,6 +284,13 @@ __global__ __launch_bounds__(64) void rdiff_server_kernel(const unsigned long lo
         const int* rec0 = rec_host;
         const int* rec1 = rec0 + (size_t)n0 * 18;
         const int* rec2 = rec1 + (size_t)n1 * 34;
+        if (wide_engine) {   // one LP per wavefront, whatever its length
+            for (int s = wg; s < n0 + n1 + n2; s += G) {
+                if (s < n0) server_slot_w<D>(s, rec0, 16, A, b, out_host, w);
+                else if (s < n0 + n1) server_slot_w<D>(s - n0, rec1, 32, A, b, out_host, w);
+                else server_slot_w<D>(s - n0 - n1, rec2, 64, A, b, out_host, w);
+            }
+        } else
         for (int s = wg; s < total; s += G) {
             if (s < s0) server_slot<D, 16>(s, n0, rec0, 16, A, b, out_host, w, force_retry);
             else if (s < s0 + s1) server_slot<D, 32>(s - s0, n1, rec1, 32, A, b, out_host, w, force_retry);
@@ -239,10 +307,13 @@ __global__ __launch_bounds__(64) void rdiff_server_kernel(const unsigned long lo
 int launch_rdiff_server(int d, int nwg, const unsigned long long* mail, const int* rec, void* out, unsigned long long* alive,
                         unsigned long long* dstate, const double* A, const double* b, unsigned long long last_word,
                         unsigned idle_polls, hipStream_t st) {
+    // PLP_RDIFF_SERVER_WIDE=0: the entries on the lane-group kernels' engine (round 4's first form)
+    const char* we = getenv("PLP_RDIFF_SERVER_WIDE");
+    const int wide_engine = (we && we[0] == '0') ? 0 : 1;
 #define PLP_SRV(K)                                                                                                      \
     case K:                                                                                                             \
         hipLaunchKernelGGL((rdiff_server_kernel<K>), dim3((unsigned)nwg), dim3(64), 0, st, mail, rec,                    \
-                           static_cast<ulonglong2*>(out), alive, dstate, A, b, last_word, idle_polls, force_retry_env()); \
+                           static_cast<ulonglong2*>(out), alive, dstate, A, b, last_word, idle_polls, force_retry_env(), wide_engine); \
         return 0;
     switch (d) {
         PLP_SRV(1) PLP_SRV(2) PLP_SRV(3) PLP_SRV(4)
