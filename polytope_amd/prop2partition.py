@@ -54,13 +54,35 @@ def _members_of(regions):
 def _device_pairs_ok(members):
     """Can the pair kernels (csrc/plp_capi.hip: plp_adjacent_pairs / plp_overlap_pairs) take these polytopes?
     They stack two members per LP in registers: 2 * m_max <= 64 rows, one dimension d <= 16."""
-    if solvers.default_solver != "hip" or len(members) < 2:
+    if solvers.default_solver != "hip":
+        return False
+    return _pair_shapes_ok(members)
+
+
+def _pair_shapes_ok(members):
+    if len(members) < 2:
         return False
     d = members[0].A.shape[1]
     return 1 <= d <= 16 and all(p.A.shape[1] == d and 1 <= p.A.shape[0] <= 32 for p in members)
 
 
-def _pair_list_device(regions, kind, abs_tol):
+def _flat_members(regions, owner=None):
+    """(members, first, pair kernels applicable) of `regions`; remembered on `owner` -- the Region whose member list
+    `regions` is -- under the rule of the reference's own caches (bounding box, Chebyshev ball, ...: computed once, never
+    invalidated; here at least the list's length and its end members are compared)."""
+    if owner is not None and regions:
+        key = (len(regions), id(regions[0]), id(regions[-1]))
+        hit = owner.__dict__.get("_p2p_flat")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    members, first = _members_of(regions)
+    out = (members, first, _pair_shapes_ok(members))
+    if owner is not None and regions:
+        owner.__dict__["_p2p_flat"] = (key, out)
+    return out
+
+
+def _pair_list_device(regions, kind, abs_tol, diagonal=False, owner=None):
     """All member pairs of all regions as one batch of stacked Chebyshev LPs formed on the device, folded to the regions:
     (rows, cols) of the region pairs (i != j, both orders, sorted by row then column) for which SOME member pair is set
     (the `any` over member polytopes of is_adjacent, ref polytope.py:1843-1853, and of Region.intersect, :815-830);
@@ -68,27 +90,35 @@ def _pair_list_device(regions, kind, abs_tol):
     packed and uploaded once (polytope._table_of): a second call on the same regions -- the adjacency after the
     disjointness check, compute_adj against a previous matrix -- moves no input bytes; the n x n result stays on the
     device and only the indices of its nonzeros come back."""
-    members, first = _members_of(regions)
-    if not _device_pairs_ok(members):
+    members, first, ok = _flat_members(regions, owner)
+    if not ok or solvers.default_solver != "hip":
         return None
     import torch
     from . import batch
-    At, bt, mt = pc._table_of(members).dev()
+    At, bt, mt = pc._table_of(members, owner=owner if len(members) == len(regions) else None).dev()
     fn = batch.adjacent_pairs if kind == "adjacent" else batch.overlap_pairs
-    nz = torch.nonzero(fn(At, bt, m=mt, abs_tol=abs_tol)).cpu().numpy()     # member pairs, row-major order
+    flat = len(members) == len(regions) and not np.any(np.diff(first) != 1)
+    M = fn(At, bt, m=mt, abs_tol=abs_tol)
+    if diagonal and flat:
+        # (`diagonal`: the caller wants ones on the diagonal as well -- set on the device, so that the indices come back
+        # sorted with them in place and no sort / unique runs on the host)
+        M.fill_diagonal_(1)
+        nz = torch.nonzero(M).cpu().numpy()
+        return nz[:, 0], nz[:, 1], True
+    nz = torch.nonzero(M).cpu().numpy()     # member pairs, row-major order
     r, c = nz[:, 0], nz[:, 1]
-    if len(members) != len(regions) or np.any(np.diff(first) != 1):
+    if not flat:
         owner = np.repeat(np.arange(len(regions)), np.diff(first))
         r, c = owner[r], owner[c]
         code = np.unique(r * len(regions) + c)
         r, c = code // len(regions), code % len(regions)
     off = r != c
-    return r[off], c[off]
+    return (r[off], c[off], False) if diagonal else (r[off], c[off])
 
 
 def _lil_from_pairs(n, r, c, dtype, diagonal=True):
-    """lil_matrix with ones at (r, c) (sorted by row, then column) and on the diagonal, built from its row lists (the
-    constructor from a dense array walks all n^2 entries)."""
+    """lil_matrix with ones at (r, c) (sorted by row, then column) and on the diagonal (`diagonal`: not among the pairs
+    yet), built from its row lists (the constructor from a dense array walks all n^2 entries)."""
     if diagonal:
         code = np.unique(np.concatenate([r * n + c, np.arange(n) * (n + 1)]))
         r, c = code // n, code % n
@@ -214,11 +244,11 @@ def compute_adj(partition, previous=None):
     return adj, ok
 
 
-def _adjacency_lil(regions, dtype):
+def _adjacency_lil(regions, dtype, owner=None):
     n = len(regions)
-    got = _pair_list_device(regions, "adjacent", pc.ABS_TOL) if n >= 2 else None
+    got = _pair_list_device(regions, "adjacent", pc.ABS_TOL, diagonal=True, owner=owner) if n >= 2 else None
     if got is not None:
-        return _lil_from_pairs(n, got[0], got[1], dtype)
+        return _lil_from_pairs(n, got[0], got[1], dtype, diagonal=not got[2])
     return sp.lil_matrix(adjacency_matrix_dense(regions).astype(dtype))
 
 
@@ -228,7 +258,7 @@ def find_adjacent_regions(partition):
     @type partition: iterable container of L{Region} (anything with `.regions`, or a list)
     @rtype: scipy.sparse.lil_matrix (n x n, int8, ones on the diagonal)
     """
-    return _adjacency_lil(_regions_of(partition), np.int8)
+    return _adjacency_lil(_regions_of(partition), np.int8, owner=partition if isinstance(partition, pc.Region) else None)
 
 
 ################################
