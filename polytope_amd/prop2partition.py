@@ -258,7 +258,7 @@ def find_adjacent_regions(partition):
     @type partition: iterable container of L{Region} (anything with `.regions`, or a list)
     @rtype: scipy.sparse.lil_matrix (n x n, int8, ones on the diagonal)
     """
-    return _adjacency_lil(_regions_of(partition), np.int8, owner=partition if isinstance(partition, pc.Region) else None)
+    return _adjacency_lil(_regions_of(partition), np.int8, owner=partition if hasattr(partition, "__dict__") else None)
 
 
 ################################
