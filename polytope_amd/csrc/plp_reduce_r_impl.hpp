@@ -1607,11 +1607,14 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
         // (without a stored dictionary, d = 14..16: (64,16) B = 250 0.228 / 0.143 / 0.112 ms with one / two / four wavefronts,
         // 1 000 0.248 / 0.170 / 0.201, 3 000 0.355 / 0.346 / 0.437, 8 000 0.704 / 0.703 / 0.951)
         const long long maxb = wb ? atoll(wb) : (dense ? PLP_REDUCE_WSPLIT_MAXB : 3000);
-        const long long maxb4 = wb4 ? atoll(wb4) : (dense ? PLP_REDUCE_WSPLIT_MAXB4 : 500);
+        // (with the presolve over the wavefronts: four ahead of two up to 12 000 polytopes at d <= 8 -- (64,8) 5 000 0.379 / 0.402,
+        // 12 000 0.803 / 0.810, 16 000 1.051 / 1.026 -- and up to ~3 000 at d = 9..13: (64,12) 3 000 0.338 / 0.366, 5 000 0.502 / 0.495)
+        const long long maxb4 = wb4 ? atoll(wb4) : (dense ? (D <= 8 ? 12000 : PLP_REDUCE_WSPLIT_MAXB4) : 500);
         const int fi = (fr && fr[0] == '1') ? 1 : 0;
         int nw = 0;
         if (B >= 1 && !(ws && ws[0] == '0')) {
             if ((ws && ws[0] == '4') || (!ws && B <= maxb4)) nw = 4;
+            else if (ws && ws[0] == '3') nw = 3;
             else if ((ws && ws[0] == '2') || (!ws && B <= maxb)) nw = 2;
         }
 #define PLP_WSPLIT_LAUNCH(NW_, DENSE_)                                                                                          \
@@ -1623,6 +1626,9 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
         }
         if constexpr (D <= PLP_REDUCE_WDENSE_MAXD) {
             if (dense && nw == 4) PLP_WSPLIT_LAUNCH(4, true)
+#ifdef PLP_REDUCE_WSPLIT_TRY3
+            if constexpr (D <= 8) { if (dense && nw == 3) PLP_WSPLIT_LAUNCH(3, true) }
+#endif
             if (dense && nw == 2) PLP_WSPLIT_LAUNCH(2, true)
         } else {
             if (!dense && nw == 4) PLP_WSPLIT_LAUNCH(4, false)
