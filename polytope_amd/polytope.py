@@ -85,13 +85,20 @@ class Polytope(object):
     def __init__(self, A=np.array([]), b=np.array([]), minrep=False, chebR=0, chebX=None,
                  fulldim=None, volume=None, vertices=None, normalize=True):
         self.A = A.astype(float)
-        self.b = b.astype(float).flatten()
+        self.b = b.astype(float).ravel()        # (a fresh 1-D array: astype copied)
         if A.size > 0 and normalize:
-            norms = np.sqrt(np.sum(A * A, 1)).flatten()
-            rows = np.nonzero(norms > 1e-10)[0]
-            scale = 1 / norms[rows]
-            self.A = self.A[rows, :] * scale[:, None]   # row-wise multiply by the reciprocal norm
-            self.b = self.b[rows].flatten() * scale
+            norms = np.sqrt(np.sum(A * A, 1)).ravel()
+            if norms.min() > 1e-10:
+                # every row stays (the usual case): the same products without the index round trip -- a quarter of the
+                # constructor's time, and a Region operation at C4 size builds ~5 000 polytopes
+                scale = 1 / norms
+                self.A = self.A * scale[:, None]
+                self.b = self.b * scale
+            else:
+                rows = np.nonzero(norms > 1e-10)[0]
+                scale = 1 / norms[rows]
+                self.A = self.A[rows, :] * scale[:, None]   # row-wise multiply by the reciprocal norm
+                self.b = self.b[rows].flatten() * scale
         self.minrep = minrep
         self._chebXc = chebX
         self._chebR = chebR
@@ -124,7 +131,7 @@ class Polytope(object):
         return 0
 
     def __copy__(self):
-        twin = Polytope(self.A.copy(), self.b.copy())
+        twin = Polytope(self.A, self.b)   # (the constructor copies: astype, then the row scaling)
         twin._chebXc, twin._chebR = self._chebXc, self._chebR
         twin.minrep, twin.bbox, twin.fulldim = self.minrep, self.bbox, self.fulldim
         return twin

@@ -13,4 +13,4 @@ f = lambda: pc.Region([c.copy() for c in cells]).intersect(P.copy())
 for _ in range(3):
     t0 = time.perf_counter(); f(); print("%.2f ms" % ((time.perf_counter() - t0) * 1e3))
 pr = cProfile.Profile(); pr.enable(); f(); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
