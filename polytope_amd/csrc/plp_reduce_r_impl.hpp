@@ -1614,7 +1614,6 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
         int nw = 0;
         if (B >= 1 && !(ws && ws[0] == '0')) {
             if ((ws && ws[0] == '4') || (!ws && B <= maxb4)) nw = 4;
-            else if (ws && ws[0] == '3') nw = 3;
             else if ((ws && ws[0] == '2') || (!ws && B <= maxb)) nw = 2;
         }
 #define PLP_WSPLIT_LAUNCH(NW_, DENSE_)                                                                                          \
@@ -1626,9 +1625,6 @@ static int launch_reduce_lazy(long long B, int m_max, const double* A, const dou
         }
         if constexpr (D <= PLP_REDUCE_WDENSE_MAXD) {
             if (dense && nw == 4) PLP_WSPLIT_LAUNCH(4, true)
-#ifdef PLP_REDUCE_WSPLIT_TRY3
-            if constexpr (D <= 8) { if (dense && nw == 3) PLP_WSPLIT_LAUNCH(3, true) }
-#endif
             if (dense && nw == 2) PLP_WSPLIT_LAUNCH(2, true)
         } else {
             if (!dense && nw == 4) PLP_WSPLIT_LAUNCH(4, false)
