@@ -729,6 +729,46 @@ def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_reduce_wavefronts_per_polytope_edge_inputs(pa, oracle, monkeypatch):
+    """The split kernel on the inputs the pipeline treats specially: polytopes of 0 / 1 / 2 rows, zero rows (feasible and
+    infeasible right-hand sides), a NaN or an infinity among the rows, every row a duplicate, unbounded polytopes, an empty
+    polytope -- every output bit of the one-wavefront form, flags and masks equal to the oracle's where its inputs are finite."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(3)
+    for (B, m, d) in [(40, 40, 5), (40, 64, 8), (30, 33, 12), (24, 20, 7), (24, 64, 15)]:
+        A, b = random_hpolytopes(B, m, d, seed=31 * m + d, stream=0)
+        rows = np.full(B, m, np.int32)
+        rows[0], rows[1], rows[2] = 0, 1, 2
+        A[3, 4] = 0.0; b[3, 4] = 1.0            # a zero row that holds
+        A[4, 5] = 0.0; b[4, 5] = -1.0           # a zero row that cannot: infeasible
+        A[5, :] = A[5, 0]; b[5, :] = b[5, 0]     # every row the same
+        A[6, : m // 2] *= -1.0                   # likely unbounded / empty
+        b[7, :] = -np.abs(b[7, :]) - 1.0         # empty
+        rows[8] = d                              # fewer rows than d + 1: unbounded
+        Af, bf = A.copy(), b.copy()
+        A[9, 3, 1] = np.nan
+        b[10, 2] = np.inf
+        b[11, 2] = -np.inf
+        outs = []
+        for ws in ("0", "2", "4"):
+            monkeypatch.setenv("PLP_REDUCE_WSPLIT", ws)
+            outs.append(pa.reduce_batch(__import__("torch").as_tensor(A).cuda(), __import__("torch").as_tensor(b).cuda(),
+                                        m=__import__("torch").as_tensor(rows).cuda()))
+        monkeypatch.delenv("PLP_REDUCE_WSPLIT", raising=False)
+        outs = [{k: v.cpu().numpy() for k, v in o.items()} for o in outs]
+        for key in outs[0]:
+            for other in outs[1:]:
+                assert np.array_equal(outs[0][key].view(np.uint8), other[key].view(np.uint8)), ((B, m, d), key)
+        masks = pa.keep_to_bool(outs[1]["keep"], m)
+        for k in list(range(9)) + list(range(12, B, 5)):
+            if rows[k] == 0:
+                continue
+            o = oracle.reduce(Af[k, :rows[k]], bf[k, :rows[k]])
+            assert int(outs[1]["flags"][k]) == o["flags"], ((m, d), k, int(outs[1]["flags"][k]), o["flags"])
+            assert np.array_equal(masks[k, :rows[k]], o["keep"]) and int(outs[1]["nlp"][k]) == o["nlp"], ((m, d), k)
+
+
+@pytest.mark.gpu
 def test_reduce_wavefronts_per_polytope_bitwise(pa, oracle, monkeypatch):
     """reduce_wsplit_kernel<D, NW> -- the polytope-per-workgroup pipeline with the independent LPs of a polytope spread over
     NW = 2 / 4 wavefronts (the default up to 16 000 / 1 500 polytopes where reduce_wdense_kernel used to run: more than 32 rows at
