@@ -1111,15 +1111,25 @@ def mldivide(a, b, save=False):
             if touch is None and len(live_all) > 1 and len({c.A.shape for c in live_all}) == 1:
                 packed = (np.stack([c.A for c in live_all]), np.stack([c.b for c in live_all]))
         row = 0
+        live_pos = None   # positions of the non-empty subtrahends in `subs` (empty ones always stay in the chain)
         for poly in a:
             touching = subs
             if _use_hip() and len(subs) > 1 and not is_empty(poly):
                 if touch is not None:
-                    keep = iter(touch[row])
+                    keep = np.asarray(touch[row], dtype=bool)
                     row += 1
                 else:
-                    keep = iter(r >= ABS_TOL for r in _radii_stacked(poly, live_all, packed))
-                touching = [c for c in subs if not c.A.size or next(keep)]
+                    keep = np.asarray(_radii_stacked(poly, live_all, packed)) >= ABS_TOL
+                # (index arithmetic instead of a Python pass over every subtrahend per member: 200 members x 1000 cells
+                # were 15 ms of is_subset's 49)
+                if len(live_all) == len(subs):
+                    touching = [subs[i] for i in np.flatnonzero(keep)]
+                else:
+                    if live_pos is None:
+                        live_pos = np.array([i for i, c in enumerate(subs) if c.A.size], dtype=np.intp)
+                    sel = np.ones(len(subs), dtype=bool)
+                    sel[live_pos] = keep
+                    touching = [subs[i] for i in np.flatnonzero(sel)]
             rest = poly
             for sub in touching:
                 rest = mldivide(rest, sub, save=save)

@@ -1,14 +1,13 @@
-import os, sys, time, itertools, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
+"""is_subset(200 cells, 1000 cells) and Partition.refines, warm: cProfile."""
+import cProfile, itertools, os, pstats, sys, time
 import numpy as np
-import polytope_amd.polytope as pc
-from polytope_amd import solvers
-solvers.default_solver = "hip"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import polytope_amd as pc
+pc.solvers.default_solver = "hip"
 shape = (10, 10, 5, 2)
 cells = [pc.box2poly([[i[k] / shape[k], (i[k] + 1) / shape[k]] for k in range(4)]) for i in itertools.product(*[range(n) for n in shape])]
-pc.is_subset(pc.Region([c.copy() for c in cells[:50]]), pc.Region([c.copy() for c in cells]))
-a, b = pc.Region([c.copy() for c in cells[:200]]), pc.Region([c.copy() for c in cells])
-pr = cProfile.Profile(); pr.enable(); t = time.perf_counter(); s = pc.is_subset(a, b); dt = time.perf_counter() - t; pr.disable()
-print("is_subset(200, 1000): %.3f s -> %s" % (dt, s))
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+f = lambda: pc.is_subset(pc.Region([c.copy() for c in cells[:200]]), pc.Region([c.copy() for c in cells]))
+for _ in range(3):
+    t0 = time.perf_counter(); r = f(); print("%.2f ms" % ((time.perf_counter() - t0) * 1e3), r)
+pr = cProfile.Profile(); pr.enable(); f(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
