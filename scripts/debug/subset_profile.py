@@ -11,3 +11,10 @@ for _ in range(3):
     t0 = time.perf_counter(); r = f(); print("%.2f ms" % ((time.perf_counter() - t0) * 1e3), r)
 pr = cProfile.Profile(); pr.enable(); f(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+coarse = pc.Partition(); coarse.regions = [pc.Region([pc.box2poly([[i / 2, (i + 1) / 2]] + [[0, 1]] * 3)]) for i in range(2)]
+fine = pc.Partition(); fine.regions = [pc.Region([c]) for c in cells]
+g = lambda: fine.refines(coarse)
+for _ in range(3):
+    t0 = time.perf_counter(); r = g(); print("refines %.2f ms" % ((time.perf_counter() - t0) * 1e3), r)
+pr = cProfile.Profile(); pr.enable(); g(); pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(26)
