@@ -1110,6 +1110,11 @@ def mldivide(a, b, save=False):
             touch = _cross_touch(mine, live_all, a, b)
             if touch is None and len(live_all) > 1 and len({c.A.shape for c in live_all}) == 1:
                 packed = (np.stack([c.A for c in live_all]), np.stack([c.b for c in live_all]))
+        if touch is not None:
+            # the Chebyshev balls region_diff wants of the subtrahends it visits (ref :2160-2165): every subtrahend that
+            # touches some member, in ONE batch here instead of a small batch per member there
+            need = np.flatnonzero(np.asarray(touch, dtype=bool).any(axis=0))
+            _cheby_fill([live_all[i] for i in need if live_all[i].fulldim is None])
         row = 0
         live_pos = None   # positions of the non-empty subtrahends in `subs` (empty ones always stay in the chain)
         for poly in a:
