@@ -929,7 +929,29 @@ def union(polyreg1, polyreg2, check_convex=False):
     if is_empty(polyreg2):
         return polyreg1
     if check_convex:
-        common = intersect(polyreg1, polyreg2)
+        common = None
+        if _use_hip():
+            # Two polytopes whose bounding boxes overlap by less than 2 abs_tol in some coordinate (touching cells, cells
+            # apart) have no full-dimensional intersection -- a ball inside it has a diameter of at most that overlap --,
+            # which is all the reference asks of `common` here (ref :1182-1190).  The boxes are wanted by the greedy merge
+            # below anyway; with them first, the repeated union of Region.intersect / mldivide (one piece joins k
+            # non-overlapping ones, k times) skips k stacked reduce LPs and four device round trips per step.
+            mem1, mem2 = _members(polyreg1), _members(polyreg2)
+            todo = [p for p in mem1 + mem2 if p.bbox is None]
+            for p, box in zip(todo, _bbox_raw(todo)):
+                p.bbox = box
+            if mem1 and mem2 and all(p.bbox is not None for p in mem1 + mem2):
+                L1 = np.hstack([p.bbox[0] for p in mem1]); U1 = np.hstack([p.bbox[1] for p in mem1])   # d x k1
+                flat = True
+                for q in mem2:
+                    ext = np.minimum(U1, q.bbox[1]) - np.maximum(L1, q.bbox[0])
+                    if not bool(np.all(np.any(ext <= 2 * ABS_TOL - 1e-9, axis=0))):
+                        flat = False
+                        break
+                if flat:
+                    common = Polytope()
+        if common is None:
+            common = intersect(polyreg1, polyreg2)
         if is_fulldim(common):
             parts = [common, polyreg2.diff(polyreg1), polyreg1.diff(polyreg2)]
         else:
