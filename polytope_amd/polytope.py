@@ -620,7 +620,31 @@ def is_subset(small, big, abs_tol=ABS_TOL):
     for x in [small, big]:
         if not isinstance(x, (Polytope, Region)):
             raise TypeError("Not a Polytope or Region, got instead:\n\t" + str(type(x)))
+    if _use_hip() and _inside_by_boxes(small, big):
+        return True
     return bool(small.diff(big).volume < abs_tol)
+
+
+def _inside_by_boxes(small, big):
+    """True when the bounding boxes ALREADY CACHED on the members of `small` show that small \ big is empty for a convex
+    `big` (one member): row j of big can be exceeded on a member's box by at most  sum_k max(a_jk l_k, a_jk u_k) - b_j,
+    and a piece  member /\ {a_j x >= b_j}  of region_diff (ref :2190-2282) holds no ball of radius above half of that --
+    below 2 ABS_TOL every piece is dropped, the difference is empty and its volume 0.  Nothing is computed here but
+    array arithmetic on what is cached (Partition.refines fills the boxes of all its elements in one batch first);
+    False means "not shown", never "not a subset"."""
+    bigs = _members(big)
+    smalls = _members(small)
+    if len(bigs) != 1 or not smalls or any(p.bbox is None for p in smalls):
+        return False
+    Q = bigs[0]
+    if Q.A.shape[1] != smalls[0].A.shape[1]:
+        return False
+    lo = np.hstack([p.bbox[0] for p in smalls])     # d x k
+    hi = np.hstack([p.bbox[1] for p in smalls])
+    if not (np.all(np.isfinite(lo)) and np.all(np.isfinite(hi))):
+        return False
+    reach = np.maximum(Q.A[:, :, None] * lo[None, :, :], Q.A[:, :, None] * hi[None, :, :]).sum(axis=1)   # rows x k
+    return bool(np.all(reach - Q.b[:, None] <= 2 * ABS_TOL - 1e-9))
 
 
 # ====================================================================================== bounding box

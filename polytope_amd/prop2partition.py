@@ -361,6 +361,14 @@ class Partition(object):
         touch = None
         if smalls and bigs and _all_polytopic(smalls) and _all_polytopic(bigs):
             touch = touch_matrix(smalls, bigs)
+            if solvers.default_solver == "hip":
+                # the bounding boxes of all elements in ONE batch: `small <= big` reads them (polytope._inside_by_boxes)
+                # before it forms a difference -- 1000 cells against two halves: 195 -> ms of array arithmetic
+                members, _ = _members_of(smalls)
+                todo = [p for p in members if p.bbox is None]
+                if todo:
+                    for p, box in zip(todo, pc._bbox_raw(todo)):
+                        p.bbox = box
         for i, small in enumerate(smalls):
             found_superset = False
             for j, big in enumerate(bigs):
