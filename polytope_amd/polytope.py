@@ -353,6 +353,12 @@ class Region(object):
             other = [other]
         pairs = [(p0, p1) for p0 in self for p1 in other]
         pieces = _intersect_pairs(pairs, abs_tol)
+        if _use_hip():
+            # the boxes union(check_convex) wants of every piece it is handed, in one batch instead of one per step
+            todo = [q for q in pieces if q.A.size and q.bbox is None and q.cheby[0] > abs_tol]
+            if len(todo) > 1 and len({q.A.shape[1] for q in todo}) == 1:
+                for q, box in zip(todo, _bbox_raw(todo)):
+                    q.bbox = box
         out = Region()
         for piece in pieces:
             rp, _ = piece.cheby
@@ -894,6 +900,28 @@ def _intersect_pairs(pairs, abs_tol):
     _cheby_fill([p for p in involved if p.fulldim is None])
     out = [None] * len(pairs)
     stacks, where = [], []
+    flat = None
+    if _use_hip() and len(pairs) >= 8 and all(isinstance(p1, Polytope) for _, p1 in pairs):
+        # Many pairs (a Region against a polytope): the bounding boxes of everything involved in ONE batch, and a pair whose
+        # boxes overlap by less than 2 abs_tol in some coordinate is not stacked at all -- its intersection holds no ball of
+        # radius abs_tol, `reduce` would return the empty polytope for it (ref :1081-1082).
+        uniq = {}
+        for p in involved:
+            uniq.setdefault(id(p), p)
+        full = [p for p in uniq.values() if p.A.size and is_fulldim(p)]
+        todo = [p for p in full if p.bbox is None]
+        if todo and len({p.A.shape[1] for p in todo}) == 1:
+            for p, box in zip(todo, _bbox_raw(todo)):
+                p.bbox = box
+        if full and all(p.bbox is not None for p in full) and len({p.A.shape[1] for p in full}) == 1:
+            pos = {id(p): i for i, p in enumerate(full)}
+            lo = np.hstack([p.bbox[0] for p in full])   # d x n
+            hi = np.hstack([p.bbox[1] for p in full])
+            i0 = np.array([pos.get(id(p0), -1) for p0, _ in pairs])
+            i1 = np.array([pos.get(id(p1), -1) for _, p1 in pairs])
+            both = (i0 >= 0) & (i1 >= 0)
+            ext = np.minimum(hi[:, i0], hi[:, i1]) - np.maximum(lo[:, i0], lo[:, i1])
+            flat = both & np.any(ext <= 2 * abs_tol - 1e-9, axis=0)
     for k, (p0, p1) in enumerate(pairs):
         if not isinstance(p1, Polytope):
             raise Exception("Polytope intersection defined only with other Polytope. Got instead: " + str(type(p1)))
@@ -902,6 +930,9 @@ def _intersect_pairs(pairs, abs_tol):
             continue
         if p0.dim != p1.dim:
             raise Exception("polytopes have different dimension")
+        if flat is not None and flat[k]:
+            out[k] = Polytope()
+            continue
         stacks.append(Polytope(np.vstack([p0.A, p1.A]), np.hstack([p0.b, p1.b])))
         where.append(k)
     if stacks:
@@ -1031,6 +1062,8 @@ def union(polyreg1, polyreg2, check_convex=False):
                 _hull_memo.clear()
             _hull_memo[hkey] = piece.copy() if not is_empty(piece) else piece   # (private: callers may edit what they get)
         elif not is_empty(piece):
+            if piece.bbox is None and _use_hip():
+                piece.bounding_box   # (kept with the remembered piece: the next union asks for it at once, every time)
             piece = piece.copy()
         if not is_empty(piece):
             final.append(piece)

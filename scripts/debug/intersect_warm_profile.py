@@ -14,8 +14,4 @@ for _ in range(3):
     t0 = time.perf_counter(); f(); print("%.2f ms" % ((time.perf_counter() - t0) * 1e3))
 pr = cProfile.Profile(); pr.enable(); f(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
-st = pstats.Stats(pr)
-st.print_callers("_intersect_pairs")
-st.print_callers("polytope.py:.*\\(intersect\\)")
-st.print_callers("_reduce_many")
-st.print_callers("_bbox_raw")
+pstats.Stats(pr).sort_stats("tottime").print_stats(16)
