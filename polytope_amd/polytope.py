@@ -1042,6 +1042,11 @@ def union(polyreg1, polyreg2, check_convex=False):
             group.append(cand)
             key = frozenset(_content_key(m) for m in group)
             convex = _convex_memo.get(key)
+            if convex is None and _use_hip() and _clearly_not_convex(group):
+                convex = False
+                if len(_convex_memo) >= _CONVEX_MEMO_MAX:
+                    _convex_memo.clear()
+                _convex_memo[key] = convex
             if convex is None:
                 convex, _ = is_convex(Region(group))
                 if len(_convex_memo) >= _CONVEX_MEMO_MAX:
@@ -1068,6 +1073,39 @@ def union(polyreg1, polyreg2, check_convex=False):
         if not is_empty(piece):
             final.append(piece)
     return Region(final)
+
+
+def _clearly_not_convex(group):
+    """A cheap witness that the union of `group` is not convex, from Chebyshev balls that are already cached: for the
+    newest member and each other one, the balls B(c1, r1) and B(c2, r2) lie in the union, so a convex union -- and the
+    envelope is_convex builds (ref :988-1014) in any case -- holds B(mid, (r1 + r2) / 2), mid = (c1 + c2) / 2.  A point
+    mid + (r1 + r2) / 4 u that every member excludes by a clear margin then sits, with a ball of radius (r1 + r2) / 4
+    around it, inside the envelope and outside the union: envelope \ union is full-dimensional and the reference's test
+    answers False.  Only array arithmetic on cached values; False means "no witness", not "convex".
+    (Region(1000 cells).intersect(P), first call of a process: most of its ~900 convexity tests are such rejections, each an
+    envelope, two reductions, bounding boxes and a region_diff.)"""
+    cand = group[-1]
+    if cand._chebXc is None or not cand._chebR or cand.A.size == 0:
+        return False
+    d = cand.A.shape[1]
+    dirs = np.vstack([np.eye(d), -np.eye(d)])                 # 2d x d
+    margin = 10 * ABS_TOL
+    for m in group[:-1]:
+        if m._chebXc is None or not m._chebR or m.A.size == 0 or m.A.shape[1] != d:
+            continue
+        step = 0.25 * (float(cand._chebR) + float(m._chebR))
+        if not step > margin:
+            continue
+        mid = 0.5 * (np.asarray(cand._chebXc, dtype=float).ravel() + np.asarray(m._chebXc, dtype=float).ravel())
+        pts = mid[None, :] + step * dirs                      # 2d x d
+        out = np.full(pts.shape[0], np.inf)
+        for q in group:
+            if q.A.size == 0 or q.A.shape[1] != d:
+                return False
+            out = np.minimum(out, np.max(pts @ q.A.T - q.b[None, :], axis=1))   # how far outside q (rows are unit)
+        if np.any(out > margin):
+            return True
+    return False
 
 
 def _union_all(pieces):
