@@ -105,6 +105,120 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
     if (lane == 0) status[p] = handed ? 1 : 0;
 }
 
+// ---- small batches: NW wavefronts per polytope (the pattern of reduce_wsplit_kernel, plp_reduce_r_impl.hpp).  One workgroup
+// per polytope: wavefront 0 runs F1 and leaves the centre in LDS, then wavefront w solves every NW-th of the 2d box LPs on the
+// rows they share -- each LP exactly as in bbox_lazy_kernel (same engine, same set-up): lb / ub / status bit for bit.
+template <int D, int NW, bool WDENSE>
+__global__ __launch_bounds__(64 * NW) void bbox_wsplit_kernel(long long B, int m_max, const double* __restrict__ A,
+                                                              const double* __restrict__ b, const int* __restrict__ mrows,
+                                                              double* __restrict__ lb, double* __restrict__ ub,
+                                                              int* __restrict__ status) {
+    constexpr int NC = D + 1;
+    __shared__ __attribute__((aligned(16))) double sA[64 * D];
+    __shared__ wide::WideShared<NC> shw[NW];
+    __shared__ double sx[NC + 1];
+    __shared__ unsigned sflag[2];   // [0]: F1 gave a usable ball, [1]: some LP was handed back
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long p = blockIdx.x;
+    if (p >= B) return;
+    const int m = mrows ? mrows[p] : m_max;
+    const bool has = lane < m;
+    double bi = 0.0;
+    if (w == 0) {
+        // ---- F1 (set-up as bbox_lazy_kernel); my row also goes to LDS for the box LPs
+        wide::WideShared<NC>& sh = shw[0];
+        typename wide::RowVec<NC>::type Tv = (typename wide::RowVec<NC>::type)(0.0);
+        double T16 = 0.0;
+        double nrm2 = 0.0;
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double v = has ? A[(p * m_max + lane) * D + k] : 0.0;
+            ROW_SET(k, v);
+            sA[lane * D + k] = v;
+            nrm2 = nrm2 + v * v;
+            finite = finite & isfinite(v);
+        }
+        bi = has ? b[p * m_max + lane] : 0.0;
+        finite = finite & isfinite(bi);
+        const double nrm = sqrt(nrm2);
+        const bool zero = !(nrm > 0.0);
+        bool rowact = has & !zero;
+        ROW_SET(D, rowact ? nrm : 0.0);
+        double beta = rowact ? bi : 0.0;
+        int rowvar = NC + lane, rowneg = 0;
+        if (lane <= NC) {
+            sh.cost[lane] = lane == D ? -1.0 : 0.0;
+            sh.cv[lane] = (lane + 1) << 1;
+        }
+        const bool infeasible0 = __ballot(has & zero & (bi < -TOL_FEAS)) != 0;
+        const bool bad = (__ballot(!finite) != 0) | (m > 64);
+        wide::wave_sync();
+        int st, iters = 0;
+        if (bad) st = ST_NUM;
+        else if (infeasible0) st = ST_INFEAS;
+        else st = wide::wide_run<NC>(lane, m, Tv, T16, beta, rowvar, rowneg, rowact, sh, NC, true, bi / nrm, iters);
+        const double mine = rowneg ? -beta : beta;
+        double xr = 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const uint64_t ob = __ballot(rowvar == j);
+            const double xj = ob ? wide::uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
+            if (lane == 0) sx[j] = xj;
+            if (j == D) xr = xj;
+        }
+        if (lane == 0) {
+            sflag[0] = ((st == ST_OPT) & (xr >= BBOX_LAZY_MIN_R)) ? 1u : 0u;
+            sflag[1] = 0u;
+        }
+    }
+    __syncthreads();
+    if (w != 0) bi = has ? b[p * m_max + lane] : 0.0;
+    const bool ok = sflag[0] != 0u;
+    double x[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = sx[k];
+    // ---- my slack at the centre (bbox_r_kernel: s by an fma chain, beta = max(b - s, 0))
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) s = fma(has ? sA[lane * D + k] : 0.0, ok ? x[k] : 0.0, s);
+    const double be0 = (ok & has) ? fmax(bi - s, 0.0) : 0.0;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    bool handed = false;
+    for (int it = w; it < 2 * D; it += NW) {  // lower_0, upper_0, lower_1, upper_1, ...: wavefront w every NW-th
+        const int kx = it >> 1;
+        const bool up = it & 1;
+        double xck = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xck = (k == kx) ? x[k] : xck;
+        double val = qnan;
+        if (__builtin_amdgcn_readfirstlane((int)ok)) {   // (the same in every lane, and said so: the LP runs on full wavefronts)
+            double negz = 0.0;
+            int s2;
+            if constexpr (WDENSE)
+                s2 = wide::solve_dense<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz,
+                                          *reinterpret_cast<wide::WideShared<D>*>(&shw[w]));
+            else
+                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
+            if (s2 == ST_OPT) val = up ? (xck + negz) : (xck - negz);
+            else if (s2 == ST_UNBND) val = up ? pinf : -pinf;
+            else handed = true;
+        }
+        if (lane == 0) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
+    }
+    if (handed & (lane == 0)) atomicOr(&sflag[1], 1u);
+    __syncthreads();
+    if ((w == 0) & (lane == 0)) status[p] = (!ok | (sflag[1] != 0u)) ? 1 : 0;
+}
+
+#ifndef PLP_BBOX_WSPLIT_MAXB
+// Measured (scripts/debug/bbox_wsplit_sweep.py, ms in use / four wavefronts per polytope): (64,8) B = 1 0.094 / 0.051, 500 0.116 /
+// 0.071, 2 000 0.168 / 0.129; (32,6) 500 0.056 / 0.041; (64,12) 500 0.136 / 0.077, 2 000 0.168 / 0.151, 4 000 0.228 / 0.258;
+// (64,16) 1 000 0.144 / 0.098
+#define PLP_BBOX_WSPLIT_MAXB 2000
+#endif
 #ifndef PLP_BBOX_WDENSE_MAXD
 #define PLP_BBOX_WDENSE_MAXD 13  // (as PLP_REDUCE_WDENSE_MAXD: beyond, the LPs are too short to pay for a dictionary reload)
 #endif
@@ -114,6 +228,19 @@ static int launch_bbox_lazy_d(long long B, int m_max, const double* A, const dou
                               double* ub, int* status, hipStream_t st) {
     if (B > 2147483647ll) return 1;
     const char* wd = getenv("PLP_BBOX_WDENSE");  // 0 / 1: never / always the dense engine for the 2d LPs (A/B)
+    // small batches: four wavefronts per polytope (PLP_BBOX_WSPLIT=0 / 1: never / always; PLP_BBOX_WSPLIT_MAXB)
+    const char* ws = getenv("PLP_BBOX_WSPLIT");
+    const char* wb = getenv("PLP_BBOX_WSPLIT_MAXB");
+    const long long maxb = wb ? atoll(wb) : PLP_BBOX_WSPLIT_MAXB;
+    if ((ws && ws[0] == '1') || (!(ws && ws[0] == '0') && B <= maxb)) {
+        if (wd ? wd[0] == '1' : (D <= PLP_BBOX_WDENSE_MAXD))
+            hipLaunchKernelGGL((bbox_wsplit_kernel<D, 4, true>), dim3((unsigned)B), dim3(256), 0, st, B, m_max, A, b, mrows, lb, ub,
+                               status);
+        else
+            hipLaunchKernelGGL((bbox_wsplit_kernel<D, 4, false>), dim3((unsigned)B), dim3(256), 0, st, B, m_max, A, b, mrows, lb, ub,
+                               status);
+        return 0;
+    }
     if (wd ? wd[0] == '1' : (D <= PLP_BBOX_WDENSE_MAXD))
         hipLaunchKernelGGL((bbox_lazy_kernel<D, true>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows,
                            lb, ub, status);

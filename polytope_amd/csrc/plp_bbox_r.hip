@@ -43,7 +43,10 @@ int launch_bbox(long long B, int m_max, int d, const double* A, const double* b,
     // against 0.157: its 2d LPs run side by side), the lane groups 32 rows and fewer ((32,6) 0.313 against 0.339).
     // PLP_BBOX_WIDE=0 / 1: never / every shape with d >= 5 (A/B)
     const char* bw = getenv("PLP_BBOX_WIDE");
-    if (d >= 5 && d <= 8 && (bw ? bw[0] == '1' : (m_max > 32 && B > 1024)) &&
+    // (round 4: and every batch of up to 2 000 polytopes, any row count: four wavefronts per polytope there, bbox_wsplit_kernel,
+    // 1.2x .. 1.85x ahead of the latency form; PLP_BBOX_SPLIT set: the lane-group forms keep their A/B meaning)
+    const bool small_batch = !bw && !getenv("PLP_BBOX_SPLIT") && !getenv("PLP_BBOX_WSPLIT") && B <= 2000;
+    if (d >= 5 && d <= 8 && (bw ? bw[0] == '1' : ((m_max > 32 && B > 1024) || small_batch)) &&
         launch_bbox_lazy(B, m_max, d, A, b, mrows, lb, ub, status, st) == 0)
         return 0;
     switch (d) {

@@ -729,6 +729,42 @@ def test_reduce_two_rows_per_lane(pa, oracle, variant, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_bbox_wavefronts_per_polytope_bitwise(pa, oracle, monkeypatch):
+    """bbox_wsplit_kernel (small batches at d >= 5: F1 on one wavefront, the 2d box LPs over four) against bbox_lazy_kernel (one
+    wavefront per polytope): lb, ub, status bit for bit -- bounded, unbounded, empty, ragged polytopes, with and without a
+    stored dictionary; a sample of the boxes against the oracle's generic LPs."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(9)
+    for (B, m, d) in [(1, 64, 8), (50, 40, 5), (300, 64, 8), (120, 33, 12), (60, 64, 16), (80, 20, 7), (40, 24, 14)]:
+        A, b = random_hpolytopes(B, m, d, seed=13 * m + d, stream=0)
+        b = b + np.einsum("bij,bj->bi", A, rng.standard_normal((B, d)))   # origin outside in general
+        for k in range(2, B, 9):
+            b[k, 0] = -50.0                                                # empty
+        for k in range(4, B, 9):
+            A[k, : m // 2] *= -1.0                                         # unbounded or empty
+        rows = rng.integers(max(d + 2, m - 9), m + 1, B).astype(np.int32)
+        for mr in (None, rows):
+            outs = []
+            for ws in ("0", "1"):
+                monkeypatch.setenv("PLP_BBOX_WIDE", "1")
+                monkeypatch.setenv("PLP_BBOX_WSPLIT", ws)
+                outs.append(pa.bbox_batch(A, b, m=mr))
+            monkeypatch.delenv("PLP_BBOX_WIDE", raising=False)
+            monkeypatch.delenv("PLP_BBOX_WSPLIT", raising=False)
+            for key in ("lb", "ub", "status"):
+                assert np.array_equal(np.asarray(outs[0][key]).view(np.uint8), np.asarray(outs[1][key]).view(np.uint8)), ((B, m, d), key)
+        res = pa.bbox_batch(A, b)   # the default route
+        for k in range(0, B, 7):
+            if int(res["status"][k]) != 0:
+                continue
+            lo, hi, bad = oracle.bounding_box(A[k], b[k])
+            if bad:
+                continue
+            assert np.allclose(res["lb"][k], lo, rtol=0, atol=1e-8, equal_nan=True), ((m, d), k)
+            assert np.allclose(res["ub"][k], hi, rtol=0, atol=1e-8, equal_nan=True), ((m, d), k)
+
+
+@pytest.mark.gpu
 def test_reduce_wavefronts_per_polytope_edge_inputs(pa, oracle, monkeypatch):
     """The split kernel on the inputs the pipeline treats specially: polytopes of 0 / 1 / 2 rows, zero rows (feasible and
     infeasible right-hand sides), a NaN or an infinity among the rows, every row a duplicate, unbounded polytopes, an empty
