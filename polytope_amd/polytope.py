@@ -1034,6 +1034,7 @@ def union(polyreg1, polyreg2, check_convex=False):
         return bool(np.any(pl - qu > gap_tol) or np.any(ql - pu > gap_tol))
 
     final = []
+    last_outer = None
     while lst:
         group = [lst[0]]
         for cand in lst[1:]:
@@ -1048,7 +1049,11 @@ def union(polyreg1, polyreg2, check_convex=False):
                     _convex_memo.clear()
                 _convex_memo[key] = convex
             if convex is None:
-                convex, _ = is_convex(Region(group))
+                convex, outer = is_convex(Region(group))
+                if convex and outer is not None:
+                    # the envelope is_convex built for exactly these members in this order: the merged piece below is
+                    # reduce(envelope(Region(group))) of the same list (ref :1226-1230) -- not computed a second time
+                    last_outer = (tuple(id(m) for m in group), outer)
                 if len(_convex_memo) >= _CONVEX_MEMO_MAX:
                     _convex_memo.clear()
                 _convex_memo[key] = convex
@@ -1061,7 +1066,10 @@ def union(polyreg1, polyreg2, check_convex=False):
         hkey = tuple(_content_key(m) for m in group)
         piece = _hull_memo.get(hkey)
         if piece is None:
-            hull = reduce(envelope(Region(group)))
+            if last_outer is not None and last_outer[0] == tuple(id(m) for m in group):
+                hull = reduce(last_outer[1])
+            else:
+                hull = reduce(envelope(Region(group)))
             piece = reduce(hull) if not is_empty(hull) else hull
             if len(_hull_memo) >= _HULL_MEMO_MAX:
                 _hull_memo.clear()
