@@ -15,10 +15,16 @@ in cache.  Extra objects of the line (N = 1): `end_to_end` = the same pass for a
 (host buffers in, host-visible results out; pageable and pinned, H2D / kernel / D2H split) and `cpu_baseline` =
 scipy.optimize.linprog called as polytope/solvers.py:152-154 calls it, on the host cores (count stated).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]; for N>1 under
+Launch:  python bench.py [--gpus N --steps K --warmup W].  For N > 1 either under a launcher,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU; every rank reduces its own 100k-polytope shard (weak scaling) and the
-step ends with the RCCL all-gather of the packed results (24 B per polytope).
+or plainly as `python bench.py --gpus N`: without WORLD_SIZE in the environment it starts its N ranks itself.
+One rank per GPU; `value` = weak scaling (every rank reduces its own 100k-polytope batches, the packed results
+-- 24 B per polytope -- are all-gathered over RCCL, coalesced and overlapped); the same run also measures ONE
+100k-polytope batch partitioned over the ranks (north_star) and reports it as the object `strong`.
+
+Timing: a region = the K steps repeated until it lasts >= 50 ms, between barrier + synchronize on both sides, max over
+ranks; five regions, the median is reported (`--steps 20` alone would be a 4 ms window).  After the clocks every
+polytope of every batch is reduced again by the CPU oracle on the host cores and compared (`parity_checked`).
 
 Prints ONE JSON line on rank 0.
 """
@@ -212,18 +218,107 @@ def _scipy_chunk(args):
     return cnt
 
 
+# ---- full-batch parity (outside the timed region): every polytope of every bench batch against the oracle -------------
+_PAR = {}
+
+
+def _parity_task(args):
+    """Pool worker (forked before HIP / RCCL exist in the parent): regenerates batch (seed, stream) -- Philox is
+    counter-based, so this is the rank's own data -- and runs the oracle's reduce() on polytopes [lo, hi)."""
+    import importlib.util
+    seed, stream, lo, hi = args
+    if _PAR.get("key") != (seed, stream):
+        if "synth" not in _PAR:   # by path: importing the package would load libplp_hip.so into every worker
+            spec = importlib.util.spec_from_file_location("_plp_synth", os.path.join(ROOT, "polytope_amd", "synth.py"))
+            _PAR["synth"] = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(_PAR["synth"])
+        _PAR["AB"] = _PAR["synth"].random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=seed, stream=stream)
+        _PAR["key"] = (seed, stream)
+    from oracle import oracle as O
+    A, b = _PAR["AB"]
+    R = O.reduce_batch(A[lo:hi], b[lo:hi])
+    return seed, lo, hi, R["keep"], R["flags"], R["nlp"], R["r"]
+
+
+def parity_check(pool, nproc, gpu_results, stream, r_tol=1e-9):
+    """gpu_results[i] = dict(keep, flags, nlp, r) (numpy) of batch i (seed i, this rank's stream).  Every polytope is
+    reduced again by oracle/plp_oracle.c (polytope.py:1053-1163 restated) on the host cores: keep mask, flags and LP
+    count must be equal, the Chebyshev radius within r_tol (north_star: 1e-9)."""
+    import numpy as np
+    t0 = time.perf_counter()
+    NB = len(gpu_results)
+    per_batch = max(1, -(-nproc // NB))
+    step = -(-B_PER_GPU // per_batch)
+    tasks = [(i, stream, lo, min(B_PER_GPU, lo + step)) for i in range(NB) for lo in range(0, B_PER_GPU, step)]
+    bad = {"keep": 0, "flags": 0, "nlp": 0, "r": 0}
+    max_r, checked, lps = 0.0, 0, 0
+    for seed, lo, hi, keep, flags, nlp, r in pool.imap_unordered(_parity_task, tasks, chunksize=1):
+        g = gpu_results[seed]
+        bad["keep"] += int(np.count_nonzero(g["keep"][lo:hi].view(np.uint64) != keep))
+        bad["flags"] += int(np.count_nonzero(g["flags"][lo:hi] != flags))
+        bad["nlp"] += int(np.count_nonzero(g["nlp"][lo:hi] != nlp))
+        dr = np.abs(g["r"][lo:hi] - r)
+        bad["r"] += int(np.count_nonzero(~(dr <= r_tol)))
+        max_r = max(max_r, float(dr.max()))
+        checked += hi - lo
+        lps += int(nlp.sum())
+    return {"checked": checked, "ok": not any(bad.values()), "mismatches": bad, "max_abs_r_err": max_r, "r_tol": r_tol,
+            "oracle_lps": lps, "seconds": time.perf_counter() - t0, "processes": nproc,
+            "what": "every polytope of every bench batch: keep mask / flags / LP count equal to oracle/plp_oracle.c's "
+                    "reduce(), Chebyshev radius within r_tol; outside the timed region"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started without a launcher: start the N ranks here (the environment
+    torch.distributed.run would give them: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rendezvous on 127.0.0.1), rank r on
+    cuda:r.  Rank 0 inherits stdout (the ONE JSON line), the others write to stderr.  Returns the first non-zero exit
+    code; a rank that fails takes the others down (exact PIDs)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on these hosts
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, alive = 0, set(range(n))
+    while alive:
+        for r in sorted(alive):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            alive.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                sys.stderr.write("bench.py: rank %d exited with %d, stopping the other ranks\n" % (r, c))
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)  # 0.3 ms each: the timed region is ~60 ms
+    ap.add_argument("--steps", type=int, default=200)  # 0.2 ms each
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the full-batch parity check against the oracle")
     ap.add_argument("--batches", type=int, default=6, help="distinct 100k-polytope batches the steps rotate over "
                     "(6 x 52.4 MB > 256 MiB Infinity Cache: every step reads its input from HBM)")
+    ap.add_argument("--regions", type=int, default=5, help="timed regions (each: barrier + synchronize, the steps, "
+                    "synchronize + barrier; max over ranks); the line reports the median region")
+    ap.add_argument("--min-region-ms", type=float, default=50.0, help="a region is the K steps repeated until it lasts "
+                    "at least this long (a 20-step region is 4 ms: the figure would move with the box's noise)")
     ap.add_argument("--force-dist", action="store_true", help="take the N > 1 code path (process group, exchange "
                     "buffers, overlapped all-gather) even at world size 1: a plumbing check of the RCCL path on a 1-GPU box")
-    ap.add_argument("--pipelined", action="store_true", help="N = 1: after the timed region run the same K steps again "
+    ap.add_argument("--pipelined", action="store_true", help="N = 1: after the timed regions run the same steps again "
                     "with two batches in flight (two HIP streams) and report them as the extra object `pipelined`. "
                     "Off by default so that a rocprofv3 run of the default command sees single-launch dispatches only")
     ap.add_argument("--streams", type=int, default=1, help="issue the steps round-robin on this many HIP streams "
@@ -231,31 +326,51 @@ def main():
                     "launch; with N > 1 the exchange is ordered against them at group boundaries).  Default 1: one "
                     "launch at a time, the regime roofline.kernel_ms and the rocprofv3 per-kernel durations describe; "
                     "`--pipelined` reports the two-stream throughput beside it")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): every GPU reduces its "
-                    "own 100k-polytope batches; strong: ONE 100k-polytope batch per step is partitioned across the GPUs "
-                    "(contiguous shards, north_star) and reassembled on every rank by the all-gather")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak (default): `value` = every GPU "
+                    "reduces its own 100k-polytope batches; at N > 1 the line also carries the object `strong` (ONE "
+                    "100k-polytope batch per step partitioned across the GPUs in contiguous shards, north_star, "
+                    "reassembled on every rank by the all-gather) measured in the same run.  strong: only that, as `value`")
     ap.add_argument("--gather-every", type=int, default=8, help="N > 1: batches per all-gather (G x 2.4 MB per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "exercise the N>1 code path with several ranks on one GPU)")
-    ap.add_argument("--verify-exchange", action="store_true", help="N > 1, after the timed region: every rank recomputes "
+    ap.add_argument("--verify-exchange", action="store_true", help="N > 1, after the timed regions: every rank recomputes "
                     "every rank's results of the last group of batches and compares them with what the all-gather "
                     "delivered (keep / flags / nlp / r bits); the line gets `exchange_verified`")
     args = ap.parse_args()
 
-    import torch
-    import polytope_amd as pa
-    from polytope_amd import _lib
-    from polytope_amd.dist import GroupedExchange
-    from polytope_amd.synth import random_hpolytopes
-
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be one.  (Under torch.distributed.run WORLD_SIZE is set and this process IS a rank.)
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start the ranks with --nproc-per-node %d (or without a launcher: "
+                         "bench.py spawns them itself)" % (args.gpus, world, args.gpus))
+
+    # The parity pool is forked NOW, before HIP and RCCL exist in this process (forking a process that holds a HIP
+    # context and RCCL's threads is asking for trouble); it idles until the timed regions are over.
+    pool, pool_n = None, 0
+    if not args.no_parity:
+        import multiprocessing as mp
+        from oracle import oracle as O
+        O.build()   # once, here: the workers only load it
+        pool_n = max(1, (os.cpu_count() or 1) // world)
+        pool = mp.get_context("fork").Pool(pool_n)
+
+    import torch
+    import polytope_amd as pa
+    from polytope_amd import _lib
+    from polytope_amd.dist import GroupedExchange, shard_bounds
+    from polytope_amd.synth import random_hpolytopes
+
     if not torch.cuda.is_available() or not _lib.available():
         raise SystemExit("bench.py needs a MI355X and polytope_amd/libplp_hip.so (no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit("--gpus %d over RCCL needs %d visible GPUs, this box has %d (several ranks on one GPU: "
+                         "--backend gloo, a plumbing check only)" % (world, world, ndev))
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -264,187 +379,146 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    rdev = dev if (multi and args.backend == "nccl") else torch.device("cpu")
 
-    # NB distinct batches, all resident in HBM before the timed region; step k reduces batch k mod NB.  6 x 52.4 MB
-    # is more than the 256 MiB Infinity Cache, so a step never finds its input cached from the previous pass.
+    def allred(val, dtype, op=None):
+        if not multi:
+            return val
+        t = torch.tensor([val], dtype=dtype, device=rdev)
+        dist.all_reduce(t, op=op if op is not None else dist.ReduceOp.SUM)
+        return t.item()
+
     NB = max(1, args.batches)
-    strong = args.scaling == "strong"
-    B_LOCAL = B_PER_GPU
-    if strong:  # every rank regenerates the same global batch (counter-based RNG) and keeps its contiguous shard
-        from polytope_amd.dist import shard_bounds
-        if B_PER_GPU % world:
-            raise SystemExit("--scaling strong: %d polytopes do not split evenly over %d ranks" % (B_PER_GPU, world))
-        lo, hi = shard_bounds(B_PER_GPU, rank, world)
-        B_LOCAL = hi - lo
-        host_batches = [tuple(v[lo:hi].copy() for v in random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=0))
-                        for i in range(NB)]
-    else:
-        host_batches = [random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=rank) for i in range(NB)]
-    dev_batches = [(torch.as_tensor(A_).to(dev), torch.as_tensor(b_).to(dev)) for A_, b_ in host_batches]
-    A, b = host_batches[0]
-
-    # N > 1: the kernel writes its results straight into a slot of a flat exchange buffer (24 B per polytope, no
-    # packing kernels); every G batches the buffer goes out as ONE all-gather (xGMI is point-to-point: fewer,
-    # larger collectives -- G x 2.4 MB per rank), on RCCL's stream while the next group of batches is computed in
-    # the other buffer.  Every batch's results are on every rank before the timed region ends (flush below).
     G = max(1, args.gather_every)
-    nb = 24 * B_LOCAL
-    ex = GroupedExchange(torch, dist, B_LOCAL, DIM, G, dev) if multi else None
+    K = max(1, args.steps)
+    counting = os.environ.get("PLP_BENCH_NO_COUNT", "0") != "1"
+    main_st = torch.cuda.current_stream()
 
-    # --streams S > 1: the steps are issued round-robin on S HIP streams, i.e. S independent batches are in flight.
-    # 100 000 polytopes are 6 250 wavefronts for 4 096 resident slots, so the last round of a launch runs half
-    # empty; with a second launch in flight that hole is filled.  The exchange (N > 1) is ordered against the side
-    # streams at group boundaries only.
-    main = torch.cuda.current_stream()
-    side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
-    nissued = [0]
+    def run_mode(dev_batches, B_LOCAL):
+        """One scaling mode on this rank's resident batches: warm-up, a calibration region, then `--regions` timed
+        regions of the same steps (every region starts the rotation at batch 0, so the regions are the same work)."""
+        nb = 24 * B_LOCAL
+        # N > 1: the kernel writes its results straight into a slot of a flat exchange buffer (24 B per polytope, no
+        # packing kernels); every G batches the buffer goes out as ONE all-gather (xGMI is point-to-point: fewer,
+        # larger collectives), on RCCL's stream while the next group of batches is computed in the other buffer.
+        # Every batch's results are on every rank before a timed region ends (drain below).
+        ex = GroupedExchange(torch, dist, B_LOCAL, DIM, G, dev) if multi else None
+        # --streams S > 1: the steps are issued round-robin on S HIP streams (S independent batches in flight); the
+        # exchange (N > 1) is ordered against the side streams at group boundaries only.
+        side = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else None
+        nissued = [0]
 
-    def join():  # the main stream waits for everything issued on the side streams
-        if side is not None:
-            for st in side:
-                main.wait_stream(st)
+        def join():
+            if side is not None:
+                for st in side:
+                    main_st.wait_stream(st)
 
-    def step():
-        k = nissued[0]
-        nissued[0] += 1
-        At, bt = dev_batches[k % NB]
-        if side is None:
+        def step():
+            k = nissued[0]
+            nissued[0] += 1
+            At, bt = dev_batches[k % NB]
+            if side is None:
+                if ex is None:
+                    return pa.reduce_batch(At, bt)  # the fused kernel on torch's current stream
+                res = pa.reduce_batch(At, bt, out=ex.slot().views)
+                ex.commit()
+                return res
+            st = side[k % len(side)]
             if ex is None:
-                return pa.reduce_batch(At, bt)  # one fused kernel (+ its idle second pass) on torch's current stream
-            res = pa.reduce_batch(At, bt, out=ex.slot().views)
+                with torch.cuda.stream(st):
+                    return pa.reduce_batch(At, bt)
+            if ex.k % G == 0:  # a new group starts in the other buffer: its last all-gather was waited for on `main`
+                for s_ in side:
+                    s_.wait_stream(main_st)
+            with torch.cuda.stream(st):
+                res = pa.reduce_batch(At, bt, out=ex.slot().views)
+            if ex.k % G == G - 1:  # the group is complete: its kernels must have run before the all-gather reads it
+                join()
             ex.commit()
             return res
-        st = side[k % len(side)]
-        if ex is None:
-            with torch.cuda.stream(st):
-                return pa.reduce_batch(At, bt)
-        if ex.k % G == 0:  # a new group starts in the other buffer: its last all-gather was waited for on `main`
-            for s_ in side:
-                s_.wait_stream(main)
-        with torch.cuda.stream(st):
-            res = pa.reduce_batch(At, bt, out=ex.slot().views)
-        if ex.k % G == G - 1:  # the group is complete: its kernels must have run before the all-gather reads it
+
+        def drain():
             join()
-        ex.commit()
-        return res
+            return ex.drain()
 
-    def drain():
-        join()
-        return ex.drain()
+        # every batch once, untimed: loads the code object and yields the results the parity check compares and the LP
+        # count of each batch (the number of lpsolve() calls the reference would issue on it: kernel output nlp[])
+        first = [pa.reduce_batch(At_, bt_) for At_, bt_ in dev_batches]
+        nlp_of = [int(v["nlp"].sum().item()) for v in first]
 
-    # every batch once, untimed: loads the code object (hipModule load is lazy) and yields the LP count of each batch
-    # (the number of lpsolve() calls the reference would issue on it: kernel output nlp[], checked against the
-    # oracle in tests/ and, for batch 0, in the cpu_baseline leg below)
-    nlp_batches = [pa.reduce_batch(At_, bt_)["nlp"] for At_, bt_ in dev_batches]
-    nlp_of = [int(v.sum().item()) for v in nlp_batches]
-    # In-run accounting (include/plp.h: plp_reduce_counters): from the first call on the fused reduce kernels add the
-    # number of LPs that ran the simplex to a device word (one atomic per tile); reset right before the timed region and
-    # read right after it, so the line can say what was SOLVED beside what was disposed of.  PLP_BENCH_NO_COUNT=1: off.
-    counting = os.environ.get("PLP_BENCH_NO_COUNT", "0") != "1"
-    if counting:
-        pa.batch.reduce_simplex_runs(dev_index, reset=True)
-    for _ in range(args.warmup):
-        step()
-    nissued[0] = 0
-    if ex is not None:
-        drain()
-    torch.cuda.synchronize()
-    if counting:
-        pa.batch.reduce_simplex_runs(dev_index, reset=True)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # one HIP event pair around the K launches on the stream they are issued on (torch's current stream): the
-    # kernel's average launch duration = elapsed / K.  It includes the idle second pass (reduce_kernel<3>, ~7 us,
-    # nothing to redo) and the launch gaps, so it is an upper bound of the reduce_r_kernel duration rocprofv3
-    # reports; event pairs around every single launch were dropped because their marker packets cost 8 % of the
-    # throughput they were there to explain.
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    evs = side[0] if side is not None else main  # with S streams: the launches of stream 0 (every S-th step)
-    n_on_evs = (args.steps + len(side) - 1) // len(side) if side is not None else args.steps
-    gathered = None
-    t0 = time.perf_counter()
-    if side is not None:
-        for st in side:
-            st.wait_stream(main)
-    ev0.record(evs)
-    for k in range(args.steps):
-        res = step()
-    ev1.record(evs)
-    join()
-    if ex is not None:
-        gathered = drain()[-1]
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    simplex_timed_local = pa.batch.reduce_simplex_runs(dev_index) if counting else None   # of the K timed steps, this rank
-    if multi:
-        rdev = dev if args.backend == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = ev0.elapsed_time(ev1) / n_on_evs  # average launch duration on the stream the events sit on
-    assert int(res["nlp"].sum().item()) == nlp_of[(args.steps - 1) % NB]  # the last step's own output
-    lps_timed_local = sum(nlp_of[k % NB] for k in range(args.steps))  # LPs of the K timed steps on this rank
-    nlp_local = lps_timed_local / args.steps                           # mean per step
-    lps_timed = lps_timed_local
-    if multi:
-        t = torch.tensor([lps_timed_local], dtype=torch.int64, device=rdev)
-        dist.all_reduce(t)
-        lps_timed = int(t.item())
-        assert gathered.numel() == world * G * nb
-    nlp_total = lps_timed / args.steps
-    simplex_timed = simplex_timed_local
-    ranks_seen, exchange_ms = None, None
-    if multi:
-        if counting:
-            t = torch.tensor([simplex_timed_local], dtype=torch.int64, device=rdev)
-            dist.all_reduce(t)
-            simplex_timed = int(t.item())
-        # self-check of the collective layer: how many ranks answer, and what ONE exchange of a group costs on its own
-        # (all-gather of G x 24 B x polytopes per rank, nothing overlapping it)
-        t = torch.ones(1, dtype=torch.int64, device=rdev)
-        dist.all_reduce(t)
-        ranks_seen = int(t.item())
-        src = ex.big[0]
-        dst = torch.empty((world * src.numel(),), dtype=torch.uint8, device=src.device)
-        for _ in range(3):
-            dist.all_gather_into_tensor(dst, src)
-        torch.cuda.synchronize()
-        dist.barrier()
-        te = time.perf_counter()
-        nrep = 10
-        for _ in range(nrep):
-            dist.all_gather_into_tensor(dst, src)
-        torch.cuda.synchronize()
-        te = torch.tensor([(time.perf_counter() - te) / nrep * 1e3], dtype=torch.float64, device=rdev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        exchange_ms = float(te.item())
-    shard_alone_ms = None
-    if strong:   # the floor of strong scaling: one rank's shard as a launch of its own (no exchange), event-timed
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            pa.reduce_batch(*dev_batches[0])
-        e0.record()
-        for k in range(50):
-            pa.reduce_batch(*dev_batches[k % NB])
-        e1.record()
-        torch.cuda.synchronize()
-        shard_alone_ms = e0.elapsed_time(e1) / 50
-    verified = None
-    if multi and args.verify_exchange:
+        def region(nsteps):
+            """barrier + synchronize | nsteps steps (+ the drain of the exchange) | synchronize + barrier; the wall time
+            is the max over ranks.  One HIP event pair sits around the launches on the stream they are issued on."""
+            nissued[0] = 0
+            if ex is not None:
+                ex.k = 0
+            torch.cuda.synchronize()
+            if counting:
+                pa.batch.reduce_simplex_runs(dev_index, reset=True)
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            evs = side[0] if side is not None else main_st
+            n_on_evs = (nsteps + len(side) - 1) // len(side) if side is not None else nsteps
+            gathered = None
+            t0 = time.perf_counter()
+            if side is not None:
+                for st in side:
+                    st.wait_stream(main_st)
+            ev0.record(evs)
+            for _ in range(nsteps):
+                res = step()
+            ev1.record(evs)
+            join()
+            if ex is not None:
+                gathered = drain()[-1]
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            el = float(allred(el, torch.float64, dist.ReduceOp.MAX if multi else None))
+            simplex = pa.batch.reduce_simplex_runs(dev_index) if counting else None
+            assert int(res["nlp"].sum().item()) == nlp_of[(nsteps - 1) % NB]   # the last step's own output
+            if multi:
+                assert gathered.numel() == world * G * nb
+            return {"elapsed": el, "kern_ms": ev0.elapsed_time(ev1) / n_on_evs, "simplex": simplex, "steps": nsteps,
+                    "gathered": gathered}
+
+        for _ in range(args.warmup):
+            step()
+        if ex is not None:
+            drain()
+        cal = region(K)["elapsed"]
+        rep = max(1, int(-(-args.min_region_ms * 1e-3 // cal))) if cal > 0 else 1
+        S = K * rep
+        regs = [region(S) for _ in range(max(1, args.regions))]
+        order = sorted(range(len(regs)), key=lambda i: regs[i]["elapsed"])
+        med = regs[order[len(order) // 2]]
+        lps_local = sum(nlp_of[k % NB] for k in range(S))
+        lps = int(allred(lps_local, torch.int64))
+        simplex = med["simplex"]
+        if simplex is not None:
+            simplex = int(allred(simplex, torch.int64))
+        return {"ex": ex, "first": first, "nlp_of": nlp_of, "S": S, "rep": rep, "regs": regs, "med": med, "lps": lps,
+                "lps_local": lps_local, "simplex": simplex, "B_LOCAL": B_LOCAL, "last_gathered": regs[-1]["gathered"],
+                "region_ms": [r_["elapsed"] * 1e3 for r_ in regs]}
+
+    def verify_exchange(mode, strong):
         # the last gathered group holds the slots of the steps of the (possibly partly filled) last group; rank q's part
         # must be what a reduce of rank q's batch of that step returns -- recomputed here, on this rank's GPU
-        gcpu = gathered.cpu()
-        first = (args.steps - 1) // G * G
+        ex, S = mode["ex"], mode["S"]
+        gcpu = mode["last_gathered"].cpu()
+        first = (S - 1) // G * G
         ok, nslots = True, 0
-        for kstep in range(first, args.steps):
+        for kstep in range(first, S):
             s_ = kstep - first
             for q in range(world):
                 if strong:
@@ -464,11 +538,93 @@ def main():
                 wantg = pa.reduce_batch(torch.as_tensor(Ag).to(dev), torch.as_tensor(bg_).to(dev))
                 gv = ex.global_views(gcpu, s_)
                 ok = ok and bool(torch.equal(gv["keep"].cpu(), wantg["keep"].cpu())) and bool(torch.equal(gv["nlp"].cpu(), wantg["nlp"].cpu()))
-        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        verified = {"ranks": world, "ok": bool(t.item() == 1), "slots_checked": nslots}
+        allok = int(allred(1 if ok else 0, torch.int64, dist.ReduceOp.MIN))
+        return {"ranks": world, "ok": allok == 1, "slots_checked": nslots}
+
+    def shard_alone(dev_batches):
+        # the floor of strong scaling: one rank's shard as a launch of its own (no exchange), event-timed
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            pa.reduce_batch(*dev_batches[0])
+        e0.record()
+        for k in range(50):
+            pa.reduce_batch(*dev_batches[k % NB])
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 50
+
+    # ---- the batches: NB distinct ones per mode, resident in HBM before any clock starts ---------------------------------
+    want_weak = args.scaling == "weak"
+    want_strong = args.scaling == "strong" or (multi and want_weak)
+    weak = strong = None
+    host_batches = None
+    if want_weak:
+        host_batches = [random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=rank) for i in range(NB)]
+        dev_w = [(torch.as_tensor(A_).to(dev), torch.as_tensor(b_).to(dev)) for A_, b_ in host_batches]
+        weak = run_mode(dev_w, B_PER_GPU)
+    if want_strong:
+        # every rank regenerates the same global batches (counter-based RNG, stream 0) and keeps its contiguous shard
+        if B_PER_GPU % world:
+            raise SystemExit("strong scaling: %d polytopes do not split evenly over %d ranks" % (B_PER_GPU, world))
+        lo, hi = shard_bounds(B_PER_GPU, rank, world)
+        glob = host_batches if (want_weak and rank == 0) else [
+            random_hpolytopes(B_PER_GPU, M_ROWS, DIM, seed=i, stream=0) for i in range(NB)]
+        if host_batches is None:
+            host_batches = glob
+        dev_s = [(torch.as_tensor(A_[lo:hi]).to(dev), torch.as_tensor(b_[lo:hi]).to(dev)) for A_, b_ in glob]
+        strong = run_mode(dev_s, hi - lo)
+        strong["shard_alone_ms"] = shard_alone(dev_s)
+    head = weak if want_weak else strong      # the mode `value` is quoted on
+    A, b = host_batches[0]
+
+    # ---- after the clocks: self-check of the collective layer, exchange verification, full-batch parity -------------------
+    ranks_seen, exchange_ms = None, None
+    if multi:
+        ranks_seen = int(allred(1, torch.int64))
+        # what ONE exchange of a group costs on its own (all-gather of G x 24 B x polytopes per rank, nothing overlapping it)
+        src = head["ex"].big[0]
+        src = src.cpu() if args.backend == "gloo" else src
+        dst = torch.empty((world * src.numel(),), dtype=torch.uint8, device=src.device)
+        for _ in range(3):
+            dist.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        dist.barrier()
+        te = time.perf_counter()
+        nrep = 10
+        for _ in range(nrep):
+            dist.all_gather_into_tensor(dst, src)
+        torch.cuda.synchronize()
+        exchange_ms = float(allred((time.perf_counter() - te) / nrep * 1e3, torch.float64, dist.ReduceOp.MAX))
+    verified = None
+    if multi and args.verify_exchange:
+        verified = verify_exchange(head, strong=not want_weak)
+        if want_weak and strong is not None:
+            verified["strong"] = verify_exchange(strong, strong=True)
+    parity = None
+    if pool is not None:
+        # this rank's own batches (weak: stream = rank; strong only: the global batches, whose shards it reduced --
+        # checked as whole batches through a launch of their own, the same kernel on the same rows)
+        if want_weak:
+            gres = [{k: v[k].cpu().numpy() for k in ("keep", "flags", "nlp", "r")} for v in weak["first"]]
+            stream = rank
+        else:
+            gres = []
+            for A_, b_ in host_batches:
+                v = pa.reduce_batch(torch.as_tensor(A_).to(dev), torch.as_tensor(b_).to(dev))
+                gres.append({k: v[k].cpu().numpy() for k in ("keep", "flags", "nlp", "r")})
+            stream = 0
+        parity = parity_check(pool, pool_n, gres, stream)
+        pool.close()
+        pool.join()
+        tot = int(allred(parity["checked"], torch.int64))
+        allok = int(allred(1 if parity["ok"] else 0, torch.int64, dist.ReduceOp.MIN if multi else None))
+        parity["checked_all_ranks"], parity["ok_all_ranks"] = tot, allok == 1
 
     if rank == 0:
+        med = head["med"]
+        B_LOCAL = head["B_LOCAL"]
+        kern_ms = med["kern_ms"]
+        elapsed, S = med["elapsed"], head["S"]
         alg_bytes = B_LOCAL * (8 * M_ROWS * (DIM + 1) + 12)  # 524 B per (16,3) polytope
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
@@ -483,48 +639,69 @@ def main():
             traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
         except Exception:
             pass
+        simplex = head["simplex"]
+        npoly = (B_PER_GPU * world if want_weak else B_PER_GPU) * S   # polytopes reduced per region, all ranks
         line = {
             "metric": "LP solves/sec (batched Chebyshev + redundancy)",
-            "value": lps_timed / elapsed,
+            "value": head["lps"] / elapsed,
             "unit": "LP/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / S * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "polytopes_per_s": npoly / elapsed,
             "config": {"workload": "reduce() of %d random H-polytopes per GPU, d=%d, m=%d (BASELINE configs[1]); %d distinct "
                                    "batches resident in HBM, one per step in rotation (%.0f MB > 256 MiB Infinity Cache)"
                                    % (B_PER_GPU, DIM, M_ROWS, NB, NB * B_PER_GPU * 8 * M_ROWS * (DIM + 1) / 1e6),
-                       "lps_per_step": nlp_total, "batches": NB, "polytopes_per_gpu": B_LOCAL, "streams": args.streams,
+                       "lps_per_step": head["lps"] / S, "batches": NB, "polytopes_per_gpu": B_LOCAL, "streams": args.streams,
+                       "timing": "`--steps` K = %d; a timed region = K x %d = %d steps (>= %.0f ms), bracketed by barrier + "
+                                 "synchronize, max over ranks; %d regions, the line reports the median one"
+                                 % (K, head["rep"], S, args.min_region_ms, len(head["regs"])),
+                       "timed_steps_per_region": S, "regions": len(head["regs"]), "region_ms": head["region_ms"],
                        "lp_accounting": "`value` counts the LPs the reference issues on these polytopes (kernel output nlp, checked "
                                         "against the oracle's count); `lps_simplex_per_step` of them ran the simplex in the timed "
                                         "steps (device counter, plp_reduce_counters), the others are redundancy LPs whose verdict the "
-                                        "two-witness presolve settled (DESIGN.md 4.2): `presolved_frac` of all LPs",
-                       "lps_simplex_per_step": None if simplex_timed is None else simplex_timed / args.steps,
-                       "presolved_frac": None if simplex_timed is None else 1.0 - simplex_timed / lps_timed,
-                       "value_simplex_only": None if simplex_timed is None else simplex_timed / elapsed,
+                                        "two-witness presolve settled (DESIGN.md 4.1): `presolved_frac` of all LPs",
+                       "lps_simplex_per_step": None if simplex is None else simplex / S,
+                       "presolved_frac": None if simplex is None else 1.0 - simplex / head["lps"],
+                       "value_simplex_only": None if simplex is None else simplex / elapsed,
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "reduce_r_mix_kernel<3>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
-                             nlp_local / (kern_ms * 1e-3))},
+                             head["lps_local"] / S / (kern_ms * 1e-3))},
         }
+        if parity is not None:
+            line["parity_checked"] = parity["checked_all_ranks"]
+            line["parity_ok"] = parity["ok_all_ranks"]
+            line["parity"] = parity
         if multi:
             line["config"]["rccl_ranks_seen"] = ranks_seen
+            line["config"]["backend"] = args.backend
             line["config"]["exchange_ms_per_group"] = exchange_ms
-            line["config"]["exchange_bytes_per_rank_per_group"] = G * nb
-        if strong:
-            line["config"]["strong_floor"] = {
-                "shard_polytopes": B_LOCAL, "shard_kernel_ms_alone": shard_alone_ms,
-                "note": "one rank's shard as a launch of its own: a launch of a few thousand tiles cannot fill 4096 wavefront "
-                        "slots for long enough to amortise its ramp and drain (12 500 polytopes: ~81 us against 203/8 = 25 us "
-                        "ideal), so strong scaling at this batch size is bounded by this figure, not by the exchange"}
+            line["config"]["exchange_bytes_per_rank_per_group"] = G * 24 * B_LOCAL
+        if strong is not None:
+            sm = strong["med"]
+            floor = {"shard_polytopes": strong["B_LOCAL"], "shard_kernel_ms_alone": strong["shard_alone_ms"],
+                     "note": "one rank's shard as a launch of its own, no exchange: what a step of the partitioned batch "
+                             "cannot go below on this build"}
+            sobj = {"what": "ONE %d-polytope batch per step partitioned over the %d GPUs in contiguous shards (north_star), "
+                            "reassembled on every rank by the all-gather; same run, same batches as rank 0's weak ones"
+                            % (B_PER_GPU, world),
+                    "value": strong["lps"] / sm["elapsed"], "unit": "LP/s", "ms_per_step": sm["elapsed"] / strong["S"] * 1e3,
+                    "polytopes_per_s": B_PER_GPU * strong["S"] / sm["elapsed"], "lps_per_step": strong["lps"] / strong["S"],
+                    "timed_steps_per_region": strong["S"], "region_ms": strong["region_ms"],
+                    "kernel_ms": sm["kern_ms"], "strong_floor": floor}
+            if want_weak:
+                line["strong"] = sobj
+            line["config"]["strong_floor"] = floor
         if verified is not None:
             line["exchange_verified"] = verified
         if valu:  # measured PMC counters of the same kernel (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU over GRBM_GUI_ACTIVE)
@@ -538,33 +715,35 @@ def main():
                 line["roofline"]["valu_issue_note"] = ("SQ_INSTS_VALU per launch (committed PMC pass) x 4 cycles / (1024 SIMDs x "
                                                        "2.4 GHz x kernel_ms of this run)")
         if args.pipelined and not multi and args.streams == 1:
-            # Not `value`: the same K steps again with two independent batches in flight (two HIP streams).  100 000
+            # Not `value`: the same steps again with two independent batches in flight (two HIP streams).  100 000
             # polytopes are 6250 wavefronts for 4096 resident slots, so the last round of a launch runs half empty;
             # with a second launch in flight that hole is filled -- what a caller with a stream of batches should do.
             two = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for k in range(2 * max(1, args.warmup)):  # untimed: the streams' queues are created on first use
                 with torch.cuda.stream(two[k & 1]):
-                    pa.reduce_batch(*dev_batches[k % NB])
+                    pa.reduce_batch(*dev_w[k % NB])
             torch.cuda.synchronize()
             tp = time.perf_counter()
             for st in two:
                 st.wait_stream(torch.cuda.current_stream())
-            for k in range(args.steps):
+            for k in range(S):
                 with torch.cuda.stream(two[k & 1]):
-                    res2 = pa.reduce_batch(*dev_batches[k % NB])
+                    res2 = pa.reduce_batch(*dev_w[k % NB])
             torch.cuda.synchronize()
             tp = time.perf_counter() - tp
-            assert int(res2["nlp"].sum().item()) == nlp_of[(args.steps - 1) % NB]
-            line["pipelined"] = {"streams": 2, "value": lps_timed_local / tp, "unit": "LP/s",
-                                 "ms_per_step": tp / args.steps * 1e3,
+            assert int(res2["nlp"].sum().item()) == head["nlp_of"][(S - 1) % NB]
+            line["pipelined"] = {"streams": 2, "value": head["lps_local"] / tp, "unit": "LP/s",
+                                 "ms_per_step": tp / S * 1e3,
                                  "note": "two batches in flight; not the headline, see DESIGN.md section 6"}
         if not multi and not args.no_end_to_end:
             line["end_to_end"] = end_to_end(torch, pa, A, b, dev)
         if not multi and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(A, b, nlp_batches[0].cpu().numpy())
+            line["cpu_baseline"] = cpu_baseline(A, b, head["first"][0]["nlp"].cpu().numpy())
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
+    if parity is not None and not parity["ok_all_ranks"]:
+        raise SystemExit("bench.py: the GPU results differ from the oracle's (see `parity` in the line)")
 
 
 if __name__ == "__main__":

@@ -44,6 +44,9 @@ def lib():
         L.plpo_reduce.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double,
                                   C.POINTER(C.c_uint64), dp, dp, dp, ip]
         L.plpo_reduce.restype = C.c_int
+        L.plpo_reduce_batch.argtypes = [C.c_int64, C.c_int, C.c_int, dp, dp, C.c_double, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_int32), dp, C.POINTER(C.c_int32)]
+        L.plpo_reduce_batch.restype = C.c_int
         L.plpo_contains.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int32),
                                     C.c_int64, dp, C.c_double, C.POINTER(C.c_uint8)]
         L.plpo_contains.restype = None
@@ -130,6 +133,24 @@ def reduce(A, b, abs_tol=1e-7):
     mask = np.array([(keep[i >> 6] >> (i & 63)) & 1 for i in range(m)], dtype=bool)
     return dict(keep=mask, mask=int(keep[0]), words=[int(w) for w in keep], flags=flags, b=bout[:m], r=r.value, xc=xc,
                 nlp=nlp.value)
+
+
+def reduce_batch(A, b, abs_tol=1e-7):
+    """plpo_reduce on every polytope of a packed batch A[B,m,d], b[B,m] (m <= 64), the loop in C.
+
+    -> dict(keep=uint64[B] (bit i <=> input row i kept), flags=int32[B], r=f64[B], nlp=int32[B])
+    """
+    A, b = _d(A), _d(b)
+    B, m, d = A.shape
+    keep = np.empty(B, dtype=np.uint64)
+    flags = np.empty(B, dtype=np.int32)
+    nlp = np.empty(B, dtype=np.int32)
+    r = np.empty(B)
+    rc = lib().plpo_reduce_batch(B, m, d, _p(A), _p(b), abs_tol, _p(keep, C.c_uint64), _p(flags, C.c_int32), _p(r),
+                                 _p(nlp, C.c_int32))
+    if rc != 0:
+        raise ValueError("oracle.reduce_batch: m <= 64, d <= 16")
+    return dict(keep=keep, flags=flags, r=r, nlp=nlp)
 
 
 def contains(A, b, X, abs_tol=1e-7, mrows=None, region=False):

@@ -64,7 +64,11 @@ __global__ __launch_bounds__(BLOCK, PLP_REDUCE_WAVES(D)) void reduce_kernel(long
                                                        unsigned long long epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // second pass: the fast kernels raise the call's word when they hand a polytope back; normally they did not
-    if (retry_only && retry_word && *retry_word != epoch) return;
+    // The word lives in a ring of 64 (slot = epoch & 63, raised with atomicMax): a value BELOW this call's epoch means no
+    // tile of this call asked for the second pass; this call's own epoch means some did; a LARGER value is a later call
+    // (64 or more calls of one context in flight on other streams) that took the slot over -- then nothing is known and
+    // the flags of the batch are swept as if the word were not there.
+    if (retry_only && retry_word && *retry_word < epoch) return;
     const Grp g(gs);
     const int NG = BLOCK / gs;
     const int gib = threadIdx.x / gs;

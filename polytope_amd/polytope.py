@@ -74,6 +74,17 @@ def _fits_lp(m, d):
 
 
 # ======================================================================================
+class _NoDeviceState(object):
+    """Objects that remember device-resident tables (`_packed`, `_p2p_flat`) pickle and deep-copy WITHOUT them: the
+    copy packs its own table on first use, and a pickle opens on a host that has no GPU."""
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.pop("_packed", None)
+        st.pop("_p2p_flat", None)
+        return st
+
+
 class Polytope(object):
     """Convex polytope {x | A x <= b} (H-representation).
 
@@ -258,7 +269,7 @@ class Polytope(object):
 
 
 # ======================================================================================
-class Region(object):
+class Region(_NoDeviceState):
     """Possibly non-convex set: a list of convex polytopes (ref :650-936)."""
 
     def __init__(self, list_poly=None, props=None):
@@ -435,25 +446,51 @@ def _pack(polys):
     return A, b, ms
 
 
-class _PackedTable(object):
-    """(A, b, m) of a list of polytopes packed once, and -- on the 'hip' backend -- resident on the device from the first
-    call that needs it there: `dev()` returns the torch CUDA tensors the `*_batch` entry points take as they are (device
-    pointers on torch's stream: nothing is packed or uploaded again).  polytope_amd.batch.h2d_bytes counts the upload."""
-    __slots__ = ("A", "b", "ms", "_dev", "_refs")
+def _torch_or_none():
+    """torch when it can be imported (device tensors, torch's stream), else None: the library's host-pointer entry points
+    take the numpy arrays as they are (the library copies them in and out itself)."""
+    try:
+        import torch
+        return torch
+    except Exception:  # pragma: no cover - torch is part of the image
+        return None
 
-    def __init__(self, polys):
-        self.A, self.b, self.ms = _pack(polys)
+
+class _PackedTable(object):
+    """(A, b, m) of a list of polytopes packed once, and -- on the 'hip' backend with torch in the process -- resident on
+    the device from the first call that needs it there: `dev()` returns the torch CUDA tensors the `*_batch` entry points
+    take as they are (device pointers on torch's stream: nothing is packed or uploaded again).  Without torch `dev()` hands
+    out the packed numpy arrays (host-pointer entry points).  polytope_amd.batch.h2d_bytes counts the upload.  Pickling /
+    deep-copying a table keeps the host arrays only."""
+    __slots__ = ("A", "b", "ms", "_dev")
+
+    def __init__(self, packed):
+        self.A, self.b, self.ms = packed
         self._dev = None
-        self._refs = [(p.A, p.b) for p in polys]   # the key's arrays stay alive: their ids cannot be handed out again
+
+    def same_content(self, packed):
+        A, b, ms = packed
+        return A.shape == self.A.shape and np.array_equal(ms, self.ms) and np.array_equal(b, self.b) \
+            and np.array_equal(A, self.A)
 
     def dev(self):
         if self._dev is None:
-            import torch
-            from . import batch, _lib
-            dev = torch.device("cuda", _lib.context().device)
-            batch._count_h2d(self.A, self.b, self.ms)
-            self._dev = tuple(torch.as_tensor(v).to(dev) for v in (self.A, self.b, self.ms))
+            torch = _torch_or_none()
+            if torch is None:
+                self._dev = (self.A, self.b, self.ms)
+            else:
+                from . import batch, _lib
+                dev = torch.device("cuda", _lib.context().device)
+                batch._count_h2d(self.A, self.b, self.ms)
+                self._dev = tuple(torch.as_tensor(v).to(dev) for v in (self.A, self.b, self.ms))
         return self._dev
+
+    def __getstate__(self):
+        return (self.A, self.b, self.ms)
+
+    def __setstate__(self, st):
+        self.A, self.b, self.ms = st
+        self._dev = None
 
 
 _tables = {}          # key (identity of the members' arrays) -> _PackedTable, most recently used last
@@ -462,19 +499,22 @@ _TABLES_MAX = 8
 
 def _table_of(polys, owner=None):
     """Packed table of a list of non-empty polytopes of one dimension.  Kept on `owner` (a Region: `_packed`) or in a small
-    most-recently-used cache, keyed by the IDENTITY of the members' A / b arrays: a list that changes (members added,
-    removed, replaced, arrays reassigned) gets a new table; arrays edited in place are not noticed -- the same rule as the
-    reference's own caches (bbox, chebR, fulldim: ref :139-147, never invalidated)."""
+    most-recently-used cache.  A remembered table is found by the identity of the members' A / b arrays and reused only
+    if its CONTENT is still what the members hold now: the rows are packed on the host on every call (one concatenate,
+    ~0.2 ms per 1000 members) and compared with the resident table's host copy, so arrays edited in place
+    (`poly.b += margin`) get a new table -- `contains` in the reference reads A and b on every call (ref :217-218).
+    What a hit saves is the upload and the device allocations."""
     key = tuple((id(p.A), id(p.b)) for p in polys)
-    if owner is not None:
-        hit = getattr(owner, "_packed", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-    tab = _tables.pop(key, None)
+    packed = _pack(polys)
+    hit = getattr(owner, "_packed", None) if owner is not None else None
+    tab = hit[1] if (hit is not None and hit[0] == key) else _tables.pop(key, None)
+    if tab is not None and not tab.same_content(packed):
+        tab = None
     if tab is None:
-        tab = _PackedTable(polys)
-        while len(_tables) >= _TABLES_MAX:
-            _tables.pop(next(iter(_tables)))
+        tab = _PackedTable(packed)
+    _tables.pop(key, None)
+    while len(_tables) >= _TABLES_MAX:
+        _tables.pop(next(iter(_tables)))
     _tables[key] = tab
     if owner is not None:
         try:
@@ -498,11 +538,13 @@ def _contains_many(polys, points, abs_tol, region=True, owner=None):
         from .batch import contains_batch
         if owner is not None and len(polys) >= 8:
             # a Region asked again and again (volume(), point-in-region queries): its rows stay on the device
-            import torch
             At, bt, mt = _table_of(polys, owner).dev()
             pts = np.ascontiguousarray(points)
             from . import batch as _b
             _b._count_h2d(pts)
+            if isinstance(At, np.ndarray):   # no torch in the process: host pointers all the way
+                return contains_batch(At, bt, pts, abs_tol, m=mt, region=True).astype(bool)
+            torch = _torch_or_none()
             Xt = torch.as_tensor(pts).to(At.device)
             return contains_batch(At, bt, Xt, abs_tol, m=mt, region=True).cpu().numpy().astype(bool)
         A, b, ms = _pack(polys)
@@ -1281,11 +1323,22 @@ def _cross_touch(firsts, seconds, owner1=None, owner2=None):
         return None
     if len(firsts) * len(seconds) > (1 << 28):
         return None
-    import torch
     from .batch import overlap_cross
     A1, b1, m1 = _table_of(firsts, owner1).dev()
     A2, b2, m2 = _table_of(seconds, owner2).dev()
     mm = max(A1.shape[1], A2.shape[1])
+    thresh = float(np.nextafter(ABS_TOL, 0.0))   # r > pred(ABS_TOL)  <=>  r >= ABS_TOL
+    if isinstance(A1, np.ndarray):   # no torch in the process: the packed host arrays, host-pointer entry point
+        def widen_np(A, b):
+            if A.shape[1] == mm:
+                return A, b
+            return np.pad(A, ((0, 0), (0, mm - A.shape[1]), (0, 0))), np.pad(b, ((0, 0), (0, mm - b.shape[1])))
+        A1, b1 = widen_np(A1, b1)
+        A2, b2 = widen_np(A2, b2)
+        got = overlap_cross(np.concatenate([A1, A2]), np.concatenate([b1, b2]), len(firsts),
+                            m=np.concatenate([m1, m2]), thresh=thresh)
+        return np.asarray(got).astype(bool)
+    torch = _torch_or_none()
 
     def widen(A, b):
         if A.shape[1] == mm:
@@ -1293,8 +1346,7 @@ def _cross_touch(firsts, seconds, owner1=None, owner2=None):
         return (torch.nn.functional.pad(A, (0, 0, 0, mm - A.shape[1])), torch.nn.functional.pad(b, (0, mm - b.shape[1])))
     A1, b1 = widen(A1, b1)
     A2, b2 = widen(A2, b2)
-    got = overlap_cross(torch.cat([A1, A2]), torch.cat([b1, b2]), len(firsts), m=torch.cat([m1, m2]),
-                        thresh=float(np.nextafter(ABS_TOL, 0.0)))   # r > pred(ABS_TOL)  <=>  r >= ABS_TOL
+    got = overlap_cross(torch.cat([A1, A2]), torch.cat([b1, b2]), len(firsts), m=torch.cat([m1, m2]), thresh=thresh)
     return got.cpu().numpy().astype(bool)
 
 

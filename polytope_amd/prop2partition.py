@@ -67,18 +67,21 @@ def _pair_shapes_ok(members):
 
 
 def _flat_members(regions, owner=None):
-    """(members, first, pair kernels applicable) of `regions`; remembered on `owner` -- the Region whose member list
-    `regions` is -- under the rule of the reference's own caches (bounding box, Chebyshev ball, ...: computed once, never
-    invalidated; here at least the list's length and its end members are compared)."""
+    """(members, first, pair kernels applicable) of `regions`; remembered on `owner` -- the object whose element list
+    `regions` is -- keyed by the identity of EVERY element, and the entry keeps the elements alive (an id cannot be handed
+    out again while its object lives), so an element replaced at the same length is seen.  Member lists edited inside an
+    element Region are caught one level down: polytope._table_of compares the packed rows' content."""
     if owner is not None and regions:
-        key = (len(regions), id(regions[0]), id(regions[-1]))
+        key = tuple(id(r) for r in regions)
         hit = owner.__dict__.get("_p2p_flat")
-        if hit is not None and hit[0] == key:
+        if hit is not None and hit[0] == key and \
+                all(len(r.list_poly) == n for r, n in zip(hit[2], hit[3]) if n is not None):
             return hit[1]
     members, first = _members_of(regions)
     out = (members, first, _pair_shapes_ok(members))
     if owner is not None and regions:
-        owner.__dict__["_p2p_flat"] = (key, out)
+        owner.__dict__["_p2p_flat"] = (key, out, list(regions),
+                                       [len(r.list_poly) if isinstance(r, pc.Region) else None for r in regions])
     return out
 
 
@@ -93,19 +96,29 @@ def _pair_list_device(regions, kind, abs_tol, diagonal=False, owner=None):
     members, first, ok = _flat_members(regions, owner)
     if not ok or solvers.default_solver != "hip":
         return None
-    import torch
     from . import batch
     At, bt, mt = pc._table_of(members, owner=owner if len(members) == len(regions) else None).dev()
     fn = batch.adjacent_pairs if kind == "adjacent" else batch.overlap_pairs
     flat = len(members) == len(regions) and not np.any(np.diff(first) != 1)
     M = fn(At, bt, m=mt, abs_tol=abs_tol)
+    if isinstance(M, np.ndarray):    # no torch in the process: the matrix came back through the host-pointer entry point
+        def nonzero(M_):
+            return np.argwhere(M_)
+        if diagonal and flat:
+            np.fill_diagonal(M, 1)
+    else:
+        torch = pc._torch_or_none()
+
+        def nonzero(M_):
+            return torch.nonzero(M_).cpu().numpy()
+        if diagonal and flat:
+            M.fill_diagonal_(1)
     if diagonal and flat:
         # (`diagonal`: the caller wants ones on the diagonal as well -- set on the device, so that the indices come back
         # sorted with them in place and no sort / unique runs on the host)
-        M.fill_diagonal_(1)
-        nz = torch.nonzero(M).cpu().numpy()
+        nz = nonzero(M)
         return nz[:, 0], nz[:, 1], True
-    nz = torch.nonzero(M).cpu().numpy()     # member pairs, row-major order
+    nz = nonzero(M)     # member pairs, row-major order
     r, c = nz[:, 0], nz[:, 1]
     if not flat:
         owner = np.repeat(np.arange(len(regions)), np.diff(first))
@@ -268,7 +281,7 @@ def _all_polytopic(items):
     return all(isinstance(x, (pc.Polytope, pc.Region)) for x in items)
 
 
-class Partition(object):
+class Partition(pc._NoDeviceState):
     """Partition of a set (ref :68-228).
 
     An iterable container of sets over `Partition.set`; the members (`self.regions`) implement union / `__add__`,

@@ -167,16 +167,18 @@ def _rank(M, tol):
 
 
 def _full_rank_clearly(D):
-    """True when the rows of D (n x d, n >= d) clearly span R^d: the eigenvalues of the d x d Gram matrix D'D are the
-    squared singular values, and with the smallest above 1e-6 of the largest -- the Gram matrix of a million rows is good
-    to ~1e-10 of its largest eigenvalue -- every singular value is far above the reference's absolute 1e-15 (:157-163).
-    One pass over the points instead of the thin SVD's several (1M x 3: 3 ms against 20); anything less clear, or not
-    finite, goes to the SVD."""
+    """True when the rows of D (n x d, n >= d) clearly span R^d by the reference's ABSOLUTE test (singular values above
+    1e-15, :157-163): the eigenvalues of the d x d Gram matrix D'D are the squared singular values; accepted only when the
+    smallest is above 1e-6 of the largest (the Gram matrix of a million rows is good to ~1e-10 of its largest eigenvalue,
+    so the smallest is then known to a few digits) AND above 1e-24, i.e. the smallest singular value is above 1e-12 --
+    three orders clear of the reference's threshold.  Tiny-scale point sets (coordinates around 1e-13 and below), anything
+    less clear, or not finite, go to the SVD itself.  One pass over the points instead of the thin SVD's several
+    (1M x 3: 3 ms against 20)."""
     G = D.T @ D
     if not np.all(np.isfinite(G)):
         return False
     lam = np.linalg.eigvalsh(G)
-    return bool(lam[0] > 1e-6 * lam[-1] and lam[-1] > 1e-200)
+    return bool(lam[0] > 1e-6 * lam[-1] and lam[0] > 1e-24)
 
 
 _BLAS_CTL = None

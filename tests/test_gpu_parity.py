@@ -1564,14 +1564,18 @@ def test_bench_force_dist_rccl_path(pa, scaling):
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["scaling"] == scaling and line["n_gpus"] == 1 and line["steps"] == 9 and line["unit"] == "LP/s"
     assert line["value"] > 1e9 and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
-    # LP count per step: the mean over the two batches in the rotation 0,1,0,1,... of 9 steps
+    # LP count per step: the mean over the two batches in the rotation 0,1,0,1,... of the region's steps
     from polytope_amd.synth import random_hpolytopes
     import torch
     n = []
     for i in range(2):
         A, b = random_hpolytopes(100000, 16, 3, seed=i, stream=0)
         n.append(int(pa.reduce_batch(torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda())["nlp"].sum().item()))
-    assert abs(line["config"]["lps_per_step"] - (5 * n[0] + 4 * n[1]) / 9) < 1e-6
+    S = line["config"]["timed_steps_per_region"]   # the 9 steps repeated until a region lasts 50 ms
+    assert S % 9 == 0 and abs(line["config"]["lps_per_step"] - sum(n[k % 2] for k in range(S)) / S) < 1e-6
+    assert line["parity_ok"] is True and line["parity_checked"] == 200000
+    if scaling == "weak":   # the same run carries the partitioned batch as `strong` (at world size 1: the whole batch)
+        assert line["strong"]["strong_floor"]["shard_polytopes"] == 100000 and line["strong"]["value"] > 1e9
 
 
 def test_region_diff_resident_lp_server(pa, monkeypatch):

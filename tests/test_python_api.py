@@ -880,5 +880,61 @@ def test_cross_pairs_and_resident_tables():
         assert batch.h2d_bytes == h0
         regs[3] = pc.Region([cells[3].copy()])          # a member replaced: a new table
         assert np.array_equal(p2p.adjacency_matrix_dense(regs), adj) and batch.h2d_bytes > h0
+        # rows edited IN PLACE (same arrays): the resident table must not answer for the old rows (ref :217-218 reads A, b per call)
+        small = pc.Region(cells[:12])
+        q = rng.random((4, 4000))
+        before = small.contains(q)
+        cells[0].b -= 0.05
+        cells[5].A[:] = -cells[5].A
+        after = small.contains(q)
+        want = np.zeros(q.shape[1], dtype=bool)
+        for c in cells[:12]:
+            want |= np.all(c.A.dot(q) - c.b[:, None] < pc.ABS_TOL, axis=0)
+        assert np.array_equal(after, want) and not np.array_equal(after, before)
     finally:
         solvers.default_solver = old
+
+
+def test_remembered_tables_follow_their_lists():
+    """(round-4 advisor) The flattened member list remembered on a partition / Region is keyed by EVERY element (an element
+    replaced in the middle at unchanged length is seen), the packed table of a list is reused only while its content is
+    what the members hold now (arrays edited in place get a new table), neither travels through pickle / deepcopy, and the
+    quickhull rank screen leaves tiny-scale point sets to the reference's SVD test."""
+    import copy
+    import pickle
+    import polytope_amd.polytope as pc
+    from polytope_amd import prop2partition as p2p, quickhull as qh
+    cells = [pc.box2poly([[i, i + 1.0], [0.0, 1.0]]) for i in range(5)]
+    regs = [pc.Region([c]) for c in cells]
+    owner = pc.Region(cells)
+    m0, _, _ = p2p._flat_members(regs, owner)
+    assert p2p._flat_members(regs, owner)[0] is m0                 # remembered
+    new = pc.box2poly([[1.0, 2.0], [5.0, 6.0]])
+    regs[2] = pc.Region([new])                                      # middle element replaced, same length
+    m1, _, _ = p2p._flat_members(regs, owner)
+    assert m1 is not m0 and m1[2] is new
+    regs[1].list_poly.append(pc.box2poly([[7.0, 8.0], [0.0, 1.0]]))  # a member list grown inside an element
+    m2, first, _ = p2p._flat_members(regs, owner)
+    assert len(m2) == 6 and first.tolist() == [0, 1, 3, 4, 5, 6]
+    # packed tables: same arrays, same content -> the same table; edited in place -> a new one with the new rows
+    t0 = pc._table_of(cells, owner)
+    assert pc._table_of(cells, owner) is t0
+    cells[3].b += 0.25
+    t1 = pc._table_of(cells, owner)
+    assert t1 is not t0 and np.array_equal(t1.b[3], cells[3].b) and not np.array_equal(t0.b[3], cells[3].b)
+    # no device state in copies: whatever the table holds on the device stays behind
+    t1._dev = ("device tensors stand-in",)
+    owner._p2p_flat = ("key", "value")
+    for clone in (pickle.loads(pickle.dumps(owner)), copy.deepcopy(owner)):
+        assert "_packed" not in clone.__dict__ and "_p2p_flat" not in clone.__dict__
+        assert len(clone.list_poly) == 5 and np.array_equal(clone.list_poly[3].b, cells[3].b)
+    tt = pickle.loads(pickle.dumps(t1))
+    assert tt._dev is None and np.array_equal(tt.A, t1.A)
+    part = p2p.Partition(pc.Region(cells))
+    part._packed = ("k", t1)
+    assert "_packed" not in pickle.loads(pickle.dumps(part)).__dict__
+    # rank screen: a full-rank set at scale 1e-14 is NOT waved through (its singular values sit near the reference's 1e-15)
+    rng = np.random.default_rng(0)
+    P = rng.random((50, 3))
+    assert qh._full_rank_clearly(P - P[0])
+    assert not qh._full_rank_clearly((P - P[0]) * 1e-14)
