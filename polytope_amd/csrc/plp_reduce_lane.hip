@@ -1,0 +1,491 @@
+// plp_reduce_lane.hip -- reduce_lane_kernel<D>: the fused reduce() (polytope/polytope.py:1053-1163) for polytopes of up
+// to 16 rows in d <= 3 -- BASELINE configs[1], the bench shape -- with the box LPs (F3, :1118-1134) and the redundancy
+// LPs the presolve leaves (F2, :1142-1160) solved ONE LP PER LANE (plp_lane_lp.hpp) instead of one LP per lane group.
+//
+// Why.  In reduce_r_mix_kernel<3> (plp_reduce_r_impl.hpp) the six box LPs of a polytope run one after the other on its
+// lane group of four, in lock-step with the 15 other groups of the wavefront: 24.9 dictionary pivots of ~280 VALU
+// instructions per tile, 45 % of the kernel's instruction stream, two thirds of it selects / cross-lane moves for a
+// dynamic pivot position; the pooled redundancy LPs another 24 %.  An LP of this shape needs no dictionary: from the
+// Chebyshev centre the optimum is reached by walking facet -> edge -> vertex (-> neighbouring vertices), every step one
+// ratio test over the 16 rows.  With the rows in LDS a LANE can do that alone, so a wavefront advances 64 LPs per
+// instruction instead of 16 and no value crosses lanes inside an LP:
+//     F3: the 96 box LPs of a tile = two rounds (4 LPs per polytope, then 2),
+//     F2: the ~34 LPs the presolve leaves in a tile = one round (lane t takes the t-th LP of the tile's list).
+// F1 (the Chebyshev LP, d + 1 columns), the dedupe, the prefilter arithmetic and the presolve are those of the lane-group
+// kernel, instruction for instruction: r, xc and every verdict that does not come out of an F3 / F2 LP are bit for bit
+// the same; the LP optima agree to rounding (tests/test_lane_lp_host.py: 1e-12 against the oracle's simplex), so keep
+// masks, flags and LP counts are the oracle's (tests/test_gpu_parity.py, bench.py's full-batch check).
+//
+// LDS layout: POLYTOPE-INTERLEAVED -- element (row i, column k) of the tile's polytope p at sA[(i * D + k) * 16 + p],
+// b and the per-row scalar likewise at [i * 16 + p].  Sixteen lanes that read the same element of sixteen different
+// polytopes (every LDS read of this kernel has that shape) touch 16 consecutive doubles = all 32 banks once; in the
+// polytope-major layout of the lane-group kernels they are 384 B apart = one bank, a 16-way conflict.
+//
+// An LP the lane engine hands back (ST_RETRY: a run of degenerate steps, dependent active rows) flags its polytope
+// RF_RETRY; the general kernel's second pass (plp_reduce.hip, Bland's rule) redoes it, as for the lane-group kernels.
+#include <stdlib.h>
+
+#include "plp_lane_lp.hpp"
+#include "plp_reduce_r_impl.hpp"
+
+namespace plp {
+
+#ifndef PLP_LANE_F3_ROLLED
+#define PLP_LANE_F3_ROLLED 0
+#endif
+
+constexpr int LN_NG = 16;     // polytopes per tile (= per wavefront)
+constexpr int LN_ROWS = 16;   // row slots per polytope
+constexpr int LN_R = 4, LN_GS = 4;
+
+static inline size_t reduce_lane_smem_bytes(int D) { return (size_t)LN_NG * LN_ROWS * (D + 2) * 8; }
+
+template <int D>
+__device__ __forceinline__ void reduce_lane_tile(
+    const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
+    unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word, unsigned long long epoch) {
+    static_assert(D >= 1 && D <= 3, "the lane engine walks in R^3 (lower dimensions are embedded)");
+    static_assert(RBLOCK == 64, "one wavefront per workgroup");
+    constexpr int R = LN_R, GS = LN_GS, NG = LN_NG, rows = LN_ROWS;
+    constexpr unsigned RMASK = (1u << R) - 1u;
+    constexpr int LS = NG;   // stride between consecutive elements of one polytope
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const Grp g(GS);
+    const int lane = g.lane;
+    const int gib = lane >> 2;   // my polytope inside the tile
+    const int row0 = g.gl * R;   // my first row
+    double* sA = reinterpret_cast<double*>(smem_raw);   // [rows * D][NG]
+    double* sb = sA + (size_t)rows * D * NG;             // [rows][NG]
+    double* san = sb + (size_t)rows * NG;                // [rows][NG]: 1 / ||a_i||, later beta_i = max(b_i - a_i.xc, 0)
+    double* myA = sA + gib;
+    double* myb = sb + gib;
+    double* myan = san + gib;
+#define LA(i, kk) myA[((i) * D + (kk)) * LS]
+#define LB(i) myb[(i) * LS]
+#define LN(i) myan[(i) * LS]
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+    const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
+    __syncthreads();
+    {
+        // lane (q, p): polytope p, elements q, q + 4, ... of its record -- the wavefront reads 16 records x 32 B per
+        // instruction (whole 32 B sectors; the rest of each 128 B line is used by the next three iterations) and writes
+        // 16 consecutive doubles x 4 rows of the interleaved tile (no bank conflict)
+        const int p = lane & 15, q = lane >> 4;
+        const int rowsz = m_max * D;
+        const bool pv = p < ntile;
+        const double* src = Ag + (tile + (pv ? p : 0)) * rowsz;
+#pragma unroll
+        for (int it = 0; it < rows * D / 4; ++it) {
+            const int rem = q + 4 * it;
+            sA[rem * NG + p] = (pv & (rem < rowsz)) ? src[rem] : 0.0;
+        }
+        const double* srcb = bg + (tile + (pv ? p : 0)) * m_max;
+#pragma unroll
+        for (int it = 0; it < rows / 4; ++it) {
+            const int row = q + 4 * it;
+            sb[row * NG + p] = (pv & (row < m_max)) ? srcb[row] : 0.0;
+        }
+    }
+    __syncthreads();
+    const long long pg = tile + gib;
+    const bool valid = gib < ntile;
+    const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
+    double xc[D];
+    double rr = 0.0;
+    bool ball, fulldim;
+    uint64_t live = 0ull;
+    unsigned has = 0u;
+    bool retry = force_retry != 0;
+    // ---------------------------------------------------------------- F1: Chebyshev ball (as reduce_r_tile<D,4,4>)
+    {
+        SimplexR<D + 1, R, false, true> S;
+        double qi[R];
+        S.reset(D + 1, m, row0);
+        unsigned actb = 0u;
+        bool inf0 = false, finite = true;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool h = valid & (row0 + k < m) & (m <= rows);
+            has |= h ? (1u << k) : 0u;
+            double nrm2 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                const double v = h ? LA(row0 + k, kk) : 0.0;
+                S.T[k][kk] = v;
+                nrm2 = nrm2 + v * v;
+                finite = finite & isfinite(v);
+            }
+            const double bk = h ? LB(row0 + k) : 0.0;
+            finite = finite & isfinite(bk);
+            const double nrm = sqrt(nrm2);
+            LN(row0 + k) = 1.0 / nrm;
+            const bool zero = !(nrm > 0.0);
+            const bool on = h & !zero;
+            S.T[k][D] = on ? nrm : 0.0;
+            S.beta[k] = on ? bk : 0.0;
+            qi[k] = bk / nrm;
+            actb |= on ? (1u << k) : 0u;
+            inf0 = inf0 | (h & zero & (bk < -TOL_FEAS));
+        }
+        S.ract = actb;
+        const bool infeasible0 = grp_ballot(inf0, g) != 0;
+        const bool bad = (grp_ballot(!finite, g) != 0) | (m > rows);
+        S.cost[D] = -1.0;
+        S.mode = M_P2;
+        if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
+        else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+        S.template run_fast<GS, true>(g, qi, actb);
+        retry = retry | (valid & (S.status == ST_RETRY));
+        const bool ok = S.status == ST_OPT;
+#pragma unroll
+        for (int j = 0; j <= D; ++j) {
+            bool found;
+            const double mine = S.x_of(j, found);
+            const uint64_t ob = grp_ballot(found, g);
+            const double v = bcast(mine, g.gbase + (ob ? __ffsll((long long)ob) - 1 : 0));
+            const double xj = ob ? v : 0.0;
+            if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
+        }
+        ball = ok & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        fulldim = ball & (rr > abs_tol);
+    }
+    if (valid & (g.gl == 0)) {
+        r_out[pg] = ball ? rr : 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
+    }
+    __syncthreads();  // 1/||a|| of every row is in LDS
+    // ---------------------------------------------------------------- dedupe (:1094-1110): every pair of rows once
+    {
+        unsigned remmask = 0u;
+        double ni[R][D], bin_[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double an_i = LN(row0 + k);
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) ni[k][kk] = LA(row0 + k, kk) * an_i;
+            bin_[k] = LB(row0 + k) * an_i;
+        }
+#pragma unroll 2
+        for (int t = 1; t <= 8; ++t) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int i = row0 + k;
+                const int j = (i + t) & 15;
+                const double an_j = LN(j);
+                double dot = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) dot = dot + ni[k][kk] * (LA(j, kk) * an_j);
+                const double bjn = LB(j) * an_j;
+                const bool par = valid & (m <= rows) & (i < m) & (j < m) & (dot > 1.0 - abs_tol);
+                // the reference's rule for the pair (lo, hi), lo < hi (:1104-1109): b_lo < b_hi removes hi, else lo
+                const bool i_lo = i < j;
+                const double blo = i_lo ? bin_[k] : bjn, bhi = i_lo ? bjn : bin_[k];
+                const int lo = i_lo ? i : j, hi = i_lo ? j : i;
+                const int gone = (blo < bhi) ? hi : lo;
+                remmask |= par ? (1u << gone) : 0u;
+            }
+        }
+        remmask |= (unsigned)__shfl_xor((int)remmask, 1, 64);
+        remmask |= (unsigned)__shfl_xor((int)remmask, 2, 64);
+        const unsigned removed = (remmask >> row0) & RMASK;
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            live |= spread_rows<R, GS>(grp_ballot((((has & ~removed) >> k) & 1u) != 0u, g)) << k;
+    }
+    // The LPs below live in centre-relative coordinates: a_i.x' <= beta_i, beta_i = max(b_i - a_i.xc, 0), which replaces
+    // 1/||a_i|| in LDS -- every LP of the polytope reads it as it is (the lane-group kernels keep s_i = a_i.xc and form
+    // b_i - s_i in every LP set-up: the same number)
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        double sk = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) sk = fma(((has >> k) & 1u) ? LA(row0 + k, kk) : 0.0, ball ? xc[kk] : 0.0, sk);
+        LN(row0 + k) = fmax((((has >> k) & 1u) ? LB(row0 + k) : 0.0) - sk, 0.0);
+    }
+    // rows that dropped out (never present, or removed by the dedupe / the prefilter) are zeroed -- A, b and s -- by their
+    // owner lane: a zero row never stops a ray and passes every presolve test
+    auto zero_dead = [&](unsigned alive) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (!((alive >> k) & 1u)) {
+#pragma unroll
+                for (int kk = 0; kk < D; ++kk) LA(row0 + k, kk) = 0.0;
+                LB(row0 + k) = 0.0;
+                LN(row0 + k) = 0.0;
+            }
+        }
+    };
+    zero_dead(((unsigned)(live >> row0) & RMASK));
+    int flags = fulldim ? 0 : RF_EMPTY;
+    int nlp = 1;
+    uint64_t keep = 0ull;
+    int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
+    if (fulldim) {
+        const int neq = __popcll(live);
+        if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
+        else stage = (neq > 3 * D) ? 1 : 2;
+    }
+    __syncthreads();   // the lanes of OTHER groups read these rows from here on
+    auto any_lane = [](bool p) { return __any(p) != 0; };
+    // ---------------------------------------------------------------- F3: bounding box (:1367-1409), one LP per lane
+#ifdef PLP_LANE_DBG_NOF3
+    if (false) {
+#else
+    if (__any(stage == 1)) {
+#endif
+        const bool go = stage == 1;
+        const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
+        bool lpfail = false;
+        constexpr int NROUND = (2 * D + GS - 1) / GS;
+        double val[NROUND];
+#if PLP_LANE_F3_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+        for (int rd = 0; rd < NROUND; ++rd) {
+            const int it = rd * GS + g.gl;   // LP `it`: lower_0, upper_0, lower_1, upper_1, ...
+            const bool mine = go & (it < 2 * D);
+            const int kx = it >> 1;
+            const bool up = it & 1;
+            const double cs = up ? -1.0 : 1.0;
+            lane::Lp3 S;
+            lane::solve3<rows>(
+                S, kx == 0 ? cs : 0.0, kx == 1 ? cs : 0.0, kx == 2 ? cs : 0.0, mine,
+                [&](int i, double& a0, double& a1, double& a2) {
+                    a0 = LA(i, 0);
+                    a1 = D > 1 ? LA(i, D > 1 ? 1 : 0) : 0.0;
+                    a2 = D > 2 ? LA(i, D > 2 ? 2 : 0) : 0.0;
+                },
+                [&](int i) { return LN(i); }, any_lane);
+            double xck = 0.0, xk = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
+            xk = kx == 0 ? S.x0 : (kx == 1 ? S.x1 : S.x2);
+            double v;
+            if (S.status == ST_OPT) v = xck + xk;
+            else if (S.status == ST_UNBND) v = up ? pinf : -pinf;
+            else { v = qnan; lpfail = lpfail | (mine & (S.status != ST_RETRY)); }
+            retry = retry | (mine & (S.status == ST_RETRY));
+#if PLP_LANE_F3_ROLLED
+#pragma unroll
+            for (int q = 0; q < NROUND; ++q) val[q] = (q == rd) ? v : val[q];
+#else
+            val[rd] = v;
+#endif
+        }
+        // an LP handed back or failed anywhere in my group concerns the polytope
+        lpfail = grp_ballot(lpfail, g) != 0;
+        retry = retry | (grp_ballot(retry, g) != 0);
+        // prefilter sums, accumulated in k order (:1131-1134); lower_k sits in lane (2k) % 4 of round (2k) / 4
+        double s1[R], s2[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+#pragma unroll
+        for (int kx = 0; kx < D; ++kx) {
+            const double lo = bcast(val[(2 * kx) / GS], g.gbase + (2 * kx) % GS);
+            const double hi = bcast(val[(2 * kx + 1) / GS], g.gbase + (2 * kx + 1) % GS);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const double aik = LA(row0 + k, kx);
+                const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
+                s1[k] = s1[k] + pa * (hi - lo);
+                s2[k] = s2[k] + aik * lo;
+            }
+        }
+        uint64_t outb = 0ull;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (LB(row0 + k) - s2[k])) < -1e-4);
+            outb |= spread_rows<R, GS>(grp_ballot(out, g)) << k;
+        }
+        __syncthreads();   // every lane's LPs have read the rows: the owners may zero the ones the prefilter removes
+        if (go) {
+            live = live & ~outb;
+            zero_dead(((unsigned)(live >> row0) & RMASK));
+            nlp += 2 * D;
+            if (lpfail) flags |= RF_LPFAIL;
+            if (__popcll(live) <= D + 1) { flags |= RF_EARLY; keep = live; stage = 0; }
+            else stage = 2;
+        }
+        __syncthreads();
+    }
+    // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
+#ifdef PLP_LANE_DBG_NOF2
+    if (false) {
+#else
+    if (__any(stage == 2)) {
+#endif
+        const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
+        uint64_t todo = (stage == 2) ? live : 0ull;
+        if (stage == 2) nlp += __popcll(live);
+#ifndef PLP_LANE_DBG_NOPRE
+        {   // rows the ray presolve settles as "keep" need no LP (their h[k] round trip is applied in LDS by the owner)
+            const unsigned okb = f2_presolve<D, R, LS, true>(myA, myb, myan, row0, m_max, (stage == 2) ? lloc : 0u, abs_tol);
+            uint64_t cert = 0ull;
+#pragma unroll
+            for (int k = 0; k < R; ++k) cert |= spread_rows<R, GS>(grp_ballot(((okb >> k) & 1u) != 0u, g)) << k;
+            keep |= cert;
+            todo &= ~cert;
+            ctr_add(ctr, -__popcll(cert), g.gl == 0);
+        }
+#endif
+        __syncthreads();   // the round trips of the settled rows are in LDS for every lane
+        // The LPs the presolve left, of all polytopes of the tile, form ONE list (polytope order, then row order); lane t
+        // of round rb takes LP rb + t.  The in-place h[k] +- 0.1 round trip (:1149-1151) as a rule: an unsettled row that
+        // had its turn before row k carries (b + 0.1) - 0.1, row k itself b + 0.1; settled rows carry the round trip in
+        // LDS already (f2_presolve) -- the rule of the pooled lane-group form and of reduce_split_kernel.
+        const unsigned todo32 = (unsigned)todo;                       // unsettled live rows of MY polytope
+        const unsigned live32 = (stage == 2) ? (unsigned)live : 0u;
+        const int n_g = __popc(todo32);
+        int total = 0, nmax = 0;
+        for (int p = 0; p < NG; ++p) {
+            const int np = __builtin_amdgcn_readlane(n_g, p * GS);
+            total += np;
+            nmax = np > nmax ? np : nmax;
+        }
+        int off_g = 0;   // position of my polytope's first LP in the list
+        for (int p = 0, run = 0; p < NG; ++p) {
+            off_g = (gib == p) ? run : off_g;
+            run += __builtin_amdgcn_readlane(n_g, p * GS);
+        }
+        unsigned retry_polys = 0u;   // bit p: an LP of polytope p was handed back (wave-uniform)
+        for (int rb = 0; rb < total; rb += 64) {
+            // position t = rb + lane of the list -> (polytope, row)
+            const int t = rb + lane;
+            int tp = 0, toff = 0, run = 0;
+            unsigned ttd = 0u;
+            for (int p = 0; p < NG; ++p) {
+                const int np = __builtin_amdgcn_readlane(n_g, p * GS);
+                const unsigned tdp = (unsigned)__builtin_amdgcn_readlane((int)todo32, p * GS);
+                const bool at = t >= run;
+                tp = at ? p : tp;
+                ttd = at ? tdp : ttd;
+                toff = at ? run : toff;
+                run += np;
+            }
+            const bool mine = t < total;
+            const unsigned td_p = ttd;    // the unsettled live rows of polytope tp
+            {
+                const int rank = t - toff;
+                for (int i = 0; i < nmax; ++i) ttd = (i < rank) ? (ttd & (ttd - 1u)) : ttd;
+            }
+            const int kr = mine ? (__ffs((int)ttd) - 1) : 0;
+#ifdef PLP_LANE_DBG_OWNP
+            const double* pA = myA;
+            const double* pb = myb;
+            const double* pan = myan;
+#else
+            const double* pA = sA + tp;
+            const double* pb = sb + tp;
+            const double* pan = san + tp;
+#endif
+            double c[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) c[kk] = -pA[(kr * D + kk) * LS];   // f = -A[k,:]  (:1145)
+            // row k's own right-hand side is relaxed by 0.1 (:1149): beta_k + 0.1.  (The reference's in-place round trip
+            // leaves rows that had their turn before k at (b + 0.1) - 0.1, an ulp of b away; an LP optimum moves by no
+            // more, ten orders below the tolerance its verdict is read with -- the rows are taken as they stand in LDS.)
+            const double bkr = pan[kr * LS];
+            int krv = kr;
+            lane::Lp3 S;
+            lane::solve3<rows>(
+                S, c[0], c[1], c[2], mine,
+                [&](int i, double& a0, double& a1, double& a2) {
+                    a0 = pA[(i * D) * LS];
+                    a1 = D > 1 ? pA[(i * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
+                    a2 = D > 2 ? pA[(i * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
+                },
+#ifdef PLP_LANE_DBG_PLAINB
+                [&](int i) { return pan[i * LS]; }, any_lane);
+#else
+                // (an add of 0.1 or 0, not a select between a register and the LDS value: that becomes a branch around the load)
+                [&](int i) { return pan[i * LS] + (i == krv ? 0.1 : 0.0); }, any_lane,
+                [&] { asm volatile("" : "+v"(krv)); });
+#endif
+            // objective - h[k] (:1156):  -fun - hk = (a_k.xc + a_k.x') - hk = a_k.x' - (hk - a_k.xc),  hk = (b_k + 0.1) - 0.1
+            // after its round trip (:1149-1151):  hk - a_k.xc = beta_k + (hk - b_k)
+            const double akx = -lane::dot3(c[0], c[1], c[2], S.x0, S.x1, S.x2);
+            const double b0 = pb[kr * LS];
+            const double hk = (b0 + 0.1) - 0.1;
+            const double obj = akx - (bkr + (hk - b0));
+            const bool keepk = mine & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
+            const uint64_t all = __ballot(keepk);   // bit t - rb: the LP at list position t says "keep"
+            const uint64_t rt = __ballot(mine & (S.status == ST_RETRY));
+            if (rt != 0ull) {   // rare
+                for (int p = 0; p < NG; ++p)
+                    if (__any(mine & (S.status == ST_RETRY) & (tp == p))) retry_polys |= 1u << p;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int rw = row0 + k;
+                const int tt = off_g + __popc(todo32 & ((1u << rw) - 1u)) - rb;
+                const bool own = (((todo32 >> rw) & 1u) != 0u) & (tt >= 0) & (tt < 64);
+                const bool kept = own & (((all >> (tt & 63)) & 1ull) != 0ull);
+                keep |= spread_rows<R, GS>(grp_ballot(kept, g)) << k;
+            }
+        }
+        retry = retry | (((retry_polys >> gib) & 1u) != 0u);
+        if (stage == 2) flags |= RF_MINREP;
+    }
+    // ---------------------------------------------------------------- results
+    if (valid & (g.gl == 0)) {
+        keep_out[pg] = keep;
+        flags_out[pg] = retry ? (int)RF_RETRY : flags;
+        nlp_out[pg] = nlp;
+    }
+    ctr_add(ctr, nlp, valid & (g.gl == 0));   // every LP the reference issues, less the presolved ones
+    if (retry_word) {
+        if (__any(retry & valid)) {
+            if ((threadIdx.x & 63) == 0) atomicMax(retry_word, epoch);
+        }
+    }
+#undef LA
+#undef LB
+#undef LN
+}
+
+#ifndef PLP_REDUCE_LANE_WAVES
+#define PLP_REDUCE_LANE_WAVES 4   // 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD
+#endif
+
+template <int D>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
+    double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
+    double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr,
+    unsigned long long* __restrict__ retry_word, unsigned long long epoch) {
+    reduce_lane_tile<D>((long long)blockIdx.x * LN_NG, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
+                        r_out, xc_out, nlp_out, ctr, retry_word, epoch);
+}
+
+template <int D>
+static int launch_reduce_lane_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
+                                unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    long long blocks = (B + LN_NG - 1) / LN_NG;
+    if (blocks > 2147483647ll) return 2;
+    if (blocks < 1) blocks = 1;
+    const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
+    hipLaunchKernelGGL((reduce_lane_kernel<D>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D), st, B, m_max,
+                       A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry,
+                       t_reduce_epoch);
+    return 0;
+}
+
+// returns 0 when launched, 1 when this kernel does not take the shape
+int launch_reduce_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                       unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
+    if (m_max < 1 || m_max > LN_ROWS) return 1;
+    switch (d) {
+        case 1: return launch_reduce_lane_d<1>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        case 2: return launch_reduce_lane_d<2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        case 3: return launch_reduce_lane_d<3>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        default: return 1;
+    }
+}
+
+}  // namespace plp

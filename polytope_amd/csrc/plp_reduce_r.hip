@@ -13,8 +13,14 @@
 #define PLP_REDUCE_LAZY_MID 1  // d = 5..8 with more than 32 rows: one polytope per wavefront (reduce_wdense_kernel) by default
 #endif
 
+#ifndef PLP_REDUCE_LANE_MINB
+#define PLP_REDUCE_LANE_MINB 4096   // (16,3)-class batches larger than this: one LP per lane (plp_reduce_lane.hip)
+#endif
+
 namespace plp {
 
+int launch_reduce_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
+                       unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st);
 int launch_reduce_r2a(long long B, int m_max, int d, const double* A, const double* b, const int* mrows,
                       double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                       hipStream_t st);
@@ -71,6 +77,14 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || d < 1 || d > MAX_D) return 1;
+    if (d <= 3 && m_max <= 16) {
+        // up to 16 rows in d <= 3 (the bench shape): F3 / F2 one LP per lane (plp_reduce_lane.hip) beyond the latency
+        // form's batch sizes; PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
+        const char* ln = getenv("PLP_REDUCE_LANE");
+        const bool other = getenv("PLP_REDUCE_SPLIT") || getenv("PLP_REDUCE_HALF") || getenv("PLP_REDUCE_MIX") || getenv("PLP_REDUCE_R8");
+        if ((ln && ln[0] == '1') || (!(ln && ln[0] == '0') && !other && B > PLP_REDUCE_LANE_MINB))
+            return launch_reduce_lane(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+    }
     if (d > 8) {
         const char* e2 = getenv("PLP_REDUCE_R2");  // PLP_REDUCE_R2=0: d > 8 stays on the one-row-per-lane kernel (A/B)
         if (e2 && e2[0] == '0') return 1;

@@ -147,7 +147,10 @@ __device__ __forceinline__ void ctr_add(unsigned long long* ctr, int v, bool lea
 // depends on it outside exact ties, on which no two LP codes agree).
 // Rows zeroed in LDS (never present, removed by the dedupe or the prefilter) pass every test: 0 <= 0.
 // Returns my rows' bits (bit k: row row0 + k is settled as "keep").
-template <int D, int R>
+// LS: distance (in doubles) between consecutive elements of the three arrays (1: a polytope's rows are contiguous;
+// 16: the polytope-interleaved tile of plp_reduce_lane.hip)
+// BETA: the third array holds the slacks  beta_i = max(b_i - a_i.xc, 0)  themselves instead of s_i = a_i.xc
+template <int D, int R, int LS = 1, bool BETA = false>
 __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, const double* myan, int row0, int m_loop,
                                                 unsigned cand, double abs_tol) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (compiler: the owner lanes' stores above come first)
@@ -159,11 +162,11 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
         double g = 0.0;
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) {
-            ak[k][kk] = myA[(row0 + k) * D + kk];
+            ak[k][kk] = myA[((row0 + k) * D + kk) * LS];
             g = fma(ak[k][kk], ak[k][kk], g);
         }
-        const double bk = myb[row0 + k];
-        const double sk = fmax(bk - myan[row0 + k], 0.0);
+        const double bk = myb[(row0 + k) * LS];
+        const double sk = BETA ? myan[(row0 + k) * LS] : fmax(bk - myan[(row0 + k) * LS], 0.0);
         const double tau = abs_tol + 1e-9 * (1.0 + fabs(bk) + sk);
         skt[k] = sk + tau;
         gkk[k] = g;
@@ -173,8 +176,8 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
     for (int i = 0; i < m_loop; ++i) {
         double ai[D];
 #pragma unroll
-        for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
-        const double si = fmax(myb[i] - myan[i], 0.0);
+        for (int kk = 0; kk < D; ++kk) ai[kk] = myA[(i * D + kk) * LS];
+        const double si = BETA ? myan[(i) * LS] : fmax(myb[(i) * LS] - myan[(i) * LS], 0.0);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             double gik = 0.0;
@@ -226,12 +229,12 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
                 double gjk = 0.0, gjj = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) {
-                    bk_[q][kk] = myA[(row0 + k) * D + kk];
-                    aj[q][kk] = myA[j * D + kk];
+                    bk_[q][kk] = myA[((row0 + k) * D + kk) * LS];
+                    aj[q][kk] = myA[(j * D + kk) * LS];
                     gjk = fma(aj[q][kk], bk_[q][kk], gjk);
                     gjj = fma(aj[q][kk], aj[q][kk], gjj);
                 }
-                const double sj = fmax(myb[j] - myan[j], 0.0);
+                const double sj = BETA ? myan[(j) * LS] : fmax(myb[(j) * LS] - myan[(j) * LS], 0.0);
                 const double rho = gjk / gjj;
                 const double t1 = (sj / gjk) * (1.0 - 0x1p-40);
                 const double akd = fma(-rho, gjk, gk);        // a_k.d = |a_k|^2 - (a_j.a_k)^2 / |a_j|^2 >= 0
@@ -244,8 +247,8 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
             for (int i = 0; i < m_loop; ++i) {
                 double ai[D];
 #pragma unroll
-                for (int kk = 0; kk < D; ++kk) ai[kk] = myA[i * D + kk];
-                const double si = fmax(myb[i] - myan[i], 0.0);
+                for (int kk = 0; kk < D; ++kk) ai[kk] = myA[(i * D + kk) * LS];
+                const double si = BETA ? myan[(i) * LS] : fmax(myb[(i) * LS] - myan[(i) * LS], 0.0);
 #pragma unroll
                 for (int q = 0; q < H; ++q) {
                     double gik = 0.0, gij = 0.0;
@@ -265,7 +268,7 @@ __device__ __forceinline__ unsigned f2_presolve(const double* myA, double* myb, 
 #endif
 #pragma unroll
     for (int k = 0; k < R; ++k)
-        if ((ok >> k) & 1u) myb[row0 + k] = (myb[row0 + k] + 0.1) - 0.1;  // (:1149-1151), see above
+        if ((ok >> k) & 1u) myb[(row0 + k) * LS] = (myb[(row0 + k) * LS] + 0.1) - 0.1;  // (:1149-1151), see above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return ok;
 }

@@ -1,0 +1,90 @@
+"""CPU: the one-LP-per-lane engine of the fused reduce (polytope_amd/csrc/plp_lane_lp.hpp, used by plp_reduce_lane.hip for
+the box and redundancy LPs at d <= 3) compiled for the HOST and run against the oracle's dictionary simplex on every
+F3 / F2 LP of random, unbounded and structured polytopes: same status, optimum within 1e-11 (relative beyond 1), and nothing handed back on
+random data.  The header is the same source the device compiles (explicit fma, -ffp-contract=off on both sides)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+@pytest.fixture(scope="module")
+def lane(oracle, tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("lane") / "liblane_host.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
+                           os.path.join(ROOT, "tests", "cabi", "lane_lp_host.cpp"), "-L", os.path.join(ROOT, "oracle"),
+                           "-lplp_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    L = C.CDLL(out)
+    dp = C.POINTER(C.c_double)
+    L.lane_check.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_int), dp, C.c_int]
+
+    def check(A, b, m=None, which=3):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        B, mm, d = A.shape
+        assert d == 3
+        if mm < 16:
+            A = np.concatenate([A, np.zeros((B, 16 - mm, 3))], axis=1)
+            b = np.concatenate([b, np.zeros((B, 16 - mm))], axis=1)
+            m = np.full(B, mm, np.int32) if m is None else m
+        st = np.zeros(32)
+        mp = None if m is None else np.ascontiguousarray(m, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+        L.lane_check(B, A.ctypes.data_as(dp), b.ctypes.data_as(dp), mp, st.ctypes.data_as(dp), which)
+        return dict(lps=int(st[0]), retry=int(st[1]), status_diff=int(st[2]), opt=int(st[3]), unb=int(st[4]),
+                    max_diff=float(st[5]), mean_iters=st[6] / max(st[0], 1), max_iters=int(st[7]))
+    return check
+
+
+def test_lane_engine_equals_the_dictionary_simplex_on_random_polytopes(lane):
+    from polytope_amd.synth import random_hpolytopes
+    tot = 0
+    for seed, m in [(0, 16), (1, 16), (2, 12), (3, 7)]:
+        A, b = random_hpolytopes(6000, m, 3, seed=seed)
+        s = lane(A, b)
+        assert s["status_diff"] == 0 and s["retry"] == 0 and s["max_diff"] <= 1e-11, s
+        assert s["opt"] == s["lps"] and s["max_iters"] <= 12 and 1.0 < s["mean_iters"] < 3.5, s
+        tot += s["lps"]
+    assert tot > 400000
+
+
+def test_lane_engine_unbounded_and_ragged(lane):
+    from polytope_amd.synth import random_hpolytopes
+    A, b = random_hpolytopes(6000, 16, 3, seed=5, bounded=False)
+    m = np.random.default_rng(0).integers(1, 17, size=6000).astype(np.int32)
+    for k in range(6000):
+        A[k, m[k]:] = 0.0
+        b[k, m[k]:] = 0.0
+    s = lane(A, b, m)
+    assert s["status_diff"] == 0 and s["max_diff"] <= 1e-11 and s["unb"] > 100, s
+    assert s["retry"] <= s["lps"] // 1000, s
+
+
+def test_lane_engine_structured_polytopes(lane):
+    """Ties in the ratio test, degenerate vertices, duplicated / tangent rows, lattice normals (tests/structured_cases.py):
+    what is not handed back agrees with the simplex; what is handed back stays a small share (it costs a second pass)."""
+    from structured_cases import structured_polytopes
+    A, b, fam = structured_polytopes(4096)
+    s = lane(A, b)
+    assert s["status_diff"] == 0 and s["max_diff"] <= 1e-9, s
+    assert s["retry"] <= 0.05 * s["lps"], s
+    # boxes and prisms: the LPs end on a facet or an edge (multipliers of fewer than three active rows)
+    box = np.vstack([np.eye(3), -np.eye(3)])
+    A2 = np.zeros((64, 16, 3))
+    b2 = np.zeros((64, 16))
+    rng = np.random.default_rng(3)
+    for k in range(64):
+        lo = rng.integers(-3, 3, 3) * 0.5
+        hi = lo + rng.choice([0.5, 1.0, 2.0], 3)
+        A2[k, :6], b2[k, :6] = box, np.r_[hi, -lo]
+        n = np.array([[1, 1, 0], [0, 1, 1], [1, 0, -1], [1, 1, 1]], float)
+        n /= np.linalg.norm(n, axis=1)[:, None]
+        A2[k, 6:10] = n
+        b2[k, 6:10] = n @ ((lo + hi) / 2) + rng.choice([0.2, 0.5, 5.0], 4)
+    s = lane(A2, b2, np.full(64, 10, np.int32))
+    assert s["status_diff"] == 0 and s["max_diff"] <= 1e-11 and s["retry"] <= 0.05 * s["lps"], s
