@@ -35,10 +35,6 @@ constexpr int BLAND_AFTER = 6;
 }  // namespace plp
 #endif
 
-#ifndef PLP_LANE_CHUNK
-#define PLP_LANE_CHUNK 0
-#endif
-
 namespace plp {
 namespace lane {
 
@@ -64,14 +60,15 @@ PLP_LANE_FN double dot3(double a0, double a1, double a2, double b0, double b1, d
     return fma(a2, b2, fma(a1, b1, a0 * b0));
 }
 
-// One LP, to the end.  ROWS(i, a0, a1, a2): row i of the polytope (zeroed rows allowed: they never block);
-// BETA(i): its right-hand side relative to the centre (>= 0).  M row slots.
+// One LP, to the end.  ROWS(i, a0, a1, a2): row i of the polytope (zeroed rows allowed: they never block).
+// RATIO(d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi): the ratio test -- over the rows with a.d > tolp the one with the smallest
+// (beta_i - a_i.x)+ / a_i.d, the FIRST such row on ties; bs / bd its slack and a.d, bi its index (-1: none).  The caller
+// owns the loop: the host build and the plain device form walk all rows in one lane (ratio_rows below), the device
+// may split the rows of one LP over two or four lanes and combine (plp_reduce_lane.hip).
 // ANY(pred): true while any lane of the wavefront still runs (device: __any; host: the predicate itself).
-// PASS(): called at the top of every ratio test (device: keeps loop-invariant per-row predicates of BETA from being
-// hoisted out of the walk -- sixteen lane masks held in SGPRs across the loop spill).
-template <int M, class RowF, class BetaF, class AnyF, class PassF>
-PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, BetaF BETA,
-                        AnyF ANY, PassF PASS) {
+template <class RowF, class RatioF, class AnyF>
+PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, RatioF RATIO,
+                       AnyF ANY) {
     S.x0 = S.x1 = S.x2 = 0.0;
     S.w0 = S.w1 = S.w2 = -1;
     S.nact = 0;
@@ -134,11 +131,14 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
                     const double r0 = -dot3(c0, c1, c2, n00, n01, n02), r1 = -dot3(c0, c1, c2, n10, n11, n12);
                     // det > 0 (checked above); lambda_0 ~ r0 g11 - r1 g01, lambda_1 ~ r1 g00 - r0 g01
                     const double l0 = fma(r0, g11, -(r1 * g01)), l1 = fma(r1, g00, -(r0 * g01));
-                    const double tol0 = TOL_D * g11 * sqrt(g00) * cn1, tol1 = TOL_D * g00 * sqrt(g11) * cn1;
+                    // lambda_j |n_j| >= -TOL_D |c|, with |n_j| <= w_j = (1 + n_j.n_j) / 2 in its place (no square root;
+                    // equal for unit rows, a little stricter otherwise) and det <= g00 g11
+                    const double w0 = 0.5 * (1.0 + g00), w1 = 0.5 * (1.0 + g11);
+                    const double tol0 = TOL_D * g11 * w0 * cn1, tol1 = TOL_D * g00 * w1 * cn1;
                     if (l0 >= -tol0 && l1 >= -tol1) S.status = ST_OPT;
                     else {
-                        // drop the more negative one (compared as true multipliers: l / det, same det)
-                        const bool drop0 = l0 * sqrt(g00) < l1 * sqrt(g11);   // lambda_j |n_j|: scale-free
+                        // drop the more negative one (as weighted multipliers; a row with a negative one either way)
+                        const bool drop0 = l0 * w0 < l1 * w1;
                         if (drop0) { S.w0 = S.w1; n00 = n10; n01 = n11; n02 = n12; }
                         S.nact = 1;
                         const double nn = dot3(n00, n01, n02, n00, n01, n02);
@@ -155,8 +155,7 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
                     const double det = dot3(n00, n01, n02, u00, u01, u02);
                     const double g00 = dot3(n00, n01, n02, n00, n01, n02), g11 = dot3(n10, n11, n12, n10, n11, n12);
                     const double g22 = dot3(n20, n21, n22, n20, n21, n22);
-                    const double vol = sqrt(g00 * g11 * g22);
-                    if (!(fabs(det) > 1e-9 * vol)) {
+                    if (!(det * det > 1e-18 * (g00 * g11 * g22))) {
                         S.status = ST_RETRY;   // three active planes that (nearly) share a line
                     } else {
                         // lambda_j = -(c.u_j) / det ; compare sign-corrected numerators lambda_j |det| = -(c.u_j) sgn(det)
@@ -164,8 +163,8 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
                         const double l0 = -sg * dot3(c0, c1, c2, u00, u01, u02);
                         const double l1 = -sg * dot3(c0, c1, c2, u10, u11, u12);
                         const double l2 = -sg * dot3(c0, c1, c2, u20, u21, u22);
-                        // scale-free: lambda_j |n_j| / |c|  =  l_j |n_j| / (|det| |c|)
-                        const double a0 = l0 * sqrt(g00), a1 = l1 * sqrt(g11), a2 = l2 * sqrt(g22);
+                        // lambda_j |n_j| / |c|  =  l_j |n_j| / (|det| |c|), with w_j = (1 + n_j.n_j) / 2 >= |n_j| in its place
+                        const double a0 = l0 * (0.5 * (1.0 + g00)), a1 = l1 * (0.5 * (1.0 + g11)), a2 = l2 * (0.5 * (1.0 + g22));
                         const double tol = TOL_D * fabs(det) * cn1;
                         if (a0 >= -tol && a1 >= -tol && a2 >= -tol) S.status = ST_OPT;
                         else {
@@ -189,27 +188,7 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
         const double tolp = TOL_PIV * dn1;
         double bs = 1.0, bd = 0.0;   // best slack / best a.d  (ratio bs / bd; bd = 0: none yet)
         int bi = -1;
-        if (ANY(step)) {
-            PASS();
-#pragma unroll
-            for (int i = 0; i < M; ++i) {
-#if defined(__HIPCC__) && PLP_LANE_CHUNK > 0
-                // the scheduler may not hoist the row loads of a later chunk above this point: all 3 M loads in flight
-                // at once are 6 M registers
-                if (i % PLP_LANE_CHUNK == 0 && i > 0) __builtin_amdgcn_sched_barrier(0);
-#endif
-                double a0, a1, a2;
-                ROWS(i, a0, a1, a2);
-                const double ad = dot3(a0, a1, a2, d0, d1, d2);
-                const double ax = dot3(a0, a1, a2, S.x0, S.x1, S.x2);
-                const double sl = fmax(BETA(i) - ax, 0.0);
-                // sl / ad < bs / bd   <=>   sl * bd < bs * ad      (ad, bd > 0; the first row: bd = 0 -> 0 < bs * ad)
-                const bool better = (ad > tolp) & (sl * bd < bs * ad);
-                bs = better ? sl : bs;
-                bd = better ? ad : bd;
-                bi = better ? i : bi;
-            }
-        }
+        if (ANY(step)) RATIO(d0, d1, d2, S.x0, S.x1, S.x2, tolp, bs, bd, bi);
         if (step) {
             ++S.iters;
             if (bi < 0) {
@@ -228,6 +207,39 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
             }
         }
     }
+}
+
+// One step of the ratio test: row (a0, a1, a2) with right-hand side `beta` and index i against the best so far.
+//     sl / ad < bs / bd   <=>   sl * bd < bs * ad      (ad, bd > 0; nothing yet: bd = 0 -> 0 < bs * ad)
+PLP_LANE_FN void ratio_row(const double a0, const double a1, const double a2, const double beta, const int i, const double d0,
+                           const double d1, const double d2, const double x0, const double x1, const double x2,
+                           const double tolp, double& bs, double& bd, int& bi) {
+    const double ad = dot3(a0, a1, a2, d0, d1, d2);
+    const double ax = dot3(a0, a1, a2, x0, x1, x2);
+    const double sl = fmax(beta - ax, 0.0);
+    const bool better = (ad > tolp) & (sl * bd < bs * ad);
+    bs = better ? sl : bs;
+    bd = better ? ad : bd;
+    bi = better ? i : bi;
+}
+
+// The whole LP in one lane, M row slots, BETA(i) the right-hand sides (>= 0).
+// PASS(): called at the top of every ratio test (device: keeps loop-invariant per-row predicates of BETA from being
+// hoisted out of the walk).
+template <int M, class RowF, class BetaF, class AnyF, class PassF>
+PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, BetaF BETA,
+                        AnyF ANY, PassF PASS) {
+    walk3(S, c0, c1, c2, go, ROWS,
+          [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
+              PASS();
+#pragma unroll
+              for (int i = 0; i < M; ++i) {
+                  double a0, a1, a2;
+                  ROWS(i, a0, a1, a2);
+                  ratio_row(a0, a1, a2, BETA(i), i, d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi);
+              }
+          },
+          ANY);
 }
 
 template <int M, class RowF, class BetaF, class AnyF>

@@ -21,24 +21,43 @@
 // polytopes (every LDS read of this kernel has that shape) touch 16 consecutive doubles = all 32 banks once; in the
 // polytope-major layout of the lane-group kernels they are 384 B apart = one bank, a 16-way conflict.
 //
-// An LP the lane engine hands back (ST_RETRY: a run of degenerate steps, dependent active rows) flags its polytope
-// RF_RETRY; the general kernel's second pass (plp_reduce.hip, Bland's rule) redoes it, as for the lane-group kernels.
+// An LP the lane engine hands back (ST_RETRY: a run of degenerate steps, dependent active rows) sends its polytope to the
+// general engine (plp_reduce_general.hpp, Bland's rule) at the end of the SAME tile: a step is one launch.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "plp_lane_lp.hpp"
+#include "plp_reduce_general.hpp"
 #include "plp_reduce_r_impl.hpp"
 
 namespace plp {
-
-#ifndef PLP_LANE_F3_ROLLED
-#define PLP_LANE_F3_ROLLED 0
-#endif
 
 constexpr int LN_NG = 16;     // polytopes per tile (= per wavefront)
 constexpr int LN_ROWS = 16;   // row slots per polytope
 constexpr int LN_R = 4, LN_GS = 4;
 
 static inline size_t reduce_lane_smem_bytes(int D) { return (size_t)LN_NG * LN_ROWS * (D + 2) * 8; }
+
+// The polytopes of a tile that the fast path handed back (bit 4 p of `rb64`: polytope p), redone by the general engine
+// (plp_reduce_general.hpp: one dictionary row per lane, 16 lanes per polytope, Bland's rule in the simplex).
+template <int D>
+__device__ __noinline__ void reduce_lane_redo(unsigned char* smem_raw, const long long tile, const int ntile, const uint64_t rb64,
+                                              int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+                                              const int* __restrict__ mrows, double abs_tol,
+                                              unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
+                                              double* __restrict__ r_out, double* __restrict__ xc_out,
+                                              int* __restrict__ nlp_out) {
+    for (int sub = 0; sub < LN_NG / 4; ++sub) {
+        const unsigned four = (unsigned)(rb64 >> (16 * sub)) & 0x1111u;
+        if (four == 0u) continue;   // wave-uniform
+        const int q = (threadIdx.x & 63) >> 4;
+        const bool mine = ((four >> (4 * q)) & 1u) != 0u;
+        const int left = ntile - 4 * sub;
+        reduce_general_tile<D, RBLOCK>(smem_raw, tile + 4 * sub, left < 4 ? left : 4, mine, m_max, 16, Ag, bg, mrows, abs_tol,
+                                       keep_out, flags_out, r_out, xc_out, nlp_out);
+    }
+}
 
 template <int D>
 __device__ __forceinline__ void reduce_lane_tile(
@@ -48,6 +67,8 @@ __device__ __forceinline__ void reduce_lane_tile(
     unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word, unsigned long long epoch) {
     static_assert(D >= 1 && D <= 3, "the lane engine walks in R^3 (lower dimensions are embedded)");
     static_assert(RBLOCK == 64, "one wavefront per workgroup");
+    (void)retry_word;
+    (void)epoch;
     constexpr int R = LN_R, GS = LN_GS, NG = LN_NG, rows = LN_ROWS;
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int LS = NG;   // stride between consecutive elements of one polytope
@@ -137,7 +158,9 @@ __device__ __forceinline__ void reduce_lane_tile(
         S.mode = M_P2;
         if (!valid | bad) { S.mode = M_DONE; S.status = ST_NUM; }
         else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
+#ifndef PLP_LANE_DBG_NOF1
         S.template run_fast<GS, true>(g, qi, actb);
+#endif
         retry = retry | (valid & (S.status == ST_RETRY));
         const bool ok = S.status == ST_OPT;
 #pragma unroll
@@ -158,6 +181,10 @@ __device__ __forceinline__ void reduce_lane_tile(
         for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
     }
     __syncthreads();  // 1/||a|| of every row is in LDS
+#ifdef PLP_LANE_DBG_F1ONLY
+    if (valid & (g.gl == 0)) { keep_out[pg] = 0; flags_out[pg] = 0; nlp_out[pg] = 1; }
+    return;
+#endif
     // ---------------------------------------------------------------- dedupe (:1094-1110): every pair of rows once
     {
         unsigned remmask = 0u;
@@ -231,7 +258,59 @@ __device__ __forceinline__ void reduce_lane_tile(
     }
     __syncthreads();   // the lanes of OTHER groups read these rows from here on
     auto any_lane = [](bool p) { return __any(p) != 0; };
-    // ---------------------------------------------------------------- F3: bounding box (:1367-1409), one LP per lane
+    // One LP per lane -- or per PAIR / QUAD of neighbouring lanes when a round has no more than 32 / 16 LPs: the lanes of an
+    // LP carry the same walk (same point, same active rows, same direction: computed redundantly), each runs the ratio
+    // test over its half / quarter of the row slots, and the candidates meet through one / two DPP exchanges (smaller
+    // ratio, on ties the lower row: the row a single lane would have found first).  `nparts` is wave-uniform.
+    // pA / pbeta: the polytope's rows / right-hand sides in the interleaved tile; RELAX: row krv's right-hand side + 0.1
+    // (:1149) -- an add of 0.1 or 0, not a select between a constant and the LDS value (that becomes a branch around the load).
+    auto lane_solve = [&](lane::Lp3& S, const double c0, const double c1, const double c2, const bool go_, const double* pA,
+                          const double* pbeta, auto relax_tag, int krv, const int nparts, const int part) {
+        constexpr bool RELAX = decltype(relax_tag)::value;
+        const int cnt = rows / nparts;   // wave-uniform
+        const int i0 = part * cnt;
+        lane::walk3(
+            S, c0, c1, c2, go_,
+            [&](int i, double& a0, double& a1, double& a2) {
+                a0 = pA[(i * D) * LS];
+                a1 = D > 1 ? pA[(i * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
+                a2 = D > 2 ? pA[(i * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
+            },
+            [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
+                if constexpr (RELAX) asm volatile("" : "+v"(krv));   // (keeps the per-row compares inside the walk)
+                const double* ra = pA + i0 * D * LS;
+                const double* rb_ = pbeta + i0 * LS;
+                int ic = i0;
+                for (int ch = 0; ch < cnt; ch += 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double a0 = ra[(r * D) * LS];
+                        const double a1 = D > 1 ? ra[(r * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
+                        const double a2 = D > 2 ? ra[(r * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
+                        double beta = rb_[r * LS];
+                        if constexpr (RELAX) beta = beta + ((ic + r == krv) ? 0.1 : 0.0);
+                        lane::ratio_row(a0, a1, a2, beta, ic + r, d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi);
+                    }
+                    ra += 4 * D * LS;
+                    rb_ += 4 * LS;
+                    ic += 4;
+                }
+                auto meet = [&](auto ctrl) {
+                    constexpr int CTRL = decltype(ctrl)::value;
+                    const double ps = dpp_d<CTRL>(bs), pd = dpp_d<CTRL>(bd);
+                    const int pi = dpp_i<CTRL>(bi);
+                    const double l = ps * bd, r_ = bs * pd;
+                    const bool theirs = (pd > 0.0) & (!(bd > 0.0) | (l < r_) | ((l == r_) & (pi < bi)));
+                    bs = theirs ? ps : bs;
+                    bd = theirs ? pd : bd;
+                    bi = theirs ? pi : bi;
+                };
+                if (nparts > 1) meet(std::integral_constant<int, PLP_DPP_XOR1>{});
+                if (nparts > 2) meet(std::integral_constant<int, PLP_DPP_XOR2>{});
+            },
+            any_lane);
+    };
+    // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
 #ifdef PLP_LANE_DBG_NOF3
     if (false) {
 #else
@@ -240,28 +319,24 @@ __device__ __forceinline__ void reduce_lane_tile(
         const bool go = stage == 1;
         const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
         bool lpfail = false;
+        // LP `it`: lower_0, upper_0, lower_1, upper_1, ...  Round 0: one LP per lane (LPs 0..3 of the polytope on its four
+        // lanes); round 1 (d = 3): LPs 4 and 5 on a pair of lanes each.
         constexpr int NROUND = (2 * D + GS - 1) / GS;
         double val[NROUND];
-#if PLP_LANE_F3_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
+        for (int q = 0; q < NROUND; ++q) val[q] = 0.0;
+#pragma unroll 1
         for (int rd = 0; rd < NROUND; ++rd) {
-            const int it = rd * GS + g.gl;   // LP `it`: lower_0, upper_0, lower_1, upper_1, ...
+            const int nparts = rd == 0 ? 1 : 2;
+            const int it = rd == 0 ? g.gl : GS + (g.gl >> 1);
+            const int part = rd == 0 ? 0 : (g.gl & 1);
             const bool mine = go & (it < 2 * D);
             const int kx = it >> 1;
             const bool up = it & 1;
             const double cs = up ? -1.0 : 1.0;
             lane::Lp3 S;
-            lane::solve3<rows>(
-                S, kx == 0 ? cs : 0.0, kx == 1 ? cs : 0.0, kx == 2 ? cs : 0.0, mine,
-                [&](int i, double& a0, double& a1, double& a2) {
-                    a0 = LA(i, 0);
-                    a1 = D > 1 ? LA(i, D > 1 ? 1 : 0) : 0.0;
-                    a2 = D > 2 ? LA(i, D > 2 ? 2 : 0) : 0.0;
-                },
-                [&](int i) { return LN(i); }, any_lane);
+            lane_solve(S, kx == 0 ? cs : 0.0, kx == 1 ? cs : 0.0, kx == 2 ? cs : 0.0, mine, myA, myan, std::false_type{}, -1,
+                       nparts, part);
             double xck = 0.0, xk = 0.0;
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
@@ -271,24 +346,22 @@ __device__ __forceinline__ void reduce_lane_tile(
             else if (S.status == ST_UNBND) v = up ? pinf : -pinf;
             else { v = qnan; lpfail = lpfail | (mine & (S.status != ST_RETRY)); }
             retry = retry | (mine & (S.status == ST_RETRY));
-#if PLP_LANE_F3_ROLLED
 #pragma unroll
             for (int q = 0; q < NROUND; ++q) val[q] = (q == rd) ? v : val[q];
-#else
-            val[rd] = v;
-#endif
         }
         // an LP handed back or failed anywhere in my group concerns the polytope
         lpfail = grp_ballot(lpfail, g) != 0;
         retry = retry | (grp_ballot(retry, g) != 0);
-        // prefilter sums, accumulated in k order (:1131-1134); lower_k sits in lane (2k) % 4 of round (2k) / 4
+        // prefilter sums, accumulated in k order (:1131-1134); LP `it` sits in lane it of round 0, or lane 2 (it - 4) of round 1
         double s1[R], s2[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
 #pragma unroll
         for (int kx = 0; kx < D; ++kx) {
-            const double lo = bcast(val[(2 * kx) / GS], g.gbase + (2 * kx) % GS);
-            const double hi = bcast(val[(2 * kx + 1) / GS], g.gbase + (2 * kx + 1) % GS);
+            constexpr int G4 = GS;
+            const int itl = 2 * kx, ith = 2 * kx + 1;
+            const double lo = bcast(val[itl / G4], g.gbase + (itl < G4 ? itl : 2 * (itl - G4)));
+            const double hi = bcast(val[ith / G4], g.gbase + (ith < G4 ? ith : 2 * (ith - G4)));
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double aik = LA(row0 + k, kx);
@@ -334,13 +407,13 @@ __device__ __forceinline__ void reduce_lane_tile(
             ctr_add(ctr, -__popcll(cert), g.gl == 0);
         }
 #endif
-        __syncthreads();   // the round trips of the settled rows are in LDS for every lane
-        // The LPs the presolve left, of all polytopes of the tile, form ONE list (polytope order, then row order); lane t
-        // of round rb takes LP rb + t.  The in-place h[k] +- 0.1 round trip (:1149-1151) as a rule: an unsettled row that
-        // had its turn before row k carries (b + 0.1) - 0.1, row k itself b + 0.1; settled rows carry the round trip in
-        // LDS already (f2_presolve) -- the rule of the pooled lane-group form and of reduce_split_kernel.
+        __syncthreads();
+        // The LPs the presolve left, of all polytopes of the tile, form ONE list (polytope order, then row order); a round
+        // takes the next 64 / 32 / 16 of them on one / two / four lanes each (whatever fills the wavefront).  Row k's own
+        // right-hand side is relaxed by 0.1 (:1149).  (The reference's in-place round trip leaves rows that had their turn
+        // before k at (b + 0.1) - 0.1, an ulp of b away; an LP optimum moves by no more, ten orders below the tolerance its
+        // verdict is read with -- the rows are taken as they stand in LDS.)
         const unsigned todo32 = (unsigned)todo;                       // unsettled live rows of MY polytope
-        const unsigned live32 = (stage == 2) ? (unsigned)live : 0u;
         const int n_g = __popc(todo32);
         int total = 0, nmax = 0;
         for (int p = 0; p < NG; ++p) {
@@ -354,9 +427,15 @@ __device__ __forceinline__ void reduce_lane_tile(
             run += __builtin_amdgcn_readlane(n_g, p * GS);
         }
         unsigned retry_polys = 0u;   // bit p: an LP of polytope p was handed back (wave-uniform)
-        for (int rb = 0; rb < total; rb += 64) {
-            // position t = rb + lane of the list -> (polytope, row)
-            const int t = rb + lane;
+        int rb = 0;
+        while (rb < total) {
+            const int nrem = total - rb;
+            const int nparts = nrem <= 16 ? 4 : (nrem <= 32 ? 2 : 1);
+            const int sh = nparts == 4 ? 2 : (nparts == 2 ? 1 : 0);
+            const int per = 64 >> sh;
+            // list position t -> (polytope, row)
+            const int t = rb + (lane >> sh);
+            const int part = lane & (nparts - 1);
             int tp = 0, toff = 0, run = 0;
             unsigned ttd = 0u;
             for (int p = 0; p < NG; ++p) {
@@ -369,52 +448,24 @@ __device__ __forceinline__ void reduce_lane_tile(
                 run += np;
             }
             const bool mine = t < total;
-            const unsigned td_p = ttd;    // the unsettled live rows of polytope tp
             {
                 const int rank = t - toff;
                 for (int i = 0; i < nmax; ++i) ttd = (i < rank) ? (ttd & (ttd - 1u)) : ttd;
             }
             const int kr = mine ? (__ffs((int)ttd) - 1) : 0;
-#ifdef PLP_LANE_DBG_OWNP
-            const double* pA = myA;
-            const double* pb = myb;
-            const double* pan = myan;
-#else
             const double* pA = sA + tp;
-            const double* pb = sb + tp;
             const double* pan = san + tp;
-#endif
             double c[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) c[kk] = -pA[(kr * D + kk) * LS];   // f = -A[k,:]  (:1145)
-            // row k's own right-hand side is relaxed by 0.1 (:1149): beta_k + 0.1.  (The reference's in-place round trip
-            // leaves rows that had their turn before k at (b + 0.1) - 0.1, an ulp of b away; an LP optimum moves by no
-            // more, ten orders below the tolerance its verdict is read with -- the rows are taken as they stand in LDS.)
-            const double bkr = pan[kr * LS];
-            int krv = kr;
             lane::Lp3 S;
-            lane::solve3<rows>(
-                S, c[0], c[1], c[2], mine,
-                [&](int i, double& a0, double& a1, double& a2) {
-                    a0 = pA[(i * D) * LS];
-                    a1 = D > 1 ? pA[(i * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
-                    a2 = D > 2 ? pA[(i * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
-                },
-#ifdef PLP_LANE_DBG_PLAINB
-                [&](int i) { return pan[i * LS]; }, any_lane);
-#else
-                // (an add of 0.1 or 0, not a select between a register and the LDS value: that becomes a branch around the load)
-                [&](int i) { return pan[i * LS] + (i == krv ? 0.1 : 0.0); }, any_lane,
-                [&] { asm volatile("" : "+v"(krv)); });
-#endif
+            lane_solve(S, c[0], c[1], c[2], mine, pA, pan, std::true_type{}, kr, nparts, part);
             // objective - h[k] (:1156):  -fun - hk = (a_k.xc + a_k.x') - hk = a_k.x' - (hk - a_k.xc),  hk = (b_k + 0.1) - 0.1
-            // after its round trip (:1149-1151):  hk - a_k.xc = beta_k + (hk - b_k)
+            // after its round trip (:1149-1151):  hk - a_k.xc = beta_k up to the rounding of that round trip (1e-17)
             const double akx = -lane::dot3(c[0], c[1], c[2], S.x0, S.x1, S.x2);
-            const double b0 = pb[kr * LS];
-            const double hk = (b0 + 0.1) - 0.1;
-            const double obj = akx - (bkr + (hk - b0));
+            const double obj = akx - pan[kr * LS];
             const bool keepk = mine & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
-            const uint64_t all = __ballot(keepk);   // bit t - rb: the LP at list position t says "keep"
+            const uint64_t all = __ballot(keepk);   // bit (t - rb) * nparts: the LP at list position t says "keep"
             const uint64_t rt = __ballot(mine & (S.status == ST_RETRY));
             if (rt != 0ull) {   // rare
                 for (int p = 0; p < NG; ++p)
@@ -424,25 +475,31 @@ __device__ __forceinline__ void reduce_lane_tile(
             for (int k = 0; k < R; ++k) {
                 const int rw = row0 + k;
                 const int tt = off_g + __popc(todo32 & ((1u << rw) - 1u)) - rb;
-                const bool own = (((todo32 >> rw) & 1u) != 0u) & (tt >= 0) & (tt < 64);
-                const bool kept = own & (((all >> (tt & 63)) & 1ull) != 0ull);
+                const bool own = (((todo32 >> rw) & 1u) != 0u) & (tt >= 0) & (tt < per);
+                const bool kept = own & (((all >> ((tt << sh) & 63)) & 1ull) != 0ull);
                 keep |= spread_rows<R, GS>(grp_ballot(kept, g)) << k;
             }
+            rb += per;
         }
         retry = retry | (((retry_polys >> gib) & 1u) != 0u);
         if (stage == 2) flags |= RF_MINREP;
     }
     // ---------------------------------------------------------------- results
-    if (valid & (g.gl == 0)) {
+    if (valid & (g.gl == 0) & !retry) {
         keep_out[pg] = keep;
-        flags_out[pg] = retry ? (int)RF_RETRY : flags;
+        flags_out[pg] = flags;
         nlp_out[pg] = nlp;
     }
     ctr_add(ctr, nlp, valid & (g.gl == 0));   // every LP the reference issues, less the presolved ones
-    if (retry_word) {
-        if (__any(retry & valid)) {
-            if ((threadIdx.x & 63) == 0) atomicMax(retry_word, epoch);
-        }
+    // Polytopes handed back (an LP that needs Bland's rule, dependent active rows; PLP_REDUCE_RETRY_ALL=1: all of them) are
+    // redone HERE by the general engine, four at a time on the wavefront's 64 lanes -- the launch is complete, no second
+    // pass follows it.  Rare: the call sits behind a wave-uniform branch and is not inlined.
+    const uint64_t rb64 = __ballot(retry & valid & (g.gl == 0));   // bit 4 p: polytope p of the tile
+    if (rb64 != 0ull) {
+        __threadfence_block();   // my r / xc stores of these polytopes are out before they are written again
+        __syncthreads();
+        reduce_lane_redo<D>(smem_raw, tile, ntile, rb64, m_max, Ag, bg, mrows, abs_tol, keep_out, flags_out, r_out, xc_out,
+                            nlp_out);
     }
 #undef LA
 #undef LB
@@ -473,10 +530,10 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
     hipLaunchKernelGGL((reduce_lane_kernel<D>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D), st, B, m_max,
                        A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry,
                        t_reduce_epoch);
-    return 0;
+    return 3;   // complete: what the fast path hands back is redone inside the kernel, no second pass
 }
 
-// returns 0 when launched, 1 when this kernel does not take the shape
+// returns 3 when launched (complete: launch_reduce adds no second pass), 1 when this kernel does not take the shape
 int launch_reduce_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
                        unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
     if (m_max < 1 || m_max > LN_ROWS) return 1;

@@ -26,8 +26,9 @@ def main():
         return {k: v.cpu().numpy() for k, v in res.items()}
 
     ok = True
+    timing_only = os.environ.get("PLP_LANE_CHECK_TIMING") == "1"
     # ---- parity: lane vs lane-group kernels (bitwise on every output), and vs the oracle
-    for (B, m, d, seed) in [(20000, 16, 3, 0), (5000, 16, 3, 7), (3000, 12, 3, 3), (3000, 16, 2, 1), (3000, 9, 2, 2),
+    for (B, m, d, seed) in [] if timing_only else [(20000, 16, 3, 0), (5000, 16, 3, 7), (3000, 12, 3, 3), (3000, 16, 2, 1), (3000, 9, 2, 2),
                             (2000, 6, 1, 4), (4099, 16, 3, 11)]:
         A, b = random_hpolytopes(B, m, d, seed=seed)
         r1, r0 = run(A, b, True), run(A, b, False)
@@ -39,6 +40,8 @@ def main():
             np.array_equal(r1["nlp"], Rr["nlp"]) and float(np.abs(r1["r"] - Rr["r"]).max()) <= 1e-9
         print("parity", (B, m, d), "lane == lane-group:", same, " lane == oracle:", vs_or, flush=True)
         ok = ok and same and vs_or
+    if timing_only:
+        return timing(torch, pa, random_hpolytopes, dev)
     # unbounded-allowed variant, ragged row counts
     A, b = random_hpolytopes(6000, 16, 3, seed=5, bounded=False)
     rng = np.random.default_rng(0)
@@ -61,7 +64,11 @@ def main():
               and np.array_equal(r1["flags"], Rr["flags"]), flush=True)
     except Exception as e:  # the fixture module has another interface: say so, the random cases above still count
         print("structured cases skipped:", repr(e))
-    # ---- timing
+    timing(torch, pa, random_hpolytopes, dev)
+    print("ALL OK" if ok else "MISMATCH")
+
+
+def timing(torch, pa, random_hpolytopes, dev):
     NB = 6
     full = [random_hpolytopes(100000, 16, 3, seed=i) for i in range(NB)]
     for B in (100000, 50000, 25000, 12500, 6000):
@@ -82,7 +89,6 @@ def main():
                 best = min(best, e0.elapsed_time(e1) / 60)
             line += " lane=%d %.4f ms" % (lane, best)
         print(line, flush=True)
-    print("ALL OK" if ok else "MISMATCH")
 
 
 if __name__ == "__main__":
