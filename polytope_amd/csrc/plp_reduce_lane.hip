@@ -33,49 +33,51 @@
 
 namespace plp {
 
-constexpr int LN_NG = 16;     // polytopes per tile (= per wavefront)
 constexpr int LN_ROWS = 16;   // row slots per polytope
-constexpr int LN_R = 4, LN_GS = 4;
+// GS lanes per polytope (4 / 8 / 16), R = 16 / GS rows per lane in the lane-group stages, NG = 64 / GS polytopes per tile
+// (= per wavefront).  GS = 4 is the throughput form; 8 and 16 put fewer polytopes on a wavefront and finish a tile in
+// about 0.6 / 0.4 of the time: the latency forms for batches that cannot fill the chip, and the tail of a large launch.
 
-static inline size_t reduce_lane_smem_bytes(int D) { return (size_t)LN_NG * LN_ROWS * (D + 2) * 8; }
+static inline size_t reduce_lane_smem_bytes(int D, int GS) { return (size_t)(64 / GS) * LN_ROWS * (D + 2) * 8; }
 
-// The polytopes of a tile that the fast path handed back (bit 4 p of `rb64`: polytope p), redone by the general engine
+// The polytopes of a tile that the fast path handed back (bit GS p of `rb64`: polytope p), redone by the general engine
 // (plp_reduce_general.hpp: one dictionary row per lane, 16 lanes per polytope, Bland's rule in the simplex).
-template <int D>
+template <int D, int GS>
 __device__ __noinline__ void reduce_lane_redo(unsigned char* smem_raw, const long long tile, const int ntile, const uint64_t rb64,
                                               int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
                                               const int* __restrict__ mrows, double abs_tol,
                                               unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
                                               double* __restrict__ r_out, double* __restrict__ xc_out,
                                               int* __restrict__ nlp_out) {
-    for (int sub = 0; sub < LN_NG / 4; ++sub) {
-        const unsigned four = (unsigned)(rb64 >> (16 * sub)) & 0x1111u;
+    for (int sub = 0; sub < (64 / GS) / 4; ++sub) {
+        unsigned four = 0u;   // bit q: polytope 4 sub + q
+#pragma unroll
+        for (int q = 0; q < 4; ++q) four |= (unsigned)((rb64 >> (GS * (4 * sub + q))) & 1ull) << q;
         if (four == 0u) continue;   // wave-uniform
         const int q = (threadIdx.x & 63) >> 4;
-        const bool mine = ((four >> (4 * q)) & 1u) != 0u;
+        const bool mine = ((four >> q) & 1u) != 0u;
         const int left = ntile - 4 * sub;
         reduce_general_tile<D, RBLOCK>(smem_raw, tile + 4 * sub, left < 4 ? left : 4, mine, m_max, 16, Ag, bg, mrows, abs_tol,
                                        keep_out, flags_out, r_out, xc_out, nlp_out);
     }
 }
 
-template <int D>
+template <int D, int GS>
 __device__ __forceinline__ void reduce_lane_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
-    unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ retry_word, unsigned long long epoch) {
+    unsigned long long* __restrict__ ctr) {
     static_assert(D >= 1 && D <= 3, "the lane engine walks in R^3 (lower dimensions are embedded)");
     static_assert(RBLOCK == 64, "one wavefront per workgroup");
-    (void)retry_word;
-    (void)epoch;
-    constexpr int R = LN_R, GS = LN_GS, NG = LN_NG, rows = LN_ROWS;
+    static_assert(GS == 4 || GS == 8 || GS == 16, "lanes per polytope");
+    constexpr int rows = LN_ROWS, R = rows / GS, NG = 64 / GS;
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int LS = NG;   // stride between consecutive elements of one polytope
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const Grp g(GS);
     const int lane = g.lane;
-    const int gib = lane >> 2;   // my polytope inside the tile
+    const int gib = lane / GS;   // my polytope inside the tile
     const int row0 = g.gl * R;   // my first row
     double* sA = reinterpret_cast<double*>(smem_raw);   // [rows * D][NG]
     double* sb = sA + (size_t)rows * D * NG;             // [rows][NG]
@@ -94,19 +96,19 @@ __device__ __forceinline__ void reduce_lane_tile(
         // lane (q, p): polytope p, elements q, q + 4, ... of its record -- the wavefront reads 16 records x 32 B per
         // instruction (whole 32 B sectors; the rest of each 128 B line is used by the next three iterations) and writes
         // 16 consecutive doubles x 4 rows of the interleaved tile (no bank conflict)
-        const int p = lane & 15, q = lane >> 4;
+        const int p = lane % NG, q = lane / NG;   // (q < GS)
         const int rowsz = m_max * D;
         const bool pv = p < ntile;
         const double* src = Ag + (tile + (pv ? p : 0)) * rowsz;
 #pragma unroll
-        for (int it = 0; it < rows * D / 4; ++it) {
-            const int rem = q + 4 * it;
+        for (int it = 0; it < rows * D / GS; ++it) {
+            const int rem = q + GS * it;
             sA[rem * NG + p] = (pv & (rem < rowsz)) ? src[rem] : 0.0;
         }
         const double* srcb = bg + (tile + (pv ? p : 0)) * m_max;
 #pragma unroll
-        for (int it = 0; it < rows / 4; ++it) {
-            const int row = q + 4 * it;
+        for (int it = 0; it < rows / GS; ++it) {
+            const int row = q + GS * it;
             sb[row * NG + p] = (pv & (row < m_max)) ? srcb[row] : 0.0;
         }
     }
@@ -216,8 +218,8 @@ __device__ __forceinline__ void reduce_lane_tile(
                 remmask |= par ? (1u << gone) : 0u;
             }
         }
-        remmask |= (unsigned)__shfl_xor((int)remmask, 1, 64);
-        remmask |= (unsigned)__shfl_xor((int)remmask, 2, 64);
+#pragma unroll
+        for (int o = 1; o < GS; o <<= 1) remmask |= (unsigned)__shfl_xor((int)remmask, o, 64);
         const unsigned removed = (remmask >> row0) & RMASK;
 #pragma unroll
         for (int k = 0; k < R; ++k)
@@ -319,17 +321,21 @@ __device__ __forceinline__ void reduce_lane_tile(
         const bool go = stage == 1;
         const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
         bool lpfail = false;
-        // LP `it`: lower_0, upper_0, lower_1, upper_1, ...  Round 0: one LP per lane (LPs 0..3 of the polytope on its four
-        // lanes); round 1 (d = 3): LPs 4 and 5 on a pair of lanes each.
-        constexpr int NROUND = (2 * D + GS - 1) / GS;
+        // LP `it`: lower_0, upper_0, lower_1, upper_1, ...
+        //   GS = 4:  round 0 one LP per lane (LPs 0..3 on the polytope's four lanes), round 1 (d = 3) LPs 4 and 5 on a pair each
+        //   GS = 8:  one round, LP `it` on lane `it` of the polytope's eight
+        //   GS = 16: one round, every LP on a pair of lanes
+        constexpr int NROUND = (GS == 4 && 2 * D > GS) ? 2 : 1;
+        auto f3_lane_of = [](int it) { return GS == 16 ? 2 * it : (it < GS ? it : 2 * (it - GS)); };
+        auto f3_round_of = [](int it) { return (GS == 4 && it >= GS) ? 1 : 0; };
         double val[NROUND];
 #pragma unroll
         for (int q = 0; q < NROUND; ++q) val[q] = 0.0;
 #pragma unroll 1
         for (int rd = 0; rd < NROUND; ++rd) {
-            const int nparts = rd == 0 ? 1 : 2;
-            const int it = rd == 0 ? g.gl : GS + (g.gl >> 1);
-            const int part = rd == 0 ? 0 : (g.gl & 1);
+            const int nparts = (GS == 16 || rd == 1) ? 2 : 1;
+            const int it = GS == 16 ? (g.gl >> 1) : (rd == 0 ? g.gl : GS + (g.gl >> 1));
+            const int part = nparts == 2 ? (g.gl & 1) : 0;
             const bool mine = go & (it < 2 * D);
             const int kx = it >> 1;
             const bool up = it & 1;
@@ -352,16 +358,15 @@ __device__ __forceinline__ void reduce_lane_tile(
         // an LP handed back or failed anywhere in my group concerns the polytope
         lpfail = grp_ballot(lpfail, g) != 0;
         retry = retry | (grp_ballot(retry, g) != 0);
-        // prefilter sums, accumulated in k order (:1131-1134); LP `it` sits in lane it of round 0, or lane 2 (it - 4) of round 1
+        // prefilter sums, accumulated in k order (:1131-1134); LP `it` sits in lane f3_lane_of(it) of round f3_round_of(it)
         double s1[R], s2[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
 #pragma unroll
         for (int kx = 0; kx < D; ++kx) {
-            constexpr int G4 = GS;
             const int itl = 2 * kx, ith = 2 * kx + 1;
-            const double lo = bcast(val[itl / G4], g.gbase + (itl < G4 ? itl : 2 * (itl - G4)));
-            const double hi = bcast(val[ith / G4], g.gbase + (ith < G4 ? ith : 2 * (ith - G4)));
+            const double lo = bcast(val[f3_round_of(itl)], g.gbase + f3_lane_of(itl));
+            const double hi = bcast(val[f3_round_of(ith)], g.gbase + f3_lane_of(ith));
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double aik = LA(row0 + k, kx);
@@ -494,11 +499,11 @@ __device__ __forceinline__ void reduce_lane_tile(
     // Polytopes handed back (an LP that needs Bland's rule, dependent active rows; PLP_REDUCE_RETRY_ALL=1: all of them) are
     // redone HERE by the general engine, four at a time on the wavefront's 64 lanes -- the launch is complete, no second
     // pass follows it.  Rare: the call sits behind a wave-uniform branch and is not inlined.
-    const uint64_t rb64 = __ballot(retry & valid & (g.gl == 0));   // bit 4 p: polytope p of the tile
+    const uint64_t rb64 = __ballot(retry & valid & (g.gl == 0));   // bit GS p: polytope p of the tile
     if (rb64 != 0ull) {
         __threadfence_block();   // my r / xc stores of these polytopes are out before they are written again
         __syncthreads();
-        reduce_lane_redo<D>(smem_raw, tile, ntile, rb64, m_max, Ag, bg, mrows, abs_tol, keep_out, flags_out, r_out, xc_out,
+        reduce_lane_redo<D, GS>(smem_raw, tile, ntile, rb64, m_max, Ag, bg, mrows, abs_tol, keep_out, flags_out, r_out, xc_out,
                             nlp_out);
     }
 #undef LA
@@ -507,29 +512,83 @@ __device__ __forceinline__ void reduce_lane_tile(
 }
 
 #ifndef PLP_REDUCE_LANE_WAVES
-#define PLP_REDUCE_LANE_WAVES 4   // 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD
+#define PLP_REDUCE_LANE_WAVES 4   // (GS = 4: 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD)
 #endif
 
-template <int D>
+template <int D, int GS>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
     double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
-    double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr,
-    unsigned long long* __restrict__ retry_word, unsigned long long epoch) {
-    reduce_lane_tile<D>((long long)blockIdx.x * LN_NG, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
-                        r_out, xc_out, nlp_out, ctr, retry_word, epoch);
+    double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
+    reduce_lane_tile<D, GS>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                            flags_out, r_out, xc_out, nlp_out, ctr);
 }
+
+// The first `nbig` workgroups take tiles of 16 polytopes, the rest tiles of 8 (which finish in about 0.6 of the time): the
+// launch drains over one tile lifetime, and with short tiles dispatched last that window shrinks.
+template <int D>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_mix_kernel(
+    int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
+    const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
+    int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
+    unsigned long long* __restrict__ ctr) {
+    if ((int)blockIdx.x < nbig)
+        reduce_lane_tile<D, 4>((long long)blockIdx.x * 16, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
+                               r_out, xc_out, nlp_out, ctr);
+    else
+        reduce_lane_tile<D, 8>((long long)nbig * 16 + (long long)((int)blockIdx.x - nbig) * 8, B, m_max, Ag, bg, mrows, abs_tol,
+                               force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
+}
+
+// Tile shape by batch size, measured on (16,3) batches (scripts/debug/lane_sweep.py, us per launch GS 4 / 8 / 16):
+//   B = 3 000: 51 / 35 / 27.5    8 000: 56 / 38 / 34    12 000: 58 / 46 / 41    16 000: 58 / 47 / 49    20 000: 66 / 56 / 62
+//   30 000: 71 / 69 / 81    40 000: 89 / 88 / 101    (lane-group kernels: 40 / 48 / 60 / 62 / 75 / 91 / 106)
+#ifndef PLP_REDUCE_LANE_GS8_MAXB
+#define PLP_REDUCE_LANE_GS8_MAXB 40000   // batches up to this size: 8 polytopes per wavefront
+#endif
+#ifndef PLP_REDUCE_LANE_GS16_MAXB
+#define PLP_REDUCE_LANE_GS16_MAXB 14000  // ... up to this size: 4 polytopes per wavefront
+#endif
+// Larger batches: 16 polytopes per wavefront, the LAST eighth of the tiles (at most 1024) as 8-polytope tiles.  The
+// workgroups of a launch are handed out over tens of microseconds and the launch ends when the ones that started last
+// end: short tiles there cut 12 us off 50 000 .. 100 000 polytopes (100 000: 166 us without, 153-155 with 2/64 .. 8/64 of
+// the tiles, 159-172 beyond 12/64; 50 000: 104 -> 91).  PLP_REDUCE_LANE_MIX=k: k / 64 of the tiles (0: none).
 
 template <int D>
 static int launch_reduce_lane_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double abs_tol,
                                 unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
-    long long blocks = (B + LN_NG - 1) / LN_NG;
-    if (blocks > 2147483647ll) return 2;
-    if (blocks < 1) blocks = 1;
+    if (B > 2147483647ll) return 2;
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
-    hipLaunchKernelGGL((reduce_lane_kernel<D>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D), st, B, m_max,
-                       A, b, mrows, abs_tol, (fr && fr[0] == '1') ? 1 : 0, keep, flags, r, xc, nlp, t_reduce_ctr, t_reduce_retry,
-                       t_reduce_epoch);
+    const int force = (fr && fr[0] == '1') ? 1 : 0;
+    const char* eg = getenv("PLP_REDUCE_LANE_GS");   // 4 / 8 / 16: that tile shape whatever the batch size (A/B)
+    int gs = B <= PLP_REDUCE_LANE_GS16_MAXB ? 16 : (B <= PLP_REDUCE_LANE_GS8_MAXB ? 8 : 4);
+    if (eg) gs = atoi(eg) == 16 ? 16 : (atoi(eg) == 8 ? 8 : 4);
+    const long long ng = 64 / gs;
+    long long blocks = (B + ng - 1) / ng;
+    if (blocks < 1) blocks = 1;
+    if (gs == 16) {
+        hipLaunchKernelGGL((reduce_lane_kernel<D, 16>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D, 16), st, B,
+                           m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
+    } else if (gs == 8) {
+        hipLaunchKernelGGL((reduce_lane_kernel<D, 8>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D, 8), st, B,
+                           m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
+    } else {
+        const char* mx = getenv("PLP_REDUCE_LANE_MIX");
+        long long tail_tiles = blocks / 8 < 1024 ? blocks / 8 : 1024;
+        if (mx) tail_tiles = blocks * atoi(mx) / 64;
+        if (eg) tail_tiles = 0;   // (a forced shape is that shape only)
+        if (tail_tiles > 0 && blocks > 512) {
+            const long long nbig = blocks - tail_tiles;
+            const long long rest = B - nbig * 16;
+            const long long nsmall = (rest + 7) / 8;
+            hipLaunchKernelGGL((reduce_lane_mix_kernel<D>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
+                               reduce_lane_smem_bytes(D, 4), st, (int)nbig, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r,
+                               xc, nlp, t_reduce_ctr);
+        } else {
+            hipLaunchKernelGGL((reduce_lane_kernel<D, 4>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D, 4), st,
+                               B, m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
+        }
+    }
     return 3;   // complete: what the fast path hands back is redone inside the kernel, no second pass
 }
 

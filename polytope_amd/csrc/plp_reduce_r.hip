@@ -14,7 +14,7 @@
 #endif
 
 #ifndef PLP_REDUCE_LANE_MINB
-#define PLP_REDUCE_LANE_MINB 4096   // (16,3)-class batches larger than this: one LP per lane (plp_reduce_lane.hip)
+#define PLP_REDUCE_LANE_MINB 0   // (16,3)-class batches larger than this: one LP per lane (plp_reduce_lane.hip); its 4-polytope tiles are ahead of the lane-group latency form down to a single polytope
 #endif
 
 namespace plp {
@@ -78,8 +78,8 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || d < 1 || d > MAX_D) return 1;
     if (d <= 3 && m_max <= 16) {
-        // up to 16 rows in d <= 3 (the bench shape): F3 / F2 one LP per lane (plp_reduce_lane.hip) beyond the latency
-        // form's batch sizes; PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
+        // up to 16 rows in d <= 3 (the bench shape): F3 / F2 one LP per lane (plp_reduce_lane.hip), at every batch size;
+        // PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
         const char* ln = getenv("PLP_REDUCE_LANE");
         const bool other = getenv("PLP_REDUCE_SPLIT") || getenv("PLP_REDUCE_HALF") || getenv("PLP_REDUCE_MIX") || getenv("PLP_REDUCE_R8");
         if ((ln && ln[0] == '1') || (!(ln && ln[0] == '0') && !other && B > PLP_REDUCE_LANE_MINB))

@@ -42,6 +42,22 @@ def main():
         ok = ok and same and vs_or
     if timing_only:
         return timing(torch, pa, random_hpolytopes, dev)
+    # the latency shapes (8 / 4 polytopes per wavefront) and the mixed launch against the 16-per-wavefront form
+    for (B, m, d, seed) in [(9000, 16, 3, 2), (5000, 13, 3, 5), (4000, 16, 2, 1), (3000, 5, 1, 9), (70001, 16, 3, 4)]:
+        A, b = random_hpolytopes(B, m, d, seed=seed)
+        os.environ["PLP_REDUCE_LANE_GS"] = "4"
+        ref = run(A, b, True)
+        outs = {}
+        for gs in ("8", "16"):
+            os.environ["PLP_REDUCE_LANE_GS"] = gs
+            outs[gs] = run(A, b, True)
+        del os.environ["PLP_REDUCE_LANE_GS"]
+        outs["default"] = run(A, b, True)
+        for k_, o in outs.items():
+            same = all(np.array_equal(o[k], ref[k]) for k in ("keep", "flags", "nlp")) and \
+                np.array_equal(o["r"].view(np.int64), ref["r"].view(np.int64)) and np.array_equal(o["xc"].view(np.int64), ref["xc"].view(np.int64))
+            print("shape", (B, m, d), "GS", k_, "== GS 4:", same, flush=True)
+            ok = ok and same
     # unbounded-allowed variant, ragged row counts
     A, b = random_hpolytopes(6000, 16, 3, seed=5, bounded=False)
     rng = np.random.default_rng(0)
@@ -71,11 +87,14 @@ def main():
 def timing(torch, pa, random_hpolytopes, dev):
     NB = 6
     full = [random_hpolytopes(100000, 16, 3, seed=i) for i in range(NB)]
-    for B in (100000, 50000, 25000, 12500, 6000):
+    for B in (100000, 50000, 25000, 12500, 6000, 3000):
         devb = [(torch.as_tensor(A_[:B]).to(dev), torch.as_tensor(b_[:B]).to(dev)) for A_, b_ in full]
         line = "B=%6d " % B
-        for lane in (0, 1):
-            os.environ["PLP_REDUCE_LANE"] = str(lane)
+        for lane in (0, 1, 4, 8, 16):
+            os.environ["PLP_REDUCE_LANE"] = "1" if lane else "0"
+            os.environ.pop("PLP_REDUCE_LANE_GS", None)
+            if lane > 1:
+                os.environ["PLP_REDUCE_LANE_GS"] = str(lane)
             for k in range(5):
                 pa.reduce_batch(*devb[k % NB])
             best = 1e9
@@ -87,7 +106,8 @@ def timing(torch, pa, random_hpolytopes, dev):
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 60)
-            line += " lane=%d %.4f ms" % (lane, best)
+            line += " %s %.4f" % ({0: "groups", 1: "lane"}.get(lane, "GS%d" % lane), best)
+        os.environ.pop("PLP_REDUCE_LANE_GS", None)
         print(line, flush=True)
 
 

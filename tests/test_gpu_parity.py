@@ -624,7 +624,8 @@ def test_reduce_structured_ties_golden_and_bench_shape(pa, oracle):
 def test_reduce_simplex_run_counter(pa):
     """plp_reduce_counters: LPs that ran the simplex in the fused reduce launches since the last reset.  Between B (F1 of
     every polytope) and nlp.sum() (what the reference issues); repeatable; equal to nlp.sum() where no presolve runs
-    (the latency form of small batches solves every LP); the host-pointer and the device-pointer calls count alike."""
+    (the lane-group latency form of small batches solves every LP); the host-pointer and the device-pointer calls count alike."""
+    import os
     import torch
     from polytope_amd import batch
     from polytope_amd.synth import random_hpolytopes
@@ -643,10 +644,16 @@ def test_reduce_simplex_run_counter(pa):
         assert batch.reduce_simplex_runs(reset=True) == n1
         small = pa.reduce_batch(Ad[:200], bd[:200])
         ns = batch.reduce_simplex_runs(reset=True)
-        if d <= 4:    # latency form (reduce_split_kernel): every LP on the simplex, no presolve
-            assert ns == int(small["nlp"].sum().item())
-        else:         # one polytope per workgroup (d >= 5: any row count while the batch is small) with the presolve
-            assert 200 <= ns < int(small["nlp"].sum().item())
+        # small batches too go through a presolve (d <= 3, up to 16 rows: reduce_lane_kernel's four-polytope tiles;
+        # d >= 5: one polytope per workgroup)
+        assert 200 <= ns < int(small["nlp"].sum().item())
+        if d == 3:    # the lane-group latency form (reduce_split_kernel, A/B switch): every LP on the simplex, no presolve
+            os.environ["PLP_REDUCE_SPLIT"] = "1"
+            try:
+                pa.reduce_batch(Ad[:200], bd[:200])
+                assert batch.reduce_simplex_runs(reset=True) == int(small["nlp"].sum().item())
+            finally:
+                del os.environ["PLP_REDUCE_SPLIT"]
     assert batch.reduce_simplex_runs() == 0
 
 
