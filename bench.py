@@ -630,9 +630,12 @@ def main():
         # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
         # passes (scripts/gpu_check.sh), whose summary is committed by scripts/summarize_profiles.py
         traffic, traffic_src, valu = None, None, {}
+        kname = "reduce_lane_mix_kernel<3>"   # plp_reduce_lane.hip: tiles of 16 polytopes, the last eighth as tiles of 8
         try:
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
                 tj = json.load(f)
+            if tj.get("kernel") != kname:
+                raise KeyError("counters of another kernel")
             traffic = tj["hbm_bytes_per_launch"]
             valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_busy_frac_measured", "effective_clock_GHz", "source")
                     if k in tj}
@@ -673,7 +676,7 @@ def main():
                        "parallelism": "batch-sharded x%d + all-gather of the packed results of every %d batches (overlapped with the next ones)" % (world, G)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "reduce_r_mix_kernel<3>", "kernel_ms": kern_ms,
+                         "kernel": kname, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "VALU-issue bound (valu_busy_frac_measured), not HBM bound: %.3g LP/s inside the kernel" % (
                              head["lps_local"] / S / (kern_ms * 1e-3))},

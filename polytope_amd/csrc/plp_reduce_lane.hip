@@ -82,12 +82,20 @@ __device__ __forceinline__ void reduce_lane_tile(
     double* sA = reinterpret_cast<double*>(smem_raw);   // [rows * D][NG]
     double* sb = sA + (size_t)rows * D * NG;             // [rows][NG]
     double* san = sb + (size_t)rows * NG;                // [rows][NG]: 1 / ||a_i||, later beta_i = max(b_i - a_i.xc, 0)
+    // (one base pointer per lane, everything else a compile-time offset from it: registers are what this kernel runs out of)
     double* myA = sA + gib;
-    double* myb = sb + gib;
-    double* myan = san + gib;
+    constexpr int OFF_B = rows * D * NG, OFF_N = OFF_B + rows * NG;   // sb - sA, san - sA in doubles
+    double* const myb = myA + OFF_B;
+    double* const myan = myA + OFF_N;
 #define LA(i, kk) myA[((i) * D + (kk)) * LS]
-#define LB(i) myb[(i) * LS]
-#define LN(i) myan[(i) * LS]
+#define LB(i) myA[OFF_B + (i) * LS]
+#define LN(i) myA[OFF_N + (i) * LS]
+    // my own rows row0 + k: two bases (the A rows have a stride of D elements, b / beta of one) and compile-time offsets
+    double* const rA = myA + row0 * D * LS;
+    double* const rS = myA + row0 * LS;
+#define OA(k, kk) rA[((k) * D + (kk)) * LS]
+#define OB(k) rS[OFF_B + (k) * LS]
+#define ON(k) rS[OFF_N + (k) * LS]
     const double qnan = __longlong_as_double(0x7ff8000000000000ll);
     const double pinf = __longlong_as_double(0x7ff0000000000000ll);
     const int ntile = (B - tile) < NG ? (int)(B - tile) : NG;
@@ -100,22 +108,43 @@ __device__ __forceinline__ void reduce_lane_tile(
         const int rowsz = m_max * D;
         const bool pv = p < ntile;
         const double* src = Ag + (tile + (pv ? p : 0)) * rowsz;
+        // (every load unconditional, from a clamped index, and all of them issued before the first LDS store: a load under
+        // a condition becomes a branch of its own, and sixteen of those in a row are sixteen HBM round trips)
+        double va[rows * D / GS], vb[rows / GS];
+        const double* srcb = bg + (tile + (pv ? p : 0)) * m_max;
+        if (m_max == rows) {   // (wave-uniform; full records: one address, immediate offsets)
+#pragma unroll
+            for (int it = 0; it < rows * D / GS; ++it) va[it] = src[q + GS * it];
+#pragma unroll
+            for (int it = 0; it < rows / GS; ++it) vb[it] = srcb[q + GS * it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < rows * D / GS; ++it) {
+                const int rem = q + GS * it;
+                va[it] = src[rem < rowsz ? rem : 0];
+            }
+#pragma unroll
+            for (int it = 0; it < rows / GS; ++it) {
+                const int row = q + GS * it;
+                vb[it] = srcb[row < m_max ? row : 0];
+            }
+        }
 #pragma unroll
         for (int it = 0; it < rows * D / GS; ++it) {
             const int rem = q + GS * it;
-            sA[rem * NG + p] = (pv & (rem < rowsz)) ? src[rem] : 0.0;
+            sA[rem * NG + p] = (pv & (rem < rowsz)) ? va[it] : 0.0;
         }
-        const double* srcb = bg + (tile + (pv ? p : 0)) * m_max;
 #pragma unroll
         for (int it = 0; it < rows / GS; ++it) {
             const int row = q + GS * it;
-            sb[row * NG + p] = (pv & (row < m_max)) ? srcb[row] : 0.0;
+            sb[row * NG + p] = (pv & (row < m_max)) ? vb[it] : 0.0;
         }
     }
     __syncthreads();
-    const long long pg = tile + gib;
+    // (outputs are addressed as (array + tile)[gib]: the tile offset is wave-uniform and lives in scalar registers, the
+    // lane keeps its 32-bit gib instead of a 64-bit polytope index)
     const bool valid = gib < ntile;
-    const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
+    const int m = valid ? (mrows ? (mrows + tile)[gib] : m_max) : 0;
     double xc[D];
     double rr = 0.0;
     bool ball, fulldim;
@@ -136,15 +165,15 @@ __device__ __forceinline__ void reduce_lane_tile(
             double nrm2 = 0.0;
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) {
-                const double v = h ? LA(row0 + k, kk) : 0.0;
+                const double v = h ? OA(k, kk) : 0.0;
                 S.T[k][kk] = v;
                 nrm2 = nrm2 + v * v;
                 finite = finite & isfinite(v);
             }
-            const double bk = h ? LB(row0 + k) : 0.0;
+            const double bk = h ? OB(k) : 0.0;
             finite = finite & isfinite(bk);
             const double nrm = sqrt(nrm2);
-            LN(row0 + k) = 1.0 / nrm;
+            ON(k) = 1.0 / nrm;
             const bool zero = !(nrm > 0.0);
             const bool on = h & !zero;
             S.T[k][D] = on ? nrm : 0.0;
@@ -178,13 +207,13 @@ __device__ __forceinline__ void reduce_lane_tile(
         fulldim = ball & (rr > abs_tol);
     }
     if (valid & (g.gl == 0)) {
-        r_out[pg] = ball ? rr : 0.0;
+        (r_out + tile)[gib] = ball ? rr : 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) xc_out[pg * D + k] = ball ? xc[k] : qnan;
+        for (int k = 0; k < D; ++k) (xc_out + tile * D)[gib * D + k] = ball ? xc[k] : qnan;
     }
     __syncthreads();  // 1/||a|| of every row is in LDS
 #ifdef PLP_LANE_DBG_F1ONLY
-    if (valid & (g.gl == 0)) { keep_out[pg] = 0; flags_out[pg] = 0; nlp_out[pg] = 1; }
+    if (valid & (g.gl == 0)) { (keep_out + tile)[gib] = 0; (flags_out + tile)[gib] = 0; (nlp_out + tile)[gib] = 1; }
     return;
 #endif
     // ---------------------------------------------------------------- dedupe (:1094-1110): every pair of rows once
@@ -193,10 +222,10 @@ __device__ __forceinline__ void reduce_lane_tile(
         double ni[R][D], bin_[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const double an_i = LN(row0 + k);
+            const double an_i = ON(k);
 #pragma unroll
-            for (int kk = 0; kk < D; ++kk) ni[k][kk] = LA(row0 + k, kk) * an_i;
-            bin_[k] = LB(row0 + k) * an_i;
+            for (int kk = 0; kk < D; ++kk) ni[k][kk] = OA(k, kk) * an_i;
+            bin_[k] = OB(k) * an_i;
         }
 #pragma unroll 2
         for (int t = 1; t <= 8; ++t) {
@@ -232,8 +261,8 @@ __device__ __forceinline__ void reduce_lane_tile(
     for (int k = 0; k < R; ++k) {
         double sk = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < D; ++kk) sk = fma(((has >> k) & 1u) ? LA(row0 + k, kk) : 0.0, ball ? xc[kk] : 0.0, sk);
-        LN(row0 + k) = fmax((((has >> k) & 1u) ? LB(row0 + k) : 0.0) - sk, 0.0);
+        for (int kk = 0; kk < D; ++kk) sk = fma(((has >> k) & 1u) ? OA(k, kk) : 0.0, ball ? xc[kk] : 0.0, sk);
+        ON(k) = fmax((((has >> k) & 1u) ? OB(k) : 0.0) - sk, 0.0);
     }
     // rows that dropped out (never present, or removed by the dedupe / the prefilter) are zeroed -- A, b and s -- by their
     // owner lane: a zero row never stops a ray and passes every presolve test
@@ -242,9 +271,9 @@ __device__ __forceinline__ void reduce_lane_tile(
         for (int k = 0; k < R; ++k) {
             if (!((alive >> k) & 1u)) {
 #pragma unroll
-                for (int kk = 0; kk < D; ++kk) LA(row0 + k, kk) = 0.0;
-                LB(row0 + k) = 0.0;
-                LN(row0 + k) = 0.0;
+                for (int kk = 0; kk < D; ++kk) OA(k, kk) = 0.0;
+                OB(k) = 0.0;
+                ON(k) = 0.0;
             }
         }
     };
@@ -369,7 +398,7 @@ __device__ __forceinline__ void reduce_lane_tile(
             const double hi = bcast(val[f3_round_of(ith)], g.gbase + f3_lane_of(ith));
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const double aik = LA(row0 + k, kx);
+                const double aik = OA(k, kx);
                 const double pa = (aik > 0.0 ? 1.0 : 0.0) * aik;
                 s1[k] = s1[k] + pa * (hi - lo);
                 s2[k] = s2[k] + aik * lo;
@@ -378,7 +407,7 @@ __device__ __forceinline__ void reduce_lane_tile(
         uint64_t outb = 0ull;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (LB(row0 + k) - s2[k])) < -1e-4);
+            const bool out = go & (((lloc >> k) & 1u) != 0u) & ((s1[k] - (OB(k) - s2[k])) < -1e-4);
             outb |= spread_rows<R, GS>(grp_ballot(out, g)) << k;
         }
         __syncthreads();   // every lane's LPs have read the rows: the owners may zero the ones the prefilter removes
@@ -459,7 +488,7 @@ __device__ __forceinline__ void reduce_lane_tile(
             }
             const int kr = mine ? (__ffs((int)ttd) - 1) : 0;
             const double* pA = sA + tp;
-            const double* pan = san + tp;
+            const double* pan = pA + OFF_N;
             double c[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) c[kk] = -pA[(kr * D + kk) * LS];   // f = -A[k,:]  (:1145)
@@ -491,9 +520,9 @@ __device__ __forceinline__ void reduce_lane_tile(
     }
     // ---------------------------------------------------------------- results
     if (valid & (g.gl == 0) & !retry) {
-        keep_out[pg] = keep;
-        flags_out[pg] = flags;
-        nlp_out[pg] = nlp;
+        (keep_out + tile)[gib] = keep;
+        (flags_out + tile)[gib] = flags;
+        (nlp_out + tile)[gib] = nlp;
     }
     ctr_add(ctr, nlp, valid & (g.gl == 0));   // every LP the reference issues, less the presolved ones
     // Polytopes handed back (an LP that needs Bland's rule, dependent active rows; PLP_REDUCE_RETRY_ALL=1: all of them) are
@@ -507,6 +536,9 @@ __device__ __forceinline__ void reduce_lane_tile(
                             nlp_out);
     }
 #undef LA
+#undef OA
+#undef OB
+#undef ON
 #undef LB
 #undef LN
 }

@@ -66,7 +66,7 @@ def ctr(passname, kernel_sub, counter, full_grid_only=True):
 
 
 # bench kernel: measured counters (passes bench_pmc_1..7 of gpu_profile_all.sh)
-K = "reduce_r_mix_kernel<3>"   # the bench kernel: tiles of 16 polytopes, the last 1/16 of them split into tiles of 8
+K = sys.argv[3] if len(sys.argv) > 3 else "reduce_lane_mix_kernel<3>"   # the bench kernel: tiles of 16 polytopes, the last eighth of them as tiles of 8
 vals = {}
 for p in sorted(summ):
     if not p.startswith("bench_pmc_"):
@@ -80,8 +80,8 @@ if vals:
     kt = [r for r in summ.get("bench", {}).get("kernels", []) if K in r["kernel"]]
     gfull = max(int(r["grid_x"]) for r in kt)
     kfull = [r for r in kt if int(r["grid_x"]) == gfull][0]
-    out = {"kernel": K, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc <set> (one pass per set); "
-                                   "durations: python bench.py --steps 50 --warmup 5 under --kernel-trace",
+    out = {"kernel": K, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-parity --regions 1 --min-region-ms 0 under rocprofv3 --pmc <set> (one pass per set); "
+                                   "durations: python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-parity under --kernel-trace --stats",
            "rocprof_avg_kernel_ns": kfull["avg_ns"], "rocprof_calls": kfull["calls"], "vgpr": kfull["vgpr"],
            "lds_bytes": kfull["lds"], "scratch_bytes": kfull["scratch"], "counters": vals}
     d = {}
