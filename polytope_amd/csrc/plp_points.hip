@@ -274,7 +274,13 @@ __global__ void assign_init_kernel(int F, unsigned long long* maxbits, unsigned 
 // strided row reads are not what holds the kernel back.
 constexpr int ASSIGN_SMALL_F = 64;
 
-template <int D, int PPT>
+// FB: a tag only (16: F <= 16, 64: beyond) -- the two regimes of this kernel (HBM-bound / VALU-bound) get their own rows
+// in a kernel trace.
+// Round 5, measured and NOT kept: the fold inside this kernel (every workgroup publishes its pairs, draws a ticket, the
+// last one folds the table -- one launch per call).  The release that must precede the ticket is a device-scope fence, and
+// on this part (eight XCDs, an L2 each) that is an L2 write-back per workgroup with the kernel's 12 MB of fresh fop / dist
+// lines behind it: 233 us per call against 23.4 us for the two launches.
+template <int D, int PPT, int FB>
 __global__ __launch_bounds__(BLOCK) void assign_small_kernel(long long N, const double* __restrict__ X, int F,
                                                              const double* __restrict__ normals,
                                                              const double* __restrict__ offsets, double tol,
@@ -375,8 +381,12 @@ static void launch_assign_small(long long N, const double* X, int F, const doubl
     const long long nblk = (N + (long long)BLOCK * PPT - 1) / ((long long)BLOCK * PPT);
     const size_t smem = ((size_t)F * (D + 1) + 2 * (size_t)F) * 8;
     unsigned long long* part = static_cast<unsigned long long*>(scratch);
-    hipLaunchKernelGGL((assign_small_kernel<D, PPT>), dim3((unsigned)nblk), dim3(BLOCK), smem, st, N, X, F, normals,
-                       offsets, tol, fop, dist, part, nblk);
+    if (F <= 16)
+        hipLaunchKernelGGL((assign_small_kernel<D, PPT, 16>), dim3((unsigned)nblk), dim3(BLOCK), smem, st, N, X, F, normals,
+                           offsets, tol, fop, dist, part, nblk);
+    else
+        hipLaunchKernelGGL((assign_small_kernel<D, PPT, 64>), dim3((unsigned)nblk), dim3(BLOCK), smem, st, N, X, F, normals,
+                           offsets, tol, fop, dist, part, nblk);
     hipLaunchKernelGGL(assign_finish_kernel, dim3((unsigned)F), dim3(BLOCK), 0, st, nblk, part,
                        reinterpret_cast<unsigned long long*>(maxd), reinterpret_cast<unsigned long long*>(argmax));
 }
