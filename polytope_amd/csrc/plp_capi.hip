@@ -72,9 +72,6 @@ struct plp_ctx {
         size_t X_bytes = 0, owner_bytes = 0, dist_bytes = 0, dead_cap = 0, io_bytes = 0;
         bool full = false;
     } hull_spare;
-    // quickhull's device-resident facet tables (plp_quickhull_dev.hip): one grow-only block
-    void* qh_block = nullptr;
-    size_t qh_block_bytes = 0;
     // large host-pointer batches (plp_stage.hpp): staging threads, pinned staging buffer, copy stream, one event per chunk
     plp::StagePool* pool = nullptr;
     char* stage = nullptr;
@@ -432,7 +429,6 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->retry_ring) (void)hipFree(ctx->retry_ring);
     for (auto& kv : ctx->as_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
-    if (ctx->qh_block) (void)hipFree(ctx->qh_block);
     if (ctx->hull_spare.full) {
         (void)hipFree(ctx->hull_spare.X); (void)hipFree(ctx->hull_spare.owner); (void)hipFree(ctx->hull_spare.dist);
         if (ctx->hull_spare.dead) (void)hipFree(ctx->hull_spare.dead);
@@ -1195,25 +1191,6 @@ int plp_hull_read(plp_hull* h, int32_t* owner, double* dist) {
 }
 
 }  // extern "C"
-
-// internal (not part of the C ABI): what the device-resident quickhull loop needs of a session and its context
-extern "C++" {
-const double* plp_internal_hull_points(plp_hull* h) { return h ? h->X : nullptr; }
-plp_ctx* plp_internal_hull_ctx(plp_hull* h) { return h ? h->ctx : nullptr; }
-hipStream_t plp_internal_ctx_stream(plp_ctx* ctx) { return ctx->stream; }
-void* plp_internal_ctx_qh_block(void* user, size_t bytes) {
-    plp_ctx* ctx = static_cast<plp_ctx*>(user);
-    if (bytes > ctx->qh_block_bytes) {
-        if (ctx->qh_block) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->qh_block); }
-        ctx->qh_block = nullptr;
-        ctx->qh_block_bytes = 0;
-        const size_t want = bytes + bytes / 4;
-        if (hipMalloc(&ctx->qh_block, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        ctx->qh_block_bytes = want;
-    }
-    return ctx->qh_block;
-}
-}
 
 extern "C" {
 

@@ -30,13 +30,6 @@
 #include <vector>
 
 #include "../../include/plp.h"
-#include "plp_quickhull_dev.hpp"
-
-// (plp_capi.hip, internal)
-const double* plp_internal_hull_points(plp_hull* h);
-plp_ctx* plp_internal_hull_ctx(plp_hull* h);
-hipStream_t plp_internal_ctx_stream(plp_ctx* ctx);
-void* plp_internal_ctx_qh_block(void* user, size_t bytes);
 
 namespace {
 
@@ -401,75 +394,11 @@ int plp_quickhull_run(plp_ctx* ctx, int64_t N, int d, const double* X0, const in
         }
         for (int j = 0; j < k; ++j) if (H.cnt[f0 + j] > 0) H.set_pending(f0 + j);
     };
-    // PLP_QH_DEVICE_TAIL=1: the tail with the facet graph ON THE DEVICE (plp_quickhull_dev.hip: one persistent kernel, bitwise
-    // the facets of the host tail).  Off by default because it is slower -- measured after the obvious fixes (reassignment
-    // one wavefront per point out of LDS, eliminations in LDS): N = 20 000, d = 6: 0.66 s against 0.24 s on host lists,
-    // N = 100 000, d = 5: 0.19 against 0.061, N = 200 000, d = 4: 0.045 against 0.012.  An iteration is ~15 dependent
-    // phases on ONE compute unit (search levels, compactions, a hash table, list rewrites), each paying workgroup barriers and
-    // ~1 us per dependent global access; the host core does the same iteration in 10-170 us.  DESIGN 4.6.
-    bool device_tail = false;
-    if (const char* e = getenv("PLP_QH_DEVICE_TAIL")) device_tail = e[0] == '1';
-    auto run_device_tail = [&]() -> int {
-        std::vector<int32_t> owner(N);
-        std::vector<double> dist_all(N);
-        int r = plp_hull_read(sess, owner.data(), dist_all.data());
-        if (r) return r;
-        const int F = (int)H.cnt.size();
-        int32_t max_id = 0;
-        for (int32_t v : H.fid) max_id = v > max_id ? v : max_id;
-        std::vector<int> slot_of(max_id + 1, -1);
-        for (int f = 0; f < F; ++f) if (H.fid[f] >= 0 && H.live[f]) slot_of[H.fid[f]] = f;
-        plp::QhTailHost T;
-        T.d = d;
-        T.tol = abs_tol;
-        T.Xdev = plp_internal_hull_points(sess);
-        T.capn = 2 * d + 8;
-        for (int64_t q = 0; q < N; ++q) {
-            const int32_t o = owner[q];
-            if (o > 0 && o <= max_id && slot_of[o] >= 0) { T.opt.push_back((int)q); T.oown.push_back(slot_of[o]); T.odist.push_back(dist_all[q]); }
-        }
-        T.FN = H.FN;
-        T.FO = H.FO;
-        T.FV.resize((size_t)F * d);
-        for (size_t t = 0; t < T.FV.size(); ++t) T.FV[t] = (int)H.verts[t];
-        T.NB.assign((size_t)F * T.capn, 0);
-        T.NBN.assign(F, 0);
-        T.CNT.assign(F, 0);
-        T.FAR.assign(F, -1);
-        T.LIVE.assign(F, 0);
-        T.INP.assign(F, 0);
-        for (int f = 0; f < F; ++f) {
-            if ((int)H.nbrs[f].size() > T.capn) {
-                snprintf(g_qh_err, sizeof(g_qh_err), "quickhull: a facet with %zu neighbours (degenerate input)", H.nbrs[f].size());
-                return PLP_EUNSUPPORTED;
-            }
-            T.NBN[f] = (int)H.nbrs[f].size();
-            for (size_t t = 0; t < H.nbrs[f].size(); ++t) T.NB[(size_t)f * T.capn + t] = H.nbrs[f][t];
-            T.CNT[f] = (int)H.cnt[f];
-            T.LIVE[f] = (unsigned char)H.live[f];
-            T.INP[f] = (unsigned char)H.in_pending[f];
-            if (H.cnt[f] > 0 && H.far[f] >= 0) {
-                const auto it = std::lower_bound(T.opt.begin(), T.opt.end(), (int)H.far[f]);
-                T.FAR[f] = (it != T.opt.end() && *it == (int)H.far[f]) ? (int)(it - T.opt.begin()) : -1;
-            }
-        }
-        for (int f : H.pending) T.PQ.push_back(f);
-        T.total_outside = total_outside;
-        plp_ctx* cx = plp_internal_hull_ctx(sess);
-        r = plp::qh_tail_run(T, plp_internal_ctx_qh_block, cx, plp_internal_ctx_stream(cx), g_qh_err, sizeof(g_qh_err));
-        if (r) return r;
-        // the facets come back in creation order: the result below is assembled from the host's tables
-        const int nf = (int)T.FO.size();
-        H.FN.swap(T.FN);
-        H.FO.swap(T.FO);
-        H.verts.resize((size_t)nf * d);
-        for (size_t t = 0; t < H.verts.size(); ++t) H.verts[t] = T.FV[t];
-        H.live.assign(T.LIVE.begin(), T.LIVE.end());
-        H.cnt.resize(nf);
-        iterations += T.iterations;
-        tail_iterations = T.iterations;
-        return 0;
-    };
+    // (Rounds 3-4 also carried this tail with the facet graph ON THE DEVICE -- one persistent kernel, bitwise the same facets.
+    // It never won: an iteration is ~15 dependent phases on ONE compute unit, each paying workgroup barriers and ~1 us per
+    // dependent global access, where the host core does the same iteration in 10-170 us.  Measured once more in round 5 on
+    // many-facet hulls (points on a sphere, d = 3..7, up to 1.5 M facets: scripts/debug/qh_device_graph.py at commit 3b66ebf)
+    // -- 0.95x .. 4.3x the host graph's time -- and removed.  DESIGN.md section 4.4.)
     std::vector<char> in_visible, seen, queued;
     std::vector<int> visible, outer, touched;
     std::vector<double> prod(d);
@@ -480,13 +409,6 @@ int plp_quickhull_run(plp_ctx* ctx, int64_t N, int d, const double* X0, const in
         const int64_t p = H.far[facet];
         if (!host_mode && total_outside < host_tail) {
             auto th = now();
-            if (device_tail && !H.use_lapack) {
-                // ---- the rest of the loop with the facet graph ON THE DEVICE (plp_quickhull_dev.hip): one persistent kernel
-                rc = run_device_tail();
-                lap(7, th);
-                if (rc) { plp_hull_destroy(sess); return rc; }
-                break;
-            }
             rc = to_host();
             if (rc) { plp_hull_destroy(sess); return rc; }
             lap(7, th);

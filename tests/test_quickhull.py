@@ -321,39 +321,13 @@ def test_hull_host_tail_and_device_loop_agree_bitwise(monkeypatch, N, d):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,d", [(60000, 3), (30000, 4), (20000, 5), (6000, 6)])
-def test_hull_with_the_facet_graph_on_the_device(monkeypatch, N, d):
-    """PLP_QH_DEVICE_TAIL=1: from the hand-over on (fewer than 32 768 points outside) the facet graph lives in device memory
-    and ONE persistent kernel runs the rest of the loop (csrc/plp_quickhull_dev.hip) -- breadth-first visibility, horizon,
-    hyperplanes, sub-ridge links, neighbour lists, reassignment, the queue of facets, all in the reference's order.  Rows
-    bitwise those of the host tail, in the same order; also when the facet tables have to grow in mid-run."""
+def test_own_hyperplane_solver_in_reference_order(monkeypatch):
+    """The g8 hulls (a few hundred points) with the library's own LU for the facet hyperplanes instead of LAPACK's dgesv
+    (PLP_QH_LAPACK_BELOW=0: what inputs of 4096 points and more always get): the reference's facets in the reference's
+    order, rows to 1e-12."""
     from polytope_amd import solvers
     from polytope_amd.quickhull import quickhull
     monkeypatch.setattr(solvers, "default_solver", "hip")
-    P = np.random.default_rng(7 * N + d).standard_normal((N, d))
-    outs = []
-    for env in ({}, {"PLP_QH_DEVICE_TAIL": "1"}, {"PLP_QH_DEVICE_TAIL": "1", "PLP_QH_DEV_CAP": "1"},
-                {"PLP_QH_DEVICE_TAIL": "1", "PLP_QH_HOST_TAIL": "1000000000"}):
-        for key in ("PLP_QH_DEVICE_TAIL", "PLP_QH_DEV_CAP", "PLP_QH_HOST_TAIL"):
-            monkeypatch.delenv(key, raising=False)
-        for key, v in env.items():
-            monkeypatch.setenv(key, v)
-        np.random.seed(5)
-        outs.append(quickhull(P))
-    A0, b0, V0 = outs[0]
-    assert A0.shape[0] > 50
-    for A, b, V in outs[1:]:
-        assert np.array_equal(A, A0) and np.array_equal(b, b0) and np.array_equal(V, V0)
-
-
-@pytest.mark.gpu
-def test_device_facet_graph_in_reference_order(monkeypatch):
-    """The g8 hulls (a few hundred points) through the device-resident loop (own LU instead of dgesv: PLP_QH_LAPACK_BELOW=0):
-    the reference's facets in the reference's order, rows to 1e-12."""
-    from polytope_amd import solvers
-    from polytope_amd.quickhull import quickhull
-    monkeypatch.setattr(solvers, "default_solver", "hip")
-    monkeypatch.setenv("PLP_QH_DEVICE_TAIL", "1")
     monkeypatch.setenv("PLP_QH_LAPACK_BELOW", "0")
     g = load_golden("g8_hull.npz")
     for k in range(int(g["hull_ncases"])):
