@@ -1282,6 +1282,26 @@ def mldivide(a, b, save=False):
             # touches some member, in ONE batch here instead of a small batch per member there
             need = np.flatnonzero(np.asarray(touch, dtype=bool).any(axis=0))
             _cheby_fill([live_all[i] for i in need if live_all[i].fulldim is None])
+        # ... and the radius of [member; its first touching subtrahend] -- the opening scan of the first region_diff of every
+        # member's chain (its minuend is still the member itself) -- for ALL members in one batch instead of one launch each
+        # (is_subset(200 cells, 1000 cells): 200 launches of one LP, half of the call)
+        first_r = None
+        if touch is not None and len(live_all) == len(subs) and len(mine) > 1:
+            tb = np.asarray(touch, dtype=bool)
+            has = tb.any(axis=1)
+            firsts = tb.argmax(axis=1)
+            pairs = [(p, live_all[int(j)]) for p, h, j in zip(mine, has, firsts) if h]
+            if len(pairs) > 1 and len({(p.A.shape, c.A.shape) for p, c in pairs}) == 1 and \
+                    _fits_lp(pairs[0][0].A.shape[0] + pairs[0][1].A.shape[0], pairs[0][0].A.shape[1]):
+                A3 = np.concatenate([np.stack([p.A for p, _ in pairs]), np.stack([c.A for _, c in pairs])], axis=1)
+                b3 = np.concatenate([np.stack([p.b for p, _ in pairs]), np.stack([c.b for _, c in pairs])], axis=1)
+                norms = np.sqrt(np.sum(A3 * A3, 2))
+                if np.all(norms > 1e-10):   # (the constructor's row normalisation, ref :130-138, as _radii_stacked applies it)
+                    from .batch import cheby_ball_batch
+                    scale = 1 / norms
+                    res_ = cheby_ball_batch(A3 * scale[:, :, None], b3 * scale)
+                    ok_ = (res_["status"] == 0) & (res_["r"] >= 0)
+                    first_r = {id(p): (c, np.double(rr) if o else 0) for (p, c), rr, o in zip(pairs, res_["r"], ok_)}
         row = 0
         live_pos = None   # positions of the non-empty subtrahends in `subs` (empty ones always stay in the chain)
         for poly in a:
@@ -1303,8 +1323,12 @@ def mldivide(a, b, save=False):
                     sel[live_pos] = keep
                     touching = [subs[i] for i in np.flatnonzero(sel)]
             rest = poly
-            for sub in touching:
-                rest = mldivide(rest, sub, save=save)
+            for k_sub, sub in enumerate(touching):
+                if k_sub == 0 and first_r is not None and first_r.get(id(poly)) is not None and first_r[id(poly)][0] is sub:
+                    # the opening scan of this region_diff (ref :2148-2152) was part of the one batch above
+                    rest = region_diff(rest, sub, save=save, _Rc=[first_r[id(poly)][1]])
+                else:
+                    rest = mldivide(rest, sub, save=save)
             out = union(out, rest, check_convex=True)
         return out
     if isinstance(a, Polytope):
@@ -1388,7 +1412,7 @@ def _radii(polys, nan_without_verdict=False):
     return out
 
 
-def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _order=None):
+def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _order=None, _Rc=None):
     """poly minus the union of the polytopes of reg, as non-overlapping pieces.
 
     The cells of `reg` are visited in the order argsort(-Rc) of the Chebyshev radii of their stacks with `poly`
@@ -1419,7 +1443,8 @@ def region_diff(poly, reg, abs_tol=ABS_TOL, intersect_tol=ABS_TOL, save=False, _
         return Polytope()
     cells = reg.list_poly
     # which cells meet the polytope at all
-    Rc = np.array(_radii_stacked(poly, cells), dtype=float)
+    # (`_Rc`: the caller has these radii already -- mldivide's one batch over all members of a Region)
+    Rc = np.array(_radii_stacked(poly, cells) if _Rc is None or len(_Rc) != len(cells) else _Rc, dtype=float)
     N = int(np.sum(Rc >= intersect_tol))
     if N == 0:
         logger.debug("no Polytope in the Region intersects the given Polytope")
