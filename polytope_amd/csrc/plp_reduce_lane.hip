@@ -33,6 +33,13 @@
 
 namespace plp {
 
+#ifndef PLP_LANE_CH
+#define PLP_LANE_CH 4   // rows per trip of the ratio loop (the fewest rows a lane tests: 16 / 4 in quad mode)
+#endif
+#ifndef PLP_LANE_DEDUPE_SCREEN
+#define PLP_LANE_DEDUPE_SCREEN 1
+#endif
+
 constexpr int LN_ROWS = 16;   // row slots per polytope
 // GS lanes per polytope (4 / 8 / 16), R = 16 / GS rows per lane in the lane-group stages, NG = 64 / GS polytopes per tile
 // (= per wavefront).  GS = 4 is the throughput form; 8 and 16 put fewer polytopes on a wavefront and finish a tile in
@@ -219,6 +226,9 @@ __device__ __forceinline__ void reduce_lane_tile(
     // ---------------------------------------------------------------- dedupe (:1094-1110): every pair of rows once
     {
         unsigned remmask = 0u;
+#if PLP_LANE_DEDUPE_SCREEN
+        const double scr_thr = sqrt(2.0 * abs_tol) * 1.0001 + 1e-12;   // (wave-uniform)
+#endif
         double ni[R][D], bin_[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -234,6 +244,11 @@ __device__ __forceinline__ void reduce_lane_tile(
                 const int i = row0 + k;
                 const int j = (i + t) & 15;
                 const double an_j = LN(j);
+#if PLP_LANE_DEDUPE_SCREEN
+                // unit rows with dot > 1 - tol differ by less than sqrt(2 tol) in every component: when no pair of the
+                // wavefront passes that test on the first component (random rows: never) the pair is skipped
+                if (!__any(fabs(ni[k][0] - LA(j, 0) * an_j) < scr_thr)) continue;
+#endif
                 double dot = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < D; ++kk) dot = dot + ni[k][kk] * (LA(j, kk) * an_j);
@@ -312,9 +327,9 @@ __device__ __forceinline__ void reduce_lane_tile(
                 const double* ra = pA + i0 * D * LS;
                 const double* rb_ = pbeta + i0 * LS;
                 int ic = i0;
-                for (int ch = 0; ch < cnt; ch += 4) {
+                for (int ch = 0; ch < cnt; ch += PLP_LANE_CH) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < PLP_LANE_CH; ++r) {
                         const double a0 = ra[(r * D) * LS];
                         const double a1 = D > 1 ? ra[(r * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
                         const double a2 = D > 2 ? ra[(r * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
@@ -322,9 +337,9 @@ __device__ __forceinline__ void reduce_lane_tile(
                         if constexpr (RELAX) beta = beta + ((ic + r == krv) ? 0.1 : 0.0);
                         lane::ratio_row(a0, a1, a2, beta, ic + r, d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi);
                     }
-                    ra += 4 * D * LS;
-                    rb_ += 4 * LS;
-                    ic += 4;
+                    ra += PLP_LANE_CH * D * LS;
+                    rb_ += PLP_LANE_CH * LS;
+                    ic += PLP_LANE_CH;
                 }
                 auto meet = [&](auto ctrl) {
                     constexpr int CTRL = decltype(ctrl)::value;
