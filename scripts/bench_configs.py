@@ -148,6 +148,21 @@ def red():
                                        "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
 
 
+def c2s():
+    """The (16,3) fused reduce below the headline batch size: the latency forms of reduce_lane_kernel (8 / 4 polytopes per
+    wavefront) -- the shard of a strong-scaling step, the chunks of the end-to-end path, single calls."""
+    full = synth.random_hpolytopes(100000, 16, 3, seed=0)
+    for B in (50000, 25000, 12500, 6000, 1000, 64, 1):
+        At, bt = torch.as_tensor(full[0][:B]).to(dev), torch.as_tensor(full[1][:B]).to(dev)
+        res = pa.reduce_batch(At, bt)
+        nlp = int(res["nlp"].sum().item())
+        ms = timeit(lambda: pa.reduce_batch(At, bt), reps=21, warm=3)
+        by = B * (8 * 16 * 4 + 12)
+        print(json.dumps({"config": "fused reduce B=%d m=16 d=3" % B, "ms": ms, "lps": nlp, "lp_per_s": nlp / (ms * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                                       "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK}}), flush=True)
+
+
 def bbox():
     """bounding_box batches: the fused kernel (Chebyshev LP + 2d LPs from its centre) against the 2d generic LPs."""
     import numpy as np
