@@ -630,7 +630,7 @@ def main():
         # HBM bytes per launch from the PMC counters: they need their own counters-only rocprofv3
         # passes (scripts/gpu_check.sh), whose summary is committed by scripts/summarize_profiles.py
         traffic, traffic_src, valu = None, None, {}
-        kname = "reduce_lane_mix_kernel<3>"   # plp_reduce_lane.hip: tiles of 16 polytopes, the last eighth as tiles of 8
+        kname = "reduce_lane_mix_kernel<3, 16, 4, 8>"   # plp_reduce_lane.hip: tiles of 16 polytopes, the last eighth as tiles of 8
         try:
             with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
                 tj = json.load(f)

@@ -40,36 +40,37 @@ namespace plp {
 #define PLP_LANE_DEDUPE_SCREEN 1
 #endif
 
-constexpr int LN_ROWS = 16;   // row slots per polytope
+constexpr int LN_ROWS = 16;   // row slots per polytope (ROWS = 32: polytopes of 17..32 rows, e.g. the stack of Polytope.intersect, ref :268-275)
 // GS lanes per polytope (4 / 8 / 16), R = 16 / GS rows per lane in the lane-group stages, NG = 64 / GS polytopes per tile
 // (= per wavefront).  GS = 4 is the throughput form; 8 and 16 put fewer polytopes on a wavefront and finish a tile in
 // about 0.6 / 0.4 of the time: the latency forms for batches that cannot fill the chip, and the tail of a large launch.
 
-static inline size_t reduce_lane_smem_bytes(int D, int GS) { return (size_t)(64 / GS) * LN_ROWS * (D + 2) * 8; }
+static inline size_t reduce_lane_smem_bytes(int D, int GS, int ROWS = LN_ROWS) { return (size_t)(64 / GS) * ROWS * (D + 2) * 8; }
 
 // The polytopes of a tile that the fast path handed back (bit GS p of `rb64`: polytope p), redone by the general engine
 // (plp_reduce_general.hpp: one dictionary row per lane, 16 lanes per polytope, Bland's rule in the simplex).
-template <int D, int GS>
+template <int D, int GS, int ROWS>
 __device__ __noinline__ void reduce_lane_redo(unsigned char* smem_raw, const long long tile, const int ntile, const uint64_t rb64,
                                               int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
                                               const int* __restrict__ mrows, double abs_tol,
                                               unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
                                               double* __restrict__ r_out, double* __restrict__ xc_out,
                                               int* __restrict__ nlp_out) {
-    for (int sub = 0; sub < (64 / GS) / 4; ++sub) {
-        unsigned four = 0u;   // bit q: polytope 4 sub + q
+    constexpr int PER = 64 / ROWS;   // polytopes per pass of the general engine (ROWS lanes each)
+    for (int sub = 0; sub < (64 / GS) / PER; ++sub) {
+        unsigned some = 0u;   // bit q: polytope PER sub + q
 #pragma unroll
-        for (int q = 0; q < 4; ++q) four |= (unsigned)((rb64 >> (GS * (4 * sub + q))) & 1ull) << q;
-        if (four == 0u) continue;   // wave-uniform
-        const int q = (threadIdx.x & 63) >> 4;
-        const bool mine = ((four >> q) & 1u) != 0u;
-        const int left = ntile - 4 * sub;
-        reduce_general_tile<D, RBLOCK>(smem_raw, tile + 4 * sub, left < 4 ? left : 4, mine, m_max, 16, Ag, bg, mrows, abs_tol,
+        for (int q = 0; q < PER; ++q) some |= (unsigned)((rb64 >> (GS * (PER * sub + q))) & 1ull) << q;
+        if (some == 0u) continue;   // wave-uniform
+        const int q = (threadIdx.x & 63) / ROWS;
+        const bool mine = ((some >> q) & 1u) != 0u;
+        const int left = ntile - PER * sub;
+        reduce_general_tile<D, RBLOCK>(smem_raw, tile + PER * sub, left < PER ? left : PER, mine, m_max, ROWS, Ag, bg, mrows, abs_tol,
                                        keep_out, flags_out, r_out, xc_out, nlp_out);
     }
 }
 
-template <int D, int GS>
+template <int D, int GS, int ROWS = LN_ROWS>
 __device__ __forceinline__ void reduce_lane_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -78,7 +79,8 @@ __device__ __forceinline__ void reduce_lane_tile(
     static_assert(D >= 1 && D <= 3, "the lane engine walks in R^3 (lower dimensions are embedded)");
     static_assert(RBLOCK == 64, "one wavefront per workgroup");
     static_assert(GS == 4 || GS == 8 || GS == 16, "lanes per polytope");
-    constexpr int rows = LN_ROWS, R = rows / GS, NG = 64 / GS;
+    static_assert((ROWS == 16 || ROWS == 32) && ROWS / GS >= 1 && ROWS / GS <= 4, "row slots per polytope, at most four per lane");
+    constexpr int rows = ROWS, R = rows / GS, NG = 64 / GS;
     constexpr unsigned RMASK = (1u << R) - 1u;
     constexpr int LS = NG;   // stride between consecutive elements of one polytope
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -238,11 +240,11 @@ __device__ __forceinline__ void reduce_lane_tile(
             bin_[k] = OB(k) * an_i;
         }
 #pragma unroll 2
-        for (int t = 1; t <= 8; ++t) {
+        for (int t = 1; t <= rows / 2; ++t) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int i = row0 + k;
-                const int j = (i + t) & 15;
+                const int j = (i + t) & (rows - 1);
                 const double an_j = LN(j);
 #if PLP_LANE_DEDUPE_SCREEN
                 // unit rows with dot > 1 - tol differ by less than sqrt(2 tol) in every component: when no pair of the
@@ -547,7 +549,7 @@ __device__ __forceinline__ void reduce_lane_tile(
     if (rb64 != 0ull) {
         __threadfence_block();   // my r / xc stores of these polytopes are out before they are written again
         __syncthreads();
-        reduce_lane_redo<D, GS>(smem_raw, tile, ntile, rb64, m_max, Ag, bg, mrows, abs_tol, keep_out, flags_out, r_out, xc_out,
+        reduce_lane_redo<D, GS, ROWS>(smem_raw, tile, ntile, rb64, m_max, Ag, bg, mrows, abs_tol, keep_out, flags_out, r_out, xc_out,
                             nlp_out);
     }
 #undef LA
@@ -562,34 +564,38 @@ __device__ __forceinline__ void reduce_lane_tile(
 #define PLP_REDUCE_LANE_WAVES 4   // (GS = 4: 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD)
 #endif
 
-template <int D, int GS>
+template <int D, int GS, int ROWS = LN_ROWS>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
     double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
     double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
-    reduce_lane_tile<D, GS>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
-                            flags_out, r_out, xc_out, nlp_out, ctr);
+    reduce_lane_tile<D, GS, ROWS>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                                  flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
-// The first `nbig` workgroups take tiles of 16 polytopes, the rest tiles of 8 (which finish in about 0.6 of the time): the
-// launch drains over one tile lifetime, and with short tiles dispatched last that window shrinks.
-template <int D>
+// The first `nbig` workgroups take tiles of 64 / GSA polytopes, the rest tiles of 64 / GSB (half as many, which finish in
+// about 0.6 of the time): the launch drains over one tile lifetime, and with short tiles dispatched last that window shrinks.
+template <int D, int ROWS, int GSA, int GSB>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_mix_kernel(
     int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
     unsigned long long* __restrict__ ctr) {
+    constexpr int NA = 64 / GSA, NB_ = 64 / GSB;
     if ((int)blockIdx.x < nbig)
-        reduce_lane_tile<D, 4>((long long)blockIdx.x * 16, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out, flags_out,
-                               r_out, xc_out, nlp_out, ctr);
+        reduce_lane_tile<D, GSA, ROWS>((long long)blockIdx.x * NA, B, m_max, Ag, bg, mrows, abs_tol, force_retry, keep_out,
+                                       flags_out, r_out, xc_out, nlp_out, ctr);
     else
-        reduce_lane_tile<D, 8>((long long)nbig * 16 + (long long)((int)blockIdx.x - nbig) * 8, B, m_max, Ag, bg, mrows, abs_tol,
-                               force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
+        reduce_lane_tile<D, GSB, ROWS>((long long)nbig * NA + (long long)((int)blockIdx.x - nbig) * NB_, B, m_max, Ag, bg, mrows,
+                                       abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
 // Tile shape by batch size, measured on (16,3) batches (scripts/debug/lane_sweep.py, us per launch GS 4 / 8 / 16):
 //   B = 3 000: 51 / 35 / 27.5    8 000: 56 / 38 / 34    12 000: 58 / 46 / 41    16 000: 58 / 47 / 49    20 000: 66 / 56 / 62
 //   30 000: 71 / 69 / 81    40 000: 89 / 88 / 101    (lane-group kernels: 40 / 48 / 60 / 62 / 75 / 91 / 106)
+#ifndef PLP_REDUCE_LANE32_GS16_MAXB
+#define PLP_REDUCE_LANE32_GS16_MAXB 16000  // 17..32 rows: batches up to this size on 4 polytopes per wavefront
+#endif
 #ifndef PLP_REDUCE_LANE_GS8_MAXB
 #define PLP_REDUCE_LANE_GS8_MAXB 40000   // batches up to this size: 8 polytopes per wavefront
 #endif
@@ -608,6 +614,31 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
     const char* fr = getenv("PLP_REDUCE_RETRY_ALL");
     const int force = (fr && fr[0] == '1') ? 1 : 0;
     const char* eg = getenv("PLP_REDUCE_LANE_GS");   // 4 / 8 / 16: that tile shape whatever the batch size (A/B)
+    if (m_max > LN_ROWS) {
+        // 17..32 rows: 32 row slots per polytope, 8 polytopes per wavefront (four rows per lane) or 4 (two rows per lane)
+        int gs32 = B <= PLP_REDUCE_LANE32_GS16_MAXB ? 16 : 8;
+        if (eg) gs32 = atoi(eg) == 16 ? 16 : 8;
+        const long long ng32 = 64 / gs32;
+        long long blocks32 = (B + ng32 - 1) / ng32;
+        if (blocks32 < 1) blocks32 = 1;
+        const char* mx32 = getenv("PLP_REDUCE_LANE_MIX");
+        long long tail32 = blocks32 / 8 < 1024 ? blocks32 / 8 : 1024;
+        if (mx32) tail32 = blocks32 * atoi(mx32) / 64;
+        if (eg) tail32 = 0;
+        if (gs32 == 16)
+            hipLaunchKernelGGL((reduce_lane_kernel<D, 16, 32>), dim3((unsigned)blocks32), dim3(RBLOCK), reduce_lane_smem_bytes(D, 16, 32),
+                               st, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
+        else if (tail32 > 0 && blocks32 > 512) {
+            const long long nbig = blocks32 - tail32;
+            const long long nsmall = (B - nbig * 8 + 3) / 4;
+            hipLaunchKernelGGL((reduce_lane_mix_kernel<D, 32, 8, 16>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
+                               reduce_lane_smem_bytes(D, 8, 32), st, (int)nbig, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r,
+                               xc, nlp, t_reduce_ctr);
+        } else
+            hipLaunchKernelGGL((reduce_lane_kernel<D, 8, 32>), dim3((unsigned)blocks32), dim3(RBLOCK), reduce_lane_smem_bytes(D, 8, 32),
+                               st, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
+        return 3;
+    }
     int gs = B <= PLP_REDUCE_LANE_GS16_MAXB ? 16 : (B <= PLP_REDUCE_LANE_GS8_MAXB ? 8 : 4);
     if (eg) gs = atoi(eg) == 16 ? 16 : (atoi(eg) == 8 ? 8 : 4);
     const long long ng = 64 / gs;
@@ -628,7 +659,7 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
             const long long nbig = blocks - tail_tiles;
             const long long rest = B - nbig * 16;
             const long long nsmall = (rest + 7) / 8;
-            hipLaunchKernelGGL((reduce_lane_mix_kernel<D>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
+            hipLaunchKernelGGL((reduce_lane_mix_kernel<D, LN_ROWS, 4, 8>), dim3((unsigned)(nbig + nsmall)), dim3(RBLOCK),
                                reduce_lane_smem_bytes(D, 4), st, (int)nbig, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r,
                                xc, nlp, t_reduce_ctr);
         } else {
@@ -642,7 +673,7 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
 // returns 3 when launched (complete: launch_reduce adds no second pass), 1 when this kernel does not take the shape
 int launch_reduce_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
                        unsigned long long* keep, int* flags, double* r, double* xc, int* nlp, hipStream_t st) {
-    if (m_max < 1 || m_max > LN_ROWS) return 1;
+    if (m_max < 1 || m_max > 2 * LN_ROWS) return 1;
     switch (d) {
         case 1: return launch_reduce_lane_d<1>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
         case 2: return launch_reduce_lane_d<2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);

@@ -77,8 +77,8 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || d < 1 || d > MAX_D) return 1;
-    if (d <= 3 && m_max <= 16) {
-        // up to 16 rows in d <= 3 (the bench shape): F3 / F2 one LP per lane (plp_reduce_lane.hip), at every batch size;
+    if (d <= 3 && m_max <= 32) {
+        // up to 32 rows in d <= 3 (the bench shape; the stacks of Polytope.intersect): F3 / F2 one LP per lane (plp_reduce_lane.hip), at every batch size;
         // PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
         const char* ln = getenv("PLP_REDUCE_LANE");
         const bool other = getenv("PLP_REDUCE_SPLIT") || getenv("PLP_REDUCE_HALF") || getenv("PLP_REDUCE_MIX") || getenv("PLP_REDUCE_R8");

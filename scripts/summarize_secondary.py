@@ -66,7 +66,7 @@ def ctr(passname, kernel_sub, counter, full_grid_only=True):
 
 
 # bench kernel: measured counters (passes bench_pmc_1..7 of gpu_profile_all.sh)
-K = sys.argv[3] if len(sys.argv) > 3 else "reduce_lane_mix_kernel<3>"   # the bench kernel: tiles of 16 polytopes, the last eighth of them as tiles of 8
+K = sys.argv[3] if len(sys.argv) > 3 else "reduce_lane_mix_kernel<3, 16, 4, 8>"   # the bench kernel: tiles of 16 polytopes, the last eighth of them as tiles of 8
 vals = {}
 for p in sorted(summ):
     if not p.startswith("bench_pmc_"):

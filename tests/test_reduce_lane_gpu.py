@@ -1,5 +1,5 @@
 """GPU: reduce_lane_kernel (polytope_amd/csrc/plp_reduce_lane.hip) -- the fused reduce() (polytope/polytope.py:1053-1163) of
-polytopes with up to 16 rows in d <= 3 with the box LPs (:1118-1134) and the redundancy LPs (:1142-1160) solved one LP per
+polytopes with up to 32 rows in d <= 3 with the box LPs (:1118-1134) and the redundancy LPs (:1142-1160) solved one LP per
 lane (plp_lane_lp.hpp).  Parity bar: keep mask, flags and LP count equal to the oracle's and to the lane-group kernels',
 r / xc bit for bit the lane-group kernels' (the same F1), every tile shape bit for bit the same, and the polytopes the
 fast path hands back redone inside the kernel with the same result."""
@@ -84,7 +84,8 @@ def _spoil(A, b, rng):
 def test_lane_kernel_equals_oracle_and_lane_group_kernels(run, oracle):
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(17)
-    for (m, d) in [(16, 3), (12, 3), (7, 3), (3, 3), (16, 2), (9, 2), (4, 2), (6, 1), (2, 1)]:
+    for (m, d) in [(16, 3), (12, 3), (7, 3), (3, 3), (16, 2), (9, 2), (4, 2), (6, 1), (2, 1),
+                   (32, 3), (24, 3), (17, 3), (32, 2), (21, 2), (20, 1)]:   # (17..32 rows: 32 row slots per polytope)
         for B in (1, 7, 130, 3000):
             A, b = random_hpolytopes(B, m, d, seed=13 * m + d + B, bounded=(B != 130))
             lane = run(A, b)
@@ -107,12 +108,12 @@ def test_lane_tile_shapes_bit_for_bit(run, oracle):
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(4)
     for (B, m, d) in [(1, 16, 3), (77, 16, 3), (9000, 16, 3), (14003, 13, 3), (41000, 16, 3), (70001, 16, 3), (5000, 16, 2),
-                      (3000, 5, 1)]:
+                      (3000, 5, 1), (9, 32, 3), (9000, 32, 3), (17000, 24, 2), (30001, 19, 3)]:
         A, b = random_hpolytopes(B, m, d, seed=B + m)
         for spoiled in (False, True):
             if spoiled:
                 _spoil(A, b, rng)
-            ref = run(A, b, PLP_REDUCE_LANE_GS=4)
+            ref = run(A, b, PLP_REDUCE_LANE_GS=4 if m <= 16 else 8)   # (17..32 rows: 8 or 4 polytopes per wavefront)
             if B <= 20000:
                 assert _vs_oracle(oracle, ref, A, b), (B, m, d)
             for env in ({"PLP_REDUCE_LANE_GS": 8}, {"PLP_REDUCE_LANE_GS": 16}, {}, {"PLP_REDUCE_LANE_MIX": 0}, {"PLP_REDUCE_LANE_MIX": 24}):
@@ -129,7 +130,7 @@ def test_lane_handover_inside_the_kernel(run, oracle):
     from test_gpu_parity import _pyramids
     rng = np.random.default_rng(23)
     for gs in (4, 8, 16):
-        for (B, m, d) in [(3000, 16, 3), (700, 11, 2), (50, 4, 1)]:
+        for (B, m, d) in [(3000, 16, 3), (700, 11, 2), (50, 4, 1), (900, 32, 3), (500, 23, 2)]:
             A, b = random_hpolytopes(B, m, d, seed=gs + B)
             _spoil(A, b, rng)
             forced = run(A, b, PLP_REDUCE_LANE_GS=gs, PLP_REDUCE_RETRY_ALL=1)
