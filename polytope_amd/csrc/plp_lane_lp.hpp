@@ -39,6 +39,11 @@ namespace plp {
 namespace lane {
 
 constexpr int LANE_MAX_ITERS = 48;   // steps + drops of one LP before it is handed back
+// The walk's own tolerances, RELATIVE to the direction's / the cost's length (the dictionary simplex's TOL_D / TOL_PIV are
+// absolute 1e-9 on dictionary entries).  A row whose a.d is below LANE_TOL_PIV |d| is not a blocking row: the walk may pass
+// it by t a.d, a few 1e-11; a projected gradient below LANE_TOL_D |c| counts as zero: the optimum is off by no more than that
+// times the distance left.  (1e-9 for both, the first version, showed as 2e-10 on 3 of 120 000 box LPs at d = 4.)
+constexpr double LANE_TOL_D = 1e-11, LANE_TOL_PIV = 1e-11;
 
 struct Lp3 {
     double x0, x1, x2;     // x' (relative to the Chebyshev centre)
@@ -112,7 +117,7 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
         }
         {
             const double dn1 = fabs(d0) + fabs(d1) + fabs(d2);
-            stalled = !(dn1 > TOL_D * dscale);
+            stalled = !(dn1 > LANE_TOL_D * dscale);
         }
         if (ANY(S.status < 0 && stalled)) {
             if (S.status < 0 && stalled) {
@@ -134,7 +139,7 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
                     // lambda_j |n_j| >= -TOL_D |c|, with |n_j| <= w_j = (1 + n_j.n_j) / 2 in its place (no square root;
                     // equal for unit rows, a little stricter otherwise) and det <= g00 g11
                     const double w0 = 0.5 * (1.0 + g00), w1 = 0.5 * (1.0 + g11);
-                    const double tol0 = TOL_D * g11 * w0 * cn1, tol1 = TOL_D * g00 * w1 * cn1;
+                    const double tol0 = LANE_TOL_D * g11 * w0 * cn1, tol1 = LANE_TOL_D * g00 * w1 * cn1;
                     if (l0 >= -tol0 && l1 >= -tol1) S.status = ST_OPT;
                     else {
                         // drop the more negative one (as weighted multipliers; a row with a negative one either way)
@@ -165,7 +170,7 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
                         const double l2 = -sg * dot3(c0, c1, c2, u20, u21, u22);
                         // lambda_j |n_j| / |c|  =  l_j |n_j| / (|det| |c|), with w_j = (1 + n_j.n_j) / 2 >= |n_j| in its place
                         const double a0 = l0 * (0.5 * (1.0 + g00)), a1 = l1 * (0.5 * (1.0 + g11)), a2 = l2 * (0.5 * (1.0 + g22));
-                        const double tol = TOL_D * fabs(det) * cn1;
+                        const double tol = LANE_TOL_D * fabs(det) * cn1;
                         if (a0 >= -tol && a1 >= -tol && a2 >= -tol) S.status = ST_OPT;
                         else {
                             // most negative goes; the edge of the other two, oriented off the dropped row: -sgn(det) u_j
@@ -185,7 +190,7 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
         // ---------------- ratio test over the rows: the first row the ray x' + t d meets
         const bool step = S.status < 0;
         const double dn1 = fabs(d0) + fabs(d1) + fabs(d2);
-        const double tolp = TOL_PIV * dn1;
+        const double tolp = LANE_TOL_PIV * dn1;
         double bs = 1.0, bd = 0.0;   // best slack / best a.d  (ratio bs / bd; bd = 0: none yet)
         int bi = -1;
         if (ANY(step)) RATIO(d0, d1, d2, S.x0, S.x1, S.x2, tolp, bs, bd, bi);
@@ -207,6 +212,217 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same walk in R^4 (d = 4: the dimension of BASELINE config 4).  Directions are projections written with the Gram
+// matrix of the active rows and its adjugate (no division: everything is scaled by the positive determinant), the
+// vertex test with generalised cross products:  for rows p, q, r of R^4,  e = gcross(p, q, r)  is orthogonal to all
+// three and  v.e = det[v; p; q; r].
+struct Lp4 {
+    double x0, x1, x2, x3;
+    int w0, w1, w2, w3;
+    int nact, status, iters, ndeg;
+};
+
+PLP_LANE_FN double dot4(double a0, double a1, double a2, double a3, double b0, double b1, double b2, double b3) {
+    return fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0)));
+}
+
+PLP_LANE_FN void gcross4(double p0, double p1, double p2, double p3, double q0, double q1, double q2, double q3, double r0,
+                         double r1, double r2, double r3, double& e0, double& e1, double& e2, double& e3) {
+    // 2 x 2 minors of (q, r), then the four 3 x 3 minors with alternating signs
+    const double m01 = fma(q0, r1, -(q1 * r0)), m02 = fma(q0, r2, -(q2 * r0)), m03 = fma(q0, r3, -(q3 * r0));
+    const double m12 = fma(q1, r2, -(q2 * r1)), m13 = fma(q1, r3, -(q3 * r1)), m23 = fma(q2, r3, -(q3 * r2));
+    e0 = fma(p1, m23, fma(-p2, m13, p3 * m12));
+    e1 = -fma(p0, m23, fma(-p2, m03, p3 * m02));
+    e2 = fma(p0, m13, fma(-p1, m03, p3 * m01));
+    e3 = -fma(p0, m12, fma(-p1, m02, p2 * m01));
+}
+
+// ROWS(i, a0, a1, a2, a3);  RATIO(d0, d1, d2, d3, x0, x1, x2, x3, tolp, bs, bd, bi);  ANY as in walk3.
+template <class RowF, class RatioF, class AnyF>
+PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2, const double c3, const bool go, RowF ROWS,
+                       RatioF RATIO, AnyF ANY) {
+    S.x0 = S.x1 = S.x2 = S.x3 = 0.0;
+    S.w0 = S.w1 = S.w2 = S.w3 = -1;
+    S.nact = 0;
+    S.iters = 0;
+    S.ndeg = 0;
+    S.status = go ? -1 : ST_OPT;
+    const double cn1 = fabs(c0) + fabs(c1) + fabs(c2) + fabs(c3);
+    if (go && !(cn1 > 0.0)) S.status = ST_OPT;
+    while (ANY(S.status < 0)) {
+        const bool run = S.status < 0;
+        double d0 = -c0, d1 = -c1, d2 = -c2, d3 = -c3;
+        double n00 = 0, n01 = 0, n02 = 0, n03 = 0, n10 = 0, n11 = 0, n12 = 0, n13 = 0;
+        double n20 = 0, n21 = 0, n22 = 0, n23 = 0, n30 = 0, n31 = 0, n32 = 0, n33 = 0;
+        if (ANY(run && S.nact >= 1)) {
+            if (S.nact >= 1) ROWS(S.w0, n00, n01, n02, n03);
+            if (S.nact >= 2) ROWS(S.w1, n10, n11, n12, n13);
+            if (S.nact >= 3) ROWS(S.w2, n20, n21, n22, n23);
+            if (S.nact >= 4) ROWS(S.w3, n30, n31, n32, n33);
+        }
+        // Gram entries and right-hand sides r_j = c.n_j of the active rows (zero rows where there is none)
+        const double g00 = dot4(n00, n01, n02, n03, n00, n01, n02, n03), g11 = dot4(n10, n11, n12, n13, n10, n11, n12, n13);
+        const double g22 = dot4(n20, n21, n22, n23, n20, n21, n22, n23);
+        const double g01 = dot4(n00, n01, n02, n03, n10, n11, n12, n13), g02 = dot4(n00, n01, n02, n03, n20, n21, n22, n23);
+        const double g12 = dot4(n10, n11, n12, n13, n20, n21, n22, n23);
+        const double r0 = dot4(c0, c1, c2, c3, n00, n01, n02, n03), r1 = dot4(c0, c1, c2, c3, n10, n11, n12, n13);
+        const double r2 = dot4(c0, c1, c2, c3, n20, n21, n22, n23);
+        // m_j: det * (coefficient of n_j in the projection of c onto the span of the active rows); lambda_j = -m_j / det
+        double det = 1.0, m0 = 0.0, m1 = 0.0, m2 = 0.0;
+        if (S.nact == 1) {
+            det = g00;
+            m0 = r0;
+        } else if (S.nact == 2) {
+            det = fma(g00, g11, -(g01 * g01));
+            m0 = fma(r0, g11, -(r1 * g01));
+            m1 = fma(r1, g00, -(r0 * g01));
+            if (run && !(det > 1e-16 * g00 * g11)) S.status = ST_RETRY;   // (numerically) parallel active rows
+        } else if (S.nact == 3) {
+            const double A00 = fma(g11, g22, -(g12 * g12)), A01 = fma(g02, g12, -(g01 * g22)), A02 = fma(g01, g12, -(g02 * g11));
+            const double A11 = fma(g00, g22, -(g02 * g02)), A12 = fma(g01, g02, -(g00 * g12)), A22 = fma(g00, g11, -(g01 * g01));
+            det = fma(g00, A00, fma(g01, A01, g02 * A02));
+            m0 = fma(A00, r0, fma(A01, r1, A02 * r2));
+            m1 = fma(A01, r0, fma(A11, r1, A12 * r2));
+            m2 = fma(A02, r0, fma(A12, r1, A22 * r2));
+            if (run && !(det > 1e-16 * g00 * g11 * g22)) S.status = ST_RETRY;   // three active planes that nearly share a plane
+        }
+        if (S.nact >= 1 && S.nact <= 3) {
+            d0 = fma(m2, n20, fma(m1, n10, fma(m0, n00, -(det * c0))));
+            d1 = fma(m2, n21, fma(m1, n11, fma(m0, n01, -(det * c1))));
+            d2 = fma(m2, n22, fma(m1, n12, fma(m0, n02, -(det * c2))));
+            d3 = fma(m2, n23, fma(m1, n13, fma(m0, n03, -(det * c3))));
+        } else if (S.nact == 4) {
+            d0 = d1 = d2 = d3 = 0.0;
+        }
+        const double dscale = (S.nact >= 1 && S.nact <= 3) ? det * cn1 : cn1;
+        const bool stalled = !(fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3) > LANE_TOL_D * dscale);
+        if (ANY(S.status < 0 && stalled)) {
+            if (S.status < 0 && stalled) {
+                // multipliers of  c + sum lambda_j n_j = 0:  lambda_j |n_j| >= -TOL_D |c|  with  w_j = (1 + n_j.n_j) / 2 >= |n_j|
+                // in its place; all fine: optimal.  Otherwise the row with the most negative one is dropped.
+                const double w0 = 0.5 * (1.0 + g00), w1 = 0.5 * (1.0 + g11), w2 = 0.5 * (1.0 + g22);
+                if (S.nact == 0) {
+                    S.status = ST_OPT;
+                } else if (S.nact <= 3) {
+                    const double tol = LANE_TOL_D * det * cn1;
+                    const double a0 = -m0 * w0, a1 = S.nact >= 2 ? -m1 * w1 : 0.0, a2 = S.nact >= 3 ? -m2 * w2 : 0.0;
+                    if (a0 >= -tol && a1 >= -tol && a2 >= -tol) {
+                        S.status = ST_OPT;
+                    } else {
+                        int j = 0;
+                        double am = a0;
+                        if (a1 < am) { am = a1; j = 1; }
+                        if (a2 < am) { am = a2; j = 2; }
+                        // remove row j from the list; the direction is the projection onto the remaining rows
+                        if (j == 0) { S.w0 = S.w1; n00 = n10; n01 = n11; n02 = n12; n03 = n13; }
+                        if (j <= 1) { S.w1 = S.w2; n10 = n20; n11 = n21; n12 = n22; n13 = n23; }
+                        S.nact -= 1;
+                        if (S.nact == 0) {
+                            d0 = -c0; d1 = -c1; d2 = -c2; d3 = -c3;
+                        } else {
+                            const double h00 = dot4(n00, n01, n02, n03, n00, n01, n02, n03);
+                            const double q0 = dot4(c0, c1, c2, c3, n00, n01, n02, n03);
+                            double dd = h00, k0 = q0, k1 = 0.0;
+                            if (S.nact == 2) {
+                                const double h11 = dot4(n10, n11, n12, n13, n10, n11, n12, n13);
+                                const double h01 = dot4(n00, n01, n02, n03, n10, n11, n12, n13);
+                                const double q1 = dot4(c0, c1, c2, c3, n10, n11, n12, n13);
+                                dd = fma(h00, h11, -(h01 * h01));
+                                k0 = fma(q0, h11, -(q1 * h01));
+                                k1 = fma(q1, h00, -(q0 * h01));
+                            }
+                            d0 = fma(k1, n10, fma(k0, n00, -(dd * c0)));
+                            d1 = fma(k1, n11, fma(k0, n01, -(dd * c1)));
+                            d2 = fma(k1, n12, fma(k0, n02, -(dd * c2)));
+                            d3 = fma(k1, n13, fma(k0, n03, -(dd * c3)));
+                        }
+                    }
+                } else {
+                    // a vertex: u_j = gcross(the other three rows) is orthogonal to them, N^-1[:, j] = u_j / (n_j.u_j),
+                    // lambda_j = -(u_j.c) / (n_j.u_j); leaving row j: along -sgn(n_j.u_j) u_j
+                    const double g33 = dot4(n30, n31, n32, n33, n30, n31, n32, n33);
+                    const double w3 = 0.5 * (1.0 + g33);
+                    double am = 0.0, bd0 = 0.0, bd1 = 0.0, bd2 = 0.0, bd3 = 0.0, dj_abs = 0.0;
+                    int jbest = -1;
+                    bool all_ok = true, singular = false;
+#define PLP_W4_VERTEX(J, P, Q, R, NJ0, NJ1, NJ2, NJ3, WJ)                                                          \
+                    {                                                                                                   \
+                        double u0, u1, u2, u3;                                                                          \
+                        gcross4(P##0, P##1, P##2, P##3, Q##0, Q##1, Q##2, Q##3, R##0, R##1, R##2, R##3, u0, u1, u2, u3); \
+                        const double dj = dot4(NJ0, NJ1, NJ2, NJ3, u0, u1, u2, u3);                                     \
+                        const double sg = dj > 0.0 ? 1.0 : -1.0;                                                        \
+                        const double lj = -sg * dot4(c0, c1, c2, c3, u0, u1, u2, u3);                                   \
+                        const double aj = lj * (WJ);                                                                    \
+                        dj_abs = fabs(dj);                                                                              \
+                        singular = singular | !(dj * dj > 1e-18 * (g00 * g11 * g22 * g33));                            \
+                        all_ok = all_ok & (aj >= -(LANE_TOL_D * dj_abs * cn1));                                              \
+                        const bool better = (jbest < 0) | (aj < am);                                                    \
+                        am = better ? aj : am;                                                                          \
+                        jbest = better ? (J) : jbest;                                                                   \
+                        bd0 = better ? -sg * u0 : bd0;                                                                  \
+                        bd1 = better ? -sg * u1 : bd1;                                                                  \
+                        bd2 = better ? -sg * u2 : bd2;                                                                  \
+                        bd3 = better ? -sg * u3 : bd3;                                                                  \
+                    }
+                    PLP_W4_VERTEX(0, n1, n2, n3, n00, n01, n02, n03, w0)
+                    PLP_W4_VERTEX(1, n0, n2, n3, n10, n11, n12, n13, w1)
+                    PLP_W4_VERTEX(2, n0, n1, n3, n20, n21, n22, n23, w2)
+                    PLP_W4_VERTEX(3, n0, n1, n2, n30, n31, n32, n33, w3)
+#undef PLP_W4_VERTEX
+                    if (singular) S.status = ST_RETRY;   // four active planes that (nearly) share a line
+                    else if (all_ok) S.status = ST_OPT;
+                    else {
+                        d0 = bd0; d1 = bd1; d2 = bd2; d3 = bd3;
+                        if (jbest == 0) S.w0 = S.w1;
+                        if (jbest <= 1) S.w1 = S.w2;
+                        if (jbest <= 2) S.w2 = S.w3;
+                        S.nact = 3;
+                    }
+                }
+            }
+        }
+        const bool step = S.status < 0;
+        const double dn1 = fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3);
+        const double tolp = LANE_TOL_PIV * dn1;
+        double bs = 1.0, bd = 0.0;
+        int bi = -1;
+        if (ANY(step)) RATIO(d0, d1, d2, d3, S.x0, S.x1, S.x2, S.x3, tolp, bs, bd, bi);
+        if (step) {
+            ++S.iters;
+            if (bi < 0) {
+                S.status = ST_UNBND;
+            } else {
+                const double t = bs / bd;
+                S.x0 = fma(t, d0, S.x0);
+                S.x1 = fma(t, d1, S.x1);
+                S.x2 = fma(t, d2, S.x2);
+                S.x3 = fma(t, d3, S.x3);
+                if (S.nact == 0) S.w0 = bi;
+                else if (S.nact == 1) S.w1 = bi;
+                else if (S.nact == 2) S.w2 = bi;
+                else S.w3 = bi;
+                S.nact += 1;
+                S.ndeg = (t * dn1 <= DEGEN_EPS) ? S.ndeg + 1 : 0;
+                if (S.ndeg >= BLAND_AFTER || S.iters >= LANE_MAX_ITERS) S.status = ST_RETRY;
+            }
+        }
+    }
+}
+
+PLP_LANE_FN void ratio_row4(const double a0, const double a1, const double a2, const double a3, const double beta, const int i,
+                            const double d0, const double d1, const double d2, const double d3, const double x0,
+                            const double x1, const double x2, const double x3, const double tolp, double& bs, double& bd,
+                            int& bi) {
+    const double ad = dot4(a0, a1, a2, a3, d0, d1, d2, d3);
+    const double ax = dot4(a0, a1, a2, a3, x0, x1, x2, x3);
+    const double sl = fmax(beta - ax, 0.0);
+    const bool better = (ad > tolp) & (sl * bd < bs * ad);
+    bs = better ? sl : bs;
+    bd = better ? ad : bd;
+    bi = better ? i : bi;
 }
 
 // One step of the ratio test: row (a0, a1, a2) with right-hand side `beta` and index i against the best so far.

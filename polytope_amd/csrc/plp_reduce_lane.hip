@@ -76,7 +76,7 @@ __device__ __forceinline__ void reduce_lane_tile(
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
     unsigned long long* __restrict__ ctr) {
-    static_assert(D >= 1 && D <= 3, "the lane engine walks in R^3 (lower dimensions are embedded)");
+    static_assert(D >= 1 && D <= 4, "the lane engine walks in R^3 (lower dimensions are embedded) or R^4");
     static_assert(RBLOCK == 64, "one wavefront per workgroup");
     static_assert(GS == 4 || GS == 8 || GS == 16, "lanes per polytope");
     static_assert((ROWS == 16 || ROWS == 32) && ROWS / GS >= 1 && ROWS / GS <= 4, "row slots per polytope, at most four per lane");
@@ -312,51 +312,82 @@ __device__ __forceinline__ void reduce_lane_tile(
     // ratio, on ties the lower row: the row a single lane would have found first).  `nparts` is wave-uniform.
     // pA / pbeta: the polytope's rows / right-hand sides in the interleaved tile; RELAX: row krv's right-hand side + 0.1
     // (:1149) -- an add of 0.1 or 0, not a select between a constant and the LDS value (that becomes a branch around the load).
-    auto lane_solve = [&](lane::Lp3& S, const double c0, const double c1, const double c2, const bool go_, const double* pA,
-                          const double* pbeta, auto relax_tag, int krv, const int nparts, const int part) {
+    using LpState = std::conditional_t<D == 4, lane::Lp4, lane::Lp3>;   // d <= 3: the walk in R^3 (lower dimensions embedded); d = 4: in R^4
+    auto lane_solve = [&](LpState& S, const double (&cv)[4], const bool go_, const double* pA, const double* pbeta, auto relax_tag,
+                          int krv, const int nparts, const int part) {
         constexpr bool RELAX = decltype(relax_tag)::value;
         const int cnt = rows / nparts;   // wave-uniform
         const int i0 = part * cnt;
-        lane::walk3(
-            S, c0, c1, c2, go_,
-            [&](int i, double& a0, double& a1, double& a2) {
-                a0 = pA[(i * D) * LS];
-                a1 = D > 1 ? pA[(i * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
-                a2 = D > 2 ? pA[(i * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
-            },
-            [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
-                if constexpr (RELAX) asm volatile("" : "+v"(krv));   // (keeps the per-row compares inside the walk)
-                const double* ra = pA + i0 * D * LS;
-                const double* rb_ = pbeta + i0 * LS;
-                int ic = i0;
-                for (int ch = 0; ch < cnt; ch += PLP_LANE_CH) {
+        auto row_of = [&](const double* base, double& a0, double& a1, double& a2, double& a3) {
+            a0 = base[0];
+            a1 = D > 1 ? base[(D > 1 ? 1 : 0) * LS] : 0.0;
+            a2 = D > 2 ? base[(D > 2 ? 2 : 0) * LS] : 0.0;
+            a3 = D > 3 ? base[(D > 3 ? 3 : 0) * LS] : 0.0;
+        };
+        // the ratio test of one pass: my share of the rows, then the exchange with the other lanes of the LP
+        auto ratio = [&](const double (&dv)[4], const double (&xv)[4], double tolp, double& bs, double& bd, int& bi) {
+            if constexpr (RELAX) asm volatile("" : "+v"(krv));   // (keeps the per-row compares inside the walk)
+            const double* ra = pA + i0 * D * LS;
+            const double* rb_ = pbeta + i0 * LS;
+            int ic = i0;
+            for (int ch = 0; ch < cnt; ch += PLP_LANE_CH) {
 #pragma unroll
-                    for (int r = 0; r < PLP_LANE_CH; ++r) {
-                        const double a0 = ra[(r * D) * LS];
-                        const double a1 = D > 1 ? ra[(r * D + (D > 1 ? 1 : 0)) * LS] : 0.0;
-                        const double a2 = D > 2 ? ra[(r * D + (D > 2 ? 2 : 0)) * LS] : 0.0;
-                        double beta = rb_[r * LS];
-                        if constexpr (RELAX) beta = beta + ((ic + r == krv) ? 0.1 : 0.0);
-                        lane::ratio_row(a0, a1, a2, beta, ic + r, d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi);
-                    }
-                    ra += PLP_LANE_CH * D * LS;
-                    rb_ += PLP_LANE_CH * LS;
-                    ic += PLP_LANE_CH;
+                for (int r = 0; r < PLP_LANE_CH; ++r) {
+                    double a0, a1, a2, a3;
+                    row_of(ra + (r * D) * LS, a0, a1, a2, a3);
+                    double beta = rb_[r * LS];
+                    if constexpr (RELAX) beta = beta + ((ic + r == krv) ? 0.1 : 0.0);
+                    if constexpr (D == 4)
+                        lane::ratio_row4(a0, a1, a2, a3, beta, ic + r, dv[0], dv[1], dv[2], dv[3], xv[0], xv[1], xv[2], xv[3], tolp,
+                                         bs, bd, bi);
+                    else
+                        lane::ratio_row(a0, a1, a2, beta, ic + r, dv[0], dv[1], dv[2], xv[0], xv[1], xv[2], tolp, bs, bd, bi);
                 }
-                auto meet = [&](auto ctrl) {
-                    constexpr int CTRL = decltype(ctrl)::value;
-                    const double ps = dpp_d<CTRL>(bs), pd = dpp_d<CTRL>(bd);
-                    const int pi = dpp_i<CTRL>(bi);
-                    const double l = ps * bd, r_ = bs * pd;
-                    const bool theirs = (pd > 0.0) & (!(bd > 0.0) | (l < r_) | ((l == r_) & (pi < bi)));
-                    bs = theirs ? ps : bs;
-                    bd = theirs ? pd : bd;
-                    bi = theirs ? pi : bi;
-                };
-                if (nparts > 1) meet(std::integral_constant<int, PLP_DPP_XOR1>{});
-                if (nparts > 2) meet(std::integral_constant<int, PLP_DPP_XOR2>{});
-            },
-            any_lane);
+                ra += PLP_LANE_CH * D * LS;
+                rb_ += PLP_LANE_CH * LS;
+                ic += PLP_LANE_CH;
+            }
+            auto meet = [&](auto ctrl) {
+                constexpr int CTRL = decltype(ctrl)::value;
+                const double ps = dpp_d<CTRL>(bs), pd = dpp_d<CTRL>(bd);
+                const int pi = dpp_i<CTRL>(bi);
+                const double l = ps * bd, r_ = bs * pd;
+                const bool theirs = (pd > 0.0) & (!(bd > 0.0) | (l < r_) | ((l == r_) & (pi < bi)));
+                bs = theirs ? ps : bs;
+                bd = theirs ? pd : bd;
+                bi = theirs ? pi : bi;
+            };
+            if (nparts > 1) meet(std::integral_constant<int, PLP_DPP_XOR1>{});
+            if (nparts > 2) meet(std::integral_constant<int, PLP_DPP_XOR2>{});
+        };
+        if constexpr (D == 4) {
+            lane::walk4(
+                S, cv[0], cv[1], cv[2], cv[3], go_,
+                [&](int i, double& a0, double& a1, double& a2, double& a3) { row_of(pA + (i * D) * LS, a0, a1, a2, a3); },
+                [&](double d0, double d1, double d2, double d3, double x0, double x1, double x2, double x3, double tolp, double& bs,
+                    double& bd, int& bi) {
+                    const double dv[4] = {d0, d1, d2, d3}, xv[4] = {x0, x1, x2, x3};
+                    ratio(dv, xv, tolp, bs, bd, bi);
+                },
+                any_lane);
+        } else {
+            lane::walk3(
+                S, cv[0], cv[1], cv[2], go_,
+                [&](int i, double& a0, double& a1, double& a2) {
+                    double a3;
+                    row_of(pA + (i * D) * LS, a0, a1, a2, a3);
+                },
+                [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
+                    const double dv[4] = {d0, d1, d2, 0.0}, xv[4] = {x0, x1, x2, 0.0};
+                    ratio(dv, xv, tolp, bs, bd, bi);
+                },
+                any_lane);
+        }
+    };
+    auto x_of_lp = [](const LpState& S, int k) {
+        double v = k == 0 ? S.x0 : (k == 1 ? S.x1 : S.x2);
+        if constexpr (D == 4) v = k == 3 ? S.x3 : v;
+        return v;
     };
     // ---------------------------------------------------------------- F3: bounding box (:1367-1409)
 #ifdef PLP_LANE_DBG_NOF3
@@ -367,32 +398,35 @@ __device__ __forceinline__ void reduce_lane_tile(
         const bool go = stage == 1;
         const unsigned lloc = ((unsigned)(live >> row0) & RMASK);
         bool lpfail = false;
-        // LP `it`: lower_0, upper_0, lower_1, upper_1, ...
-        //   GS = 4:  round 0 one LP per lane (LPs 0..3 on the polytope's four lanes), round 1 (d = 3) LPs 4 and 5 on a pair each
-        //   GS = 8:  one round, LP `it` on lane `it` of the polytope's eight
-        //   GS = 16: one round, every LP on a pair of lanes
-        constexpr int NROUND = (GS == 4 && 2 * D > GS) ? 2 : 1;
-        auto f3_lane_of = [](int it) { return GS == 16 ? 2 * it : (it < GS ? it : 2 * (it - GS)); };
-        auto f3_round_of = [](int it) { return (GS == 4 && it >= GS) ? 1 : 0; };
+        // LP `it`: lower_0, upper_0, lower_1, upper_1, ...  A round takes the next GS of the polytope's 2 D LPs, one per lane
+        // -- or, when no more than GS / 2 are left for it, one per PAIR of lanes (GS = 16: always pairs):
+        //   d = 3:  GS = 4: LPs 0..3, then 4, 5 in pairs;  GS = 8: one round;  GS = 16: one round in pairs
+        //   d = 4:  GS = 4: LPs 0..3, then 4..7;           GS = 8: one round;  GS = 16: one round in pairs
+        constexpr int NLP = 2 * D;
+        constexpr int NROUND = GS == 16 ? 1 : (NLP + GS - 1) / GS;
+        auto f3_pair = [](int rd) { return GS == 16 || 2 * (NLP - rd * GS < GS ? NLP - rd * GS : GS) <= GS; };
+        auto f3_round_of = [](int it) { return GS == 16 ? 0 : it / GS; };
+        auto f3_lane_of = [&](int it) { const int rd = f3_round_of(it); return f3_pair(rd) ? 2 * (it - rd * GS) : it - rd * GS; };
         double val[NROUND];
 #pragma unroll
         for (int q = 0; q < NROUND; ++q) val[q] = 0.0;
 #pragma unroll 1
         for (int rd = 0; rd < NROUND; ++rd) {
-            const int nparts = (GS == 16 || rd == 1) ? 2 : 1;
-            const int it = GS == 16 ? (g.gl >> 1) : (rd == 0 ? g.gl : GS + (g.gl >> 1));
-            const int part = nparts == 2 ? (g.gl & 1) : 0;
+            const bool pair = f3_pair(rd);
+            const int nparts = pair ? 2 : 1;
+            const int it = rd * GS + (pair ? (g.gl >> 1) : g.gl);
+            const int part = pair ? (g.gl & 1) : 0;
             const bool mine = go & (it < 2 * D);
             const int kx = it >> 1;
             const bool up = it & 1;
             const double cs = up ? -1.0 : 1.0;
-            lane::Lp3 S;
-            lane_solve(S, kx == 0 ? cs : 0.0, kx == 1 ? cs : 0.0, kx == 2 ? cs : 0.0, mine, myA, myan, std::false_type{}, -1,
-                       nparts, part);
-            double xck = 0.0, xk = 0.0;
+            LpState S;
+            const double cv[4] = {kx == 0 ? cs : 0.0, kx == 1 ? cs : 0.0, kx == 2 ? cs : 0.0, kx == 3 ? cs : 0.0};
+            lane_solve(S, cv, mine, myA, myan, std::false_type{}, -1, nparts, part);
+            double xck = 0.0;
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) xck = (kk == kx) ? xc[kk] : xck;
-            xk = kx == 0 ? S.x0 : (kx == 1 ? S.x1 : S.x2);
+            const double xk = x_of_lp(S, kx);
             double v;
             if (S.status == ST_OPT) v = xck + xk;
             else if (S.status == ST_UNBND) v = up ? pinf : -pinf;
@@ -506,14 +540,15 @@ __device__ __forceinline__ void reduce_lane_tile(
             const int kr = mine ? (__ffs((int)ttd) - 1) : 0;
             const double* pA = sA + tp;
             const double* pan = pA + OFF_N;
-            double c[3] = {0.0, 0.0, 0.0};
+            double c[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < D; ++kk) c[kk] = -pA[(kr * D + kk) * LS];   // f = -A[k,:]  (:1145)
-            lane::Lp3 S;
-            lane_solve(S, c[0], c[1], c[2], mine, pA, pan, std::true_type{}, kr, nparts, part);
+            LpState S;
+            lane_solve(S, c, mine, pA, pan, std::true_type{}, kr, nparts, part);
             // objective - h[k] (:1156):  -fun - hk = (a_k.xc + a_k.x') - hk = a_k.x' - (hk - a_k.xc),  hk = (b_k + 0.1) - 0.1
             // after its round trip (:1149-1151):  hk - a_k.xc = beta_k up to the rounding of that round trip (1e-17)
-            const double akx = -lane::dot3(c[0], c[1], c[2], S.x0, S.x1, S.x2);
+            double akx = -lane::dot3(c[0], c[1], c[2], S.x0, S.x1, S.x2);
+            if constexpr (D == 4) akx = -lane::dot4(c[0], c[1], c[2], c[3], S.x0, S.x1, S.x2, S.x3);
             const double obj = akx - pan[kr * LS];
             const bool keepk = mine & (((S.status == ST_OPT) & (obj > abs_tol)) | (S.status == ST_UNBND));
             const uint64_t all = __ballot(keepk);   // bit (t - rb) * nparts: the LP at list position t says "keep"
@@ -561,11 +596,11 @@ __device__ __forceinline__ void reduce_lane_tile(
 }
 
 #ifndef PLP_REDUCE_LANE_WAVES
-#define PLP_REDUCE_LANE_WAVES 4   // (GS = 4: 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD)
+#define PLP_REDUCE_LANE_WAVES(D) ((D) <= 3 ? 4 : 3)   // (d <= 3, GS = 4: 16 one-wavefront workgroups of 10 240 B are the CU's 160 KB: four waves per SIMD; d = 4: F1's five-column dictionary wants the registers of three)
 #endif
 
 template <int D, int GS, int ROWS = LN_ROWS>
-__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_kernel(
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void reduce_lane_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
     double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out, int* __restrict__ flags_out,
     double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out, unsigned long long* __restrict__ ctr) {
@@ -576,7 +611,7 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_ker
 // The first `nbig` workgroups take tiles of 64 / GSA polytopes, the rest tiles of 64 / GSB (half as many, which finish in
 // about 0.6 of the time): the launch drains over one tile lifetime, and with short tiles dispatched last that window shrinks.
 template <int D, int ROWS, int GSA, int GSB>
-__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES) void reduce_lane_mix_kernel(
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void reduce_lane_mix_kernel(
     int nbig, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
     int* __restrict__ flags_out, double* __restrict__ r_out, double* __restrict__ xc_out, int* __restrict__ nlp_out,
@@ -624,7 +659,7 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
         const char* mx32 = getenv("PLP_REDUCE_LANE_MIX");
         long long tail32 = blocks32 / 8 < 1024 ? blocks32 / 8 : 1024;
         if (mx32) tail32 = blocks32 * atoi(mx32) / 64;
-        if (eg) tail32 = 0;
+        if (eg || D == 4) tail32 = 0;   // (d = 4: the short tiles do not pay at 32 row slots, (20,4) x 50 000: 315 us with, 300 without)
         if (gs32 == 16)
             hipLaunchKernelGGL((reduce_lane_kernel<D, 16, 32>), dim3((unsigned)blocks32), dim3(RBLOCK), reduce_lane_smem_bytes(D, 16, 32),
                                st, B, m_max, A, b, mrows, abs_tol, force, keep, flags, r, xc, nlp, t_reduce_ctr);
@@ -678,6 +713,7 @@ int launch_reduce_lane(long long B, int m_max, int d, const double* A, const dou
         case 1: return launch_reduce_lane_d<1>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
         case 2: return launch_reduce_lane_d<2>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
         case 3: return launch_reduce_lane_d<3>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
+        case 4: return launch_reduce_lane_d<4>(B, m_max, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
         default: return 1;
     }
 }

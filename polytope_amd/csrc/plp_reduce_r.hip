@@ -17,6 +17,10 @@
 #define PLP_REDUCE_LANE_MINB 0   // (16,3)-class batches larger than this: one LP per lane (plp_reduce_lane.hip); its 4-polytope tiles are ahead of the lane-group latency form down to a single polytope
 #endif
 
+#ifndef PLP_REDUCE_LANE4_MINB
+#define PLP_REDUCE_LANE4_MINB 30000   // d = 4: batches larger than this
+#endif
+
 namespace plp {
 
 int launch_reduce_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double abs_tol,
@@ -77,12 +81,16 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
                     double abs_tol, unsigned long long* keep, int* flags, double* r, double* xc, int* nlp,
                     hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || d < 1 || d > MAX_D) return 1;
-    if (d <= 3 && m_max <= 32) {
-        // up to 32 rows in d <= 3 (the bench shape; the stacks of Polytope.intersect): F3 / F2 one LP per lane (plp_reduce_lane.hip), at every batch size;
+    if (d <= 4 && m_max <= 32) {
+        // up to 32 rows in d <= 4 (the bench shape; the stacks of Polytope.intersect): F3 / F2 one LP per lane (plp_reduce_lane.hip), at every batch size;
         // PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
         const char* ln = getenv("PLP_REDUCE_LANE");
         const bool other = getenv("PLP_REDUCE_SPLIT") || getenv("PLP_REDUCE_HALF") || getenv("PLP_REDUCE_MIX") || getenv("PLP_REDUCE_R8");
-        if ((ln && ln[0] == '1') || (!(ln && ln[0] == '0') && !other && B > PLP_REDUCE_LANE_MINB))
+        // d = 4 (the walk in R^4, three waves per SIMD): ahead of the lane-group kernels only on large batches -- measured
+        // (scripts/debug/rows32_base.py, us lane-group / lane): (16,4) x 50 000 199 / 188, x 10 000 84 / 61; (12,4) x 50 000 96 / 73, x 10 000
+        // 38 / 62; (32,4) x 50 000 458 / 415, x 10 000 173 / 216; (20,4) x 50 000 338 / 300, x 10 000 133 / 159
+        const long long minb = d == 4 ? PLP_REDUCE_LANE4_MINB : PLP_REDUCE_LANE_MINB;
+        if ((ln && ln[0] == '1') || (!(ln && ln[0] == '0') && !other && B > minb))
             return launch_reduce_lane(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     }
     if (d > 8) {

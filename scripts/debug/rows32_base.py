@@ -7,7 +7,7 @@ import polytope_amd as pa
 from polytope_amd.synth import random_hpolytopes
 from polytope_amd import batch
 dev = torch.device("cuda:0")
-for (m, d) in [(32, 3), (24, 3), (20, 3), (32, 2), (24, 2)]:
+for (m, d) in [(16, 4), (12, 4), (9, 4), (32, 4), (20, 4), (16, 3), (32, 3)]:
     for B in (50000, 10000, 1000):
         A, b = random_hpolytopes(B, m, d, seed=m + d)
         At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)

@@ -107,3 +107,92 @@ extern "C" int lane_check(long long B, const double* A, const double* b, const i
 extern "C" int lane_solve_one(const double* A16, const double* beta16, const double* c, double* x, int* iters) {
     return run_lane<16>(A16, beta16, c, x, iters);
 }
+
+// ---- d = 4 (walk4): the same comparison, A[B][16][4]
+namespace {
+int run_lane4(const double* A, const double* beta, const double* c, double* x, int* iters) {
+    plp::lane::Lp4 S;
+    plp::lane::walk4(
+        S, c[0], c[1], c[2], c[3], true,
+        [&](int i, double& a0, double& a1, double& a2, double& a3) { a0 = A[i * 4]; a1 = A[i * 4 + 1]; a2 = A[i * 4 + 2]; a3 = A[i * 4 + 3]; },
+        [&](double d0, double d1, double d2, double d3, double x0, double x1, double x2, double x3, double tolp, double& bs,
+            double& bd, int& bi) {
+            for (int i = 0; i < 16; ++i)
+                plp::lane::ratio_row4(A[i * 4], A[i * 4 + 1], A[i * 4 + 2], A[i * 4 + 3], beta[i], i, d0, d1, d2, d3, x0, x1, x2, x3,
+                                      tolp, bs, bd, bi);
+        },
+        [](bool p) { return p; });
+    x[0] = S.x0; x[1] = S.x1; x[2] = S.x2; x[3] = S.x3;
+    *iters = S.iters;
+    return S.status;
+}
+}  // namespace
+
+extern "C" int lane_check4(long long B, const double* A, const double* b, const int* mrows, double* stats_out, int which) {
+    Stats st;
+    memset(&st, 0, sizeof st);
+    for (long long p = 0; p < B; ++p) {
+        const int m = mrows ? mrows[p] : 16;
+        const double* Ap = A + p * 64;
+        const double* bp = b + p * 16;
+        double r, xc[4];
+        const int s1 = plpo_cheby(m, 4, Ap, bp, &r, xc, nullptr);
+        if (s1 != 0 || !(r > 1e-7)) continue;
+        double Az[64], beta[16], sxc[16];
+        memset(Az, 0, sizeof Az);
+        for (int i = 0; i < 16; ++i) {
+            beta[i] = 0.0;
+            sxc[i] = 0.0;
+            if (i < m) {
+                for (int k = 0; k < 4; ++k) Az[i * 4 + k] = Ap[i * 4 + k];
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s = fma(Ap[i * 4 + k], xc[k], s);
+                sxc[i] = s;
+                beta[i] = fmax(bp[i] - s, 0.0);
+            }
+        }
+        auto one = [&](const double* c, const double* bt) {
+            double xl[4], xo[4], fo = 0.0;
+            int itl = 0;
+            const int sl = run_lane4(Az, bt, c, xl, &itl);
+            const int so = plpo_lp_solve(m, 4, c, Az, bt, xo, &fo, nullptr);
+            ++st.lps;
+            st.iters_sum += itl;
+            if (itl > st.iters_max) st.iters_max = itl;
+            ++st.hist[itl < 15 ? itl : 15];
+            if (sl == plp::ST_RETRY) { ++st.retry; return; }
+            if (sl != so) { ++st.status_diff; st.worst_poly = p; return; }
+            if (sl == 0) {
+                ++st.opt_both;
+                double fl = 0.0;
+                for (int k = 0; k < 4; ++k) fl = fma(c[k], xl[k], fl);
+                const double d = fabs(fl - fo) / fmax(1.0, fabs(fo));
+                if (d > st.max_abs_diff) { st.max_abs_diff = d; st.worst_lp = p; }
+            } else if (sl == 3) ++st.unb_both;
+        };
+        if (which & 1)
+            for (int it = 0; it < 8; ++it) {
+                double c[4] = {0, 0, 0, 0};
+                c[it >> 1] = (it & 1) ? -1.0 : 1.0;
+                one(c, beta);
+            }
+        if (which & 2)
+            for (int k = 0; k < m; ++k) {
+                double c[4] = {-Az[k * 4], -Az[k * 4 + 1], -Az[k * 4 + 2], -Az[k * 4 + 3]};
+                double bt[16];
+                memcpy(bt, beta, sizeof bt);
+                bt[k] = fmax((bp[k] + 0.1) - sxc[k], 0.0);
+                one(c, bt);
+            }
+    }
+    double* o = stats_out;
+    o[0] = (double)st.lps; o[1] = (double)st.retry; o[2] = (double)st.status_diff; o[3] = (double)st.opt_both;
+    o[4] = (double)st.unb_both; o[5] = st.max_abs_diff; o[6] = (double)st.iters_sum; o[7] = (double)st.iters_max;
+    for (int i = 0; i < 16; ++i) o[8 + i] = (double)st.hist[i];
+    o[24] = (double)st.worst_poly; o[25] = (double)st.worst_lp;
+    return 0;
+}
+
+extern "C" int lane_solve_one4(const double* A16, const double* beta16, const double* c, double* x, int* iters) {
+    return run_lane4(A16, beta16, c, x, iters);
+}

@@ -23,19 +23,21 @@ def lane(oracle, tmp_path_factory):
     L = C.CDLL(out)
     dp = C.POINTER(C.c_double)
     L.lane_check.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_int), dp, C.c_int]
+    L.lane_check4.argtypes = L.lane_check.argtypes
 
     def check(A, b, m=None, which=3):
         A = np.ascontiguousarray(A, dtype=np.float64)
         b = np.ascontiguousarray(b, dtype=np.float64)
         B, mm, d = A.shape
-        assert d == 3
+        assert d in (3, 4)
+        fn = L.lane_check if d == 3 else L.lane_check4
         if mm < 16:
-            A = np.concatenate([A, np.zeros((B, 16 - mm, 3))], axis=1)
+            A = np.concatenate([A, np.zeros((B, 16 - mm, d))], axis=1)
             b = np.concatenate([b, np.zeros((B, 16 - mm))], axis=1)
             m = np.full(B, mm, np.int32) if m is None else m
         st = np.zeros(32)
         mp = None if m is None else np.ascontiguousarray(m, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
-        L.lane_check(B, A.ctypes.data_as(dp), b.ctypes.data_as(dp), mp, st.ctypes.data_as(dp), which)
+        fn(B, A.ctypes.data_as(dp), b.ctypes.data_as(dp), mp, st.ctypes.data_as(dp), which)
         return dict(lps=int(st[0]), retry=int(st[1]), status_diff=int(st[2]), opt=int(st[3]), unb=int(st[4]),
                     max_diff=float(st[5]), mean_iters=st[6] / max(st[0], 1), max_iters=int(st[7]))
     return check
@@ -104,3 +106,29 @@ def test_lane_engine_structured_polytopes(lane):
         b2[k, 6:10] = n @ ((lo + hi) / 2) + rng.choice([0.2, 0.5, 5.0], 4)
     s = lane(A2, b2, np.full(64, 10, np.int32))
     assert s["status_diff"] == 0 and s["max_diff"] <= 1e-11 and s["retry"] <= 0.05 * s["lps"], s
+
+
+def test_walk_in_r4_equals_the_dictionary_simplex(lane):
+    """walk4 (d = 4: projections by the Gram matrix of the active rows and its adjugate, the vertex test by generalised
+    cross products): every box and redundancy LP of random (16,4), (12,4), (9,4) polytopes, bounded and not."""
+    from polytope_amd.synth import random_hpolytopes
+    for seed, m, bounded in [(0, 16, True), (1, 12, True), (2, 16, False), (3, 9, True)]:
+        A, b = random_hpolytopes(5000, m, 4, seed=seed, bounded=bounded)
+        s = lane(A, b)
+        assert s["status_diff"] == 0 and s["max_diff"] <= 1e-10 and s["retry"] <= s["lps"] // 5000, s
+        assert s["opt"] + s["unb"] + s["retry"] == s["lps"] and s["max_iters"] <= 16, s
+    # boxes with cuts through their corners / along their edges: walks that end on a facet, an edge or a 2-face
+    rng = np.random.default_rng(8)
+    box = np.vstack([np.eye(4), -np.eye(4)])
+    A2 = np.zeros((200, 16, 4))
+    b2 = np.zeros((200, 16))
+    for k in range(200):
+        lo = rng.integers(-3, 3, 4) * 0.5
+        hi = lo + rng.choice([0.5, 1.0, 2.0], 4)
+        A2[k, :8], b2[k, :8] = box, np.r_[hi, -lo]
+        n = np.array([[1, 1, 0, 0], [0, 1, 1, 0], [1, 0, 0, -1], [1, 1, 1, 1], [0, 0, 1, -1]], float)
+        n /= np.linalg.norm(n, axis=1)[:, None]
+        A2[k, 8:13] = n
+        b2[k, 8:13] = n @ ((lo + hi) / 2) + rng.choice([0.2, 0.5, 5.0], 5)
+    s = lane(A2, b2, np.full(200, 13, np.int32))
+    assert s["status_diff"] == 0 and s["max_diff"] <= 1e-10 and s["retry"] <= 0.05 * s["lps"], s

@@ -146,3 +146,21 @@ def test_lane_handover_inside_the_kernel(run, oracle):
         got = run(As, bs, PLP_REDUCE_LANE_GS=gs)
         assert _same_bits(got, ref, keys=("keep", "flags", "nlp")), gs
         assert _vs_oracle(oracle, got, As, bs), gs
+
+
+def test_lane_kernel_at_d4(run, oracle):
+    """d = 4 (walk4, plp_lane_lp.hpp): the dispatch takes it for batches beyond 30 000 polytopes only; here it is forced
+    (PLP_REDUCE_LANE=1) on small ones too -- verdicts equal to the oracle's and the lane-group kernels', every tile shape."""
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(41)
+    for (B, m) in [(1, 16), (300, 16), (2000, 12), (1500, 9), (1200, 32), (700, 21), (33000, 16)]:
+        A, b = random_hpolytopes(B, m, 4, seed=B + m, bounded=(B != 1500))
+        _spoil(A, b, rng)
+        groups = run(A, b, PLP_REDUCE_LANE=0)
+        if B <= 2000:
+            assert _vs_oracle(oracle, groups, A, b), (B, m)
+        for env in ({"PLP_REDUCE_LANE": 1}, {"PLP_REDUCE_LANE": 1, "PLP_REDUCE_LANE_GS": 8}, {"PLP_REDUCE_LANE": 1, "PLP_REDUCE_LANE_GS": 16},
+                    {"PLP_REDUCE_LANE": 1, "PLP_REDUCE_RETRY_ALL": 1}, {}):
+            if B > 5000 and "PLP_REDUCE_RETRY_ALL" in env:
+                continue
+            assert _same(run(A, b, **env), groups), (B, m, env)
