@@ -5,6 +5,9 @@
 
 namespace plp {
 
+int launch_bbox_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
+                     int* status, hipStream_t st);
+
 template <int D, int GS>
 static int launch_bbox_r_dg(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
                             double* ub, int* status, hipStream_t st) {
@@ -37,6 +40,13 @@ static int launch_bbox_r_d(long long B, int m_max, const double* A, const double
 int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
                 double* ub, int* status, hipStream_t st) {
     if (m_max < 1 || m_max > MAX_M || B < 1) return 1;
+    // up to 32 rows in d <= 3: the 2 d box LPs one LP per lane (plp_reduce_lane.hip, bbox_lane_kernel); PLP_BBOX_LANE=0: never (A/B)
+    {
+        const char* bl = getenv("PLP_BBOX_LANE");
+        if (d <= 3 && m_max <= 32 && !(bl && bl[0] == '0') && !getenv("PLP_BBOX_SPLIT") &&
+            launch_bbox_lane(B, m_max, d, A, b, mrows, lb, ub, status, st) == 0)
+            return 0;
+    }
     // d = 5..8 with more than 32 rows, beyond the latency form's batch sizes: one polytope per wavefront, wave-uniform
     // pivots (plp_bbox_lazy.hip).  Measured (scripts/debug/bbox_wide_ab.py, ms): (64,8) B = 5 000 0.523 -> 0.262, B = 20 000
     // 1.31 -> 0.82, (48,6) 0.52 -> 0.45, (33,5) 0.32 -> 0.30; the latency form keeps B <= 1024 ((64,8) B = 1000: 0.103

@@ -70,7 +70,11 @@ __device__ __noinline__ void reduce_lane_redo(unsigned char* smem_raw, const lon
     }
 }
 
-template <int D, int GS, int ROWS = LN_ROWS>
+// BBOX: the stand-alone bounding boxes of plp_bbox_batch (polytope.py:1314-1411) instead of reduce(): the same load, F1 and
+// box LPs on lanes; no dedupe, no prefilter, no redundancy LPs.  r_out / xc_out then are lb / ub [B][D], flags_out the status
+// (0: lb / ub hold the box, -inf / +inf where an LP is unbounded (:1376, :1398); 1: not settled here -- empty, flat or
+// unbounded-ball polytopes, an LP handed back -- the caller solves the generic LPs), the contract of bbox_r_kernel.
+template <int D, int GS, int ROWS = LN_ROWS, bool BBOX = false>
 __device__ __forceinline__ void reduce_lane_tile(
     const long long tile, long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg,
     const int* __restrict__ mrows, double abs_tol, int force_retry, unsigned long long* __restrict__ keep_out,
@@ -214,8 +218,9 @@ __device__ __forceinline__ void reduce_lane_tile(
         }
         ball = ok & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
         fulldim = ball & (rr > abs_tol);
+        if constexpr (BBOX) fulldim = ball & (rr >= 1e-6);   // (BBOX_MIN_R of bbox_r_kernel: a centre worth starting from)
     }
-    if (valid & (g.gl == 0)) {
+    if (!BBOX && (valid & (g.gl == 0))) {
         (r_out + tile)[gib] = ball ? rr : 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) (xc_out + tile * D)[gib * D + k] = ball ? xc[k] : qnan;
@@ -226,7 +231,10 @@ __device__ __forceinline__ void reduce_lane_tile(
     return;
 #endif
     // ---------------------------------------------------------------- dedupe (:1094-1110): every pair of rows once
-    {
+    if constexpr (BBOX) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) live |= spread_rows<R, GS>(grp_ballot(((has >> k) & 1u) != 0u, g)) << k;
+    } else {
         unsigned remmask = 0u;
 #if PLP_LANE_DEDUPE_SCREEN
         const double scr_thr = sqrt(2.0 * abs_tol) * 1.0001 + 1e-12;   // (wave-uniform)
@@ -303,6 +311,7 @@ __device__ __forceinline__ void reduce_lane_tile(
         const int neq = __popcll(live);
         if (neq <= D + 1) { flags = RF_EARLY; keep = live; }
         else stage = (neq > 3 * D) ? 1 : 2;
+        if constexpr (BBOX) stage = 1;   // every polytope with a usable centre gets its 2 d LPs
     }
     __syncthreads();   // the lanes of OTHER groups read these rows from here on
     auto any_lane = [](bool p) { return __any(p) != 0; };
@@ -438,6 +447,16 @@ __device__ __forceinline__ void reduce_lane_tile(
         // an LP handed back or failed anywhere in my group concerns the polytope
         lpfail = grp_ballot(lpfail, g) != 0;
         retry = retry | (grp_ballot(retry, g) != 0);
+        if constexpr (BBOX) {
+            // lb / ub from the lanes that hold them; a polytope with an LP handed back or failed is left to the caller
+#pragma unroll
+            for (int it2 = 0; it2 < NLP; ++it2) {
+                const double v = bcast(val[f3_round_of(it2)], g.gbase + f3_lane_of(it2));
+                if (valid & (g.gl == 0)) ((it2 & 1) ? xc_out + tile * D : r_out + tile * D)[gib * D + (it2 >> 1)] = go ? v : qnan;
+            }
+            if (valid & (g.gl == 0)) (flags_out + tile)[gib] = (go & !retry & !lpfail) ? 0 : 1;
+            return;
+        }
         // prefilter sums, accumulated in k order (:1131-1134); LP `it` sits in lane f3_lane_of(it) of round f3_round_of(it)
         double s1[R], s2[R];
 #pragma unroll
@@ -471,6 +490,14 @@ __device__ __forceinline__ void reduce_lane_tile(
             else stage = 2;
         }
         __syncthreads();
+    }
+    if constexpr (BBOX) {   // (no polytope of the tile had a usable centre)
+        if (valid & (g.gl == 0)) {
+            (flags_out + tile)[gib] = 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { (r_out + tile * D)[gib * D + k] = qnan; (xc_out + tile * D)[gib * D + k] = qnan; }
+        }
+        return;
     }
     // ---------------------------------------------------------------- F2: redundancy LPs (:1142-1160)
 #ifdef PLP_LANE_DBG_NOF2
@@ -625,6 +652,14 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void reduce_lane_
                                        abs_tol, force_retry, keep_out, flags_out, r_out, xc_out, nlp_out, ctr);
 }
 
+template <int D, int GS, int ROWS>
+__global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void bbox_lane_kernel(
+    long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
+    int force_retry, double* __restrict__ lb, double* __restrict__ ub, int* __restrict__ status) {
+    reduce_lane_tile<D, GS, ROWS, true>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, 0.0, force_retry, nullptr,
+                                        status, lb, ub, nullptr, nullptr);
+}
+
 // Tile shape by batch size, measured on (16,3) batches (scripts/debug/lane_sweep.py, us per launch GS 4 / 8 / 16):
 //   B = 3 000: 51 / 35 / 27.5    8 000: 56 / 38 / 34    12 000: 58 / 46 / 41    16 000: 58 / 47 / 49    20 000: 66 / 56 / 62
 //   30 000: 71 / 69 / 81    40 000: 89 / 88 / 101    (lane-group kernels: 40 / 48 / 60 / 62 / 75 / 91 / 106)
@@ -703,6 +738,39 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
         }
     }
     return 3;   // complete: what the fast path hands back is redone inside the kernel, no second pass
+}
+
+template <int D>
+static int launch_bbox_lane_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb, double* ub,
+                              int* status, hipStream_t st) {
+    if (B > 2147483647ll) return 1;
+    const int force = 0;   // (nothing to force: what this kernel does not settle goes back to the caller as status 1)
+    const bool wide = m_max > LN_ROWS;
+    int gs = wide ? (B <= PLP_REDUCE_LANE32_GS16_MAXB ? 16 : 8) : (B <= PLP_REDUCE_LANE_GS16_MAXB ? 16 : (B <= PLP_REDUCE_LANE_GS8_MAXB ? 8 : 4));
+    const long long ng = 64 / gs;
+    long long blocks = (B + ng - 1) / ng;
+    if (blocks < 1) blocks = 1;
+#define PLP_BBL(GSV, RV)                                                                                                     \
+    hipLaunchKernelGGL((bbox_lane_kernel<D, GSV, RV>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D, GSV, RV), st, B, \
+                       m_max, A, b, mrows, force, lb, ub, status)
+    if (wide) { if (gs == 16) PLP_BBL(16, 32); else PLP_BBL(8, 32); }
+    else if (gs == 16) PLP_BBL(16, 16);
+    else if (gs == 8) PLP_BBL(8, 16);
+    else PLP_BBL(4, 16);
+#undef PLP_BBL
+    return 0;
+}
+
+// bounding boxes of polytopes with up to 32 rows in d <= 3 (the contract of launch_bbox); 0 when launched, 1 when not taken
+int launch_bbox_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
+                     int* status, hipStream_t st) {
+    if (m_max < 1 || m_max > 2 * LN_ROWS) return 1;
+    switch (d) {
+        case 1: return launch_bbox_lane_d<1>(B, m_max, A, b, mrows, lb, ub, status, st);
+        case 2: return launch_bbox_lane_d<2>(B, m_max, A, b, mrows, lb, ub, status, st);
+        case 3: return launch_bbox_lane_d<3>(B, m_max, A, b, mrows, lb, ub, status, st);
+        default: return 1;
+    }
 }
 
 // returns 3 when launched (complete: launch_reduce adds no second pass), 1 when this kernel does not take the shape

@@ -164,3 +164,42 @@ def test_lane_kernel_at_d4(run, oracle):
             if B > 5000 and "PLP_REDUCE_RETRY_ALL" in env:
                 continue
             assert _same(run(A, b, **env), groups), (B, m, env)
+
+
+def test_bbox_lane_kernel(pa, oracle):
+    """plp_bbox_batch at (<= 32 rows, d <= 3): the 2 d box LPs one LP per lane (bbox_lane_kernel) against the lane-group
+    kernels (PLP_BBOX_LANE=0) and the oracle's generic LPs: the same boxes to 1e-9, +-inf in the same places, and the same
+    status except for the rare polytope whose walk is handed back (status 1: the caller's generic LPs take it)."""
+    import torch
+    from polytope_amd.synth import random_hpolytopes
+    rng = np.random.default_rng(6)
+    for (B, m, d, bounded) in [(5000, 16, 3, True), (3000, 32, 3, True), (70000, 16, 3, True), (4000, 12, 2, True), (3000, 24, 2, False),
+                               (2000, 7, 1, True), (1500, 9, 3, False), (1, 16, 3, True)]:
+        A, b = random_hpolytopes(B, m, d, seed=m + d + B, bounded=bounded)
+        b = b + np.einsum("bij,bj->bi", A, rng.standard_normal((B, d)))   # boxes away from the origin
+        for k in range(3, B, 17):
+            b[k, 0] = -40.0                                                # empty polytopes: status 1
+        At, bt = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
+        out = {}
+        for lane in ("0", "1"):
+            os.environ["PLP_BBOX_LANE"] = lane
+            try:
+                out[lane] = {k: v.cpu().numpy() for k, v in pa.bbox_batch(At, bt).items()}
+            finally:
+                os.environ.pop("PLP_BBOX_LANE", None)
+        g, ln = out["0"], out["1"]
+        both = (g["status"] == 0) & (ln["status"] == 0)
+        assert np.count_nonzero(g["status"] != ln["status"]) <= max(1, B // 5000), (B, m, d)
+        assert not np.any((ln["status"] == 0) & (g["status"] == 1)), (B, m, d)   # never settles what the lane groups leave
+        for key in ("lb", "ub"):
+            x, y = g[key][both], ln[key][both]
+            assert np.array_equal(np.isinf(x), np.isinf(y)) and np.array_equal(np.sign(x[np.isinf(x)]), np.sign(y[np.isinf(y)]))
+            fin = np.isfinite(x)
+            assert np.all(np.abs(x[fin] - y[fin]) <= 1e-9 * np.maximum(1.0, np.abs(x[fin]))), (B, m, d, key)
+        for k in range(0, min(B, 400), 7):
+            if ln["status"][k] == 0:
+                lb, ub, bad = oracle.bounding_box(A[k], b[k])
+                assert bad == 0
+                for got, want in ((ln["lb"][k], lb.ravel()), (ln["ub"][k], ub.ravel())):
+                    fin = np.isfinite(want)
+                    assert np.array_equal(np.isfinite(got), fin) and np.all(np.abs(got[fin] - want[fin]) <= 1e-9 * np.maximum(1.0, np.abs(want[fin])))
