@@ -35,6 +35,7 @@ Sets:
                    triangles, multi-member regions, a non-cover and overlapping sets  (prop2partition.py:46-306)
   g17_structured.npz  reduce() keep masks on structured (16,3) polytopes: ties, duplicates, tangent rows, corner cuts (:1053-1163)
   g18_distance_order.npz  quickhull distance() at d = 7..16, bitwise: numpy's sum keeps 8 partial sums from 8 elements on (quickhull.py:117-121)
+  g20_reduce_rows32.npz reduce() on 17..32 rows at d = 1..3, incl. the stacks of Polytope.intersect (round 5: reduce_lane_kernel with 32 row slots)
   g19_hull_highdim.npz  quickhull() end to end at d = 8, 9, 12: rows in the reference's order (quickhull.py:141-359)
   g8_hull.npz      quickhull() rows in the reference's own ORDER for seeded RNG, degenerate inputs,
                    qhull() and extreme() vertex sets                                (quickhull.py:141-359,
@@ -1169,7 +1170,54 @@ def gen_g19():
     np.savez_compressed(os.path.join(HERE, "g19_hull_highdim.npz"), **out)
 
 
+# ----------------------------------------------------------------------------- G20
+def gen_g20():
+    """reduce() of the reference on polytopes of 17..32 rows in d = 1..3 -- the shapes reduce_lane_kernel takes with 32 row
+    slots per polytope (round 5) -- among them the stacks Polytope.intersect builds from two 16-row polytopes
+    (polytope.py:268-275: vstack, then reduce): same record layout as g2 / g15."""
+    rng = np.random.default_rng(2020)
+    recs = []
+
+    def record(A, b, m, d):
+        p = pc.Polytope(A.copy(), b.copy())
+        An, bn = p.A.copy(), p.b.copy()
+        q = pc.reduce(p)
+        kept = [] if q.A.size == 0 else match_rows(An, bn, q.A, q.b)
+        mask = np.zeros(64, bool)
+        mask[kept] = True
+        recs.append(dict(m=m, d=d, A=An, b=bn, mask=mask, empty=(q.A.size == 0), minrep=bool(q.minrep),
+                         r=float(p._chebR), Aout=q.A, bout=q.b))
+
+    for (m, d, cnt) in [(32, 3, 12), (24, 3, 10), (17, 3, 8), (32, 2, 10), (20, 2, 8), (24, 1, 4)]:
+        for t in range(cnt):
+            A, b = rand_hpoly(rng, m, d, bounded=(t % 6 != 5))
+            if t % 4 == 1:   # a duplicated and a slightly shifted row (the dedupe step, :1094-1110)
+                A[1], b[1] = A[0], b[0]
+                A[3], b[3] = A[2], b[2] + 0.05
+            record(A, b, m, d)
+    for t in range(14):       # the stack of P.intersect(Q): two (16,3) polytopes, the second one moved a little
+        A1, b1 = rand_hpoly(rng, 16, 3)
+        A2, b2 = rand_hpoly(rng, 16, 3)
+        shift = 0.4 * rng.standard_normal(3) if t % 5 else 4.0 * np.ones(3)    # (every fifth pair does not meet: empty)
+        record(np.vstack([A1, A2]), np.hstack([b1, b2 + A2 @ shift]), 32, 3)
+    out = dict(
+        m=np.array([r["m"] for r in recs], np.int32),
+        d=np.array([r["d"] for r in recs], np.int32),
+        A=pad([r["A"].ravel() for r in recs], 64 * 16),
+        b=pad([r["b"] for r in recs], 64),
+        mask=np.array([r["mask"] for r in recs]),
+        empty=np.array([r["empty"] for r in recs]),
+        minrep=np.array([r["minrep"] for r in recs]),
+        r=np.array([r["r"] for r in recs]),
+        Aout=pad([r["Aout"].ravel() for r in recs], 64 * 16),
+        bout=pad([r["bout"] for r in recs], 64),
+    )
+    np.savez_compressed(os.path.join(HERE, "g20_reduce_rows32.npz"), **out)
+    print("g20:", len(recs), "polytopes; empty", int(out["empty"].sum()), "minrep", int(out["minrep"].sum()),
+          "mean kept", out["mask"].sum(1).mean())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     for w in which:
         globals()["gen_" + w]()

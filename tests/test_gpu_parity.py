@@ -456,7 +456,7 @@ def test_cheby_kernel_variants(pa, oracle, variant, monkeypatch):
 
 
 # ------------------------------------------------------------------------------ reduce
-@pytest.mark.parametrize("fixture", ["g2_reduce.npz", "g15_reduce_mid.npz"])
+@pytest.mark.parametrize("fixture", ["g2_reduce.npz", "g15_reduce_mid.npz", "g20_reduce_rows32.npz"])
 def test_reduce_golden(pa, fixture):
     """reduce() of the reference: g2 (224 polytopes, d = 2..16) and g15 (50 polytopes of 33..64 rows, d = 5..13: the shapes
     that run one polytope per wavefront, reduce_wdense_kernel)."""

@@ -203,3 +203,29 @@ def test_bbox_lane_kernel(pa, oracle):
                 for got, want in ((ln["lb"][k], lb.ravel()), (ln["ub"][k], ub.ravel())):
                     fin = np.isfinite(want)
                     assert np.array_equal(np.isfinite(got), fin) and np.all(np.abs(got[fin] - want[fin]) <= 1e-9 * np.maximum(1.0, np.abs(want[fin])))
+
+
+def test_lane_kernel_reference_fixtures_in_batches(run):
+    """The reference's own reduce() results (fixtures g2: up to 16 rows, g20: 17..32 rows incl. the stacks of
+    Polytope.intersect; tests/golden/make_golden.py) through the lane kernel as BATCHES per shape, every tile shape:
+    the reference's kept-row sets exactly, its Chebyshev radius to 1e-9."""
+    from conftest import load_golden
+    from polytope_amd import _lib
+    for fixture in ("g2_reduce.npz", "g20_reduce_rows32.npz"):
+        g = load_golden(fixture)
+        shapes = sorted({(int(m), int(d)) for m, d in zip(g["m"], g["d"]) if d <= 3 and m <= 32})
+        assert shapes
+        for (m, d) in shapes:
+            idx = [i for i in range(len(g["m"])) if int(g["m"][i]) == m and int(g["d"][i]) == d]
+            A = np.stack([g["A"][i, :m * d].reshape(m, d) for i in idx])
+            b = np.stack([g["b"][i, :m] for i in idx])
+            for gs in (4, 8, 16):
+                res = run(A, b, PLP_REDUCE_LANE=1, PLP_REDUCE_LANE_GS=gs)
+                for k, i in enumerate(idx):
+                    empty = bool(int(res["flags"][k]) & _lib.RF_EMPTY)
+                    assert empty == bool(g["empty"][i]), (fixture, m, d, gs, i)
+                    if empty:
+                        continue
+                    mask = np.array([(int(res["keep"][k]) >> r) & 1 for r in range(m)], dtype=bool)
+                    assert np.array_equal(mask, g["mask"][i, :m]), (fixture, m, d, gs, i)
+                    assert abs(res["r"][k] - g["r"][i]) <= 1e-9, (fixture, m, d, gs, i)
