@@ -65,6 +65,37 @@ PLP_LANE_FN double dot3(double a0, double a1, double a2, double b0, double b1, d
     return fma(a2, b2, fma(a1, b1, a0 * b0));
 }
 
+// -c projected onto the plane of ONE active row n, scaled by n.n > 0:  p = (c.n) n - (n.n) c  -- and, where little of c is
+// left, once more against n (then scaled by (n.n)^2; `scale` says which).  p is the difference of two vectors of length
+// |c| n.n: when c is nearly along n (a box LP against a row that is nearly an axis) what is left of them is orthogonal to
+// n only up to THEIR rounding, 1e-16 |c| n.n, and a step of length t along it leaves the plane by t (n.p) -- 5e-9 on box rows
+// tilted by 1e-8 (scripts/soak_lane.py).  The second pass removes it; it runs per lane (the result of an LP does not depend
+// on its neighbours in the wavefront) and only when some lane of the wavefront needs it (ANY).
+template <class AnyF>
+PLP_LANE_FN void proj1(const double c0, const double c1, const double c2, const double cn1, const double n0, const double n1,
+                       const double n2, const double nn, double& d0, double& d1, double& d2, double& scale, AnyF ANY) {
+    const double cn = dot3(c0, c1, c2, n0, n1, n2);
+    d0 = fma(cn, n0, -(nn * c0));
+    d1 = fma(cn, n1, -(nn * c1));
+    d2 = fma(cn, n2, -(nn * c2));
+    scale = nn;
+    const double pn1 = fabs(d0) + fabs(d1) + fabs(d2);
+    const bool small = (pn1 > 0.0) & (pn1 < 1e-4 * (nn * cn1));
+    if (ANY(small)) {
+        const double np_ = dot3(n0, n1, n2, d0, d1, d2);
+        const double q0 = fma(nn, d0, -(np_ * n0)), q1 = fma(nn, d1, -(np_ * n1)), q2 = fma(nn, d2, -(np_ * n2));
+        d0 = small ? q0 : d0;
+        d1 = small ? q1 : d1;
+        d2 = small ? q2 : d2;
+        scale = small ? nn * nn : nn;
+    }
+}
+
+// Two active rows closer than this (sin^2 of their angle) do not define an edge the walk can follow: their cross product
+// carries a relative error of 1e-16 / sin, and the walk would drift off both planes by that times the step.  1e-10 = 1e-5 rad:
+// drift below 1e-10 of the step.  (The fused reduce removes rows closer than 4.5e-4 rad before any LP runs, ref :1094-1110.)
+constexpr double LANE_PAIR_SIN2 = 1e-10;
+
 // One LP, to the end.  ROWS(i, a0, a1, a2): row i of the polytope (zeroed rows allowed: they never block).
 // RATIO(d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi): the ratio test -- over the rows with a.d > tolp the one with the smallest
 // (beta_i - a_i.x)+ / a_i.d, the FIRST such row on ties; bs / bd its slack and a.d, bi its index (-1: none).  The caller
@@ -96,11 +127,9 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
         double dscale = cn1;       // |d|_1 of a direction that is "as long as c" (what TOL_D is relative to)
         if (S.nact == 1) {
             const double nn = dot3(n00, n01, n02, n00, n01, n02);
-            const double cn = dot3(c0, c1, c2, n00, n01, n02);
-            d0 = fma(cn, n00, -(nn * c0));
-            d1 = fma(cn, n01, -(nn * c1));
-            d2 = fma(cn, n02, -(nn * c2));
-            dscale = nn * cn1;
+            double sc;
+            proj1(c0, c1, c2, cn1, n00, n01, n02, nn, d0, d1, d2, sc, ANY);
+            dscale = sc * cn1;
         } else if (S.nact == 2) {
             double e0, e1, e2;
             cross3(n00, n01, n02, n10, n11, n12, e0, e1, e2);
@@ -111,7 +140,7 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
             dscale = dot3(e0, e1, e2, e0, e1, e2) * cn1;
             // the two active rows (numerically) parallel: their planes do not define an edge
             const double nn0 = dot3(n00, n01, n02, n00, n01, n02), nn1 = dot3(n10, n11, n12, n10, n11, n12);
-            if (run && !(dot3(e0, e1, e2, e0, e1, e2) > 1e-16 * nn0 * nn1)) S.status = ST_RETRY;
+            if (run && !(dot3(e0, e1, e2, e0, e1, e2) > LANE_PAIR_SIN2 * nn0 * nn1)) S.status = ST_RETRY;
         } else if (S.nact == 3) {
             d0 = d1 = d2 = 0.0;
         }
@@ -146,11 +175,8 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
                         const bool drop0 = l0 * w0 < l1 * w1;
                         if (drop0) { S.w0 = S.w1; n00 = n10; n01 = n11; n02 = n12; }
                         S.nact = 1;
-                        const double nn = dot3(n00, n01, n02, n00, n01, n02);
-                        const double cn = dot3(c0, c1, c2, n00, n01, n02);
-                        d0 = fma(cn, n00, -(nn * c0));
-                        d1 = fma(cn, n01, -(nn * c1));
-                        d2 = fma(cn, n02, -(nn * c2));
+                        double sc;
+                        proj1(c0, c1, c2, cn1, n00, n01, n02, dot3(n00, n01, n02, n00, n01, n02), d0, d1, d2, sc, [](bool q) { return q; });
                     }
                 } else {
                     double u00, u01, u02, u10, u11, u12, u20, u21, u22;
@@ -178,10 +204,12 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
                             double am = a0;
                             if (a1 < am) { am = a1; j = 1; }
                             if (a2 < am) { am = a2; j = 2; }
-                            if (j == 0) { d0 = -sg * u00; d1 = -sg * u01; d2 = -sg * u02; S.w0 = S.w1; S.w1 = S.w2; }
-                            else if (j == 1) { d0 = -sg * u10; d1 = -sg * u11; d2 = -sg * u12; S.w1 = S.w2; }
-                            else { d0 = -sg * u20; d1 = -sg * u21; d2 = -sg * u22; }
+                            double gg;   // n_a.n_a n_b.n_b of the two rows that stay: u_j is THEIR cross product
+                            if (j == 0) { d0 = -sg * u00; d1 = -sg * u01; d2 = -sg * u02; S.w0 = S.w1; S.w1 = S.w2; gg = g11 * g22; }
+                            else if (j == 1) { d0 = -sg * u10; d1 = -sg * u11; d2 = -sg * u12; S.w1 = S.w2; gg = g22 * g00; }
+                            else { d0 = -sg * u20; d1 = -sg * u21; d2 = -sg * u22; gg = g00 * g11; }
                             S.nact = 2;
+                            if (!(dot3(d0, d1, d2, d0, d1, d2) > LANE_PAIR_SIN2 * gg)) S.status = ST_RETRY;
                         }
                     }
                 }
@@ -279,7 +307,7 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
             det = fma(g00, g11, -(g01 * g01));
             m0 = fma(r0, g11, -(r1 * g01));
             m1 = fma(r1, g00, -(r0 * g01));
-            if (run && !(det > 1e-16 * g00 * g11)) S.status = ST_RETRY;   // (numerically) parallel active rows
+            if (run && !(det > LANE_PAIR_SIN2 * g00 * g11)) S.status = ST_RETRY;   // (numerically) parallel active rows
         } else if (S.nact == 3) {
             const double A00 = fma(g11, g22, -(g12 * g12)), A01 = fma(g02, g12, -(g01 * g22)), A02 = fma(g01, g12, -(g02 * g11));
             const double A11 = fma(g00, g22, -(g02 * g02)), A12 = fma(g01, g02, -(g00 * g12)), A22 = fma(g00, g11, -(g01 * g01));
@@ -294,10 +322,17 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
             d1 = fma(m2, n21, fma(m1, n11, fma(m0, n01, -(det * c1))));
             d2 = fma(m2, n22, fma(m1, n12, fma(m0, n02, -(det * c2))));
             d3 = fma(m2, n23, fma(m1, n13, fma(m0, n03, -(det * c3))));
+            if (S.nact == 1) {   // once more against the row (proj1's reason)
+                const double nd = dot4(n00, n01, n02, n03, d0, d1, d2, d3);
+                d0 = fma(g00, d0, -(nd * n00));
+                d1 = fma(g00, d1, -(nd * n01));
+                d2 = fma(g00, d2, -(nd * n02));
+                d3 = fma(g00, d3, -(nd * n03));
+            }
         } else if (S.nact == 4) {
             d0 = d1 = d2 = d3 = 0.0;
         }
-        const double dscale = (S.nact >= 1 && S.nact <= 3) ? det * cn1 : cn1;
+        const double dscale = (S.nact >= 1 && S.nact <= 3) ? (S.nact == 1 ? det * det : det) * cn1 : cn1;
         const bool stalled = !(fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3) > LANE_TOL_D * dscale);
         if (ANY(S.status < 0 && stalled)) {
             if (S.status < 0 && stalled) {

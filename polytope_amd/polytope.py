@@ -30,6 +30,7 @@ from . import solvers
 from .solvers import lpsolve
 
 logger = logging.getLogger(__name__)
+_F64 = np.dtype(np.float64)
 
 # global default absolute tolerance (module global so the magic methods can use it; ref :83)
 ABS_TOL = 1e-7
@@ -95,9 +96,21 @@ class Polytope(object):
 
     def __init__(self, A=np.array([]), b=np.array([]), minrep=False, chebR=0, chebX=None,
                  fulldim=None, volume=None, vertices=None, normalize=True):
-        self.A = A.astype(float)
-        self.b = b.astype(float).ravel()        # (a fresh 1-D array: astype copied)
-        if A.size > 0 and normalize:
+        done = False
+        if normalize and type(A) is np.ndarray and type(b) is np.ndarray and A.dtype == _F64 and b.dtype == _F64 \
+                and A.ndim == 2 and A.size > 0:
+            # the usual call -- float64 arrays, every row stays -- without the wrappers around the same ufuncs (np.sum,
+            # .min, astype + a second product): the constructor runs thousands of times per Region operation
+            norms = np.sqrt(np.add.reduce(A * A, 1))
+            if np.minimum.reduce(norms) > 1e-10:
+                scale = 1 / norms
+                self.A = A * scale[:, None]
+                self.b = b.ravel() * scale
+                done = True
+        if not done:
+            self.A = A.astype(float)
+            self.b = b.astype(float).ravel()        # (a fresh 1-D array: astype copied)
+        if A.size > 0 and normalize and not done:
             norms = np.sqrt(np.sum(A * A, 1)).ravel()
             if norms.min() > 1e-10:
                 # every row stays (the usual case): the same products without the index round trip -- a quarter of the

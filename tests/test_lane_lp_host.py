@@ -24,6 +24,7 @@ def lane(oracle, tmp_path_factory):
     dp = C.POINTER(C.c_double)
     L.lane_check.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_int), dp, C.c_int]
     L.lane_check4.argtypes = L.lane_check.argtypes
+    L.lane_solve_one.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_int)]
 
     def check(A, b, m=None, which=3):
         A = np.ascontiguousarray(A, dtype=np.float64)
@@ -40,6 +41,14 @@ def lane(oracle, tmp_path_factory):
         fn(B, A.ctypes.data_as(dp), b.ctypes.data_as(dp), mp, st.ctypes.data_as(dp), which)
         return dict(lps=int(st[0]), retry=int(st[1]), status_diff=int(st[2]), opt=int(st[3]), unb=int(st[4]),
                     max_diff=float(st[5]), mean_iters=st[6] / max(st[0], 1), max_iters=int(st[7]))
+    def solve_one(A16, beta16, c):
+        """one LP  min c.x  s.t.  A16 x <= beta16  from x = 0 through walk3: (status, x)"""
+        x = np.zeros(3)
+        it = C.c_int(0)
+        st = L.lane_solve_one(np.ascontiguousarray(A16).ctypes.data_as(dp), np.ascontiguousarray(beta16).ctypes.data_as(dp),
+                              np.ascontiguousarray(c, dtype=np.float64).ctypes.data_as(dp), x.ctypes.data_as(dp), C.byref(it))
+        return st, x
+    check.solve_one = solve_one
     return check
 
 
@@ -132,3 +141,61 @@ def test_walk_in_r4_equals_the_dictionary_simplex(lane):
         b2[k, 8:13] = n @ ((lo + hi) / 2) + rng.choice([0.2, 0.5, 5.0], 5)
     s = lane(A2, b2, np.full(200, 13, np.int32))
     assert s["status_diff"] == 0 and s["max_diff"] <= 1e-10 and s["retry"] <= 0.05 * s["lps"], s
+
+
+def test_walk_stays_on_its_planes_when_the_cost_is_nearly_a_row_normal(lane, oracle):
+    """Box LPs of a cube with copies of its rows tilted by 1e-9 .. 1e-4 (found by scripts/soak_lane.py): the projection of
+    the cost onto such a row's plane is the small difference of two long vectors, and before it was orthogonalised a second
+    time the walk left the plane by 5e-9 .. 3e-8 over a step.  The reference here is EXACT: every vertex of the polytope
+    (all row triples, solved in extended precision), the best feasible one -- the dictionary simplex, the oracle's too,
+    stops at reduced costs below its absolute 1e-9 and is itself 6e-9 off on some of these."""
+    import itertools
+    LD = np.longdouble
+    rng = np.random.default_rng(3)
+    box = np.vstack([np.eye(3), -np.eye(3)])
+
+    def det3(M):
+        return (M[0, 0] * (M[1, 1] * M[2, 2] - M[1, 2] * M[2, 1]) - M[0, 1] * (M[1, 0] * M[2, 2] - M[1, 2] * M[2, 0])
+                + M[0, 2] * (M[1, 0] * M[2, 1] - M[1, 1] * M[2, 0]))
+
+    worst = 0.0
+    solved = handed = 0
+    for k in range(60):
+        A = np.zeros((16, 3))
+        b = np.zeros(16)
+        A[:6], b[:6] = box, 3.0
+        for j in range(6, 9):
+            i = int(rng.integers(0, 6))
+            A[j] = A[i] + rng.choice([1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4]) * rng.standard_normal(3)
+            b[j] = b[i] + rng.choice([0.0, 0.0, 1e-7, -1e-7])
+        so, r, xc = oracle.cheby(A[:9], b[:9])
+        assert so == 0 and r > 1.0
+        beta = np.zeros(16)
+        beta[:9] = np.maximum(b[:9] - A[:9] @ xc, 0.0)
+        Al, bl = A[:9].astype(LD), beta[:9].astype(LD)
+        verts = []
+        for t in itertools.combinations(range(9), 3):
+            M = Al[list(t)]
+            D = det3(M)
+            if abs(D) < 1e-14:   # (pairs of tilted copies: no vertex worth the name; the optimum is never only there)
+                continue
+            x = np.zeros(3, LD)
+            for q in range(3):
+                Mq = M.copy()
+                Mq[:, q] = bl[list(t)]
+                x[q] = det3(Mq) / D
+            if np.all(Al @ x - bl <= 1e-13):
+                verts.append(x)
+        verts = np.array(verts)
+        for it in range(6):
+            c = np.zeros(3)
+            c[it >> 1] = -1.0 if it & 1 else 1.0
+            st, x = lane.solve_one(A, beta, c)
+            if st == 5:
+                handed += 1
+                continue
+            assert st == 0, (k, it, st)
+            exact = float((verts @ c.astype(LD)).min())
+            worst = max(worst, abs(float(c @ x) - exact))
+            solved += 1
+    assert worst <= 1e-12 and solved >= 300 and handed <= 60, (worst, solved, handed)
