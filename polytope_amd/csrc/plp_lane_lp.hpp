@@ -102,9 +102,11 @@ constexpr double LANE_PAIR_SIN2 = 1e-10;
 // owns the loop: the host build and the plain device form walk all rows in one lane (ratio_rows below), the device
 // may split the rows of one LP over two or four lanes and combine (plp_reduce_lane.hip).
 // ANY(pred): true while any lane of the wavefront still runs (device: __any; host: the predicate itself).
-template <class RowF, class RatioF, class AnyF>
+// RATIO0(d0, d1, d2, tolp, bs, bd, bi): the same test from x' = 0, where every slack is its beta_i (the first pass of every
+// walk: no a_i.x to form; the values are the ones RATIO would find, bit for bit).
+template <class RowF, class RatioF, class Ratio0F, class AnyF>
 PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, RatioF RATIO,
-                       AnyF ANY) {
+                       Ratio0F RATIO0, AnyF ANY) {
     S.x0 = S.x1 = S.x2 = 0.0;
     S.w0 = S.w1 = S.w2 = -1;
     S.nact = 0;
@@ -113,6 +115,30 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
     S.status = go ? -1 : ST_OPT;
     const double cn1 = fabs(c0) + fabs(c1) + fabs(c2);
     if (go && !(cn1 > 0.0)) S.status = ST_OPT;   // c = 0: every point is optimal
+    // ---------------- first pass, all lanes together: from the interior point along -c to the first facet (what the
+    // general pass below does at nact = 0, without its case distinctions)
+    if (ANY(S.status < 0)) {
+        const bool step = S.status < 0;
+        const double d0 = -c0, d1 = -c1, d2 = -c2;
+        const double tolp = LANE_TOL_PIV * cn1;
+        double bs = 1.0, bd = 0.0;
+        int bi = -1;
+        RATIO0(d0, d1, d2, tolp, bs, bd, bi);
+        if (step) {
+            S.iters = 1;
+            if (bi < 0) {
+                S.status = ST_UNBND;
+            } else {
+                const double t = bs / bd;
+                S.x0 = fma(t, d0, 0.0);
+                S.x1 = fma(t, d1, 0.0);
+                S.x2 = fma(t, d2, 0.0);
+                S.w0 = bi;
+                S.nact = 1;
+                S.ndeg = (t * cn1 <= DEGEN_EPS) ? 1 : 0;
+            }
+        }
+    }
     while (ANY(S.status < 0)) {
         const bool run = S.status < 0;
         // ---------------- direction: -c projected onto the planes of the active rows (scaled by positive factors)
@@ -243,6 +269,16 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+template <class RowF, class RatioF, class AnyF>
+PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, RatioF RATIO,
+                       AnyF ANY) {
+    walk3(S, c0, c1, c2, go, ROWS, RATIO,
+          [&](double d0, double d1, double d2, double tolp, double& bs, double& bd, int& bi) {
+              RATIO(d0, d1, d2, 0.0, 0.0, 0.0, tolp, bs, bd, bi);
+          },
+          ANY);
+}
+
 // The same walk in R^4 (d = 4: the dimension of BASELINE config 4).  Directions are projections written with the Gram
 // matrix of the active rows and its adjugate (no division: everything is scaled by the positive determinant), the
 // vertex test with generalised cross products:  for rows p, q, r of R^4,  e = gcross(p, q, r)  is orthogonal to all
@@ -468,6 +504,17 @@ PLP_LANE_FN void ratio_row(const double a0, const double a1, const double a2, co
     const double ad = dot3(a0, a1, a2, d0, d1, d2);
     const double ax = dot3(a0, a1, a2, x0, x1, x2);
     const double sl = fmax(beta - ax, 0.0);
+    const bool better = (ad > tolp) & (sl * bd < bs * ad);
+    bs = better ? sl : bs;
+    bd = better ? ad : bd;
+    bi = better ? i : bi;
+}
+
+// ... from x' = 0: the slack is beta itself
+PLP_LANE_FN void ratio_row0(const double a0, const double a1, const double a2, const double beta, const int i, const double d0,
+                            const double d1, const double d2, const double tolp, double& bs, double& bd, int& bi) {
+    const double ad = dot3(a0, a1, a2, d0, d1, d2);
+    const double sl = fmax(beta, 0.0);
     const bool better = (ad > tolp) & (sl * bd < bs * ad);
     bs = better ? sl : bs;
     bd = better ? ad : bd;

@@ -334,7 +334,8 @@ __device__ __forceinline__ void reduce_lane_tile(
             a3 = D > 3 ? base[(D > 3 ? 3 : 0) * LS] : 0.0;
         };
         // the ratio test of one pass: my share of the rows, then the exchange with the other lanes of the LP
-        auto ratio = [&](const double (&dv)[4], const double (&xv)[4], double tolp, double& bs, double& bd, int& bi) {
+        auto ratio = [&](auto x0_tag, const double (&dv)[4], const double (&xv)[4], double tolp, double& bs, double& bd, int& bi) {
+            constexpr bool X0 = decltype(x0_tag)::value;   // the walk's first pass: x' = 0, every slack is its beta
             if constexpr (RELAX) asm volatile("" : "+v"(krv));   // (keeps the per-row compares inside the walk)
             const double* ra = pA + i0 * D * LS;
             const double* rb_ = pbeta + i0 * LS;
@@ -349,6 +350,8 @@ __device__ __forceinline__ void reduce_lane_tile(
                     if constexpr (D == 4)
                         lane::ratio_row4(a0, a1, a2, a3, beta, ic + r, dv[0], dv[1], dv[2], dv[3], xv[0], xv[1], xv[2], xv[3], tolp,
                                          bs, bd, bi);
+                    else if constexpr (X0)
+                        lane::ratio_row0(a0, a1, a2, beta, ic + r, dv[0], dv[1], dv[2], tolp, bs, bd, bi);
                     else
                         lane::ratio_row(a0, a1, a2, beta, ic + r, dv[0], dv[1], dv[2], xv[0], xv[1], xv[2], tolp, bs, bd, bi);
                 }
@@ -376,7 +379,7 @@ __device__ __forceinline__ void reduce_lane_tile(
                 [&](double d0, double d1, double d2, double d3, double x0, double x1, double x2, double x3, double tolp, double& bs,
                     double& bd, int& bi) {
                     const double dv[4] = {d0, d1, d2, d3}, xv[4] = {x0, x1, x2, x3};
-                    ratio(dv, xv, tolp, bs, bd, bi);
+                    ratio(std::false_type{}, dv, xv, tolp, bs, bd, bi);
                 },
                 any_lane);
         } else {
@@ -388,7 +391,11 @@ __device__ __forceinline__ void reduce_lane_tile(
                 },
                 [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
                     const double dv[4] = {d0, d1, d2, 0.0}, xv[4] = {x0, x1, x2, 0.0};
-                    ratio(dv, xv, tolp, bs, bd, bi);
+                    ratio(std::false_type{}, dv, xv, tolp, bs, bd, bi);
+                },
+                [&](double d0, double d1, double d2, double tolp, double& bs, double& bd, int& bi) {
+                    const double dv[4] = {d0, d1, d2, 0.0}, xv[4] = {0.0, 0.0, 0.0, 0.0};
+                    ratio(std::true_type{}, dv, xv, tolp, bs, bd, bi);
                 },
                 any_lane);
         }
