@@ -104,20 +104,25 @@ constexpr double LANE_PAIR_SIN2 = 1e-10;
 // ANY(pred): true while any lane of the wavefront still runs (device: __any; host: the predicate itself).
 // RATIO0(d0, d1, d2, tolp, bs, bd, bi): the same test from x' = 0, where every slack is its beta_i (the first pass of every
 // walk: no a_i.x to form; the values are the ones RATIO would find, bit for bit).
+// `warm` (the same for every lane of the wavefront): S comes filled in by the caller -- a feasible point x' ON the planes
+// of its nact active rows w0.. (a vertex, an edge or a facet point another LP of the same polytope ended on), iters =
+// ndeg = 0 -- and the walk goes on from there instead of from the centre.
 template <class RowF, class RatioF, class Ratio0F, class AnyF>
 PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, RatioF RATIO,
-                       Ratio0F RATIO0, AnyF ANY) {
-    S.x0 = S.x1 = S.x2 = 0.0;
-    S.w0 = S.w1 = S.w2 = -1;
-    S.nact = 0;
-    S.iters = 0;
-    S.ndeg = 0;
+                       Ratio0F RATIO0, AnyF ANY, const bool warm = false) {
+    if (!warm) {
+        S.x0 = S.x1 = S.x2 = 0.0;
+        S.w0 = S.w1 = S.w2 = -1;
+        S.nact = 0;
+        S.iters = 0;
+        S.ndeg = 0;
+    }
     S.status = go ? -1 : ST_OPT;
     const double cn1 = fabs(c0) + fabs(c1) + fabs(c2);
     if (go && !(cn1 > 0.0)) S.status = ST_OPT;   // c = 0: every point is optimal
     // ---------------- first pass, all lanes together: from the interior point along -c to the first facet (what the
     // general pass below does at nact = 0, without its case distinctions)
-    if (ANY(S.status < 0)) {
+    if (!warm && ANY(S.status < 0)) {
         const bool step = S.status < 0;
         const double d0 = -c0, d1 = -c1, d2 = -c2;
         const double tolp = LANE_TOL_PIV * cn1;
@@ -271,12 +276,12 @@ PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2
 // ------------------------------------------------------------------------------------------------------------------
 template <class RowF, class RatioF, class AnyF>
 PLP_LANE_FN void walk3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, RatioF RATIO,
-                       AnyF ANY) {
+                       AnyF ANY, const bool warm = false) {
     walk3(S, c0, c1, c2, go, ROWS, RATIO,
           [&](double d0, double d1, double d2, double tolp, double& bs, double& bd, int& bi) {
               RATIO(d0, d1, d2, 0.0, 0.0, 0.0, tolp, bs, bd, bi);
           },
-          ANY);
+          ANY, warm);
 }
 
 // The same walk in R^4 (d = 4: the dimension of BASELINE config 4).  Directions are projections written with the Gram
@@ -526,7 +531,7 @@ PLP_LANE_FN void ratio_row0(const double a0, const double a1, const double a2, c
 // hoisted out of the walk).
 template <int M, class RowF, class BetaF, class AnyF, class PassF>
 PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, BetaF BETA,
-                        AnyF ANY, PassF PASS) {
+                        AnyF ANY, PassF PASS, const bool warm = false) {
     walk3(S, c0, c1, c2, go, ROWS,
           [&](double d0, double d1, double d2, double x0, double x1, double x2, double tolp, double& bs, double& bd, int& bi) {
               PASS();
@@ -537,13 +542,13 @@ PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c
                   ratio_row(a0, a1, a2, BETA(i), i, d0, d1, d2, x0, x1, x2, tolp, bs, bd, bi);
               }
           },
-          ANY);
+          ANY, warm);
 }
 
 template <int M, class RowF, class BetaF, class AnyF>
 PLP_LANE_FN void solve3(Lp3& S, const double c0, const double c1, const double c2, const bool go, RowF ROWS, BetaF BETA,
-                        AnyF ANY) {
-    solve3<M>(S, c0, c1, c2, go, ROWS, BETA, ANY, [] {});
+                        AnyF ANY, const bool warm = false) {
+    solve3<M>(S, c0, c1, c2, go, ROWS, BETA, ANY, [] {}, warm);
 }
 
 }  // namespace lane

@@ -196,3 +196,88 @@ extern "C" int lane_check4(long long B, const double* A, const double* b, const 
 extern "C" int lane_solve_one4(const double* A16, const double* beta16, const double* c, double* x, int* iters) {
     return run_lane4(A16, beta16, c, x, iters);
 }
+
+// ---- warm starts: the redundancy LP of row k started from the best of the vertices the polytope's box LPs ended on
+// (instead of from the centre).  stats: [0] LPs compared, [1] status differences, [2] max objective difference,
+// [3..18] histogram of cold iterations, [19..34] of warm iterations (rows whose LP says "redundant" only),
+// [35] lock-step model: groups of 34 such LPs, sum of max cold iterations, [36] of max warm iterations, [37] groups,
+// [38] warm walks handed back, [39] cold walks handed back
+extern "C" int lane_warm_stats(long long B, const double* A, const double* b, double* o) {
+    for (int i = 0; i < 48; ++i) o[i] = 0.0;
+    long long gc[34], gw[34], ng = 0;
+    for (long long p = 0; p < B; ++p) {
+        const double* Ap = A + p * 48;
+        const double* bp = b + p * 16;
+        double r, xc[3];
+        if (plpo_cheby(16, 3, Ap, bp, &r, xc, nullptr) != 0 || !(r > 1e-7)) continue;
+        double beta[16];
+        for (int i = 0; i < 16; ++i)
+            beta[i] = fmax(bp[i] - fma(Ap[i * 3 + 2], xc[2], fma(Ap[i * 3 + 1], xc[1], Ap[i * 3] * xc[0])), 0.0);
+        auto rows = [&](int i, double& a0, double& a1, double& a2) { a0 = Ap[i * 3]; a1 = Ap[i * 3 + 1]; a2 = Ap[i * 3 + 2]; };
+        plp::lane::Lp3 V[6];
+        for (int it = 0; it < 6; ++it) {
+            double c[3] = {0, 0, 0};
+            c[it >> 1] = (it & 1) ? -1.0 : 1.0;
+            plp::lane::solve3<16>(V[it], c[0], c[1], c[2], true, rows, [&](int i) { return beta[i]; }, [](bool q) { return q; });
+        }
+        // [40] box LPs 4, 5 cold iterations (sum), [41] warm from the best of the vertices of LPs 0..3, [42] count
+        for (int it = 4; it < 6; ++it) {
+            double c[3] = {0, 0, (it & 1) ? -1.0 : 1.0};
+            int best = -1;
+            double bv = 0.0;
+            for (int q = 0; q < 4; ++q) {
+                if (V[q].status != plp::ST_OPT) continue;
+                const double v = -(c[2] * V[q].x2);
+                if (best < 0 || v > bv) { best = q; bv = v; }
+            }
+            if (best < 0 || V[it].status != plp::ST_OPT) continue;
+            plp::lane::Lp3 W = V[best];
+            W.iters = 0; W.ndeg = 0;
+            plp::lane::solve3<16>(W, c[0], c[1], c[2], true, rows, [&](int i) { return beta[i]; }, [](bool q) { return q; }, true);
+            o[40] += V[it].iters; o[41] += W.iters; o[42] += 1;
+            o[43] = fmax(o[43], fabs(W.x2 - V[it].x2));
+        }
+        for (int k = 0; k < 16; ++k) {
+            const double c[3] = {-Ap[k * 3], -Ap[k * 3 + 1], -Ap[k * 3 + 2]};
+            auto bt = [&](int i) { return beta[i] + (i == k ? 0.1 : 0.0); };
+            plp::lane::Lp3 C, W;
+            plp::lane::solve3<16>(C, c[0], c[1], c[2], true, rows, bt, [](bool q) { return q; });
+            int best = -1;
+            double bv = 0.0;
+            for (int it = 0; it < 6; ++it) {
+                if (V[it].status != plp::ST_OPT) continue;
+                const double v = -(c[0] * V[it].x0 + c[1] * V[it].x1 + c[2] * V[it].x2);
+                if (best < 0 || v > bv) { best = it; bv = v; }
+            }
+            if (best < 0) continue;
+            W = V[best];
+            // row k itself among the active rows: its plane moves away by 0.1, the point stays on the others
+            if (W.nact >= 1 && W.w0 == k) { W.w0 = W.w1; W.w1 = W.w2; --W.nact; }
+            else if (W.nact >= 2 && W.w1 == k) { W.w1 = W.w2; --W.nact; }
+            else if (W.nact >= 3 && W.w2 == k) { --W.nact; }
+            W.iters = 0;
+            W.ndeg = 0;
+            plp::lane::solve3<16>(W, c[0], c[1], c[2], true, rows, bt, [](bool q) { return q; }, true);
+            o[38] += W.status == plp::ST_RETRY;
+            o[39] += C.status == plp::ST_RETRY;
+            if (W.status == plp::ST_RETRY || C.status == plp::ST_RETRY) continue;
+            o[0] += 1;
+            if (W.status != C.status) { o[1] += 1; continue; }
+            if (C.status != plp::ST_OPT) continue;
+            const double fc = c[0] * C.x0 + c[1] * C.x1 + c[2] * C.x2, fw = c[0] * W.x0 + c[1] * W.x1 + c[2] * W.x2;
+            o[2] = fmax(o[2], fabs(fc - fw));
+            const double obj = -fc - beta[k];
+            if (obj > 1e-7) continue;   // "keep": the presolve settles nearly all of these before any LP
+            o[3 + (C.iters < 15 ? C.iters : 15)] += 1;
+            o[19 + (W.iters < 15 ? W.iters : 15)] += 1;
+            gc[ng] = C.iters; gw[ng] = W.iters;
+            if (++ng == 34) {
+                long long mc = 0, mw = 0;
+                for (int q = 0; q < 34; ++q) { mc = gc[q] > mc ? gc[q] : mc; mw = gw[q] > mw ? gw[q] : mw; }
+                o[35] += mc; o[36] += mw; o[37] += 1;
+                ng = 0;
+            }
+        }
+    }
+    return 0;
+}
