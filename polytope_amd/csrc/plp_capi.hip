@@ -1881,6 +1881,15 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
         for (int32_t r : cur) mult[r]--;
         return frames.empty() ? all_cells : frames.back().alive;
     };
+    // How far the speculation goes (A/B knobs; scripts/debug/rdiff_spec_sweep.sh).  Rounds 3-4 tuned it for the
+    // fewest batches (SIB = 600, DEEP = 1: 751 batches of 89 724 LPs at config 4); the host pays ~50 ns per speculated list
+    // (assembling + storing) and only 8 833 radii are ever read.  Measured: SIB = 100, DEEP = 0 -> 808 batches of 41 335 LPs,
+    // the call 21.2-23 -> 18.8-19.2 ms; no speculation beyond the chain (SIB = 0): 985 batches, 19.8-20.6 ms.
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    const int spec_sib = env_int("PLP_RDIFF_SPEC_SIB", 100);        // bound on the lists of a cell's sibling chain
+    const int spec_chain_scan = env_int("PLP_RDIFF_SPEC_CHAIN_SCAN", 6), spec_chain_node = env_int("PLP_RDIFF_SPEC_CHAIN_NODE", 8);
+    const int spec_deep = env_int("PLP_RDIFF_SPEC_DEEP", 0);        // the first alive cell's child scan one level down
+    const int spec_child = env_int("PLP_RDIFF_SPEC_CHILD", 1);      // the first child of every alive cell with a scan
     // queue, for every alive cell j >= from: the stack of the current rows with ALL its new rows (the scan, ref
     // :2212-2224) and with its first new row negated (the node the search enters when j is the first hit)
     std::vector<int32_t> child;
@@ -1895,6 +1904,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
             for (int t = 0; t < mi[j]; ++t) { suf[t] = (int32_t)(beg[j] + t); k = key_push(k, suf[t]); }
             R.want(k, base.data(), base.size(), suf.data(), suf.size(), required);
         }
+        if (spec_child)
         for (int j : alive) {
             if (j < from) continue;
             const int32_t neg = (int32_t)(beg[j] + M);
@@ -1907,7 +1917,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
         queue_scan1(alive, from, kbase, cur, required);
         for (int j : alive) {
             if (j < from) continue;
-            if (j < N - 1) {
+            if (j < N - 1 && spec_deep) {
                 child = cur;
                 child.push_back((int32_t)(beg[j] + M));
                 queue_scan1(alive, (long long)j + 1, key_push(kbase, (int32_t)(beg[j] + M)), child, false);
@@ -1916,7 +1926,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
             // they are not empty, as long as that stays a few hundred lists
             long long n_after = 0;
             for (int a : alive) n_after += a > j;
-            if ((long long)mi[j] * (2 * n_after + 1) <= 600) {
+            if ((long long)mi[j] * (2 * n_after + 1) <= spec_sib) {
                 child = cur;
                 Key kc = kbase;
                 for (int c = 2; c <= mi[j]; ++c) {
@@ -1983,7 +1993,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
                     std::vector<int> c2 = counter, o2 = open_cells;
                     std::vector<long long> i2 = idx;
                     long long l2 = level, s2 = sumc;
-                    if (!leaf_on(c2, o2, i2, l2, s2) && want_state(i2)) queue_empty_chain(c2, o2, i2, l2, s2, 6);
+                    if (!leaf_on(c2, o2, i2, l2, s2) && want_state(i2)) queue_empty_chain(c2, o2, i2, l2, s2, spec_chain_scan);
                 }
                 t_spec += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
                 rc = R.flush();
@@ -2044,7 +2054,7 @@ int plp_region_diff_search(plp_ctx* ctx, int d, int m, int N, const int32_t* mi,
             {
                 std::vector<int> c2 = counter, o2 = open_cells;
                 std::vector<long long> i2 = idx;
-                queue_empty_chain(c2, o2, i2, level, sumc, 8);
+                queue_empty_chain(c2, o2, i2, level, sumc, spec_chain_node);
             }
             // what it needs next when it is NOT empty: its scan and the first child of every cell still alive
             if (level >= 0 && level < N - 1) queue_scan(alive_now(), level + 1, knode, false);
