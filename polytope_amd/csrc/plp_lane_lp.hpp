@@ -358,22 +358,53 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
             m2 = fma(A02, r0, fma(A12, r1, A22 * r2));
             if (run && !(det > 1e-16 * g00 * g11 * g22)) S.status = ST_RETRY;   // three active planes that nearly share a plane
         }
-        if (S.nact >= 1 && S.nact <= 3) {
-            d0 = fma(m2, n20, fma(m1, n10, fma(m0, n00, -(det * c0))));
-            d1 = fma(m2, n21, fma(m1, n11, fma(m0, n01, -(det * c1))));
-            d2 = fma(m2, n22, fma(m1, n12, fma(m0, n02, -(det * c2))));
-            d3 = fma(m2, n23, fma(m1, n13, fma(m0, n03, -(det * c3))));
+        // The direction  det * (-c projected off the active rows) = sum m_j n_j - det c  is the difference of vectors of length
+        // det |c|: where the cost lies nearly IN the span of the active rows (a box LP against a row tilted by 1e-9 from its
+        // axis) what is left of them is orthogonal to the rows only up to THEIR rounding, and the step along it -- as long as
+        // the direction is short -- leaves the planes by that much (1.4e-4 on such a polytope: scripts/soak_lane.py, seed 23;
+        // the box value then fails the prefilter's 1e-4 by a hair and a facet is dropped).  One row: projected a second
+        // time, always (proj1's reason).  Two rows: projected a second time where less than 1e-4 of the cost is left.
+        // Three rows: the complement is a line, e = gcross(n_0, n_1, n_2) (orthogonal to all three to rounding of ITS
+        // length, |e|^2 = det), and the direction is -(c.e) e -- the same vector, det * (projection of -c), without a
+        // difference.
+        bool twice = false;   // (nact == 2: the direction carries another factor det)
+        if (S.nact == 3) {
+            double e0, e1, e2, e3;
+            gcross4(n00, n01, n02, n03, n10, n11, n12, n13, n20, n21, n22, n23, e0, e1, e2, e3);
+            const double ce = dot4(c0, c1, c2, c3, e0, e1, e2, e3);
+            d0 = -(ce * e0);
+            d1 = -(ce * e1);
+            d2 = -(ce * e2);
+            d3 = -(ce * e3);
+        } else if (S.nact >= 1 && S.nact <= 2) {
+            d0 = fma(m1, n10, fma(m0, n00, -(det * c0)));
+            d1 = fma(m1, n11, fma(m0, n01, -(det * c1)));
+            d2 = fma(m1, n12, fma(m0, n02, -(det * c2)));
+            d3 = fma(m1, n13, fma(m0, n03, -(det * c3)));
             if (S.nact == 1) {   // once more against the row (proj1's reason)
                 const double nd = dot4(n00, n01, n02, n03, d0, d1, d2, d3);
                 d0 = fma(g00, d0, -(nd * n00));
                 d1 = fma(g00, d1, -(nd * n01));
                 d2 = fma(g00, d2, -(nd * n02));
                 d3 = fma(g00, d3, -(nd * n03));
+            } else {
+                const double dn = fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3);
+                twice = (dn > 0.0) & (dn < 1e-4 * (det * cn1));
+                if (ANY(run && twice)) {
+                    const double s0 = dot4(d0, d1, d2, d3, n00, n01, n02, n03), s1 = dot4(d0, d1, d2, d3, n10, n11, n12, n13);
+                    const double k0 = fma(s0, g11, -(s1 * g01)), k1 = fma(s1, g00, -(s0 * g01));
+                    const double q0 = fma(det, d0, -fma(k1, n10, k0 * n00)), q1 = fma(det, d1, -fma(k1, n11, k0 * n01));
+                    const double q2 = fma(det, d2, -fma(k1, n12, k0 * n02)), q3 = fma(det, d3, -fma(k1, n13, k0 * n03));
+                    d0 = twice ? q0 : d0;
+                    d1 = twice ? q1 : d1;
+                    d2 = twice ? q2 : d2;
+                    d3 = twice ? q3 : d3;
+                }
             }
         } else if (S.nact == 4) {
             d0 = d1 = d2 = d3 = 0.0;
         }
-        const double dscale = (S.nact >= 1 && S.nact <= 3) ? (S.nact == 1 ? det * det : det) * cn1 : cn1;
+        const double dscale = (S.nact >= 1 && S.nact <= 3) ? ((S.nact == 1 || twice) ? det * det : det) * cn1 : cn1;
         const bool stalled = !(fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3) > LANE_TOL_D * dscale);
         if (ANY(S.status < 0 && stalled)) {
             if (S.status < 0 && stalled) {

@@ -197,6 +197,24 @@ extern "C" int lane_solve_one4(const double* A16, const double* beta16, const do
     return run_lane4(A16, beta16, c, x, iters);
 }
 
+// ... with m row slots (the 17..32-row tiles of the device kernel)
+extern "C" int lane_solve_one4m(int m, const double* A, const double* beta, const double* c, double* x, int* iters) {
+    plp::lane::Lp4 S;
+    plp::lane::walk4(
+        S, c[0], c[1], c[2], c[3], true,
+        [&](int i, double& a0, double& a1, double& a2, double& a3) { a0 = A[i * 4]; a1 = A[i * 4 + 1]; a2 = A[i * 4 + 2]; a3 = A[i * 4 + 3]; },
+        [&](double d0, double d1, double d2, double d3, double x0, double x1, double x2, double x3, double tolp, double& bs,
+            double& bd, int& bi) {
+            for (int i = 0; i < m; ++i)
+                plp::lane::ratio_row4(A[i * 4], A[i * 4 + 1], A[i * 4 + 2], A[i * 4 + 3], beta[i], i, d0, d1, d2, d3, x0, x1, x2, x3,
+                                      tolp, bs, bd, bi);
+        },
+        [](bool p) { return p; });
+    x[0] = S.x0; x[1] = S.x1; x[2] = S.x2; x[3] = S.x3;
+    *iters = S.iters;
+    return S.status;
+}
+
 // ---- warm starts: the redundancy LP of row k started from the best of the vertices the polytope's box LPs ended on
 // (instead of from the centre).  stats: [0] LPs compared, [1] status differences, [2] max objective difference,
 // [3..18] histogram of cold iterations, [19..34] of warm iterations (rows whose LP says "redundant" only),

@@ -25,6 +25,7 @@ def lane(oracle, tmp_path_factory):
     L.lane_check.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_int), dp, C.c_int]
     L.lane_check4.argtypes = L.lane_check.argtypes
     L.lane_solve_one.argtypes = [dp, dp, dp, dp, C.POINTER(C.c_int)]
+    L.lane_solve_one4m.argtypes = [C.c_int, dp, dp, dp, dp, C.POINTER(C.c_int)]
 
     def check(A, b, m=None, which=3):
         A = np.ascontiguousarray(A, dtype=np.float64)
@@ -49,6 +50,16 @@ def lane(oracle, tmp_path_factory):
                               np.ascontiguousarray(c, dtype=np.float64).ctypes.data_as(dp), x.ctypes.data_as(dp), C.byref(it))
         return st, x
     check.solve_one = solve_one
+
+    def solve_one4(A, beta, c):
+        """the same in R^4 through walk4, any number of row slots: (status, x)"""
+        x = np.zeros(4)
+        it = C.c_int(0)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        st = L.lane_solve_one4m(A.shape[0], A.ctypes.data_as(dp), np.ascontiguousarray(beta, dtype=np.float64).ctypes.data_as(dp),
+                                np.ascontiguousarray(c, dtype=np.float64).ctypes.data_as(dp), x.ctypes.data_as(dp), C.byref(it))
+        return st, x
+    check.solve_one4 = solve_one4
     return check
 
 
@@ -199,3 +210,38 @@ def test_walk_stays_on_its_planes_when_the_cost_is_nearly_a_row_normal(lane, ora
             worst = max(worst, abs(float(c @ x) - exact))
             solved += 1
     assert worst <= 1e-12 and solved >= 300 and handed <= 60, (worst, solved, handed)
+
+
+def test_walk4_stays_on_its_planes_when_the_cost_is_nearly_in_their_span(lane, oracle):
+    """Nine (23,4) polytopes of scripts/soak_lane.py 60 23 (trial 47, family `dup`: row 9 is a copy of the box row +e_1 tilted by
+    1e-9).  With two or three active rows that nearly contain the cost, walk4's direction `sum m_j n_j - det c` was what
+    rounding left of two long vectors; a step of 1.4e12 times its length left the planes by 1.4e-4, the box value upper_1 came
+    out 1.4e-4 short, the prefilter (-1e-4) dropped a facet: keep masks and LP counts off on 9 of 32 388 polytopes.  Now: three
+    active rows -> the line gcross(n_0, n_1, n_2); two -> projected a second time where little of the cost is left."""
+    from conftest import load_golden
+    g = load_golden("lane_w4_tilted.npz")
+    worst = 0.0
+    for A, b, m in zip(g["A"], g["b"], g["m"]):
+        A, b = A[:m].copy(), b[:m].copy()
+        nrm = np.sqrt((A * A).sum(1))
+        An, bn = A / nrm[:, None], b / nrm
+        live = np.ones(m, bool)
+        for i in range(m):            # the dedupe of reduce (ref :1094-1110), as the kernel applies it before the box LPs
+            for j in range(i + 1, m):
+                if An[i] @ An[j] > 1 - 1e-7:
+                    live[j if bn[i] < bn[j] else i] = False
+        so, r, xc = oracle.cheby(A, b)
+        assert so == 0
+        Ad = np.where(live[:, None], A, 0.0)
+        beta = np.where(live, np.maximum(b - A @ xc, 0.0), 0.0)
+        lo, hi, bad = oracle.bounding_box(A, b)
+        assert not bad
+        for it in range(8):
+            c = np.zeros(4)
+            c[it >> 1] = -1.0 if it & 1 else 1.0
+            st, x = lane.solve_one4(Ad, beta, c)
+            assert st == 0, (it, st)
+            assert np.all(Ad @ x - beta <= 1e-9)                         # on the polytope
+            worst = max(worst, abs(xc[it >> 1] + x[it >> 1] - (hi if it & 1 else lo)[it >> 1]))
+    # (the oracle's own simplex stops at reduced costs below an absolute 1e-9: it is the looser side on these rows)
+    assert worst <= 5e-9, worst

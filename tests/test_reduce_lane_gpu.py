@@ -229,3 +229,25 @@ def test_lane_kernel_reference_fixtures_in_batches(run):
                     mask = np.array([(int(res["keep"][k]) >> r) & 1 for r in range(m)], dtype=bool)
                     assert np.array_equal(mask, g["mask"][i, :m]), (fixture, m, d, gs, i)
                     assert abs(res["r"][k] - g["r"][i]) <= 1e-9, (fixture, m, d, gs, i)
+
+
+def test_lane_kernel_d4_rows_tilted_from_the_cost(run, oracle):
+    """tests/golden/lane_w4_tilted.npz (see tests/test_lane_lp_host.py: nine (23,4) polytopes on which walk4 left its planes
+    by 1.4e-4 and the fused reduce lost a facet to the prefilter): every tile shape of the lane kernel at d = 4 against the
+    oracle and the lane-group kernels, the nine alone and scattered through a batch large enough for the default dispatch."""
+    from conftest import load_golden
+    from polytope_amd.synth import random_hpolytopes
+    g = load_golden("lane_w4_tilted.npz")
+    A9, b9, m9 = g["A"], g["b"], g["m"].astype(np.int32)
+    for env in ({"PLP_REDUCE_LANE": 1}, {"PLP_REDUCE_LANE": 1, "PLP_REDUCE_LANE_GS": 8}, {"PLP_REDUCE_LANE": 1, "PLP_REDUCE_LANE_GS": 16},
+                {"PLP_REDUCE_LANE": 0}):
+        assert _vs_oracle(oracle, run(A9, b9, m9, **env), A9, b9, m9), env
+    B = 31000
+    A, b = random_hpolytopes(B, A9.shape[1], 4, seed=5)
+    m = np.full(B, A9.shape[1], np.int32)
+    at = np.arange(9) * 3301 + 17
+    A[at], b[at], m[at] = A9, b9, m9
+    lane = run(A, b, m)                       # beyond 30 000 polytopes: the lane kernel by default
+    assert _same(lane, run(A, b, m, PLP_REDUCE_LANE=0))
+    sub = {k: v[at] for k, v in lane.items()}
+    assert _vs_oracle(oracle, sub, A9, b9, m9)
