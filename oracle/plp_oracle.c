@@ -53,7 +53,9 @@
 #define PLPO_MAXN 18 /* d+1 structural columns (<=17) + phase-1 artificial */
 
 #define TOL_D 1e-9     /* reduced-cost (dual feasibility) tolerance            */
-#define TOL_PIV 1e-9   /* smallest admissible pivot element                    */
+#ifndef TOL_PIV
+#define TOL_PIV 1e-7   /* smallest admissible pivot element (1e-9 until round 5: see polytope_amd/csrc/plp_common.hpp) */
+#endif
 #define TOL_FEAS 1e-7  /* phase-1 infeasibility accepted (HiGHS primal tol)    */
 #define DEGEN_EPS 1e-12 /* step length regarded as degenerate                  */
 #define BLAND_AFTER 6  /* consecutive degenerate pivots before Bland's rule    */

@@ -43,6 +43,10 @@ int launch_bbox(long long B, int m_max, int d, const double* A, const double* b,
     // up to 32 rows in d <= 3: the 2 d box LPs one LP per lane (plp_reduce_lane.hip, bbox_lane_kernel); PLP_BBOX_LANE=0: never (A/B)
     {
         const char* bl = getenv("PLP_BBOX_LANE");
+        // (d = 4 through walk4, measured and not enabled: 20-30 % ahead of the lane-group kernels from 2 000 polytopes on --
+        // (16,4) x 100 000 209 -> 173 us, (32,4) 400 -> 290 -- but with no dedupe in front of it (bounding_box has none, ref
+        // :1314-1411) 20 of 6 407 polytopes with rows duplicated 1e-16 .. 1e-5 rad apart came out with a bound that is off by 2
+        // (scripts/soak_lane.py 150 101, trial 97); the walk in R^3 hands such pairs back)
         if (d <= 3 && m_max <= 32 && !(bl && bl[0] == '0') && !getenv("PLP_BBOX_SPLIT") &&
             launch_bbox_lane(B, m_max, d, A, b, mrows, lb, ub, status, st) == 0)
             return 0;

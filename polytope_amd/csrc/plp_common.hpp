@@ -23,7 +23,15 @@ enum : int {
 
 // tolerances of the simplex core (identical in oracle/plp_oracle.c)
 constexpr double TOL_D = 1e-9;      // reduced-cost tolerance
-constexpr double TOL_PIV = 1e-9;    // smallest admissible pivot
+// Smallest admissible pivot.  1e-9 until round 5: two rows a hair apart (normals 1e-9 .. 1e-7 rad apart, or equal with right-hand
+// sides 1e-10 apart -- what stacking polytopes that share a facet produces) leave, once one of them is in the basis, a
+// dictionary row whose entries ARE that hair; a pivot on it multiplies the dictionary's rounding by 1e9, two in a row by
+// 1e18: Chebyshev balls that stuck 0.05 .. 6 out of their polytope, an F1 called unbounded on a box (scripts/soak_lane.py,
+// soak_wide.py, family `dup`; the oracle's simplex, which shares the constant, failed the same way on other members of the
+// family).  At 1e-7 such a row is not a blocking row: the step may pass it by 1e-7 times its length -- HiGHS's own primal
+// feasibility tolerance, i.e. what the reference's answers are good to on such rows -- and every one of those cases
+// agrees with HiGHS (600 `dup` polytopes of (37,8): 4 wrong balls -> 0, largest difference 2e-8).
+constexpr double TOL_PIV = 1e-7;
 constexpr double TOL_FEAS = 1e-7;   // phase-1 infeasibility accepted (HiGHS primal tolerance)
 constexpr double DEGEN_EPS = 1e-12; // step length regarded as degenerate
 constexpr int BLAND_AFTER = 6;      // consecutive degenerate pivots before Bland's rule

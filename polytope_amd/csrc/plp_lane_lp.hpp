@@ -30,7 +30,7 @@
 namespace plp {
 enum : int { ST_OPT = 0, ST_ITER = 1, ST_INFEAS = 2, ST_UNBND = 3, ST_NUM = 4 };
 constexpr int ST_RETRY = 5;
-constexpr double TOL_D = 1e-9, TOL_PIV = 1e-9, DEGEN_EPS = 1e-12;
+constexpr double TOL_D = 1e-9, TOL_PIV = 1e-7, DEGEN_EPS = 1e-12;
 constexpr int BLAND_AFTER = 6;
 }  // namespace plp
 #endif

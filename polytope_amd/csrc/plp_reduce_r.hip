@@ -18,7 +18,10 @@
 #endif
 
 #ifndef PLP_REDUCE_LANE4_MINB
-#define PLP_REDUCE_LANE4_MINB 30000   // d = 4: batches larger than this
+#define PLP_REDUCE_LANE4_MINB 40000   // d = 4, fewer than 14 rows: batches larger than this
+#endif
+#ifndef PLP_REDUCE_LANE4_MINB_ROWS14
+#define PLP_REDUCE_LANE4_MINB_ROWS14 3000   // d = 4, 14..32 rows: batches larger than this
 #endif
 
 namespace plp {
@@ -86,10 +89,12 @@ int launch_reduce_r(long long B, int m_max, int d, const double* A, const double
         // PLP_REDUCE_LANE=0 / 1: never / always (A/B).  Any switch of the lane-group forms keeps them.
         const char* ln = getenv("PLP_REDUCE_LANE");
         const bool other = getenv("PLP_REDUCE_SPLIT") || getenv("PLP_REDUCE_HALF") || getenv("PLP_REDUCE_MIX") || getenv("PLP_REDUCE_R8");
-        // d = 4 (the walk in R^4, three waves per SIMD): ahead of the lane-group kernels only on large batches -- measured
-        // (scripts/debug/rows32_base.py, us lane-group / lane): (16,4) x 50 000 199 / 188, x 10 000 84 / 61; (12,4) x 50 000 96 / 73, x 10 000
-        // 38 / 62; (32,4) x 50 000 458 / 415, x 10 000 173 / 216; (20,4) x 50 000 338 / 300, x 10 000 133 / 159
-        const long long minb = d == 4 ? PLP_REDUCE_LANE4_MINB : PLP_REDUCE_LANE_MINB;
+        // d = 4 (the walk in R^4, three waves per SIMD) -- measured after the walk's direction with three active rows became a
+        // generalised cross product (scripts/debug/lane_d4_sweep.py, us lane-group / lane): (8,4) x 20 000 21 / 24, x 50 000 51 / 37;
+        // (12,4) x 10 000 37 / 39, x 30 000 63 / 68, x 50 000 99 / 76; (16,4) x 2 000 43 / 44, x 5 000 68 / 51, x 10 000 87 / 70,
+        // x 50 000 209 / 150; (20,4) x 2 000 61 / 58, x 5 000 102 / 75, x 50 000 359 / 276; (32,4) x 500 57 / 60, x 2 000 79 / 63,
+        // x 5 000 144 / 89, x 10 000 183 / 123, x 50 000 483 / 325
+        const long long minb = d == 4 ? (m_max >= 14 ? PLP_REDUCE_LANE4_MINB_ROWS14 : PLP_REDUCE_LANE4_MINB) : PLP_REDUCE_LANE_MINB;
         if ((ln && ln[0] == '1') || (!(ln && ln[0] == '0') && !other && B > minb))
             return launch_reduce_lane(B, m_max, d, A, b, mrows, abs_tol, keep, flags, r, xc, nlp, st);
     }

@@ -42,6 +42,16 @@ def oracle_all(pool, kind, A, b, m, chunk=64):
     return res
 
 
+def highs_radius_agrees(Ak, bk, r_mine):
+    """the Chebyshev LP (ref :1283-1288) by scipy / HiGHS: does its radius agree with r_mine to HiGHS's own tolerance?"""
+    from scipy.optimize import linprog
+    nrm = np.sqrt(np.sum(Ak * Ak, 1))
+    c = np.zeros(Ak.shape[1] + 1)
+    c[-1] = -1.0
+    rs = linprog(c, np.hstack([Ak, nrm[:, None]]), bk, bounds=(None, None))
+    return rs.status == 0 and abs(-rs.fun - r_mine) <= 1e-6 * max(1.0, abs(r_mine))
+
+
 def make(rng, B, m, d, fam):
     A = rng.standard_normal((B, m, d))
     A /= np.linalg.norm(A, axis=2, keepdims=True)
@@ -99,7 +109,7 @@ def main():
     fams = ["random", "ragged", "unbounded", "dup", "scaled", "flat", "lattice"]
     bad = 0
     npoly = 0
-    n_oracle_off = 0
+    n_oracle_off = 0   # answers on nearly duplicated rows where HiGHS sides with the kernel against the oracle
     t0 = time.time()
     for trial in range(trials):
         d = int(rng.choice([1, 2, 3, 3, 3, 4, 4]))
@@ -110,7 +120,7 @@ def main():
         if m > 16 or d == 4:
             B = min(B, 36000)
         fam = fams[int(rng.integers(0, len(fams)))]
-        force = bool(rng.random() < 0.5)   # d = 4 below 30 000 polytopes goes to the lane kernel only when asked to
+        force = bool(rng.random() < 0.5)   # d = 4: small batches (plp_reduce_r.hip: PLP_REDUCE_LANE4_MINB*) go to the lane kernel only when asked to
         for k_ in ("PLP_REDUCE_LANE", "PLP_REDUCE_LANE_GS"):
             os.environ.pop(k_, None)
         if force:
@@ -131,6 +141,11 @@ def main():
         for k, (mk, fl, nl, rr) in enumerate(ref):
             ok = int(keep[k]) == mk and int(flags[k]) == fl and int(nlp[k]) == nl and \
                 (abs(r[k] - rr) <= 1e-9 * max(1.0, abs(rr)) or (not np.isfinite(rr) and not np.isfinite(r[k])))
+            if not ok and fam == "dup" and int(keep[k]) == mk and int(flags[k]) == fl and int(nlp[k]) == nl:
+                # only the Chebyshev radius differs: on nearly duplicated rows the ORACLE's dictionary simplex can be the wrong
+                # one (seed 103, trial 25: its ball sticks 0.046 out of the polytope).  HiGHS arbitrates, as for the boxes below.
+                ok = highs_radius_agrees(A[k, :mrows[k]], b[k, :mrows[k]], r[k])
+                n_oracle_off += int(ok)
             if not ok:
                 nb += 1
                 first = first if first is not None else (k, hex(int(keep[k])), hex(mk), int(flags[k]), fl, int(nlp[k]), nl, r[k], rr)

@@ -428,6 +428,26 @@ def test_cheby_vs_oracle(pa, oracle):
                 assert np.max(Ak @ res["xc"][k] + res["r"][k] - b[k, :mrows[k]]) <= 1e-9
 
 
+def test_cheby_and_reduce_on_rows_a_hair_apart(pa, oracle):
+    """tests/golden/twin_rows.npz (see tests/test_oracle_golden.py): the Chebyshev LP through every engine that takes the shape, and
+    the fused reduce (whose F1 it is: a wrong ball made one of these polytopes `empty`), against HiGHS's radius / the oracle."""
+    import torch
+    g = load_golden("twin_rows.npz")
+    for name in "abc":
+        A, b, want = g["A_" + name], g["b_" + name], float(g["r_" + name])
+        for B in (1, 300, 20000):         # (the dispatch changes engine with the batch size)
+            At = torch.as_tensor(np.broadcast_to(A, (B,) + A.shape).copy()).cuda()
+            bt = torch.as_tensor(np.broadcast_to(b, (B,) + b.shape).copy()).cuda()
+            ch = pa.cheby_ball_batch(At, bt)
+            assert int(ch["status"].abs().max()) == 0, (name, B)
+            assert float((ch["r"] - want).abs().max()) <= 1e-7, (name, B)
+            rd = pa.reduce_batch(At, bt)
+            o = oracle.reduce(A, b)
+            keep = rd["keep"].cpu().numpy().view(np.uint64)
+            assert np.all(keep == np.uint64(o["mask"])) and np.all(rd["flags"].cpu().numpy() == o["flags"]), (name, B)
+            assert np.all(rd["nlp"].cpu().numpy() == o["nlp"]) and float((rd["r"] - want).abs().max()) <= 1e-7, (name, B)
+
+
 @pytest.mark.parametrize("variant", ["PLP_CHEBY_1ROW", "PLP_CHEBY_RETRY_ALL"])
 def test_cheby_kernel_variants(pa, oracle, variant, monkeypatch):
     """Chebyshev batches: the one-row-per-lane kernel, and the four-rows-per-lane kernel with every LP

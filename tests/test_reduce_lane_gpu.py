@@ -149,7 +149,7 @@ def test_lane_handover_inside_the_kernel(run, oracle):
 
 
 def test_lane_kernel_at_d4(run, oracle):
-    """d = 4 (walk4, plp_lane_lp.hpp): the dispatch takes it for batches beyond 30 000 polytopes only; here it is forced
+    """d = 4 (walk4, plp_lane_lp.hpp): the dispatch takes it beyond 3 000 polytopes of 14..32 rows and beyond 40 000 of fewer; here it is forced
     (PLP_REDUCE_LANE=1) on small ones too -- verdicts equal to the oracle's and the lane-group kernels', every tile shape."""
     from polytope_amd.synth import random_hpolytopes
     rng = np.random.default_rng(41)
