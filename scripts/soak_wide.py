@@ -56,10 +56,53 @@ def main():
             if not ok:
                 nb += 1
                 first = first if first is not None else (k, hex(int(keep[k])), hex(mk), int(flags[k]), fl, int(nlp[k]), nl, r[k], rr)
+        # stand-alone Chebyshev balls (every polytope) and bounding boxes (a part of the batch), HiGHS arbitrating on `dup`
+        nc = nbb = 0
+        ch = pa.cheby_ball_batch(At, bt, m=mt)
+        torch.cuda.synchronize()
+        cs, cr = ch["status"].cpu().numpy(), ch["r"].cpu().numpy()
+        nq = min(B, 1500)
+        bb = pa.bbox_batch(At[:nq], bt[:nq], mt[:nq])
+        refb = SL.oracle_all(pool, "bbox", A[:nq], b[:nq], mrows[:nq], chunk=16)
+        if bb is not None:
+            torch.cuda.synchronize()
+            st, lb, ub = bb["status"].cpu().numpy(), bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
+        for k, (lo, hi, bd, so, ro) in enumerate(refb):
+            okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro)))
+            if not okc and fam == "dup":
+                okc = int(cs[k]) == 0 and SL.highs_radius_agrees(A[k, :mrows[k]], b[k, :mrows[k]], cr[k])
+                n_off += int(okc)
+            if not okc:
+                nc += 1
+                first = first if first is not None else ("cheby", k, int(cs[k]), so, cr[k], ro)
+            if bb is None or st[k] != 0:
+                continue
+            tb = 5e-8 if fam == "dup" else 1e-9
+            okb = bd == 0 and np.allclose(lb[k], lo, rtol=tb, atol=tb) and np.allclose(ub[k], hi, rtol=tb, atol=tb)
+            if not okb and fam == "dup":
+                from scipy.optimize import linprog
+                Ak, bk = A[k, :mrows[k]], b[k, :mrows[k]]
+                okb = True
+                for i in range(d):
+                    for sgn, mine_ in ((1.0, lb[k][i]), (-1.0, ub[k][i])):
+                        c = np.zeros(d)
+                        c[i] = sgn
+                        rs = linprog(c, Ak, bk, bounds=(None, None))
+                        if rs.status == 3:
+                            okb = okb and not np.isfinite(mine_)
+                        elif rs.status == 0:
+                            okb = okb and abs(rs.x[i] - mine_) <= 1e-6 * max(1.0, abs(mine_))
+                        else:
+                            okb = False
+                n_off += int(okb)
+            if not okb:
+                nbb += 1
+                first = first if first is not None else ("bbox", k, lb[k], lo, ub[k], hi, bd)
         npoly += B
-        bad += nb
-        print("trial %3d  d %2d m %2d B %6d  %-9s reduce bad %d   %s" % (trial, d, m, B, fam, nb, "" if first is None else first), flush=True)
-    print("WIDE SOAK %s: %d polytopes, %d mismatches, %.0f s  (radii on nearly duplicated rows where HiGHS sides with the kernel against the "
+        bad += nb + nc + nbb
+        print("trial %3d  d %2d m %2d B %6d  %-9s reduce bad %d  cheby bad %d  bbox bad %d   %s" % (
+            trial, d, m, B, fam, nb, nc, nbb, "" if first is None else first), flush=True)
+    print("WIDE SOAK %s: %d polytopes, %d mismatches, %.0f s  (answers on nearly duplicated rows where HiGHS sides with the kernel against the "
           "oracle: %d)" % ("FAILED" if bad else "OK", npoly, bad, time.time() - t0, n_off), flush=True)
     pool.close()
     return 1 if bad else 0
