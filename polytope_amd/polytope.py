@@ -1082,6 +1082,7 @@ def union(polyreg1, polyreg2, check_convex=False):
     todo = [p for p in lst if p.bbox is None and not is_empty(p)]
     for p, box in zip(todo, _bbox_raw(todo)):
         p.bbox = box
+    _cheby_fill(lst)   # (one batch; _ref_index below reads the cached balls)
     gap_tol = 1e-4
 
     def apart(p, q):
@@ -1094,27 +1095,40 @@ def union(polyreg1, polyreg2, check_convex=False):
         group = [lst[0]]
         for cand in lst[1:]:
             if cand.bbox is not None and all(m.bbox is not None and apart(cand, m) for m in group):
-                continue
-            group.append(cand)
-            key = frozenset(_content_key(m) for m in group)
-            convex = _convex_memo.get(key)
-            if convex is None and _use_hip() and _clearly_not_convex(group):
                 convex = False
-                if len(_convex_memo) >= _CONVEX_MEMO_MAX:
-                    _convex_memo.clear()
-                _convex_memo[key] = convex
-            if convex is None:
-                convex, outer = is_convex(Region(group))
-                if convex and outer is not None:
-                    # the envelope is_convex built for exactly these members in this order: the merged piece below is
-                    # reduce(envelope(Region(group))) of the same list (ref :1226-1230) -- not computed a second time
-                    last_outer = (tuple(id(m) for m in group), outer)
-                if len(_convex_memo) >= _CONVEX_MEMO_MAX:
-                    _convex_memo.clear()
-                _convex_memo[key] = convex
-            if not convex:
+            else:
+                group.append(cand)
+                key = frozenset(_content_key(m) for m in group)
+                convex = _convex_memo.get(key)
+                if convex is None and _use_hip() and _clearly_not_convex(group):
+                    convex = False
+                    if len(_convex_memo) >= _CONVEX_MEMO_MAX:
+                        _convex_memo.clear()
+                    _convex_memo[key] = convex
+                if convex is None:
+                    convex, outer = is_convex(Region(group))
+                    if convex and outer is not None:
+                        # the envelope is_convex built for exactly these members in this order: the merged piece below is
+                        # reduce(envelope(Region(group))) of the same list (ref :1226-1230) -- not computed a second time
+                        last_outer = (tuple(id(m) for m in group), outer)
+                    if len(_convex_memo) >= _CONVEX_MEMO_MAX:
+                        _convex_memo.clear()
+                    _convex_memo[key] = convex
                 group.pop()
-        lst = [p for p in lst if not any(p is q for q in group)]
+            if convex:
+                group.append(cand)
+            else:
+                # the reference appends the candidate and, when the union is not convex, takes it out again with
+                # list.remove (ref :1222-1226) -- which removes the FIRST element that compares equal, and Polytope.__eq__
+                # is "both differences have a volume below 1e-7" (ref :220-230, :1032-1050): among pieces that small (a
+                # simplex of radius 3e-3 in R^4 has a volume of 1e-10) an EARLIER member goes and the candidate stays
+                k = _ref_index(group, cand)
+                if k is not None:
+                    del group[k]
+                    group.append(cand)
+        for poly in group:   # ... and the same for the group's members in the list (ref :1227-1228)
+            k = _ref_index(lst, poly)
+            del lst[len(lst) if k is None else k]
         # The merged piece is a pure function of the group's members (envelope + reduce of their rows), and the repeated
         # union of Region.intersect / mldivide (ref :815-830, :1484-1496) meets the same groups at every step: kept like
         # the convexity verdicts above (Region(1000 cells).intersect(P): 656 envelopes and 844 reduce calls without).
@@ -1136,6 +1150,39 @@ def union(polyreg1, polyreg2, check_convex=False):
         if not is_empty(piece):
             final.append(piece)
     return Region(final)
+
+
+def _unit_ball_volume(d):
+    from math import gamma, pi
+    return pi ** (d / 2.0) / gamma(d / 2.0 + 1.0)
+
+
+def _surely_not_inside(e, x):
+    """True when a ball of volume >= 1e-6 lies in e and outside x (so volume(e \\ x) is nowhere near the 1e-7 below which the
+    reference calls e a subset of x, ref :1032-1050): the Chebyshev ball of e, CACHED, shrunk to the amount by which its
+    centre violates a row of x.  Array arithmetic only; False means "not shown"."""
+    if e._chebXc is None or not e._chebR or not x.A.size:
+        return False
+    viol = float(np.max(x.A @ np.asarray(e._chebXc, dtype=float).ravel() - x.b))
+    rho = min(float(e._chebR), viol)
+    return rho > 0.0 and _unit_ball_volume(x.A.shape[1]) * rho ** x.A.shape[1] >= 1e-6
+
+
+def _ref_index(seq, x):
+    """Position of the element list.remove(x) would take out of a list of the reference's polytopes: the first one that IS x
+    or compares equal to it -- `e == x` there is  volume(e \\ x) < 1e-7 and volume(x \\ e) < 1e-7  (ref :220-230, :1032-1050), which
+    holds between ANY two pieces whose own volumes are that small (a simplex of radius 3e-3 in R^4).  The comparison itself
+    (two differences and their sampled volumes) runs only where it can come out True: not when a ball of volume 1e-6 lies in
+    one and outside the other (_surely_not_inside on the cached Chebyshev balls -- neighbouring pieces of any size that
+    matters).  None: x is not in the list (cannot happen here)."""
+    for k, e in enumerate(seq):
+        if e is x:
+            return k
+        if not e.A.size or not x.A.size or _surely_not_inside(e, x) or _surely_not_inside(x, e):
+            continue
+        if e == x:
+            return k
+    return None
 
 
 def _clearly_not_convex(group):

@@ -27,6 +27,7 @@ Sets:
   g11_convex.npz   envelope / is_convex / union(check_convex=True) / mldivide / is_adjacent / intersect on random
                    overlapping, touching and separated polytope pairs (d = 2, 3) and on splits of one polytope
                    by a hyperplane (convex unions)            (polytope.py:1414-1464, 988-1014, 1166-1238, 1470-1505)
+  g21_convex_more.npz  g11's record for 32 more pairs, d = 4 included (boxes against polytopes, splits)
   g12_config4.npz  BASELINE config 4: region_diff / Region.intersect / adjacency on the 81-cell 3x3x3x3 grid and
                    region_diff + an adjacency sample on the full 1000-cell 10x10x5x2 grid  (polytope.py:2117-2282)
   g13_volume_subset.npz  seeded volume(), is_subset, == / <= / >= on polytopes and Regions (polytope.py:1529-1594, :1032-1050)
@@ -644,6 +645,60 @@ def gen_g11():
     np.savez_compressed(os.path.join(HERE, "g11_convex.npz"), **out)
 
 
+def gen_g21():
+    """g11's record for more pairs, d = 4 included (g11: 16 pairs at d = 2, 3): overlapping / touching / separated random
+    polytopes, boxes against polytopes, hyperplane splits.  Same layout as g11_convex.npz."""
+    rng = np.random.default_rng(21)
+    out = {}
+    names = []
+
+    def store(tag, P, Q):
+        env = alg.envelope(pc.Region([P.copy(), Q.copy()]))
+        convex = bool(alg.is_convex(pc.Region([P.copy(), Q.copy()]))[0])
+        U = alg.union(P.copy(), Q.copy(), check_convex=True)
+        D = alg.mldivide(P.copy(), Q.copy())
+        I = P.copy().intersect(Q.copy())
+        out[tag + "_PA"], out[tag + "_Pb"], out[tag + "_QA"], out[tag + "_Qb"] = P.A, P.b, Q.A, Q.b
+        out[tag + "_convex"] = np.int8(convex)
+        out[tag + "_adjacent"] = np.int8(bool(pc.is_adjacent(P.copy(), Q.copy())))
+        for key, X in (("env", env), ("union", U), ("diff", D), ("isect", I)):
+            ps = pieces_of(X)
+            out[f"{tag}_{key}_n"] = np.int32(len(ps))
+            out[f"{tag}_{key}_m"] = np.array([q.A.shape[0] for q in ps], np.int32)
+            out[f"{tag}_{key}_Ab"] = pad([np.c_[q.A, q.b].ravel() for q in ps], 64 * (P.A.shape[1] + 1)) if ps \
+                else np.zeros((0, 64 * (P.A.shape[1] + 1)))
+            out[f"{tag}_{key}_r"] = np.array([float(pc.cheby_ball(q)[0]) for q in ps])
+        names.append(tag)
+        print("g21", tag, "d", P.A.shape[1], "convex", convex, "union", len(pieces_of(U)), "diff", len(pieces_of(D)), flush=True)
+
+    k = 0
+    for d, npairs, nsplit in ((2, 12, 4), (3, 7, 3), (4, 4, 2)):
+        for trial in range(npairs):
+            A1, b1 = rand_hpoly(rng, 3 * d + 2 + int(rng.integers(0, 4)), d, bounded=True)
+            if trial % 3 == 2:     # a box against a polytope
+                A2 = np.vstack([np.eye(d), -np.eye(d)])
+                b2 = np.r_[rng.uniform(0.3, 0.9, d), rng.uniform(0.3, 0.9, d)]
+            else:
+                A2, b2 = rand_hpoly(rng, 2 * d + 2 + int(rng.integers(0, 4)), d, bounded=True)
+                b2 = 0.5 * b2
+            shift = float(rng.choice([0.0, 0.3, 0.8, 1.4, 2.2, 5.0])) * np.eye(d)[int(rng.integers(0, d))] + 0.15 * rng.standard_normal(d)
+            P = pc.Polytope(A1, 0.6 * b1)
+            Q = pc.Polytope(A2, b2 + A2 @ shift)
+            store("pair%d" % k, P, Q)
+            k += 1
+        for trial in range(nsplit):
+            A, b = rand_hpoly(rng, 3 * d + 1, d, bounded=True)
+            n = rng.standard_normal(d)
+            n /= np.linalg.norm(n)
+            c = 0.25 * rng.standard_normal()
+            P = pc.reduce(pc.Polytope(np.vstack([A, n]), np.r_[0.7 * b, c]))
+            Q = pc.reduce(pc.Polytope(np.vstack([A, -n]), np.r_[0.7 * b, -c]))
+            store("split%d" % k, P, Q)
+            k += 1
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "g21_convex_more.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- G12
 def _store_pieces(out, key, ps, d):
     """Pieces of a Region in the reference's order: row counts, [A|b] rows (NaN padded), Chebyshev radii."""
@@ -1218,6 +1273,6 @@ def gen_g20():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     for w in which:
         globals()["gen_" + w]()

@@ -293,15 +293,17 @@ def test_region_intersect_merges_convex(pc, name):
 
 
 def _g11_names():
-    return [str(n) for n in load_golden("g11_convex.npz")["names"]]
+    return [("g11_convex.npz", str(n)) for n in load_golden("g11_convex.npz")["names"]] + \
+           [("g21_convex_more.npz", str(n)) for n in load_golden("g21_convex_more.npz")["names"]]
 
 
-@pytest.mark.parametrize("name", _g11_names())
-def test_envelope_convexity_union_vs_reference(pc, name):
-    """g11: envelope / is_convex / union(check_convex=True) / mldivide / intersect / is_adjacent of polytope pairs as
+@pytest.mark.parametrize("fixture,name", _g11_names())
+def test_envelope_convexity_union_vs_reference(pc, fixture, name):
+    """g11 / g21: envelope / is_convex / union(check_convex=True) / mldivide / intersect / is_adjacent of polytope pairs as
     the reference computes them (polytope.py:1414-1464, 988-1014, 1166-1238, 1470-1505): overlapping, touching,
-    separated pairs and hyperplane splits (convex unions).  Same pieces in the same order, rows within 1e-9."""
-    g = load_golden("g11_convex.npz")
+    separated pairs, boxes against polytopes and hyperplane splits (convex unions), d = 2, 3 (g11) and 2..4 (g21).  Same pieces
+    in the same order, rows within 1e-9."""
+    g = load_golden(fixture)
     P = pc.Polytope(g[name + "_PA"], g[name + "_Pb"], normalize=False)
     Q = pc.Polytope(g[name + "_QA"], g[name + "_Qb"], normalize=False)
     d = P.dim
