@@ -300,7 +300,19 @@ class Region(_NoDeviceState):
             for poly in list_poly:
                 if poly.dim != dim:
                     raise Exception("Region error: Polytopes must be of same dimension!")
-        self.list_poly = [p for p in list_poly if not is_empty(p)]
+        empties = [p for p in list_poly if is_empty(p)]
+        if not empties:
+            self.list_poly = list(list_poly)
+        else:
+            # the reference takes every empty member out with list.remove (ref :694-696): the first element that IS it or
+            # compares equal to it -- another empty one, or an earlier member whose sampled volume is below 1e-7 (`==` is
+            # "both differences have a volume below 1e-7", ref :220-230)
+            self.list_poly = list(list_poly)
+            for poly in empties:
+                for k, e in enumerate(self.list_poly):
+                    if e is poly or is_empty(e) or (e.A.size and e == poly):
+                        del self.list_poly[k]
+                        break
         self.props = set(props)
         self.bbox = None
         self.fulldim = None

@@ -91,8 +91,16 @@ def test_polytope_ctor_normalises(pc):
     assert box.minrep and np.array_equal(box.b, [1.0, 2.0, 0.0, 0.0])
     with pytest.raises(Exception):
         pc.Polytope.from_box([[1.0, 0.0]])
-    r = pc.Region([p, pc.Polytope()])
+    r = pc.Region([box, pc.Polytope()])
     assert len(r) == 1 and r.dim == 2
+    # The reference takes empty members out with list.remove (ref :694-696), i.e. the first element that compares EQUAL to the
+    # empty polytope -- and `==` is "both differences have a volume below 1e-7" (ref :220-230, :1032-1050): an earlier member
+    # without a volume (the unbounded p; a box of side 1e-3 in R^3) goes instead and the empty one stays.  Mirrored.
+    r = pc.Region([p, pc.Polytope()])
+    assert len(r) == 1 and pc.is_empty(r.list_poly[0])
+    tiny, big = pc.box2poly([[0.0, 1e-3]] * 3), pc.box2poly([[0.0, 1.0]] * 3)
+    r = pc.Region([big, tiny, pc.Polytope(), pc.box2poly([[2.0, 3.0]] * 3)])
+    assert [q.A.shape[0] for q in r.list_poly] == [6, 0, 6]
 
 
 # ------------------------------------------------------------------ cheby / bbox edge cases (g3)
