@@ -310,7 +310,13 @@ class Region(_NoDeviceState):
             self.list_poly = list(list_poly)
             for poly in empties:
                 for k, e in enumerate(self.list_poly):
-                    if e is poly or is_empty(e) or (e.A.size and e == poly):
+                    if e is poly or is_empty(e):
+                        del self.list_poly[k]
+                        break
+                    if e._chebR and e._chebXc is not None and \
+                            _unit_ball_volume(e.A.shape[1]) * float(e._chebR) ** e.A.shape[1] >= 1e-6:
+                        continue   # (a cached ball of that volume: its sampled volume is nowhere near 1e-7)
+                    if e == poly:
                         del self.list_poly[k]
                         break
         self.props = set(props)
