@@ -823,6 +823,8 @@ def bounding_box(polyreg):
         return polyreg.bbox
     if isinstance(polyreg, Region):
         members = polyreg.list_poly
+        if not members:
+            polyreg.dim   # (a Region without members: the reference fails on `.dim` here, IndexError, ref :1330-1332)
         todo = [p for p in members if p.bbox is None]
         for p, box in zip(todo, _bbox_raw(todo)):
             p.bbox = box
@@ -1310,6 +1312,8 @@ def envelope(reg, abs_tol=ABS_TOL):
     other member reaches beyond it (one Chebyshev LP per (facet, other member)); empty Polytope
     when the envelope is not full-dimensional (ref :1414-1464)."""
     members = reg.list_poly
+    if not members:   # (the reference ends up in Polytope(None, None) here, ref :1460-1464 -> :126)
+        raise AttributeError("'NoneType' object has no attribute 'astype'")
     crossed = _envelope_crossed_packed(members, abs_tol) if _use_hip() else None
     if crossed is None:
         crossed = set()
