@@ -51,3 +51,25 @@ if len(sys.argv) > 3 and sys.argv[3] == "gpu":
             one = pa.cheby_ball_batch(At[k:k + 1], bt[k:k + 1], m=mt[k:k + 1])
             print("     ", env, "status", int(one["status"][0]), "r", float(one["r"][0]))
             for e in env: os.environ.pop(e)
+if len(sys.argv) > 3 and sys.argv[3] == "bbox":
+    import torch, polytope_amd as pa
+    from scipy.optimize import linprog
+    dev = torch.device("cuda:0")
+    ks = [int(x) for x in sys.argv[4:]]
+    for k in ks:
+        Ak, bk = A[k:k + 1, :mrows[k]], b[k:k + 1, :mrows[k]]
+        lo, hi, bd = O.bounding_box(Ak[0], bk[0])
+        hl, hh = [], []
+        for i in range(d):
+            for sgn, dst in ((1.0, hl), (-1.0, hh)):
+                c = np.zeros(d); c[i] = sgn
+                rs = linprog(c, Ak[0], bk[0], bounds=(None, None))
+                dst.append(rs.x[i] if rs.status == 0 else (-np.inf if sgn > 0 else np.inf))
+        print("poly", k, "\n  oracle lb", lo, "\n  HiGHS  lb", np.array(hl), "\n  oracle ub", hi, "\n  HiGHS  ub", np.array(hh))
+        for env in ({}, {"PLP_BBOX_SPLIT": "0"}, {"PLP_BBOX_SPLIT": "1"}):
+            os.environ.update(env)
+            for B in (1, 3000):
+                bb = pa.bbox_batch(torch.as_tensor(np.repeat(Ak, B, 0)).to(dev), torch.as_tensor(np.repeat(bk, B, 0)).to(dev))
+                print("  kernel", env, "B", B, "status", int(bb["status"][0]), "lb", bb["lb"][0].cpu().numpy(), "ub", bb["ub"][0].cpu().numpy())
+            for e in env: os.environ.pop(e)
+        np.savez("gpurun_out/bbox_repro_%d_%d_%d.npz" % (seed, want, k), A=Ak[0], b=bk[0])
