@@ -312,6 +312,9 @@ def test_envelope_convexity_union_vs_reference(pc, fixture, name):
     separated pairs, boxes against polytopes and hyperplane splits (convex unions), d = 2, 3 (g11) and 2..4 (g21).  Same pieces
     in the same order, rows within 1e-9."""
     g = load_golden(fixture)
+    if fixture.startswith("g21") and pc.solvers.default_solver == "scipy" and name != "pair27" and \
+            list(g["names"]).index(name) % 3 != 0:
+        pytest.skip("g21 on the scipy backend: every third pair + the list.remove case (the whole fixture runs on 'hip')")
     P = pc.Polytope(g[name + "_PA"], g[name + "_Pb"], normalize=False)
     Q = pc.Polytope(g[name + "_QA"], g[name + "_Qb"], normalize=False)
     d = P.dim
