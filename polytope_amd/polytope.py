@@ -1397,25 +1397,71 @@ def mldivide(a, b, save=False):
                 # (index arithmetic instead of a Python pass over every subtrahend per member: 200 members x 1000 cells
                 # were 15 ms of is_subset's 49)
                 if len(live_all) == len(subs):
-                    touching = [subs[i] for i in np.flatnonzero(keep)]
+                    sel = keep
                 else:
                     if live_pos is None:
                         live_pos = np.array([i for i, c in enumerate(subs) if c.A.size], dtype=np.intp)
                     sel = np.ones(len(subs), dtype=bool)
                     sel[live_pos] = keep
-                    touching = [subs[i] for i in np.flatnonzero(sel)]
+                touching = [subs[i] for i in np.flatnonzero(sel)]
+                skipped_before = np.diff(np.concatenate([[-1], np.flatnonzero(sel), [len(subs)]])) - 1
+            else:
+                skipped_before = np.zeros(len(touching) + 1, dtype=int)
             rest = poly
             for k_sub, sub in enumerate(touching):
-                if k_sub == 0 and first_r is not None and first_r.get(id(poly)) is not None and first_r[id(poly)][0] is sub:
+                rest = _passed_untouched(rest, int(skipped_before[k_sub]))
+                if k_sub == 0 and first_r is not None and first_r.get(id(poly)) is not None and first_r[id(poly)][0] is sub \
+                        and skipped_before[0] == 0:
                     # the opening scan of this region_diff (ref :2148-2152) was part of the one batch above
                     rest = region_diff(rest, sub, save=save, _Rc=[first_r[id(poly)][1]])
                 else:
                     rest = mldivide(rest, sub, save=save)
+            rest = _passed_untouched(rest, int(skipped_before[len(touching)]))
             out = union(out, rest, check_convex=True)
         return out
     if isinstance(a, Polytope):
         return region_diff(a, b)
     raise Exception("a neither Region nor Polytope")
+
+
+def _renormalised(p, passes):
+    """p after `passes` runs through the constructor's row scaling (ref :130-138), which is what a copy is in the reference
+    (ref :178-185): rows of norm 1 +- 1e-16 move by an ulp in the first pass or two and then stay -- the loop ends there."""
+    A, b = p.A, p.b
+    changed = False
+    for _ in range(passes):
+        if not A.size:
+            break
+        norms = np.sqrt(np.add.reduce(A * A, 1))
+        if not np.minimum.reduce(norms) > 1e-10:
+            return p.copy() if passes == 1 else _renormalised(p.copy(), passes - 1)   # (a row the constructor drops: the plain way)
+        scale = 1 / norms
+        A2, b2 = A * scale[:, None], b * scale
+        if np.array_equal(A2, A) and np.array_equal(b2, b):
+            break
+        A, b, changed = A2, b2, True
+    if not changed:
+        return p
+    q = Polytope(A, b, normalize=False)
+    q._chebXc, q._chebR = p._chebXc, p._chebR
+    q.minrep, q.bbox, q.fulldim = p.minrep, p.bbox, p.fulldim
+    return q
+
+
+def _passed_untouched(rest, nskipped):
+    """What `nskipped` subtrahends that do not touch the minuend leave of `rest` in the reference's chain (ref :1484-1487): a
+    Polytope comes back from each region_diff as a COPY (ref :2128, :2157), i.e. with its rows run through the constructor's scaling
+    once more; the members of a Region go through a copy and the envelope / reduce of union(check_convex) (ref :1488, :1229-1231) -- three
+    scalings each -- and, being the merge's own output, through nothing else.  The arithmetic matters: an ulp in a right-hand side
+    decides which of two coinciding rows a later dedupe keeps (ref :1104-1109), i.e. the ORDER of a merged piece's rows."""
+    if nskipped <= 0 or is_empty(rest):
+        return rest
+    if isinstance(rest, Region):
+        new = [_renormalised(m, 3 * nskipped) for m in rest.list_poly]
+        if all(n is m for n, m in zip(new, rest.list_poly)):
+            return rest
+        return Region(new, rest.props)
+    return _renormalised(rest, nskipped)
 
 
 def _cross_touch(firsts, seconds, owner1=None, owner2=None):
