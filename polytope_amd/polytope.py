@@ -1424,22 +1424,33 @@ def mldivide(a, b, save=False):
     raise Exception("a neither Region nor Polytope")
 
 
-def _renormalised(p, passes):
-    """p after `passes` runs through the constructor's row scaling (ref :130-138), which is what a copy is in the reference
-    (ref :178-185): rows of norm 1 +- 1e-16 move by an ulp in the first pass or two and then stay -- the loop ends there."""
+def _renormalised(p, ops):
+    """p after the arithmetic the reference's chain applies to a piece it does not change, `ops` a string of
+      P  a pass through the constructor's row scaling (ref :130-138) -- what a copy is there (ref :178-185), and what envelope and
+         reduce end with (ref :1460, :1162);
+      R  reduce's in-place round trip of every right-hand side, h[k] = (h[k] + 0.1) - 0.1 (ref :1149-1151).
+    Rows of norm 1 +- 1e-16 move by an ulp in the first pass or two and then stay: the loop ends when a whole cycle of `ops`
+    changes nothing."""
     A, b = p.A, p.b
+    if not A.size:
+        return p
     changed = False
-    for _ in range(passes):
-        if not A.size:
-            break
-        norms = np.sqrt(np.add.reduce(A * A, 1))
-        if not np.minimum.reduce(norms) > 1e-10:
-            return p.copy() if passes == 1 else _renormalised(p.copy(), passes - 1)   # (a row the constructor drops: the plain way)
-        scale = 1 / norms
-        A2, b2 = A * scale[:, None], b * scale
+    k = 0
+    quiet = 0
+    while k < len(ops) and quiet < 3:
+        if ops[k] == "P":
+            norms = np.sqrt(np.add.reduce(A * A, 1))
+            if not np.minimum.reduce(norms) > 1e-10:
+                return p.copy()   # (a row the constructor would drop: not a piece of a difference; the plain copy)
+            scale = 1 / norms
+            A2, b2 = A * scale[:, None], b * scale
+        else:
+            A2, b2 = A, (b + 0.1) - 0.1
         if np.array_equal(A2, A) and np.array_equal(b2, b):
-            break
-        A, b, changed = A2, b2, True
+            quiet += 1
+        else:
+            A, b, changed, quiet = A2, b2, True, 0
+        k += 1
     if not changed:
         return p
     q = Polytope(A, b, normalize=False)
@@ -1449,19 +1460,25 @@ def _renormalised(p, passes):
 
 
 def _passed_untouched(rest, nskipped):
-    """What `nskipped` subtrahends that do not touch the minuend leave of `rest` in the reference's chain (ref :1484-1487): a
-    Polytope comes back from each region_diff as a COPY (ref :2128, :2157), i.e. with its rows run through the constructor's scaling
-    once more; the members of a Region go through a copy and the envelope / reduce of union(check_convex) (ref :1488, :1229-1231) -- three
-    scalings each -- and, being the merge's own output, through nothing else.  The arithmetic matters: an ulp in a right-hand side
-    decides which of two coinciding rows a later dedupe keeps (ref :1104-1109), i.e. the ORDER of a merged piece's rows."""
+    """What `nskipped` subtrahends that do not touch the minuend leave of `rest` in the reference's chain (ref :1484-1487).  A
+    Polytope comes back from each region_diff as a COPY (ref :2128, :2157): one pass through the constructor's scaling.  A Region is
+    taken apart and put together again (ref :1480-1488): member i of n is copied, then stands in n - i unions, each of which
+    rebuilds it as reduce(envelope(.)) -- constructor, reduce's round trip of the right-hand sides (not for d + 1 rows or fewer:
+    ref :1136-1138 returns early, and the piece is reduced three times), constructor.  The arithmetic matters: an ulp in a
+    right-hand side decides which of two coinciding rows a later dedupe keeps (ref :1104-1109), i.e. the ORDER of a merged piece's
+    rows."""
     if nskipped <= 0 or is_empty(rest):
         return rest
     if isinstance(rest, Region):
-        new = [_renormalised(m, 3 * nskipped) for m in rest.list_poly]
-        if all(n is m for n, m in zip(new, rest.list_poly)):
+        n = len(rest.list_poly)
+        new = []
+        for i, m in enumerate(rest.list_poly):
+            cyc = "PPPP" if m.A.shape[0] <= m.A.shape[1] + 1 else "PRP"
+            new.append(_renormalised(m, ("P" + cyc * (n - i)) * nskipped))
+        if all(x is m for x, m in zip(new, rest.list_poly)):
             return rest
         return Region(new, rest.props)
-    return _renormalised(rest, nskipped)
+    return _renormalised(rest, "P" * nskipped)
 
 
 def _cross_touch(firsts, seconds, owner1=None, owner2=None):
