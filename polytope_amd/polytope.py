@@ -1410,9 +1410,10 @@ def mldivide(a, b, save=False):
             rest = poly
             for k_sub, sub in enumerate(touching):
                 rest = _passed_untouched(rest, int(skipped_before[k_sub]))
-                if k_sub == 0 and first_r is not None and first_r.get(id(poly)) is not None and first_r[id(poly)][0] is sub \
-                        and skipped_before[0] == 0:
-                    # the opening scan of this region_diff (ref :2148-2152) was part of the one batch above
+                if k_sub == 0 and first_r is not None and first_r.get(id(poly)) is not None and first_r[id(poly)][0] is sub:
+                    # the opening scan of this region_diff (ref :2148-2152) was part of the one batch above (formed with the
+                    # member's rows before the skipped subtrahends' copies moved them by an ulp: the radius is read against
+                    # 1e-7 only)
                     rest = region_diff(rest, sub, save=save, _Rc=[first_r[id(poly)][1]])
                 else:
                     rest = mldivide(rest, sub, save=save)
@@ -1469,6 +1470,18 @@ def _passed_untouched(rest, nskipped):
     rows."""
     if nskipped <= 0 or is_empty(rest):
         return rest
+    if isinstance(rest, Region) and not getattr(rest, "_merged_once", False):
+        # pieces as region_diff cut them have not been through the greedy convex merge yet: the first subtrahend that
+        # does not touch them takes them apart and puts them together with union(check_convex) (ref :1480-1488) -- pieces
+        # whose union is convex become one.  That pass is run for real; the ones after it only repeat its arithmetic.
+        P = Region()
+        for m in rest.list_poly:
+            P = union(P, _renormalised(m, "P"), check_convex=True)
+        if isinstance(P, Region):
+            P._merged_once = True
+        rest, nskipped = P, nskipped - 1
+        if nskipped <= 0 or is_empty(rest):
+            return rest
     if isinstance(rest, Region):
         n = len(rest.list_poly)
         new = []
@@ -1477,7 +1490,9 @@ def _passed_untouched(rest, nskipped):
             new.append(_renormalised(m, ("P" + cyc * (n - i)) * nskipped))
         if all(x is m for x, m in zip(new, rest.list_poly)):
             return rest
-        return Region(new, rest.props)
+        out = Region(new, rest.props)
+        out._merged_once = True
+        return out
     return _renormalised(rest, "P" * nskipped)
 
 

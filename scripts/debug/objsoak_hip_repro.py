@@ -352,3 +352,22 @@ if len(sys.argv) > 4 and sys.argv[4] == "ulp":
     for k in ("P0", "P2", "a", "b", "I", "D1", "D2"):
         x, y = res["scipy"][k], res["hip"][k]
         print(k, [(bool(np.array_equal(p.A, q.A)), bool(np.array_equal(p.b, q.b)), float(np.abs(p.b - q.b).max()) if p.b.shape == q.b.shape else None) for p, q in zip(x, y)])
+if len(sys.argv) > 4 and sys.argv[4] == "rc":
+    import polytope_amd.polytope as pp
+    for backend in ("scipy", "hip"):
+        solvers.default_solver = backend
+        P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+        Rc = pp._radii_stacked(P[0].copy(), [P[1], P[2]])
+        print(backend, "Rc", ["%.17g" % float(v) for v in Rc], "r(P0) %.17g" % float(pc.cheby_ball(P[0])[0]))
+if len(sys.argv) > 4 and sys.argv[4] == "ulp2":
+    i1, i2, i0 = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    res = {}
+    for backend in ("scipy", "hip"):
+        solvers.default_solver = backend
+        P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+        a = pc.mldivide(P[i1], P[i0]); b_ = pc.mldivide(P[i2], P[i0])
+        I = pc.intersect(a, b_); D1 = b_.diff(a); D2 = a.diff(b_)
+        res[backend] = dict(a=pieces(a), b=pieces(b_), I=pieces(I), D1=pieces(D1), D2=pieces(D2))
+    for k in ("a", "b", "I", "D1", "D2"):
+        x, y = res["scipy"][k], res["hip"][k]
+        print(k, len(x), len(y), [(bool(p.A.shape == q.A.shape and np.array_equal(p.A, q.A)), bool(p.b.shape == q.b.shape and np.array_equal(p.b, q.b))) for p, q in zip(x, y)])
