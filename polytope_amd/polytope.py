@@ -1470,18 +1470,22 @@ def _passed_untouched(rest, nskipped):
     rows."""
     if nskipped <= 0 or is_empty(rest):
         return rest
-    if isinstance(rest, Region) and not getattr(rest, "_merged_once", False):
-        # pieces as region_diff cut them have not been through the greedy convex merge yet: the first subtrahend that
-        # does not touch them takes them apart and puts them together with union(check_convex) (ref :1480-1488) -- pieces
-        # whose union is convex become one.  That pass is run for real; the ones after it only repeat its arithmetic.
+    while isinstance(rest, Region) and nskipped > 0 and not getattr(rest, "_merge_stable", False):
+        # pieces as region_diff cut them have not been through the greedy convex merge yet: a subtrahend that does not
+        # touch them takes them apart and puts them together with union(check_convex) (ref :1480-1488) -- pieces whose union
+        # is convex become one, and list.remove's equality (union, above) may take a tiny piece out or keep one twice, again
+        # at every pass.  Passes are run for real until one leaves the pieces as they were; the rest repeat its arithmetic.
         P = Region()
         for m in rest.list_poly:
             P = union(P, _renormalised(m, "P"), check_convex=True)
-        if isinstance(P, Region):
-            P._merged_once = True
-        rest, nskipped = P, nskipped - 1
-        if nskipped <= 0 or is_empty(rest):
-            return rest
+        nskipped -= 1
+        if isinstance(P, Region) and len(P.list_poly) == len(rest.list_poly) and all(
+                x.A.shape == y.A.shape and np.allclose(x.A, y.A, rtol=0, atol=1e-12) and np.allclose(x.b, y.b, rtol=0, atol=1e-12)
+                for x, y in zip(P.list_poly, rest.list_poly)):
+            P._merge_stable = True
+        rest = P
+    if nskipped <= 0 or is_empty(rest):
+        return rest
     if isinstance(rest, Region):
         n = len(rest.list_poly)
         new = []
@@ -1491,7 +1495,7 @@ def _passed_untouched(rest, nskipped):
         if all(x is m for x, m in zip(new, rest.list_poly)):
             return rest
         out = Region(new, rest.props)
-        out._merged_once = True
+        out._merge_stable = True
         return out
     return _renormalised(rest, "P" * nskipped)
 

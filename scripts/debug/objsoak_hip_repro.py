@@ -371,3 +371,50 @@ if len(sys.argv) > 4 and sys.argv[4] == "ulp2":
     for k in ("a", "b", "I", "D1", "D2"):
         x, y = res["scipy"][k], res["hip"][k]
         print(k, len(x), len(y), [(bool(p.A.shape == q.A.shape and np.array_equal(p.A, q.A)), bool(p.b.shape == q.b.shape and np.array_equal(p.b, q.b))) for p, q in zip(x, y)])
+if len(sys.argv) > 4 and sys.argv[4] == "verdicts":
+    import hashlib
+    import polytope_amd.polytope as pp
+    i1, i2, i0 = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    def kp(p): return hashlib.sha1(np.round(np.c_[p.A, p.b], 9).tobytes()).hexdigest()[:6]
+    logs = {}
+    for backend in ("scipy", "hip"):
+        solvers.default_solver = backend
+        pp._hull_memo.clear(); pp._convex_memo.clear()
+        P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+        a = pc.mldivide(P[i1], P[i0]); b_ = pc.mldivide(P[i2], P[i0])
+        log = []
+        o_ic, o_cnc = pp.is_convex, pp._clearly_not_convex
+        def ic(reg, abs_tol=pp.ABS_TOL):
+            out = o_ic(reg, abs_tol); log.append(("+".join(kp(p) for p in reg.list_poly), bool(out[0]), "lp")); return out
+        def cnc(group):
+            out = o_cnc(group)
+            if out: log.append(("+".join(kp(p) for p in group), False, "witness"))
+            return out
+        pp.is_convex, pp._clearly_not_convex = ic, cnc
+        U = pc.union(a, b_, check_convex=True)
+        pp.is_convex, pp._clearly_not_convex = o_ic, o_cnc
+        logs[backend] = (log, [kp(p) for p in pieces(U)])
+    ls, lh = dict((k, (v, w)) for k, v, w in logs["scipy"][0]), dict((k, (v, w)) for k, v, w in logs["hip"][0])
+    for k in lh:
+        if k in ls and ls[k][0] != lh[k][0]:
+            print("verdict differs for group", k, "scipy", ls[k], "hip", lh[k])
+    print("groups tested only on scipy:", len([k for k in ls if k not in lh]), "only on hip:", len([k for k in lh if k not in ls]))
+    print("pieces scipy", len(logs["scipy"][1]), "hip", len(logs["hip"][1]), "first difference at", next((i for i, (x, y) in enumerate(zip(logs["scipy"][1], logs["hip"][1])) if x != y), None))
+if len(sys.argv) > 4 and sys.argv[4] == "eqs":
+    import hashlib
+    import polytope_amd.polytope as pp
+    def kp(p): return hashlib.sha1(np.round(np.c_[p.A, p.b], 9).tobytes()).hexdigest()[:6]
+    oeq = pp.Polytope.__eq__
+    for backend in ("scipy", "hip", "scipy", "hip"):
+        solvers.default_solver = backend
+        pp._hull_memo.clear(); pp._convex_memo.clear()
+        log = []
+        def eq(self, other):
+            r = oeq(self, other)
+            if self is not other: log.append((kp(self), kp(other), bool(r), round(float(pc.cheby_ball(self)[0]), 6), round(float(pc.cheby_ball(other)[0]), 6)))
+            return r
+        pp.Polytope.__eq__ = eq
+        P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+        out = ops[op](P)
+        pp.Polytope.__eq__ = oeq
+        print(backend, "pieces", len(pieces(out)), "== evaluated", len(log), "True:", [l for l in log if l[2]])

@@ -59,6 +59,8 @@ def main():
     assert "hip" in solvers.installed_solvers, "needs the HIP backend"
     rng = np.random.default_rng(seed)
     bad = nops = 0
+    unstable = [0]
+    ties = [0]
     t0 = time.time()
     eqb = lambda x, y, w: None if bool(x) == bool(y) else "%s: %s against %s" % (w, x, y)   # noqa: E731
     eqbox = lambda x, y, w: None if all(np.allclose(u, v, rtol=0, atol=1e-9, equal_nan=True) for u, v in zip(x, y)) else w + ": boxes differ"  # noqa: E731
@@ -86,11 +88,38 @@ def main():
                     out.append(("ok", fn(P)))
                 except Exception as e:
                     out.append(("exc", type(e).__name__))
+            e = None
             if out[0][0] != out[1][0] or (out[0][0] == "exc" and out[0][1] != out[1][1]):
-                errs.append("%s: scipy %s, hip %s" % (what, out[0] if out[0][0] == "exc" else "ok", out[1] if out[1][0] == "exc" else "ok"))
+                e = "%s: scipy %s, hip %s" % (what, out[0] if out[0][0] == "exc" else "ok", out[1] if out[1][0] == "exc" else "ok")
             elif out[0][0] == "ok":
                 e = cmp(out[0][1], out[1][1], what)
-                if e:
+            if e:
+                # Is the scipy side -- the reference's own flow -- reproducible on this input at all?  `==` between pieces of
+                # tiny volume is decided by volumes sampled with an UNSEEDED generator (ref :1586, :220-230), and list.remove
+                # acts on it (ref :1226-1228): two more runs of the same backend.
+                again = []
+                for _ in range(2):
+                    solvers.default_solver = "scipy"
+                    pc.polytope._hull_memo.clear(); pc.polytope._convex_memo.clear()
+                    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+                    try:
+                        again.append(("ok", fn(P)))
+                    except Exception as ex:
+                        again.append(("exc", type(ex).__name__))
+                stable = all(a[0] == out[0][0] and (a[1] == out[0][1] if a[0] == "exc" else cmp(out[0][1], a[1], what) is None) for a in again)
+                tie = False
+                if stable and what == "mldivide(P, Region)":
+                    # region_diff visits the cells in the order argsort(-Rc) (ref :2153-2157); two cells that both hold the minuend's
+                    # own Chebyshev ball have the SAME radius, and which comes first in the reference is the last bit of its LP code
+                    solvers.default_solver = "hip"
+                    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+                    rc = [float(v) for v in pc.polytope._radii_stacked(P[0].copy(), [P[1], P[2]])]
+                    tie = abs(rc[0] - rc[1]) <= 1e-12 * max(1.0, abs(rc[0])) and rc[0] > 0
+                if not stable:
+                    unstable[0] += 1
+                elif tie:
+                    ties[0] += 1
+                else:
                     errs.append(e)
 
         heavy = d <= 2 or trial % 5 == 0     # (the scipy side of the chains of union(check_convex) is what takes the time)
@@ -122,8 +151,10 @@ def main():
             bad += 1
             print("trial %d  d %d %s:" % (trial, d, kinds), "; ".join(errs[:4]), flush=True)
     solvers.default_solver = "scipy"
-    print("OBJECT SOAK ('hip' against 'scipy' backend) %s: %d trials, %d operations, %d trials with a difference, %.0f s" % (
-        "FAILED" if bad else "OK", trials, nops, bad, time.time() - t0), flush=True)
+    print("OBJECT SOAK ('hip' against 'scipy' backend) %s: %d trials, %d operations, %d trials with a difference, %.0f s  (operations whose "
+          "result the scipy backend itself does not reproduce -- sampled volumes deciding `==`: %d; region_diff on two cells of EQUAL radius, "
+          "ordered by the last bit of the LP code: %d)" % (
+              "FAILED" if bad else "OK", trials, nops, bad, time.time() - t0, unstable[0], ties[0]), flush=True)
     return 1 if bad else 0
 
 
