@@ -418,3 +418,122 @@ if len(sys.argv) > 4 and sys.argv[4] == "eqs":
         out = ops[op](P)
         pp.Polytope.__eq__ = oeq
         print(backend, "pieces", len(pieces(out)), "== evaluated", len(log), "True:", [l for l in log if l[2]])
+if len(sys.argv) > 4 and sys.argv[4] == "members":
+    i1, i2, i0 = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    res = {}
+    for backend in ("scipy", "hip"):
+        solvers.default_solver = backend
+        P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+        a = pc.mldivide(P[i1], P[i0]); b_ = pc.mldivide(P[i2], P[i0])
+        res[backend] = [pieces(pc.mldivide(pc.Region([m.copy()]), b_)) for m in pieces(a)]
+    for k, (x, y) in enumerate(zip(res["scipy"], res["hip"])):
+        eq = len(x) == len(y) and all(p.A.shape == q.A.shape and np.array_equal(p.A, q.A) and np.array_equal(p.b, q.b) for p, q in zip(x, y))
+        close = len(x) == len(y) and all(p.A.shape == q.A.shape and np.allclose(p.A, q.A, atol=1e-9) and np.allclose(p.b, q.b, atol=1e-9) for p, q in zip(x, y))
+        print("member", k, "pieces", len(x), len(y), "bits equal", eq, "1e-9 equal", close)
+if len(sys.argv) > 4 and sys.argv[4] == "member2":
+    import polytope_amd.polytope as pp
+    solvers.default_solver = "scipy"
+    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+    a = pc.mldivide(P[1], P[0]); b_ = pc.mldivide(P[2], P[0])
+    m = pieces(a)[2]; sub = pieces(b_)[4]
+    cut = pieces(pc.mldivide(m.copy(), sub))
+    print("cut pieces", len(cut))
+    for backend in ("scipy", "hip"):
+        solvers.default_solver = backend
+        pp._hull_memo.clear(); pp._convex_memo.clear()
+        o_cnc = pp._clearly_not_convex
+        wit = []
+        def cnc(group):
+            out = o_cnc(group)
+            if out:
+                # is the reference's test of the same group really False?
+                solvers.default_solver = "scipy"
+                truth = bool(pp.is_convex(pc.Region([g_.copy() for g_ in group]))[0])
+                solvers.default_solver = backend
+                wit.append(truth)
+            return out
+        pp._clearly_not_convex = cnc
+        Pm = pc.Region()
+        for x in cut:
+            Pm = pc.union(Pm, pp._renormalised(x.copy(), "P"), check_convex=True)
+        pp._clearly_not_convex = o_cnc
+        print(backend, "after one merge pass:", len(pieces(Pm)), "witness said not convex", len(wit), "times; of those the LP test says convex:", sum(wit))
+if len(sys.argv) > 4 and sys.argv[4] == "member2b":
+    import polytope_amd.polytope as pp
+    solvers.default_solver = "hip"
+    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+    a = pc.mldivide(P[1], P[0]); b_ = pc.mldivide(P[2], P[0])
+    m = pieces(a)[2]; subs = pieces(b_)
+    cut = pc.mldivide(m.copy(), subs[4])
+    print("cut", type(cut).__name__, len(pieces(cut)))
+    out = pp._passed_untouched(cut, 11)
+    print("_passed_untouched(cut, 11) ->", len(pieces(out)))
+    touch = pp._cross_touch([m], subs, None, None)
+    print("touch row", None if touch is None else np.asarray(touch[0], dtype=int))
+    full = pc.mldivide(pc.Region([m.copy()]), b_)
+    print("mldivide(Region([m]), b_) ->", len(pieces(full)))
+if len(sys.argv) > 4 and sys.argv[4] == "member2c":
+    import polytope_amd.polytope as pp
+    solvers.default_solver = "hip"
+    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+    a = pc.mldivide(P[1], P[0]); b_ = pc.mldivide(P[2], P[0])
+    m = pieces(a)[2]; subs = pieces(b_)
+    cut = pc.mldivide(m.copy(), subs[4])
+    print("memo sizes", len(pp._convex_memo), len(pp._hull_memo))
+    keys = [pp._content_key(x) for x in pieces(cut)]
+    import itertools
+    hits = [(i, j, pp._convex_memo.get(frozenset([keys[i], keys[j]]))) for i, j in itertools.combinations(range(len(keys)), 2) if frozenset([keys[i], keys[j]]) in pp._convex_memo]
+    print("pairs of the cut's pieces already in the memo:", hits)
+    out1 = pp._passed_untouched(pc.Region([x for x in pieces(cut)]), 11)
+    print("with the memo as it is ->", len(pieces(out1)))
+    pp._convex_memo.clear(); pp._hull_memo.clear()
+    out2 = pp._passed_untouched(pc.Region([x for x in pieces(cut)]), 11)
+    print("memos cleared ->", len(pieces(out2)))
+    # one pass by hand, verbose
+    solvers.default_solver = "hip"
+    Pm = pc.Region()
+    for x in pieces(cut):
+        Pm = pc.union(Pm, x, check_convex=True)
+        print("   after adding a piece:", len(pieces(Pm)))
+if len(sys.argv) > 4 and sys.argv[4] == "member2d":
+    import polytope_amd.polytope as pp
+    solvers.default_solver = "hip"
+    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+    a = pc.mldivide(P[1], P[0]); b_ = pc.mldivide(P[2], P[0])
+    m = pieces(a)[2]; subs = pieces(b_)
+    cut = pieces(pc.mldivide(m.copy(), subs[4]))
+    solvers.default_solver = "scipy"
+    cut_s = pieces(pc.mldivide(m.copy(), subs[4]))
+    print("same pieces in the same order (1e-9):", [bool(x.A.shape == y.A.shape and np.allclose(x.A, y.A, atol=1e-9) and np.allclose(x.b, y.b, atol=1e-9)) for x, y in zip(cut, cut_s)])
+    for k, x in enumerate(cut):
+        fresh = pc.Polytope(x.A.copy(), x.b.copy(), normalize=False)
+        lo, hi = fresh.bounding_box
+        r, xc = pc.cheby_ball(fresh)
+        print(k, "cached bbox", None if x.bbox is None else "ok" if np.allclose(x.bbox[0], lo, atol=1e-7) and np.allclose(x.bbox[1], hi, atol=1e-7) else ("WRONG", x.bbox[0].ravel(), lo.ravel(), x.bbox[1].ravel(), hi.ravel()),
+              "| cached ball", x._chebR, "fresh", float(r), "| minrep", x.minrep, "fulldim", x.fulldim)
+if len(sys.argv) > 4 and sys.argv[4] == "leaf":
+    import polytope_amd.polytope as pp
+    from oracle import oracle as O
+    solvers.default_solver = "hip"
+    P = [pc.Polytope(A.copy(), b.copy()) for A, b in data]
+    a = pc.mldivide(P[1], P[0]); b_ = pc.mldivide(P[2], P[0])
+    m = pieces(a)[2]; subs = pieces(b_)
+    o_rm = pp._reduce_many
+    caught = []
+    def rm(polys, *a_, **k):
+        out = o_rm(polys, *a_, **k); caught.append(([(p.A.copy(), p.b.copy()) for p in polys], out)); return out
+    pp._reduce_many = rm
+    cut = pieces(pc.mldivide(m.copy(), subs[4]))
+    pp._reduce_many = o_rm
+    np.set_printoptions(precision=6, linewidth=200, suppress=True)
+    for polys, outs in caught:
+        for (Aq, bq), q in zip(polys, outs):
+            solvers.default_solver = "scipy"
+            ref = pc.reduce(pc.Polytope(Aq.copy(), bq.copy(), normalize=False))
+            solvers.default_solver = "hip"
+            o = O.reduce(Aq, bq)
+            same = q is not None and q.A.shape == ref.A.shape and np.allclose(q.A, ref.A, atol=1e-9) and np.allclose(q.b, ref.b, atol=1e-9)
+            print("leaf rows", Aq.shape[0], "hip kept", None if q is None else q.A.shape[0], "scipy kept", ref.A.shape[0], "oracle mask", bin(int(o["mask"])), "nlp", o["nlp"], "same:", same)
+            if not same:
+                np.savez("gpurun_out/leaf_%d.npz" % Aq.shape[0], A=Aq, b=bq)
+                print(np.c_[Aq, bq])
