@@ -79,6 +79,7 @@ typedef struct {
     int rowact[PLPO_MAXM]; /* row takes part in the ratio test             */
     int coldead[PLPO_MAXN];
     int iters, maxit;
+    int unb_col;           /* run(): the entering column when it returned ST_UNBND */
 } dict_t;
 
 /* ids: 0..n-1 structural (free) x_j; n..n+m-1 slack of row i; -1 artificial t
@@ -165,7 +166,7 @@ static int run(dict_t *D)
             /* ties: Dantzig mode keeps the first (lowest) row, Bland mode the lowest variable id */
             if (r < 0 || q < rmin || (bland && q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
         }
-        if (r < 0) return ST_UNBND;
+        if (r < 0) { D->unb_col = e; return ST_UNBND; }
         ndeg = (rmin <= DEGEN_EPS) ? ndeg + 1 : 0;
         pivot(D, r, e);
     }
@@ -178,7 +179,7 @@ static void dict_init(dict_t *D, int m, int n)
     memset(D->beta, 0, (size_t)m * sizeof(double));
     memset(D->cost, 0, sizeof(D->cost)); memset(D->cost2, 0, sizeof(D->cost2));
     memset(D->coldead, 0, sizeof(D->coldead));
-    D->negz = D->negz2 = 0.0; D->carry = 0; D->iters = 0;
+    D->negz = D->negz2 = 0.0; D->carry = 0; D->iters = 0; D->unb_col = -1;
     D->m = m; D->n = n; D->nc = n;
     for (int i = 0; i < m; ++i) { D->rowvar[i] = n + i; D->rowsgn[i] = 1; D->rowact[i] = 1; }
     for (int j = 0; j < PLPO_MAXN; ++j) { D->colvar[j] = j; D->colsgn[j] = 1; }
@@ -193,9 +194,13 @@ static void extract_x(const dict_t *D, double *x)
 }
 
 /* min c'x s.t. Gx<=h, x free.  G is m x n row-major.  x/fun written only for status 0
- * (NaN otherwise).  solvers.py:149-158 semantics. */
-int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *h,
-                  double *x, double *fun, int *iters)
+ * (NaN otherwise).  solvers.py:149-158 semantics.  The double-precision dictionary simplex on its own: what the
+ * fused reduce (plpo_reduce) calls, and the first stage of plpo_lp_solve below.
+ * basis (optional, n + 2 ints; status 0 and 3): the n nonbasic variables of the final dictionary -- i >= 0: the slack of
+ * row i (the row is active), -1 - j: the free variable x_j left at zero --, then for status 3 the position (in that
+ * list) of the variable along which the LP is unbounded and the sign with which it moves. */
+int plpo_lp_solve_raw(int m, int n, const double *c, const double *G, const double *h,
+                      double *x, double *fun, int *iters, int *basis)
 {
     static const double qnan = NAN;
     dict_t D;
@@ -263,6 +268,16 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
     }
     st = run(&D);
     if (iters) *iters = D.iters;
+    if (basis && (st == ST_OPT || st == ST_UNBND)) {
+        int k = 0;
+        basis[n] = -1; basis[n + 1] = 0;
+        for (int j = 0; j < D.nc && k < n; ++j) {
+            if (D.coldead[j] || D.colvar[j] == ID_T) continue;
+            if (st == ST_UNBND && j == D.unb_col) { basis[n] = k; basis[n + 1] = D.colsgn[j]; }
+            basis[k++] = ISFREE(&D, D.colvar[j]) ? -1 - D.colvar[j] : D.colvar[j] - n;
+        }
+        while (k < n) basis[k++] = -1000;   /* (cannot happen: n live columns) */
+    }
     if (st != ST_OPT) return st;
     extract_x(&D, x);
     double f = 0.0;
@@ -271,9 +286,249 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
     return ST_OPT;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * A-posteriori certificate of an LP answer (round 6).  The dictionary simplex above stops on ABSOLUTE tolerances
+ * (reduced costs above -1e-9, pivots above 1e-7) applied to a dictionary that carries the rounding of every pivot
+ * it went through.  On rows a hair apart (polytope.py's bounding_box, :1314-1411, has no dedupe in front of its LPs)
+ * that is worth 1e-7 .. 1e-5 on a box of size 3, and sides that are finite come out infinite.  So the answer is
+ * checked against the ORIGINAL rows, from the final basis alone:
+ *   M = the n rows that define the vertex (active rows; e_j for a free variable left at zero),
+ *   x = M^-1 rhs and y = -M^-T c by LU with partial pivoting + iterative refinement (residuals in binary128),
+ *   primal:  h_i - G_i.x >= -1e-10 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
+ *   dual:    y_k |G_k|_inf >= -1e-11 |c|_inf on active rows, |y_k| <= 1e-11 |c|_inf on the free variables
+ * -- an optimal basis of the LP as given, its vertex computed to the last bits whatever path led there.  An
+ * unbounded answer is checked the same way (ray w = M^-1 (-/+ u_e): G_i.w <= 1e-12 |G_i| |w| for every row, c.w < 0).
+ * What fails is solved again by plpo_lp_solve_q (binary128; plp_oracle_q.c): the oracle never returns an answer it
+ * could not verify.  The HIP library does the same with its own verifier kernel and a double-double engine
+ * (polytope_amd/csrc/plp_verify.hip). */
+#include <quadmath.h>
+int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double *h,
+                    double *x, double *fun, int *iters, int *basis);
+
+/* An LP whose optimum lies beyond PLPO_BIG times the scale of its data is UNBOUNDED for the reference: HiGHS takes no
+ * pivot below ~1e-9 of a (scaled) column, so a row that stops a ray only that far out is no blocking row -- measured on
+ * polytopes with two rows 1e-9 .. 1e-11 rad apart facing each other (scripts/soak_lane.py, family `dup`): box sides
+ * whose exact value is 1e5 .. 1.5e9 come back from scipy.optimize.linprog as that value, beyond ~2e9 as +-inf, with
+ * garbage in between (exact 2.4e9 -> 4.8e9).  The exact optimum decides, so the rule is independent of the path: both
+ * this oracle and the HIP library apply it to the certified / re-solved value.  scale = |c|_inf * max(1, max_i
+ * |h_i| / |G_i|_inf). */
+#define PLPO_BIG 1e9
+static double g_tol_dual = 1e-12;   /* plpo_set_tol_dual: experiments */
+#define PLPO_TOL_DUAL g_tol_dual
+void plpo_set_tol_dual(double t) { g_tol_dual = t; }
+static double lp_scale(int m, int n, const double *c, const double *G, const double *h)
+{
+    double cmax = 0.0, hs = 1.0;
+    for (int j = 0; j < n; ++j) if (fabs(c[j]) > cmax) cmax = fabs(c[j]);
+    for (int i = 0; i < m; ++i) {
+        double gmax = 0.0;
+        for (int j = 0; j < n; ++j) if (fabs(G[i * n + j]) > gmax) gmax = fabs(G[i * n + j]);
+        if (gmax > 0.0 && fabs(h[i]) > hs * gmax) hs = fabs(h[i]) / gmax;
+    }
+    return cmax * hs;
+}
+
+static int g_certify = 1;            /* plpo_set_certify(0): plpo_lp_solve = the raw double engine (experiments) */
+static long g_cert_stat[4];          /* answers certified, handed to binary128, of those: status changed, - */
+void plpo_set_certify(int on) { g_certify = on; }
+void plpo_cert_stats(long *out) { for (int k = 0; k < 4; ++k) out[k] = g_cert_stat[k]; }
+
+/* LU of the n x n matrix M (row-major, overwritten) with partial pivoting; perm[k] = row of M in position k.
+ * Returns 0 when a pivot is below 1e-13 of the largest entry (singular to working precision). */
+static int lu_factor(int n, double *M, int *perm)
+{
+    double big = 0.0;
+    for (int k = 0; k < n * n; ++k) if (fabs(M[k]) > big) big = fabs(M[k]);
+    if (!(big > 0.0)) return 0;
+    for (int k = 0; k < n; ++k) perm[k] = k;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int i = k + 1; i < n; ++i) if (fabs(M[i * n + k]) > fabs(M[p * n + k])) p = i;
+        if (!(fabs(M[p * n + k]) > 1e-13 * big)) return 0;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { const double t = M[k * n + j]; M[k * n + j] = M[p * n + j]; M[p * n + j] = t; }
+            const int t = perm[k]; perm[k] = perm[p]; perm[p] = t;
+        }
+        const double inv = 1.0 / M[k * n + k];
+        for (int i = k + 1; i < n; ++i) {
+            const double f = M[i * n + k] * inv;
+            M[i * n + k] = f;
+            for (int j = k + 1; j < n; ++j) M[i * n + j] = fma(-f, M[k * n + j], M[i * n + j]);
+        }
+    }
+    return 1;
+}
+/* solve M z = r  (LU, perm from lu_factor) */
+static void lu_solve(int n, const double *LU, const int *perm, const double *r, double *z)
+{
+    double t[PLPO_MAXN];
+    for (int k = 0; k < n; ++k) {
+        double s = r[perm[k]];
+        for (int j = 0; j < k; ++j) s = fma(-LU[k * n + j], t[j], s);
+        t[k] = s;
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double s = t[k];
+        for (int j = k + 1; j < n; ++j) s = fma(-LU[k * n + j], z[j], s);
+        z[k] = s / LU[k * n + k];
+    }
+}
+/* solve M' z = r */
+static void lu_solve_t(int n, const double *LU, const int *perm, const double *r, double *z)
+{
+    double t[PLPO_MAXN];
+    for (int k = 0; k < n; ++k) {          /* U' t = r */
+        double s = r[k];
+        for (int j = 0; j < k; ++j) s = fma(-LU[j * n + k], t[j], s);
+        t[k] = s / LU[k * n + k];
+    }
+    for (int k = n - 1; k >= 0; --k) {     /* L' w = t */
+        double s = t[k];
+        for (int j = k + 1; j < n; ++j) s = fma(-LU[j * n + k], t[j], s);
+        t[k] = s;
+    }
+    for (int k = 0; k < n; ++k) z[perm[k]] = t[k];
+}
+
+/* z = M^-1 r with three rounds of refinement (residuals in binary128); TRANS: M' z = r */
+static void lu_solve_refined(int n, const double *M0, const double *LU, const int *perm, const double *r, double *z, int trans)
+{
+    double rr[PLPO_MAXN], dz[PLPO_MAXN];
+    if (trans) lu_solve_t(n, LU, perm, r, z); else lu_solve(n, LU, perm, r, z);
+    for (int it = 0; it < 3; ++it) {
+        for (int k = 0; k < n; ++k) {
+            __float128 s = r[k];
+            for (int j = 0; j < n; ++j) s -= (__float128)(trans ? M0[j * n + k] : M0[k * n + j]) * z[j];
+            rr[k] = (double)s;
+        }
+        if (trans) lu_solve_t(n, LU, perm, rr, dz); else lu_solve(n, LU, perm, rr, dz);
+        for (int j = 0; j < n; ++j) z[j] += dz[j];
+    }
+}
+
+/* status 0 / 3 of the raw engine with its basis -> 1 and (status 0) the polished x, fun when the certificate holds */
+#include <stdio.h>
+static int g_cert_dbg = 0;
+void plpo_set_cert_debug(int on) { g_cert_dbg = on; }
+#define CERT_FAIL(code) do { if (g_cert_dbg) fprintf(stderr, "lp_certify: fail %d (m %d n %d status %d)\n", code, m, n, status); return 0; } while (0)
+static int lp_certify(int m, int n, const double *c, const double *G, const double *h, const int *basis, int status,
+                      double *x, double *fun)
+{
+    double M0[PLPO_MAXN * PLPO_MAXN], LU[PLPO_MAXN * PLPO_MAXN], rhs[PLPO_MAXN], z[PLPO_MAXN];
+    int perm[PLPO_MAXN];
+    if (n > PLPO_MAXN - 1) CERT_FAIL(1);
+    for (int k = 0; k < n; ++k) {
+        const int v = basis[k];
+        if (v >= 0) {
+            if (v >= m) CERT_FAIL(2);
+            for (int j = 0; j < n; ++j) M0[k * n + j] = G[v * n + j];
+            rhs[k] = h[v];
+        } else {
+            const int j0 = -1 - v;
+            if (j0 < 0 || j0 >= n) CERT_FAIL(3);
+            for (int j = 0; j < n; ++j) M0[k * n + j] = (j == j0) ? 1.0 : 0.0;
+            rhs[k] = 0.0;
+        }
+    }
+    memcpy(LU, M0, sizeof(double) * (size_t)n * n);
+    if (!lu_factor(n, LU, perm)) CERT_FAIL(4);
+    double cmax = 0.0;
+    for (int j = 0; j < n; ++j) if (fabs(c[j]) > cmax) cmax = fabs(c[j]);
+    /* the vertex */
+    lu_solve_refined(n, M0, LU, perm, rhs, z, 0);
+    double zmax = 0.0;
+    for (int j = 0; j < n; ++j) { if (!isfinite(z[j])) CERT_FAIL(5); if (fabs(z[j]) > zmax) zmax = fabs(z[j]); }
+    const double xs = zmax > 1.0 ? zmax : 1.0;
+    if (status == ST_UNBND) {
+        /* the vertex z the engine stood on and the ray w it left along: every row that w runs into must lie beyond
+         * the point where the objective passes PLPO_BIG times the scale of the data (lp_scale) */
+        const int e = basis[n];
+        double w[PLPO_MAXN], ru[PLPO_MAXN];
+        if (e < 0 || e >= n) CERT_FAIL(6);
+        for (int k = 0; k < n; ++k) ru[k] = 0.0;
+        ru[e] = basis[e] >= 0 ? -1.0 : (double)basis[n + 1];   /* the slack of an active row grows / the free variable moves by its sign */
+        lu_solve_refined(n, M0, LU, perm, ru, w, 0);
+        __float128 cw = 0, cz = 0;
+        double wmax = 0.0;
+        for (int j = 0; j < n; ++j) { if (!isfinite(w[j])) CERT_FAIL(7); if (fabs(w[j]) > wmax) wmax = fabs(w[j]); cw += (__float128)c[j] * w[j]; cz += (__float128)c[j] * z[j]; }
+        if (!((double)cw < 0.0)) CERT_FAIL(8);
+        const double big = PLPO_BIG * lp_scale(m, n, c, G, h);
+        for (int i = 0; i < m; ++i) {
+            __float128 gw = 0, sl = h[i];
+            double gmax = 0.0;
+            for (int j = 0; j < n; ++j) {
+                gw += (__float128)G[i * n + j] * w[j]; sl -= (__float128)G[i * n + j] * z[j];
+                if (fabs(G[i * n + j]) > gmax) gmax = fabs(G[i * n + j]);
+            }
+            double tol = gmax * xs;
+            if (fabs(h[i]) > tol) tol = fabs(h[i]);
+            if ((double)sl < -1e-10 * tol) CERT_FAIL(9);             /* the vertex itself must be feasible */
+            int inb = 0;                                          /* rows of the basis: G_k.w = 0 (or -1) by construction */
+            for (int k = 0; k < n; ++k) inb |= (basis[k] == i);
+            if (inb || !((double)gw > 1e-14 * gmax * wmax)) continue;   /* (below the rounding of w: not a blocking row) */
+            if (sl < 0) sl = 0;
+            const __float128 t = sl / gw;                        /* the ray meets row i here ... */
+            if (fabsq(cz + t * cw) <= (__float128)big) CERT_FAIL(10); /* ... before the objective is out of range */
+        }
+        return 1;
+    }
+    /* dual: M' y = -c */
+    double y[PLPO_MAXN], nc_[PLPO_MAXN];
+    for (int j = 0; j < n; ++j) nc_[j] = -c[j];
+    lu_solve_refined(n, M0, LU, perm, nc_, y, 1);
+    for (int k = 0; k < n; ++k) {
+        if (!isfinite(y[k])) CERT_FAIL(11);
+        if (basis[k] >= 0) {
+            double gmax = 0.0;
+            for (int j = 0; j < n; ++j) if (fabs(M0[k * n + j]) > gmax) gmax = fabs(M0[k * n + j]);
+            if (y[k] * gmax < -PLPO_TOL_DUAL * cmax) CERT_FAIL(12);
+        } else if (fabs(y[k]) > PLPO_TOL_DUAL * cmax) CERT_FAIL(13);
+    }
+    for (int i = 0; i < m; ++i) {
+        __float128 s = h[i];
+        double gmax = 0.0;
+        for (int j = 0; j < n; ++j) { s -= (__float128)G[i * n + j] * z[j]; if (fabs(G[i * n + j]) > gmax) gmax = fabs(G[i * n + j]); }
+        double tol = gmax * xs;
+        if (fabs(h[i]) > tol) tol = fabs(h[i]);
+        if ((double)s < -1e-10 * tol) CERT_FAIL(14);
+    }
+    __float128 f = 0;
+    for (int j = 0; j < n; ++j) { f += (__float128)c[j] * z[j]; x[j] = z[j]; }
+    *fun = (double)f;
+    return 1;
+}
+
+/* lpsolve (solvers.py:76-106, :149-158): the double engine, its answer certified, binary128 where that fails; an
+ * optimum out of range (PLPO_BIG) is reported unbounded. */
+int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *h,
+                  double *x, double *fun, int *iters)
+{
+    static const double qnan = NAN;
+    int basis[PLPO_MAXN + 2];
+    int st = plpo_lp_solve_raw(m, n, c, G, h, x, fun, iters, basis);
+    if (!g_certify || st == ST_INFEAS || m > PLPO_MAXM || n > PLPO_MAXN - 1 || n < 1) return st;
+    if ((st == ST_OPT || st == ST_UNBND) && lp_certify(m, n, c, G, h, basis, st, x, fun)) {
+        ++g_cert_stat[0];
+    } else {
+        if (st == ST_NUM) {   /* non-finite input (the raw engine's argument check): nothing to solve */
+            int fin = 1;
+            for (int j = 0; j < n; ++j) if (!isfinite(c[j])) fin = 0;
+            for (int i = 0; i < m && fin; ++i) { if (!isfinite(h[i])) fin = 0; for (int j = 0; j < n; ++j) if (!isfinite(G[i * n + j])) fin = 0; }
+            if (!fin) return st;
+        }
+        ++g_cert_stat[1];
+        const int sq = plpo_lp_solve_q(m, n, c, G, h, x, fun, NULL, NULL);
+        if (sq != st) ++g_cert_stat[2];
+        st = sq;
+    }
+    if (st == ST_OPT && fabs(*fun) > PLPO_BIG * lp_scale(m, n, c, G, h)) st = ST_UNBND;
+    if (st != ST_OPT) { for (int j = 0; j < n; ++j) x[j] = qnan; *fun = qnan; }
+    return st;
+}
+
 /* F1 (polytope.py:1283-1288): c = -e_{d+1}, G = [A | sqrt(sum(A*A,1))], h = b.
  * Returns the raw LP status; r = x[-1], xc = x[:-1] (NaN unless status 0). */
-int plpo_cheby(int m, int d, const double *A, const double *b, double *r, double *xc, int *iters)
+static int cheby_impl(int m, int d, const double *A, const double *b, double *r, double *xc, int *iters, int cert)
 {
     double G[PLPO_MAXM * PLPO_MAXN], c[PLPO_MAXN], x[PLPO_MAXN], fun;
     const int n = d + 1;
@@ -285,22 +540,27 @@ int plpo_cheby(int m, int d, const double *A, const double *b, double *r, double
     }
     for (int k = 0; k < d; ++k) c[k] = 0.0;
     c[d] = -1.0;
-    const int st = plpo_lp_solve(m, n, c, G, b, x, &fun, iters);
+    const int st = cert ? plpo_lp_solve(m, n, c, G, b, x, &fun, iters) : plpo_lp_solve_raw(m, n, c, G, b, x, &fun, iters, NULL);
     *r = x[d];
     for (int k = 0; k < d; ++k) xc[k] = x[k];
     return st;
 }
 
+int plpo_cheby(int m, int d, const double *A, const double *b, double *r, double *xc, int *iters)
+{
+    return cheby_impl(m, d, A, b, r, xc, iters, 1);
+}
+
 /* F3 (polytope.py:1367-1409).  lb/ub get +-inf on status 3, 0 / lb on status 2.
  * Returns 0, or the offending LP status (1/4) where the reference raises RuntimeError. */
-int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb, double *ub, int *nlp)
+static int bbox_impl(int m, int d, const double *A, const double *b, double *lb, double *ub, int *nlp, int cert)
 {
     double c[PLPO_MAXN], x[PLPO_MAXN], fun;
     int bad = 0;
     for (int i = 0; i < d; ++i) {
         for (int k = 0; k < d; ++k) c[k] = 0.0;
         c[i] = 1.0;
-        int st = plpo_lp_solve(m, d, c, A, b, x, &fun, NULL);
+        int st = cert ? plpo_lp_solve(m, d, c, A, b, x, &fun, NULL) : plpo_lp_solve_raw(m, d, c, A, b, x, &fun, NULL, NULL);
         if (nlp) ++*nlp;
         if (st == ST_OPT) lb[i] = x[i];
         else if (st == ST_UNBND) lb[i] = -INFINITY;
@@ -310,7 +570,7 @@ int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb
     for (int i = 0; i < d; ++i) {
         for (int k = 0; k < d; ++k) c[k] = 0.0;
         c[i] = -1.0;
-        int st = plpo_lp_solve(m, d, c, A, b, x, &fun, NULL);
+        int st = cert ? plpo_lp_solve(m, d, c, A, b, x, &fun, NULL) : plpo_lp_solve_raw(m, d, c, A, b, x, &fun, NULL, NULL);
         if (nlp) ++*nlp;
         if (st == ST_OPT) ub[i] = x[i];
         else if (st == ST_UNBND) ub[i] = INFINITY;
@@ -318,6 +578,11 @@ int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb
         else { ub[i] = NAN; bad = st; }
     }
     return bad;
+}
+
+int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb, double *ub, int *nlp)
+{
+    return bbox_impl(m, d, A, b, lb, ub, nlp, 1);
 }
 
 /* flags returned by plpo_reduce */
@@ -340,7 +605,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     for (int i = 0; i < m; ++i) bout[i] = b[i];
     if (m > PLPO_MAXM_RED) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; return RF_EMPTY; }
     /* :1081 is_fulldim -> cheby_ball -> F1 */
-    int st = plpo_cheby(m, d, A, b, r, xc, NULL);
+    int st = cheby_impl(m, d, A, b, r, xc, NULL, 0);   /* the fused kernels' engine: not certified (see lp_certify) */
     ++*nlp;
     if (!(st == ST_OPT && *r >= 0.0)) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; }
     if (!(*r > abs_tol)) return RF_EMPTY;
@@ -383,7 +648,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     /* :1118-1134 bounding-box prefilter */
     if (neq > 3 * d) {
         double lb[16], ub[16];
-        if (plpo_bounding_box(neq, d, Aw, bw, lb, ub, nlp)) flags |= RF_LPFAIL;
+        if (bbox_impl(neq, d, Aw, bw, lb, ub, nlp, 0)) flags |= RF_LPFAIL;
         int k2 = 0;
         for (int p = 0; p < neq; ++p) {
             double s1 = 0.0, s2 = 0.0;
@@ -413,7 +678,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
         double c[16], x[16], fun;
         for (int j = 0; j < d; ++j) c[j] = -Aw[k * d + j];
         bw[k] += 0.1;
-        st = plpo_lp_solve(neq, d, c, Aw, bw, x, &fun, NULL);
+        st = plpo_lp_solve_raw(neq, d, c, Aw, bw, x, &fun, NULL, NULL);
         ++*nlp;
         bw[k] -= 0.1;
         if (st == ST_OPT) {
