@@ -23,7 +23,8 @@ template <int D, bool WDENSE>
 __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max, const double* __restrict__ A,
                                                           const double* __restrict__ b, const int* __restrict__ mrows,
                                                           double* __restrict__ lb, double* __restrict__ ub,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, signed char* __restrict__ basis8,
+                                                          double* __restrict__ centre) {
     constexpr int NC = D + 1;
     __shared__ __attribute__((aligned(16))) double sA[64 * D];
     __shared__ wide::WideShared<NC> sh;
@@ -90,11 +91,12 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
         if (__builtin_amdgcn_readfirstlane((int)ok)) {
             double negz = 0.0;
             int s2;
+            signed char* bo = basis8 ? basis8 + ((size_t)p * 2 * D + it) * D : nullptr;  // the LP's final basis, for the verifier
             if constexpr (WDENSE)
                 s2 = wide::solve_dense<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz,
-                                          *reinterpret_cast<wide::WideShared<D>*>(&sh));
+                                          *reinterpret_cast<wide::WideShared<D>*>(&sh), bo);
             else
-                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
+                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz, bo);
             // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
             if (s2 == ST_OPT) val = up ? (xck + negz) : (xck - negz);
             else if (s2 == ST_UNBND) val = up ? pinf : -pinf;
@@ -103,6 +105,10 @@ __global__ __launch_bounds__(64, 3) void bbox_lazy_kernel(long long B, int m_max
         if (lane == 0) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
     }
     if (lane == 0) status[p] = handed ? 1 : 0;
+    if (centre && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) centre[(size_t)p * D + k] = ok ? x[k] : qnan;
+    }
 }
 
 // ---- small batches: NW wavefronts per polytope (the pattern of reduce_wsplit_kernel, plp_reduce_r_impl.hpp).  One workgroup
@@ -112,7 +118,8 @@ template <int D, int NW, bool WDENSE>
 __global__ __launch_bounds__(64 * NW) void bbox_wsplit_kernel(long long B, int m_max, const double* __restrict__ A,
                                                               const double* __restrict__ b, const int* __restrict__ mrows,
                                                               double* __restrict__ lb, double* __restrict__ ub,
-                                                              int* __restrict__ status) {
+                                                              int* __restrict__ status, signed char* __restrict__ basis8,
+                                                              double* __restrict__ centre) {
     constexpr int NC = D + 1;
     __shared__ __attribute__((aligned(16))) double sA[64 * D];
     __shared__ wide::WideShared<NC> shw[NW];
@@ -197,11 +204,12 @@ __global__ __launch_bounds__(64 * NW) void bbox_wsplit_kernel(long long B, int m
         if (__builtin_amdgcn_readfirstlane((int)ok)) {   // (the same in every lane, and said so: the LP runs on full wavefronts)
             double negz = 0.0;
             int s2;
+            signed char* bo = basis8 ? basis8 + ((size_t)p * 2 * D + it) * D : nullptr;  // the LP's final basis, for the verifier
             if constexpr (WDENSE)
                 s2 = wide::solve_dense<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz,
-                                          *reinterpret_cast<wide::WideShared<D>*>(&shw[w]));
+                                          *reinterpret_cast<wide::WideShared<D>*>(&shw[w]), bo);
             else
-                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz);
+                s2 = lazy::solve<D>(lane, m, sA, (lane == kx) ? (up ? -1.0 : 1.0) : 0.0, be0, has, negz, bo);
             if (s2 == ST_OPT) val = up ? (xck + negz) : (xck - negz);
             else if (s2 == ST_UNBND) val = up ? pinf : -pinf;
             else handed = true;
@@ -211,6 +219,7 @@ __global__ __launch_bounds__(64 * NW) void bbox_wsplit_kernel(long long B, int m
     if (handed & (lane == 0)) atomicOr(&sflag[1], 1u);
     __syncthreads();
     if ((w == 0) & (lane == 0)) status[p] = (!ok | (sflag[1] != 0u)) ? 1 : 0;
+    if (centre && (w == 0) && lane < D) centre[(size_t)p * D + lane] = ok ? sx[lane] : qnan;
 }
 
 #ifndef PLP_BBOX_WSPLIT_MAXB
@@ -225,8 +234,11 @@ __global__ __launch_bounds__(64 * NW) void bbox_wsplit_kernel(long long B, int m
 
 template <int D>
 static int launch_bbox_lazy_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb,
-                              double* ub, int* status, hipStream_t st) {
+                              double* ub, int* status, hipStream_t st, BoxHandover* ho) {
     if (B > 2147483647ll) return 1;
+    signed char* b8 = ho ? ho->basis8 : nullptr;
+    double* ctr = ho ? ho->centre : nullptr;
+    if (ho) ho->mode = (b8 && ctr) ? 1 : 0;
     const char* wd = getenv("PLP_BBOX_WDENSE");  // 0 / 1: never / always the dense engine for the 2d LPs (A/B)
     // small batches: four wavefronts per polytope (PLP_BBOX_WSPLIT=0 / 1: never / always; PLP_BBOX_WSPLIT_MAXB)
     const char* ws = getenv("PLP_BBOX_WSPLIT");
@@ -235,26 +247,27 @@ static int launch_bbox_lazy_d(long long B, int m_max, const double* A, const dou
     if ((ws && ws[0] == '1') || (!(ws && ws[0] == '0') && B <= maxb)) {
         if (wd ? wd[0] == '1' : (D <= PLP_BBOX_WDENSE_MAXD))
             hipLaunchKernelGGL((bbox_wsplit_kernel<D, 4, true>), dim3((unsigned)B), dim3(256), 0, st, B, m_max, A, b, mrows, lb, ub,
-                               status);
+                               status, b8, ctr);
         else
             hipLaunchKernelGGL((bbox_wsplit_kernel<D, 4, false>), dim3((unsigned)B), dim3(256), 0, st, B, m_max, A, b, mrows, lb, ub,
-                               status);
+                               status, b8, ctr);
         return 0;
     }
     if (wd ? wd[0] == '1' : (D <= PLP_BBOX_WDENSE_MAXD))
         hipLaunchKernelGGL((bbox_lazy_kernel<D, true>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows,
-                           lb, ub, status);
+                           lb, ub, status, b8, ctr);
     else
         hipLaunchKernelGGL((bbox_lazy_kernel<D, false>), dim3((unsigned)(B < 1 ? 1 : B)), dim3(64), 0, st, B, m_max, A, b, mrows,
-                           lb, ub, status);
+                           lb, ub, status, b8, ctr);
     return 0;
 }
 
-#define PLP_CASE_BL(K) case K: return launch_bbox_lazy_d<K>(B, m_max, A, b, mrows, lb, ub, status, st);
+#define PLP_CASE_BL(K) case K: return launch_bbox_lazy_d<K>(B, m_max, A, b, mrows, lb, ub, status, st, ho);
 
 // d = 5..16, m_max <= 64; returns 1 when it does not apply
 int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
-                     double* ub, int* status, hipStream_t st) {
+                     double* ub, int* status, hipStream_t st, BoxHandover* ho) {
+    if (ho) ho->mode = 0;
     if (m_max < 1 || m_max > 64 || B < 1) return 1;
     switch (d) {
         PLP_CASE_BL(5) PLP_CASE_BL(6) PLP_CASE_BL(7) PLP_CASE_BL(8)

@@ -38,6 +38,18 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace
 
+namespace plp {
+size_t verify_scratch_bytes(long long nlp, int m_max);
+bool verify_enabled();
+int launch_verify_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
+                     double* x, double* fun, int* status, void* scratch, hipStream_t st);
+int launch_verify_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
+                        double* xc, int* status, void* scratch, hipStream_t st);
+int launch_verify_box(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
+                      int* status, const signed char* basis8, const double* centre, const double* xfin, void* scratch,
+                      hipStream_t st);
+}  // namespace plp
+
 struct plp_ctx {
     int device;
     hipStream_t stream;
@@ -92,6 +104,10 @@ struct plp_ctx {
     // beyond 16 the table is emptied after a device synchronisation)
     struct StreamBuf { void* p = nullptr; size_t bytes = 0; };
     std::unordered_map<void*, StreamBuf> as_scratch;
+    // the verifier behind the LP / Chebyshev / bounding-box batches (plp_verify.hip): fail list + the careful engine's
+    // dictionaries, one grow-only buffer per stream like as_scratch; bounding boxes: the engines' bases and centres
+    std::unordered_map<void*, StreamBuf> vf_scratch;
+    std::unordered_map<void*, StreamBuf> vf_basis;
 };
 
 namespace {
@@ -109,6 +125,24 @@ struct Arena {
 };
 
 size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+// a grow-only device buffer of this stream (see plp_ctx::as_scratch); nullptr: allocation failed
+void* stream_buf(std::unordered_map<void*, plp_ctx::StreamBuf>& table, void* stream, size_t need) {
+    if (table.size() >= 16 && !table.count(stream)) {
+        (void)hipDeviceSynchronize();
+        for (auto& kv : table) if (kv.second.p) (void)hipFree(kv.second.p);
+        table.clear();
+    }
+    plp_ctx::StreamBuf& sb = table[stream];
+    if (need > sb.bytes) {
+        if (sb.p) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(sb.p); }  // (its last user ran on this stream)
+        sb.p = nullptr;
+        sb.bytes = 0;
+        if (hipMalloc(&sb.p, need + need / 4) == hipSuccess) sb.bytes = need + need / 4;
+        else (void)hipGetLastError();
+    }
+    return sb.p;
+}
 
 int ensure_arena(plp_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->arena_bytes) return PLP_OK;
@@ -428,6 +462,8 @@ int plp_ctx_destroy(plp_ctx* ctx) {
     if (ctx->reduce_ctr) (void)hipFree(ctx->reduce_ctr);
     if (ctx->retry_ring) (void)hipFree(ctx->retry_ring);
     for (auto& kv : ctx->as_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->vf_scratch) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->vf_basis) if (kv.second.p) (void)hipFree(kv.second.p);
     if (ctx->mf_ev) (void)hipEventDestroy(ctx->mf_ev);
     if (ctx->hull_spare.full) {
         (void)hipFree(ctx->hull_spare.X); (void)hipFree(ctx->hull_spare.owner); (void)hipFree(ctx->hull_spare.dist);
@@ -450,6 +486,26 @@ int plp_ctx_synchronize(plp_ctx* ctx, void* stream) {
     return PLP_OK;
 }
 
+// Every answer of the LP engines passes the verifier before it leaves the library (plp_verify.hip; PLP_VERIFY=0: A/B)
+static int verify_lp_answers(plp_ctx* ctx, hipStream_t st, int64_t B, int m_max, int n, const double* c, const double* G,
+                             const double* h, const int32_t* m, double* x, double* fun, int32_t* status) {
+    if (!plp::verify_enabled()) return PLP_OK;
+    void* sc = stream_buf(ctx->vf_scratch, (void*)st, plp::verify_scratch_bytes(B, m_max));
+    if (!sc) return fail(PLP_EHIP, "verifier: no device memory for its scratch (%zu bytes)", plp::verify_scratch_bytes(B, m_max));
+    if (plp::launch_verify_lp(B, m_max, n, c, G, h, m, x, fun, status, sc, st))
+        return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
+    return check_launch("verify_x_kernel");
+}
+static int verify_cheby_answers(plp_ctx* ctx, hipStream_t st, int64_t B, int m_max, int d, const double* A, const double* b,
+                                const int32_t* m, double* r, double* xc, int32_t* status) {
+    if (!plp::verify_enabled()) return PLP_OK;
+    void* sc = stream_buf(ctx->vf_scratch, (void*)st, plp::verify_scratch_bytes(B, m_max));
+    if (!sc) return fail(PLP_EHIP, "verifier: no device memory for its scratch (%zu bytes)", plp::verify_scratch_bytes(B, m_max));
+    if (plp::launch_verify_cheby(B, m_max, d, A, b, m, r, xc, status, sc, st))
+        return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
+    return check_launch("verify_x_kernel");
+}
+
 // ------------------------------------------------------------------------------- lp_solve
 int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int n, const double* c,
                            const double* G, const double* h, const int32_t* m, double* x, double* fun,
@@ -463,7 +519,9 @@ int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_lp(B, m_max, n, c, G, h, m, x, fun, status, iters, st))
         return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
-    return check_launch("lp_kernel");
+    int rc = check_launch("lp_kernel");
+    if (rc) return rc;
+    return verify_lp_answers(ctx, st, B, m_max, n, c, G, h, m, x, fun, status);
 }
 
 int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* c, const double* G,
@@ -511,11 +569,11 @@ int plp_lp_solve_batch(plp_ctx* ctx, int64_t B, int m_max, int n, const double* 
                                {dm, m, nullptr, m ? (size_t)B * 4 : 0}});
         if (rc) return rc;
         // small batches: the fast kernels now; the general kernel only if a status, host-visible below anyway, asks for it
-        if (B <= 16384) {
+        if (B <= 16384 && !plp::verify_enabled()) {
             if (plp::launch_lp_phase(B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit, st, 1, &more))
                 return fail(PLP_EUNSUPPORTED, "lp kernel: unsupported size");
             rc = check_launch("lp_kernel");
-        } else {
+        } else {  // (with the verifier behind the engines both passes are launched: it has to see final answers)
             rc = plp_lp_solve_batch_dev(ctx, st, B, m_max, n, dc, dG, dh, m ? dm : nullptr, dx, dfun, dst, dit);
         }
         if (rc) return rc;
@@ -546,7 +604,9 @@ int plp_cheby_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d,
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
     if (plp::launch_cheby(B, m_max, d, A, b, m, r, xc, status, st))
         return fail(PLP_EUNSUPPORTED, "cheby kernel: unsupported size");
-    return check_launch("cheby_kernel");
+    int rc = check_launch("cheby_kernel");
+    if (rc) return rc;
+    return verify_cheby_answers(ctx, st, B, m_max, d, A, b, m, r, xc, status);
 }
 
 int plp_cheby_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b,
@@ -603,9 +663,29 @@ int plp_bbox_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, 
         return fail(PLP_EUNSUPPORTED, "m_max=%d d=%d outside envelope (m<=64, d<=16)", m_max, d);
     if (m_max < 1) return fail(PLP_EUNSUPPORTED, "bbox kernel: m_max=%d (needs m_max >= 1)", m_max);
     hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default stream
-    if (plp::launch_bbox(B, m_max, d, A, b, m, lb, ub, status, st))
+    // the verifier behind the fused kernels (plp_verify.hip): they hand over each box LP's final basis + the centre, or the
+    // point the LP ended on; one buffer per stream: [bases 2 d d bytes | centres d doubles | points 2 d d doubles] per polytope
+    plp::BoxHandover ho{nullptr, nullptr, nullptr, 0};
+    void* vsc = nullptr;
+    if (plp::verify_enabled()) {
+        const size_t nb8 = ((size_t)B * 2 * d * d + 255) & ~(size_t)255, nct = (size_t)B * d * 8;
+        const bool lane_form = d <= 3 && m_max <= 32;   // (launch_bbox: the shapes bbox_lane_kernel may take)
+        const size_t nxf = lane_form ? (size_t)B * 2 * d * d * 8 : 0;
+        char* hb = static_cast<char*>(stream_buf(ctx->vf_basis, stream, nb8 + nct + nxf + 256));
+        vsc = stream_buf(ctx->vf_scratch, stream, plp::verify_scratch_bytes(B * 2 * d, m_max));
+        if (!hb || !vsc) return fail(PLP_EHIP, "verifier: no device memory for its scratch");
+        ho.basis8 = reinterpret_cast<signed char*>(hb);
+        ho.centre = reinterpret_cast<double*>(hb + nb8);
+        ho.xfin = lane_form ? reinterpret_cast<double*>(hb + nb8 + nct) : nullptr;
+    }
+    if (plp::launch_bbox(B, m_max, d, A, b, m, lb, ub, status, st, &ho))
         return fail(PLP_EUNSUPPORTED, "bbox kernel: unsupported size");
-    return check_launch("bbox_r_kernel");
+    int rc = check_launch("bbox_r_kernel");
+    if (rc || !ho.mode) return rc;
+    if (plp::launch_verify_box(B, m_max, d, A, b, m, lb, ub, status, ho.mode == 1 ? ho.basis8 : nullptr,
+                               ho.mode == 1 ? ho.centre : nullptr, ho.mode == 2 ? ho.xfin : nullptr, vsc, st))
+        return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
+    return check_launch("verify_box_kernel");
 }
 
 int plp_bbox_batch(plp_ctx* ctx, int64_t B, int m_max, int d, const double* A, const double* b, const int32_t* m,

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lon
                                                                          const int* __restrict__ mrows,
                                                                          double* __restrict__ lb,
                                                                          double* __restrict__ ub,
-                                                                         int* __restrict__ status, int force_retry) {
+                                                                         int* __restrict__ status, int force_retry,
+                                                                        signed char* __restrict__ basis8, double* __restrict__ centre) {
     const Grp g(GS);
     constexpr int gpb = RBLK / GS;
     const int gib = threadIdx.x / GS;
@@ -215,6 +216,10 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lon
         S.ract = has;
         S.mode = ok ? M_P2 : M_DONE;
         S.template run_fast<GS>(g);
+        if (basis8 && (valid & (g.gl == 0))) {  // the final basis, for the verifier (plp_verify.hip)
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) basis8[((size_t)p * 2 * D + it) * D + kk] = (signed char)(S.cv[kk] < D ? -1 - S.cv[kk] : S.cv[kk] - D);
+        }
         // zeta = c.x' = -negz ; x_k = xc_k + x'_k ; lower: c = +e_k, upper: c = -e_k
         double val;
         if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
@@ -223,6 +228,10 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_r_kernel(long lon
         if (valid & (g.gl == 0)) (up ? ub : lb)[p * D + kx] = ok ? val : qnan;
     }
     if (valid & (g.gl == 0)) status[p] = handed ? 1 : 0;
+    if (centre && (valid & (g.gl == 0))) {
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) centre[(size_t)p * D + kk] = ok ? x[kk] : qnan;
+    }
 }
 
 // The same for small batches (latency form, cf. reduce_split_kernel): ONE polytope per wavefront, every lane group solves
@@ -235,7 +244,8 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_split_kernel(long
                                                                              const int* __restrict__ mrows,
                                                                              double* __restrict__ lb,
                                                                              double* __restrict__ ub,
-                                                                             int* __restrict__ status, int force_retry) {
+                                                                             int* __restrict__ status, int force_retry,
+                                                                        signed char* __restrict__ basis8, double* __restrict__ centre) {
     static_assert(RBLK == 64, "one wavefront per workgroup: the polytope's verdict is a wave-wide vote");
     const Grp g(GS);
     constexpr int NGRP = RBLK / GS;
@@ -290,6 +300,10 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_split_kernel(long
         S.ract = has;
         S.mode = (ok & mine) ? M_P2 : M_DONE;
         S.template run_fast<GS>(g);
+        if (basis8 && (valid & mine & (g.gl == 0))) {  // the final basis, for the verifier (plp_verify.hip)
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) basis8[((size_t)p * 2 * D + it) * D + kk] = (signed char)(S.cv[kk] < D ? -1 - S.cv[kk] : S.cv[kk] - D);
+        }
         double val;
         if (S.status == ST_OPT) val = up ? (xck + S.negz) : (xck - S.negz);
         else if (S.status == ST_UNBND) val = up ? pinf : -pinf;
@@ -298,6 +312,10 @@ __global__ __launch_bounds__(RBLK, (D <= 4 ? 3 : 1)) void bbox_split_kernel(long
     }
     const bool any_handed = __any(handed);  // (all lanes of the wavefront work on this one polytope)
     if (valid & (threadIdx.x == 0)) status[p] = any_handed ? 1 : 0;
+    if (centre && (valid & (threadIdx.x == 0))) {
+#pragma unroll
+        for (int kk = 0; kk < D; ++kk) centre[(size_t)p * D + kk] = ok ? x[kk] : qnan;
+    }
 }
 
 // One lane group per pair (i, j < i): the rows of both cells are stacked with b + inflate, and the pair

@@ -69,11 +69,21 @@ int launch_cheby_r(long long B, int m_max, int d, const double* A, const double*
 
 // bounding boxes, Chebyshev LP + 2d LPs from its centre per polytope (d <= 8, plp_bbox_r.hip): status 0 = lb/ub
 // valid, 1 = polytope left to the generic LPs; returns 1 when the kernel does not apply
+// What the fused bounding-box kernels hand to the verifier (plp_verify.hip), per box LP (2d per polytope, lower_0, upper_0,
+// lower_1, ...): `basis8` -- its final basis, d signed bytes (>= 0: an active row; -1 - j: the free variable x'_j left at the
+// centre) -- with `centre` (d doubles per polytope), or `xfin` -- the point it ended on (d doubles; the one-LP-per-lane
+// kernel, whose walk has no basis of d entries when it ends on a face).  `mode` (out): 0 nothing written, 1 bases, 2 points.
+struct BoxHandover {
+    signed char* basis8;
+    double* centre;
+    double* xfin;
+    int mode;
+};
 int launch_bbox(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
-                double* ub, int* status, hipStream_t st);
+                double* ub, int* status, hipStream_t st, BoxHandover* ho = nullptr);
 // d = 9..16 (plp_bbox_lazy.hip); same contract
 int launch_bbox_lazy(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb,
-                     double* ub, int* status, hipStream_t st);
+                     double* ub, int* status, hipStream_t st, BoxHandover* ho = nullptr);
 
 // adjacency of all pairs of n cells (2*m_max <= 64, d <= 8) into the n x n matrix adj (compact == nullptr),
 // or of the pairs p_lo <= p < p_hi, p = i (i - 1) / 2 + j, j < i, into compact[p - p_lo]

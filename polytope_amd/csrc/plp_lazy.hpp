@@ -74,9 +74,11 @@ __device__ __forceinline__ bool price(const int lane, const double c, const unsi
 // min c.x' over { A x' <= beta } from x' = 0 (the rows of A in LDS at sA[i * D + j], row i = lane i; beta >= 0 in
 // lane i; rowact: row i exists).  c: lane j < D holds c_j.
 // Returns the status (ST_OPT / ST_UNBND / ST_NUM / ST_ITER / ST_RETRY); negz = -(optimal value) as in SimplexR.
+// basis_out (optional): the final basis for the verifier (plp_verify.hip), D signed bytes -- >= 0 an active row, -1 - j the free
+// variable x'_j still at zero; costs two read-lanes per pivot when asked for.
 template <int D>
 __device__ __forceinline__ int solve(const int lane, const int m_rows, const double* sA, double c, double beta, bool rowact,
-                                     double& negz_out) {
+                                     double& negz_out, signed char* __restrict__ basis_out = nullptr) {
     constexpr int K = K_STEPS;
     // (ur / qr / str are only ever indexed by unrolled loop counters: registers; ux / qx by t: private memory)
     double ur_[K_REG], qr_[K_REG];  // u_s of my row; my entry of rho_s (lanes j < D)
@@ -94,7 +96,12 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
     int status;
     int e, chi;
     double best;
-    if (!price<D>(lane, c, cfree, e, best, chi)) { negz_out = negz; return ST_OPT; }
+    int colvar = lane, rowvar = D + lane;  // (basis_out) lane j < D: the variable of column j; lane i: the basic variable of row i
+    if (!price<D>(lane, c, cfree, e, best, chi)) {
+        negz_out = negz;
+        if (basis_out && lane < D) basis_out[lane] = (signed char)(-1 - lane);
+        return ST_OPT;
+    }
     for (;;) {
         if (ndeg >= BLAND_AFTER) { status = ST_RETRY; break; }  // (as SimplexR::run_fast)
         if (t >= maxit) { status = ST_ITER; break; }
@@ -173,10 +180,16 @@ __device__ __forceinline__ int solve(const int lane, const int m_rows, const dou
         if (is_r & efree) rowact = false;  // a free variable never leaves again
         cfree &= ~(1u << e);
         steps = (lane == t) ? stt : steps;
+        if (basis_out) {
+            const int vin = __builtin_amdgcn_readlane(colvar, e), vout = __builtin_amdgcn_readlane(rowvar, r);
+            rowvar = is_r ? vin : rowvar;
+            colvar = (lane == e) ? vout : colvar;
+        }
         ++t;
         if (!price<D>(lane, c, cfree, e, best, chi)) { status = ST_OPT; break; }
     }
     negz_out = negz;
+    if (basis_out && lane < D) basis_out[lane] = (signed char)(colvar < D ? -1 - colvar : colvar - D);
     return status;
 }
 

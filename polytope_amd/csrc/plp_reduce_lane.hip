@@ -448,6 +448,14 @@ __device__ __forceinline__ void reduce_lane_tile(
             else if (S.status == ST_UNBND) v = up ? pinf : -pinf;
             else { v = qnan; lpfail = lpfail | (mine & (S.status != ST_RETRY)); }
             retry = retry | (mine & (S.status == ST_RETRY));
+            if constexpr (BBOX) {
+                // the point the walk ended on, for the verifier (plp_verify.hip: it reads a basis off it); BBOX: keep_out is that buffer
+                double* xfin = reinterpret_cast<double*>(keep_out);
+                if (xfin && (valid & mine & (part == 0))) {
+#pragma unroll
+                    for (int kk = 0; kk < D; ++kk) xfin[((size_t)(tile + gib) * 2 * D + it) * D + kk] = xc[kk] + x_of_lp(S, kk);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NROUND; ++q) val[q] = (q == rd) ? v : val[q];
         }
@@ -662,9 +670,10 @@ __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void reduce_lane_
 template <int D, int GS, int ROWS>
 __global__ __launch_bounds__(RBLOCK, PLP_REDUCE_LANE_WAVES(D)) void bbox_lane_kernel(
     long long B, int m_max, const double* __restrict__ Ag, const double* __restrict__ bg, const int* __restrict__ mrows,
-    int force_retry, double* __restrict__ lb, double* __restrict__ ub, int* __restrict__ status) {
-    reduce_lane_tile<D, GS, ROWS, true>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, 0.0, force_retry, nullptr,
-                                        status, lb, ub, nullptr, nullptr);
+    int force_retry, double* __restrict__ lb, double* __restrict__ ub, int* __restrict__ status, double* __restrict__ xfin) {
+    // (BBOX: the tile's keep_out argument carries the verifier's buffer of final points, [B][2 D][D] doubles or nullptr)
+    reduce_lane_tile<D, GS, ROWS, true>((long long)blockIdx.x * (64 / GS), B, m_max, Ag, bg, mrows, 0.0, force_retry,
+                                        reinterpret_cast<unsigned long long*>(xfin), status, lb, ub, nullptr, nullptr);
 }
 
 // Tile shape by batch size, measured on (16,3) batches (scripts/debug/lane_sweep.py, us per launch GS 4 / 8 / 16):
@@ -749,7 +758,7 @@ static int launch_reduce_lane_d(long long B, int m_max, const double* A, const d
 
 template <int D>
 static int launch_bbox_lane_d(long long B, int m_max, const double* A, const double* b, const int* mrows, double* lb, double* ub,
-                              int* status, hipStream_t st) {
+                              int* status, hipStream_t st, double* xfin) {
     if (B > 2147483647ll) return 1;
     const int force = 0;   // (nothing to force: what this kernel does not settle goes back to the caller as status 1)
     const bool wide = m_max > LN_ROWS;
@@ -759,7 +768,7 @@ static int launch_bbox_lane_d(long long B, int m_max, const double* A, const dou
     if (blocks < 1) blocks = 1;
 #define PLP_BBL(GSV, RV)                                                                                                     \
     hipLaunchKernelGGL((bbox_lane_kernel<D, GSV, RV>), dim3((unsigned)blocks), dim3(RBLOCK), reduce_lane_smem_bytes(D, GSV, RV), st, B, \
-                       m_max, A, b, mrows, force, lb, ub, status)
+                       m_max, A, b, mrows, force, lb, ub, status, xfin)
     if (wide) { if (gs == 16) PLP_BBL(16, 32); else PLP_BBL(8, 32); }
     else if (gs == 16) PLP_BBL(16, 16);
     else if (gs == 8) PLP_BBL(8, 16);
@@ -770,12 +779,12 @@ static int launch_bbox_lane_d(long long B, int m_max, const double* A, const dou
 
 // bounding boxes of polytopes with up to 32 rows in d <= 3 (the contract of launch_bbox); 0 when launched, 1 when not taken
 int launch_bbox_lane(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
-                     int* status, hipStream_t st) {
+                     int* status, hipStream_t st, double* xfin) {
     if (m_max < 1 || m_max > 2 * LN_ROWS) return 1;
     switch (d) {
-        case 1: return launch_bbox_lane_d<1>(B, m_max, A, b, mrows, lb, ub, status, st);
-        case 2: return launch_bbox_lane_d<2>(B, m_max, A, b, mrows, lb, ub, status, st);
-        case 3: return launch_bbox_lane_d<3>(B, m_max, A, b, mrows, lb, ub, status, st);
+        case 1: return launch_bbox_lane_d<1>(B, m_max, A, b, mrows, lb, ub, status, st, xfin);
+        case 2: return launch_bbox_lane_d<2>(B, m_max, A, b, mrows, lb, ub, status, st, xfin);
+        case 3: return launch_bbox_lane_d<3>(B, m_max, A, b, mrows, lb, ub, status, st, xfin);
         default: return 1;
     }
 }

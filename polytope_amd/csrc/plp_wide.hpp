@@ -399,7 +399,8 @@ __device__ __forceinline__ int wide_run(const int lane, const int m, typename Ro
 // retry.  cj: lane j < D holds c_j.  `sh`: this wavefront's LDS block.
 template <int D>
 __device__ __forceinline__ int solve_dense(const int lane, const int nrows, const double* __restrict__ rowsA, const double cj,
-                                           const double beta0, const bool act, double& negz, WideShared<D>& sh) {
+                                           const double beta0, const bool act, double& negz, WideShared<D>& sh,
+                                           signed char* __restrict__ basis_out = nullptr) {
     typename RowVec<D>::type Tv = (typename RowVec<D>::type)(0.0);
     double T16 = 0.0;
 #pragma unroll
@@ -414,7 +415,14 @@ __device__ __forceinline__ int solve_dense(const int lane, const int nrows, cons
     }
     wave_sync();
     negz = 0.0;
-    return wide_run<D>(lane, nrows, Tv, T16, beta, rowvar, rowneg, rowact, sh, D, false, 0.0, iters, &negz);
+    const int st = wide_run<D>(lane, nrows, Tv, T16, beta, rowvar, rowneg, rowact, sh, D, false, 0.0, iters, &negz);
+    if (basis_out) {  // the final basis, for the verifier (plp_verify.hip): column j holds variable (cv >> 1) - 1
+        if (lane < D) {
+            const int id = (sh.cv[lane] >> 1) - 1;
+            basis_out[lane] = (signed char)(id < D ? -1 - id : id - D);
+        }
+    }
+    return st;
 }
 
 }  // namespace wide

@@ -69,32 +69,12 @@ def main():
             st, lb, ub = bb["status"].cpu().numpy(), bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
         for k, (lo, hi, bd, so, ro) in enumerate(refb):
             okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro)))
-            if not okc and fam == "dup":
-                okc = int(cs[k]) == 0 and SL.highs_radius_agrees(A[k, :mrows[k]], b[k, :mrows[k]], cr[k])
-                n_off += int(okc)
             if not okc:
                 nc += 1
                 first = first if first is not None else ("cheby", k, int(cs[k]), so, cr[k], ro)
             if bb is None or st[k] != 0:
                 continue
-            tb = 5e-8 if fam == "dup" else 1e-9
-            okb = bd == 0 and np.allclose(lb[k], lo, rtol=tb, atol=tb) and np.allclose(ub[k], hi, rtol=tb, atol=tb)
-            if not okb and fam == "dup":
-                from scipy.optimize import linprog
-                Ak, bk = A[k, :mrows[k]], b[k, :mrows[k]]
-                okb = True
-                for i in range(d):
-                    for sgn, mine_ in ((1.0, lb[k][i]), (-1.0, ub[k][i])):
-                        c = np.zeros(d)
-                        c[i] = sgn
-                        rs = linprog(c, Ak, bk, bounds=(None, None))
-                        if rs.status == 3:
-                            okb = okb and not np.isfinite(mine_)
-                        elif rs.status == 0:
-                            okb = okb and abs(rs.x[i] - mine_) <= 1e-6 * max(1.0, abs(mine_))
-                        else:
-                            okb = False
-                n_off += int(okb)
+            okb = bd == 0 and SL.box_equal(lb[k], ub[k], lo, hi)
             if not okb:
                 nbb += 1
                 first = first if first is not None else ("bbox", k, lb[k], lo, ub[k], hi, bd)
