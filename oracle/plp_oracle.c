@@ -294,7 +294,7 @@ int plpo_lp_solve_raw(int m, int n, const double *c, const double *G, const doub
  * checked against the ORIGINAL rows, from the final basis alone:
  *   M = the n rows that define the vertex (active rows; e_j for a free variable left at zero),
  *   x = M^-1 rhs and y = -M^-T c by LU with partial pivoting + iterative refinement (residuals in binary128),
- *   primal:  h_i - G_i.x >= -1e-10 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
+ *   primal:  h_i - G_i.x >= -1e-13 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
  *   dual:    y_k |G_k|_inf >= -1e-11 |c|_inf on active rows, |y_k| <= 1e-11 |c|_inf on the free variables
  * -- an optimal basis of the LP as given, its vertex computed to the last bits whatever path led there.  An
  * unbounded answer is checked the same way (ray w = M^-1 (-/+ u_e): G_i.w <= 1e-12 |G_i| |w| for every row, c.w < 0).
@@ -313,6 +313,7 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
  * this oracle and the HIP library apply it to the certified / re-solved value.  scale = |c|_inf * max(1, max_i
  * |h_i| / |G_i|_inf). */
 #define PLPO_BIG 1e9
+#define PLPO_TOL_PRIMAL 1e-13   /* (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on an optimum of 235) */
 static double g_tol_dual = 1e-12;   /* plpo_set_tol_dual: experiments */
 #define PLPO_TOL_DUAL g_tol_dual
 void plpo_set_tol_dual(double t) { g_tol_dual = t; }
@@ -462,7 +463,7 @@ static int lp_certify(int m, int n, const double *c, const double *G, const doub
             }
             double tol = gmax * xs;
             if (fabs(h[i]) > tol) tol = fabs(h[i]);
-            if ((double)sl < -1e-10 * tol) CERT_FAIL(9);             /* the vertex itself must be feasible */
+            if ((double)sl < -PLPO_TOL_PRIMAL * tol) CERT_FAIL(9);             /* the vertex itself must be feasible */
             int inb = 0;                                          /* rows of the basis: G_k.w = 0 (or -1) by construction */
             for (int k = 0; k < n; ++k) inb |= (basis[k] == i);
             if (inb || !((double)gw > 1e-14 * gmax * wmax)) continue;   /* (below the rounding of w: not a blocking row) */
@@ -490,7 +491,7 @@ static int lp_certify(int m, int n, const double *c, const double *G, const doub
         for (int j = 0; j < n; ++j) { s -= (__float128)G[i * n + j] * z[j]; if (fabs(G[i * n + j]) > gmax) gmax = fabs(G[i * n + j]); }
         double tol = gmax * xs;
         if (fabs(h[i]) > tol) tol = fabs(h[i]);
-        if ((double)s < -1e-10 * tol) CERT_FAIL(14);
+        if ((double)s < -PLPO_TOL_PRIMAL * tol) CERT_FAIL(14);
     }
     __float128 f = 0;
     for (int j = 0; j < n; ++j) { f += (__float128)c[j] * z[j]; x[j] = z[j]; }

@@ -42,12 +42,12 @@ namespace plp {
 size_t verify_scratch_bytes(long long nlp, int m_max);
 bool verify_enabled();
 int launch_verify_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
-                     double* x, double* fun, int* status, void* scratch, hipStream_t st);
+                     double* x, double* fun, int* status, void* scratch, int parity, hipStream_t st);
 int launch_verify_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
-                        double* xc, int* status, void* scratch, hipStream_t st);
+                        double* xc, int* status, void* scratch, int parity, hipStream_t st);
 int launch_verify_box(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
                       int* status, const signed char* basis8, const double* centre, const double* xfin, void* scratch,
-                      hipStream_t st);
+                      int parity, hipStream_t st);
 }  // namespace plp
 
 struct plp_ctx {
@@ -102,7 +102,7 @@ struct plp_ctx {
     // plp_assign_dev (few facets): the workgroups' (max, index) partials, one grow-only buffer PER STREAM -- calls on
     // different streams never share one, so nothing has to order them (a handful of streams per context in practice;
     // beyond 16 the table is emptied after a device synchronisation)
-    struct StreamBuf { void* p = nullptr; size_t bytes = 0; };
+    struct StreamBuf { void* p = nullptr; size_t bytes = 0; unsigned calls = 0; };
     std::unordered_map<void*, StreamBuf> as_scratch;
     // the verifier behind the LP / Chebyshev / bounding-box batches (plp_verify.hip): fail list + the careful engine's
     // dictionaries, one grow-only buffer per stream like as_scratch; bounding boxes: the engines' bases and centres
@@ -138,8 +138,13 @@ void* stream_buf(std::unordered_map<void*, plp_ctx::StreamBuf>& table, void* str
         if (sb.p) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(sb.p); }  // (its last user ran on this stream)
         sb.p = nullptr;
         sb.bytes = 0;
-        if (hipMalloc(&sb.p, need + need / 4) == hipSuccess) sb.bytes = need + need / 4;
-        else (void)hipGetLastError();
+        if (hipMalloc(&sb.p, need + need / 4) == hipSuccess) {
+            sb.bytes = need + need / 4;
+            sb.calls = 0;
+            (void)hipMemsetAsync(sb.p, 0, 256, (hipStream_t)stream);   // (the verifier's list counters start at zero)
+        } else {
+            (void)hipGetLastError();
+        }
     }
     return sb.p;
 }
@@ -492,7 +497,7 @@ static int verify_lp_answers(plp_ctx* ctx, hipStream_t st, int64_t B, int m_max,
     if (!plp::verify_enabled()) return PLP_OK;
     void* sc = stream_buf(ctx->vf_scratch, (void*)st, plp::verify_scratch_bytes(B, m_max));
     if (!sc) return fail(PLP_EHIP, "verifier: no device memory for its scratch (%zu bytes)", plp::verify_scratch_bytes(B, m_max));
-    if (plp::launch_verify_lp(B, m_max, n, c, G, h, m, x, fun, status, sc, st))
+    if (plp::launch_verify_lp(B, m_max, n, c, G, h, m, x, fun, status, sc, (int)(ctx->vf_scratch[(void*)st].calls++ & 1u), st))
         return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
     return check_launch("verify_x_kernel");
 }
@@ -501,7 +506,7 @@ static int verify_cheby_answers(plp_ctx* ctx, hipStream_t st, int64_t B, int m_m
     if (!plp::verify_enabled()) return PLP_OK;
     void* sc = stream_buf(ctx->vf_scratch, (void*)st, plp::verify_scratch_bytes(B, m_max));
     if (!sc) return fail(PLP_EHIP, "verifier: no device memory for its scratch (%zu bytes)", plp::verify_scratch_bytes(B, m_max));
-    if (plp::launch_verify_cheby(B, m_max, d, A, b, m, r, xc, status, sc, st))
+    if (plp::launch_verify_cheby(B, m_max, d, A, b, m, r, xc, status, sc, (int)(ctx->vf_scratch[(void*)st].calls++ & 1u), st))
         return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
     return check_launch("verify_x_kernel");
 }
@@ -683,7 +688,8 @@ int plp_bbox_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int d, 
     int rc = check_launch("bbox_r_kernel");
     if (rc || !ho.mode) return rc;
     if (plp::launch_verify_box(B, m_max, d, A, b, m, lb, ub, status, ho.mode == 1 ? ho.basis8 : nullptr,
-                               ho.mode == 1 ? ho.centre : nullptr, ho.mode == 2 ? ho.xfin : nullptr, vsc, st))
+                               ho.mode == 1 ? ho.centre : nullptr, ho.mode == 2 ? ho.xfin : nullptr, vsc,
+                               (int)(ctx->vf_scratch[stream].calls++ & 1u), st))
         return fail(PLP_EUNSUPPORTED, "verifier: unsupported size");
     return check_launch("verify_box_kernel");
 }

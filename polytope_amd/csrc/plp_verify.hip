@@ -1,19 +1,20 @@
 // plp_verify.hip -- the verifier kernels behind plp_lp_solve_batch / plp_cheby_batch / plp_bbox_batch (round 6; the
 // arithmetic is plp_verify.hpp, which says why).  Three launches follow the engines' own, on the same stream:
 //
-//   verify_x_kernel<KIND, VN>   one LP per thread (generic LPs and Chebyshev LPs: the engines hand over x): an optimal
-//        answer gets a basis read off its x and the certificate; certified -> x / fun (r / xc) are REPLACED by the polished
-//        vertex (LU of the original rows + refinement: the value no longer depends on the path the engine took), and an
-//        optimum out of range becomes "unbounded"; anything else that is not a plain "infeasible" (a failed certificate,
-//        unbounded, iteration limit, numerical trouble) is appended to the launch's list;
-//   verify_box_kernel<VN>       one box LP per thread (2d per polytope): the fused bounding-box kernels hand over each
-//        LP's final basis (d bytes) and the Chebyshev centre they started from; same rule, the list gets (polytope, side);
+//   verify_kernel<KIND, VN>   generic LPs and Chebyshev LPs (the engines hand over x): an optimal answer gets a basis read
+//        off its x and the certificate; certified -> x / fun (r / xc) are REPLACED by the polished vertex (LU of the
+//        original rows + refinement: the value no longer depends on the path the engine took), and an optimum out of
+//        range becomes "unbounded"; anything else that is not a plain "infeasible" (a failed certificate, unbounded,
+//        iteration limit, numerical trouble) is appended to the launch's list;  box LPs (2d per polytope): the fused
+//        bounding-box kernels hand over each LP's final basis (d bytes) and the Chebyshev centre they started from, or
+//        the point the LP ended on; same rule, the list gets (polytope, side);
 //   careful_kernel<KIND>        the list, one LP per thread, solved from scratch by the double-double engine
 //        (careful_solve) with its dictionary in global memory, element by element interleaved over the threads
 //        (coalesced); empty list -> the launch ends at once (no host round trip decides whether it is needed).
 //
-// HBM traffic of the verifier: the rows once more (they come from the L2 / Infinity Cache right behind the engine that
-// read them), x in and out.  Per-thread arrays (LU, the Gram-Schmidt basis) are sized by VN = 5 / 9 / 17 columns.
+// HBM traffic of the verifier: the rows twice more (they come from the L2 / Infinity Cache right behind the engine that
+// read them), x in and out.  The certificate's work arrays live in LDS, sized by VN = 5 / 9 / 17 columns (64 / 32 / 8 LPs per
+// workgroup): as private arrays they were scratch memory, and the verifier took ten times the engines' own time.
 #include <stdlib.h>
 
 #include "plp_kernels.hpp"
@@ -29,7 +30,8 @@ constexpr int VBLK = 64;
 constexpr long long CAREFUL_SLOTS = 4096;  // LPs the careful engine solves side by side (its dictionaries: slots x ~21 KB at 64 rows)
 
 struct Scratch {
-    unsigned* count;  // [0]: entries of the list
+    unsigned* count;  // entries of this launch's list; `other`: the counter of the stream's NEXT launch, zeroed by this one's careful
+    unsigned* other;  // kernel (two counters in turn: no reset launch, no host round trip)
     int* list;
     double* hi;
     double* lo;
@@ -39,10 +41,11 @@ struct Scratch {
 
 __host__ __device__ inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-Scratch carve(void* base, long long cap, int m_max) {
+Scratch carve(void* base, long long cap, int m_max, int parity) {
     char* p = static_cast<char*>(base);
     Scratch s;
-    s.count = reinterpret_cast<unsigned*>(p);
+    s.count = reinterpret_cast<unsigned*>(p + ((parity & 1) ? 64 : 0));
+    s.other = reinterpret_cast<unsigned*>(p + ((parity & 1) ? 0 : 64));
     p += 256;
     s.list = reinterpret_cast<int*>(p);
     p += pad256((size_t)cap * 4);
@@ -63,95 +66,183 @@ __device__ __forceinline__ void push(const Scratch& s, int v) {
 
 __device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000ll); }
 
-// ---- generic LPs / Chebyshev LPs: x is there
+// ---- the verifier kernel.  LPB LPs per 64-lane workgroup, each with its work arrays in LDS (element e of LP l at
+// ws[e * LPB + l]: consecutive LPs, consecutive banks) and GSL = 64 / LPB lanes: the leader lane runs the certificate's serial
+// part (candidates -> basis -> LU -> polished vertex -> multipliers), all GSL lanes share the two passes over the rows.
+//   KIND LP_GENERIC / LP_CHEBY: LP t of the batch, x handed over by the engine (x / fun; xc / r);
+//   KIND LP_BOXSIDE: t = polytope * 2 d + side; the fused bounding-box kernels handed over the LP's basis (d bytes) and the
+//   polytope's centre, or (the one-LP-per-lane kernel) the point the LP ended on.
+struct VArgs {
+    long long T;       // LPs
+    int m_max, n;      // n: columns (d + 1 for LP_CHEBY, d for LP_BOXSIDE)
+    const double* c;   // generic only
+    const double* G;   // G, or A
+    const double* h;   // h, or b
+    const int* mrows;
+    double* x;         // x [B][n] | xc [B][d] | lb [B][d]
+    double* fun;       // fun [B]  | r [B]     | ub [B][d]
+    int* status;       // [B]
+    const signed char* basis8;
+    const double* centre;
+    const double* xfin;
+};
+
+template <int VN>
+struct VShape {
+    static constexpr int LPB = VN <= 5 ? 64 : (VN <= 9 ? 16 : 8);   // (LDS: 816 B / 2 KB / 6 KB of work arrays per LP)
+    static constexpr int GSL = VBLK / LPB;
+};
+
 template <int KIND, int VN>
-__global__ __launch_bounds__(VBLK) void verify_x_kernel(long long B, int m_max, int n, const double* __restrict__ c,
-                                                        const double* __restrict__ G, const double* __restrict__ h,
-                                                        const int* __restrict__ mrows, double* __restrict__ x,
-                                                        double* __restrict__ fun, int* __restrict__ status, Scratch sc) {
-    const long long p = (long long)blockIdx.x * VBLK + threadIdx.x;
-    if (p >= B) return;
-    const int st = status[p];
-    if (st == ST_INFEAS) return;  // (phase 1's verdict, read with a 1e-7 margin: not a question of rounding)
+__global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
+    constexpr int LPB = VShape<VN>::LPB, GSL = VShape<VN>::GSL;
+    using CT = Cert<VN, LPB>;
+    using Vec = typename CT::Vec;
+    __shared__ double s_ws[CT::WS_DOUBLES * LPB];
+    __shared__ int s_cn[LPB];
+    __shared__ int s_mode[LPB];   // 0: nothing to do, 1: read the basis off x, 2: basis handed over, 3: to the list
+    __shared__ int s_ok[LPB];
+    __shared__ unsigned s_bad[LPB];
+    __shared__ double s_xs[LPB], s_fun[LPB];
+    const int li = threadIdx.x / GSL, gl = threadIdx.x % GSL;
+    const long long t = (long long)blockIdx.x * LPB + li;
+    const bool valid = t < a.T;
+    const int n = a.n;
+    double* ws = s_ws + li;
+    // ---- which LP
+    long long p = valid ? t : 0;
+    int side = 0;
+    if constexpr (KIND == LP_BOXSIDE) {
+        p = (valid ? t : 0) / (2 * n);
+        side = (int)((valid ? t : 0) - p * 2 * n);
+    }
     const int ng = KIND == LP_CHEBY ? n - 1 : n;
     LpView lp;
-    lp.m = mrows ? mrows[p] : m_max;
+    lp.m = valid ? (a.mrows ? a.mrows[p] : a.m_max) : 0;
     lp.n = n;
     lp.kind = KIND;
-    lp.side = 0;
-    lp.G = G + (size_t)p * m_max * ng;
-    lp.h = h + (size_t)p * m_max;
-    lp.c = KIND == LP_GENERIC ? c + (size_t)p * n : nullptr;
-    if (st == ST_OPT) {
-        // generic: x[p][n]; Chebyshev: x = xc[p][d] (passed as `x`), fun = r[p] (passed as `fun`)
-        double xin[VN], xo[VN], f = 0.0;
-        int basis[VN + 2];
-        if constexpr (KIND == LP_CHEBY) {
-            for (int j = 0; j < n - 1; ++j) xin[j] = x[(size_t)p * (n - 1) + j];
-            xin[n - 1] = fun[p];
-        } else {
-            for (int j = 0; j < n; ++j) xin[j] = x[(size_t)p * n + j];
-        }
-        if (Cert<VN>::basis_from_x(lp, xin, basis) && Cert<VN>::certify(lp, V_OPT, basis, xin, xo, &f)) {
-            const bool out = range_rule(lp, V_OPT, f) != V_OPT;
-            if constexpr (KIND == LP_CHEBY) {
-                for (int j = 0; j < n - 1; ++j) x[(size_t)p * (n - 1) + j] = out ? qnan() : xo[j];
-                fun[p] = out ? qnan() : xo[n - 1];
+    lp.side = side;
+    lp.G = a.G + (size_t)p * a.m_max * ng;
+    lp.h = a.h + (size_t)p * a.m_max;
+    lp.c = KIND == LP_GENERIC ? a.c + (size_t)p * n : nullptr;
+    // ---- leader: what is to be done, the point / basis into the workspace
+    if (gl == 0) {
+        int mode = 0;
+        const Vec xv = CT::at(ws, CT::O_X), bas = CT::at(ws, CT::O_BAS);
+        if (valid) {
+            if constexpr (KIND == LP_BOXSIDE) {
+                if (a.status[p] == 0) {   // (status 1: handed to the caller's generic LPs, which pass this kernel as LP_GENERIC)
+                    const double val = ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)];
+                    if (!(fabs(val) < 1e300)) mode = 3;   // unbounded: the careful engine decides
+                    else if (a.xfin) {
+                        for (int j = 0; j < n; ++j) xv[j] = a.xfin[((size_t)p * 2 * n + side) * n + j];
+                        mode = 1;
+                    } else {
+                        for (int j = 0; j < n; ++j) {
+                            xv[j] = a.centre[(size_t)p * n + j];
+                            bas[j] = (double)a.basis8[((size_t)p * 2 * n + side) * n + j];
+                        }
+                        mode = 2;
+                    }
+                }
             } else {
-                for (int j = 0; j < n; ++j) x[(size_t)p * n + j] = out ? qnan() : xo[j];
-                fun[p] = out ? qnan() : f;
+                const int st = a.status[p];
+                // (infeasible: phase 1's verdict, read with a 1e-7 margin -- not a question of rounding; it stands)
+                if (st == ST_OPT) {
+                    if constexpr (KIND == LP_CHEBY) {
+                        for (int j = 0; j < n - 1; ++j) xv[j] = a.x[(size_t)p * (n - 1) + j];
+                        xv[n - 1] = a.fun[p];
+                    } else {
+                        for (int j = 0; j < n; ++j) xv[j] = a.x[(size_t)p * n + j];
+                    }
+                    mode = 1;
+                } else if (st != ST_INFEAS) {
+                    mode = 3;
+                }
             }
-            if (out) status[p] = ST_UNBND;
-            return;
+        }
+        if (mode == 1) {
+            bool fin;
+            s_xs[li] = CT::x_scale(lp, xv, &fin);
+            if (!fin) mode = 3;
+        }
+        s_mode[li] = mode;
+        s_cn[li] = 0;
+        s_ok[li] = 0;
+        s_bad[li] = 0u;
+    }
+    __syncthreads();
+    // ---- pass 1 (a basis is to be read off x): the candidate rows, unsorted, into the workspace's list
+    if (s_mode[li] == 1) {
+        const Vec xv = CT::at(ws, CT::O_X), cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
+        const double xs = s_xs[li];
+        for (int i = gl; i < lp.m; i += GSL) {
+            double sl;
+            if (CT::row_candidate(lp, i, xv, xs, &sl)) {
+                const int k = atomicAdd(&s_cn[li], 1);
+                if (k < CT::KC) { cs[k] = sl; ci[k] = (double)i; }
+            }
         }
     }
-    push(sc, (int)p);
-}
-
-// ---- the fused bounding boxes: value per side, basis per side, centre per polytope
-template <int VN>
-__global__ __launch_bounds__(VBLK) void verify_box_kernel(long long B, int m_max, int d, const double* __restrict__ A,
-                                                          const double* __restrict__ b, const int* __restrict__ mrows,
-                                                          double* __restrict__ lb, double* __restrict__ ub,
-                                                          const int* __restrict__ status,
-                                                          const signed char* __restrict__ basis8,
-                                                          const double* __restrict__ centre,
-                                                          const double* __restrict__ xfin, Scratch sc) {
-    const long long t = (long long)blockIdx.x * VBLK + threadIdx.x;
-    if (t >= B * 2 * d) return;
-    const long long p = t / (2 * d);
-    const int side = (int)(t - p * 2 * d);  // 2k: lower_k, 2k + 1: upper_k
-    if (status[p] != 0) return;             // (handed to the caller's generic LPs, which pass verify_x_kernel)
-    const int k = side >> 1;
-    double* out = (side & 1) ? ub : lb;
-    const double val = out[p * d + k];
-    LpView lp;
-    lp.m = mrows ? mrows[p] : m_max;
-    lp.n = d;
-    lp.kind = LP_BOXSIDE;
-    lp.side = side;
-    lp.G = A + (size_t)p * m_max * d;
-    lp.h = b + (size_t)p * m_max;
-    lp.c = nullptr;
-    if (fabs(val) < 1e300) {
-        int basis[VN + 2];
-        double xo[VN], f = 0.0;
+    __syncthreads();
+    // ---- leader: basis, factorisation, vertex, multipliers
+    if ((gl == 0) & ((s_mode[li] == 1) | (s_mode[li] == 2))) {
         bool have = true;
-        const double* xref;
-        if (xfin) {  // the one-LP-per-lane kernel: the point its walk ended on; the basis is read off it
-            xref = xfin + ((size_t)p * 2 * d + side) * d;
-            have = Cert<VN>::basis_from_x(lp, xref, basis);
-        } else {
-            const signed char* bs = basis8 + ((size_t)p * 2 * d + side) * d;
-            for (int j = 0; j < d; ++j) basis[j] = bs[j];
-            xref = centre + (size_t)p * d;
+        if (s_mode[li] == 1) {
+            const Vec cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
+            int cn = s_cn[li];
+            if (cn > CT::KC) cn = CT::KC + 1;
+            else {   // in place, by (slack, row): the order the host version inserts in
+                for (int k = 1; k < cn; ++k) {
+                    const double sk = cs[k], ik = ci[k];
+                    int q = k;
+                    while (q > 0 && (cs[q - 1] > sk || (cs[q - 1] == sk && ci[q - 1] > ik))) {
+                        cs[q] = cs[q - 1];
+                        ci[q] = ci[q - 1];
+                        --q;
+                    }
+                    cs[q] = sk;
+                    ci[q] = ik;
+                }
+            }
+            have = CT::select_basis(lp, ws, cn);
         }
-        if (have && Cert<VN>::certify(lp, V_OPT, basis, xref, xo, &f)) {
-            const bool oor = range_rule(lp, V_OPT, f) != V_OPT;
+        double f = 0.0, zs = 1.0;
+        if (have && CT::vertex_and_dual(lp, true, true, ws, &f, &zs)) {
+            s_xs[li] = zs;
+            s_fun[li] = f;
+            s_ok[li] = 1;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: every row against the polished vertex
+    if (s_ok[li]) {
+        const Vec z = CT::at(ws, CT::O_Z);
+        const double zs = s_xs[li];
+        bool bad = false;
+        for (int i = gl; i < lp.m; i += GSL) bad = bad | !CT::row_feasible(lp, i, z, zs);
+        if (bad) atomicOr(&s_bad[li], 1u);
+    }
+    __syncthreads();
+    if ((gl != 0) | (s_mode[li] == 0)) return;
+    if (s_ok[li] & (s_bad[li] == 0u)) {
+        const Vec z = CT::at(ws, CT::O_Z);
+        const double f = s_fun[li];
+        bool out = false;
+        if (fabs(f) > V_BIG * lp.c_inf()) out = range_rule(lp, V_OPT, f) != V_OPT;   // (the full scale only where it can matter)
+        if constexpr (KIND == LP_BOXSIDE) {
             const double pinf = __longlong_as_double(0x7ff0000000000000ll);
-            out[p * d + k] = oor ? ((side & 1) ? pinf : -pinf) : xo[k];
-            return;
+            ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)] = out ? ((side & 1) ? pinf : -pinf) : z[side >> 1];
+        } else if constexpr (KIND == LP_CHEBY) {
+            for (int j = 0; j < n - 1; ++j) a.x[(size_t)p * (n - 1) + j] = out ? qnan() : z[j];
+            a.fun[p] = out ? qnan() : z[n - 1];
+            if (out) a.status[p] = ST_UNBND;
+        } else {
+            for (int j = 0; j < n; ++j) a.x[(size_t)p * n + j] = out ? qnan() : z[j];
+            a.fun[p] = out ? qnan() : f;
+            if (out) a.status[p] = ST_UNBND;
         }
+        return;
     }
     push(sc, (int)t);
 }
@@ -164,6 +255,7 @@ __global__ __launch_bounds__(VBLK) void careful_kernel(int m_max, int n, const d
                                                        double* __restrict__ fun, int* __restrict__ status,
                                                        double* __restrict__ ub, Scratch sc) {
     const long long slot = (long long)blockIdx.x * VBLK + threadIdx.x;
+    if (slot == 0) *sc.other = 0u;
     unsigned cnt = *sc.count;
     if ((long long)cnt > sc.cap) cnt = (unsigned)sc.cap;
     CarefulMem M{sc.hi + slot, sc.lo + slot, sc.rowinfo + slot, CAREFUL_SLOTS};
@@ -213,8 +305,6 @@ __global__ __launch_bounds__(VBLK) void careful_kernel(int m_max, int n, const d
     }
 }
 
-__global__ void verify_reset_kernel(unsigned* count) { *count = 0u; }
-
 bool verify_off() {
     static const int off = [] {
         const char* e = getenv("PLP_VERIFY");
@@ -233,39 +323,141 @@ size_t verify_scratch_bytes(long long nlp, int m_max) {
 
 bool verify_enabled() { return !verify_off(); }
 
-#define PLP_VN_DISPATCH(nn, CALL5, CALL9, CALL17) \
-    do {                                          \
-        if ((nn) <= 5) { CALL5; }                 \
-        else if ((nn) <= 9) { CALL9; }            \
-        else { CALL17; }                          \
-    } while (0)
+// ---- the same for LPs of N <= 5 columns (d <= 4: most of what the library is asked): ONE LP PER LANE, the column count a
+// compile-time constant, the certificate's arrays in registers (Cert<N, 1, N>: static indices only) -- no LDS, no
+// workgroup barriers, eight waves per SIMD instead of one.
+template <int KIND, int N>
+__global__ __launch_bounds__(256) void verify_small_kernel(VArgs a, Scratch sc) {
+    using CT = Cert<N, 1, N>;
+    using Vec = typename CT::Vec;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.T) return;
+    constexpr int n = N;
+    long long p = t;
+    int side = 0;
+    if constexpr (KIND == LP_BOXSIDE) {
+        p = t / (2 * n);
+        side = (int)(t - p * 2 * n);
+    }
+    constexpr int ng = KIND == LP_CHEBY ? n - 1 : n;
+    LpView lp;
+    lp.m = a.mrows ? a.mrows[p] : a.m_max;
+    lp.n = n;
+    lp.kind = KIND;
+    lp.side = side;
+    lp.G = a.G + (size_t)p * a.m_max * ng;
+    lp.h = a.h + (size_t)p * a.m_max;
+    lp.c = KIND == LP_GENERIC ? a.c + (size_t)p * n : nullptr;
+    double ws[CT::WS_DOUBLES];
+    const Vec xv = CT::at(ws, CT::O_X), bas = CT::at(ws, CT::O_BAS), z = CT::at(ws, CT::O_Z);
+    int mode = 0;   // 0: nothing to do, 1: read the basis off x, 2: basis handed over, 3: to the list
+    if constexpr (KIND == LP_BOXSIDE) {
+        if (a.status[p] != 0) return;   // (handed to the caller's generic LPs, which pass this kernel as LP_GENERIC)
+        const double val = ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)];
+        if (!(fabs(val) < 1e300)) mode = 3;   // unbounded: the careful engine decides
+        else if (a.xfin) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) xv[j] = a.xfin[((size_t)p * 2 * n + side) * n + j];
+            mode = 1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                xv[j] = a.centre[(size_t)p * n + j];
+                bas[j] = (double)a.basis8[((size_t)p * 2 * n + side) * n + j];
+            }
+            mode = 2;
+        }
+    } else {
+        const int st = a.status[p];
+        if (st == ST_INFEAS) return;   // (phase 1's verdict, read with a 1e-7 margin -- not a question of rounding; it stands)
+        if (st == ST_OPT) {
+            if constexpr (KIND == LP_CHEBY) {
+#pragma unroll
+                for (int j = 0; j < n - 1; ++j) xv[j] = a.x[(size_t)p * (n - 1) + j];
+                xv[n - 1] = a.fun[p];
+            } else {
+#pragma unroll
+                for (int j = 0; j < n; ++j) xv[j] = a.x[(size_t)p * n + j];
+            }
+            mode = 1;
+        } else {
+            mode = 3;
+        }
+    }
+    bool ok = false;
+    double f = 0.0, zs = 1.0;
+    if (mode == 1) ok = CT::basis_from_x(lp, ws);
+    else if (mode == 2) ok = true;
+    if (ok) ok = CT::vertex_and_dual(lp, true, true, ws, &f, &zs);
+    if (ok) {
+        for (int i = 0; i < lp.m; ++i) ok = ok & CT::row_feasible(lp, i, z, zs);
+    }
+    if (ok) {
+        bool out = false;
+        if (fabs(f) > V_BIG * lp.c_inf()) out = range_rule(lp, V_OPT, f) != V_OPT;   // (the full scale only where it can matter)
+        if constexpr (KIND == LP_BOXSIDE) {
+            const double pinf = __longlong_as_double(0x7ff0000000000000ll);
+            double zk = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) zk = (j == (side >> 1)) ? z[j] : zk;
+            ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)] = out ? ((side & 1) ? pinf : -pinf) : zk;
+        } else if constexpr (KIND == LP_CHEBY) {
+#pragma unroll
+            for (int j = 0; j < n - 1; ++j) a.x[(size_t)p * (n - 1) + j] = out ? qnan() : z[j];
+            a.fun[p] = out ? qnan() : z[n - 1];
+            if (out) a.status[p] = ST_UNBND;
+        } else {
+#pragma unroll
+            for (int j = 0; j < n; ++j) a.x[(size_t)p * n + j] = out ? qnan() : z[j];
+            a.fun[p] = out ? qnan() : f;
+            if (out) a.status[p] = ST_UNBND;
+        }
+        return;
+    }
+    push(sc, (int)t);
+}
+
+// `parity`: the launches of a stream take the scratch's two list counters in turn (carve)
+template <int KIND>
+static void launch_verify_kind(const VArgs& a, const Scratch& sc, hipStream_t st) {
+    const dim3 gsmall((unsigned)((a.T + 255) / 256));
+    if (a.n == 1 && KIND != LP_CHEBY) {
+        hipLaunchKernelGGL((verify_small_kernel<KIND, 1>), gsmall, dim3(256), 0, st, a, sc);
+    } else if (a.n == 2) {
+        hipLaunchKernelGGL((verify_small_kernel<KIND, 2>), gsmall, dim3(256), 0, st, a, sc);
+    } else if (a.n == 3) {
+        hipLaunchKernelGGL((verify_small_kernel<KIND, 3>), gsmall, dim3(256), 0, st, a, sc);
+    } else if (a.n == 4) {
+        hipLaunchKernelGGL((verify_small_kernel<KIND, 4>), gsmall, dim3(256), 0, st, a, sc);
+    } else if (a.n == 5) {
+        hipLaunchKernelGGL((verify_small_kernel<KIND, 5>), gsmall, dim3(256), 0, st, a, sc);
+    } else if (a.n <= 9) {
+        constexpr int LPB = VShape<9>::LPB;
+        hipLaunchKernelGGL((verify_kernel<KIND, 9>), dim3((unsigned)((a.T + LPB - 1) / LPB)), dim3(VBLK), 0, st, a, sc);
+    } else {
+        constexpr int LPB = VShape<17>::LPB;
+        hipLaunchKernelGGL((verify_kernel<KIND, 17>), dim3((unsigned)((a.T + LPB - 1) / LPB)), dim3(VBLK), 0, st, a, sc);
+    }
+}
 
 int launch_verify_lp(long long B, int m_max, int n, const double* c, const double* G, const double* h, const int* mrows,
-                     double* x, double* fun, int* status, void* scratch, hipStream_t st) {
+                     double* x, double* fun, int* status, void* scratch, int parity, hipStream_t st) {
     if (B < 1 || n < 1 || n > VNMAX || B > 2147483647ll) return 1;
-    const Scratch sc = carve(scratch, B, m_max);
-    hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, st, sc.count);
-    const dim3 grid((unsigned)((B + VBLK - 1) / VBLK));
-    PLP_VN_DISPATCH(n,
-                    hipLaunchKernelGGL((verify_x_kernel<LP_GENERIC, 5>), grid, dim3(VBLK), 0, st, B, m_max, n, c, G, h, mrows, x, fun, status, sc),
-                    hipLaunchKernelGGL((verify_x_kernel<LP_GENERIC, 9>), grid, dim3(VBLK), 0, st, B, m_max, n, c, G, h, mrows, x, fun, status, sc),
-                    hipLaunchKernelGGL((verify_x_kernel<LP_GENERIC, 17>), grid, dim3(VBLK), 0, st, B, m_max, n, c, G, h, mrows, x, fun, status, sc));
+    const Scratch sc = carve(scratch, B, m_max, parity);
+    const VArgs a{B, m_max, n, c, G, h, mrows, x, fun, status, nullptr, nullptr, nullptr};
+    launch_verify_kind<LP_GENERIC>(a, sc, st);
     hipLaunchKernelGGL((careful_kernel<LP_GENERIC>), dim3((unsigned)(CAREFUL_SLOTS / VBLK)), dim3(VBLK), 0, st, m_max, n, c, G, h,
                        mrows, x, fun, status, (double*)nullptr, sc);
     return 0;
 }
 
 int launch_verify_cheby(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* r,
-                        double* xc, int* status, void* scratch, hipStream_t st) {
+                        double* xc, int* status, void* scratch, int parity, hipStream_t st) {
     const int n = d + 1;
     if (B < 1 || d < 1 || n > VNMAX || B > 2147483647ll) return 1;
-    const Scratch sc = carve(scratch, B, m_max);
-    hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, st, sc.count);
-    const dim3 grid((unsigned)((B + VBLK - 1) / VBLK));
-    PLP_VN_DISPATCH(n,
-                    hipLaunchKernelGGL((verify_x_kernel<LP_CHEBY, 5>), grid, dim3(VBLK), 0, st, B, m_max, n, (const double*)nullptr, A, b, mrows, xc, r, status, sc),
-                    hipLaunchKernelGGL((verify_x_kernel<LP_CHEBY, 9>), grid, dim3(VBLK), 0, st, B, m_max, n, (const double*)nullptr, A, b, mrows, xc, r, status, sc),
-                    hipLaunchKernelGGL((verify_x_kernel<LP_CHEBY, 17>), grid, dim3(VBLK), 0, st, B, m_max, n, (const double*)nullptr, A, b, mrows, xc, r, status, sc));
+    const Scratch sc = carve(scratch, B, m_max, parity);
+    const VArgs a{B, m_max, n, nullptr, A, b, mrows, xc, r, status, nullptr, nullptr, nullptr};
+    launch_verify_kind<LP_CHEBY>(a, sc, st);
     hipLaunchKernelGGL((careful_kernel<LP_CHEBY>), dim3((unsigned)(CAREFUL_SLOTS / VBLK)), dim3(VBLK), 0, st, m_max, n,
                        (const double*)nullptr, A, b, mrows, xc, r, status, (double*)nullptr, sc);
     return 0;
@@ -273,16 +465,12 @@ int launch_verify_cheby(long long B, int m_max, int d, const double* A, const do
 
 int launch_verify_box(long long B, int m_max, int d, const double* A, const double* b, const int* mrows, double* lb, double* ub,
                       int* status, const signed char* basis8, const double* centre, const double* xfin, void* scratch,
-                      hipStream_t st) {
+                      int parity, hipStream_t st) {
     const long long T = B * 2 * d;
     if (B < 1 || d < 1 || d > MAX_D || T > 2147483647ll) return 1;
-    const Scratch sc = carve(scratch, T, m_max);
-    hipLaunchKernelGGL(verify_reset_kernel, dim3(1), dim3(1), 0, st, sc.count);
-    const dim3 grid((unsigned)((T + VBLK - 1) / VBLK));
-    PLP_VN_DISPATCH(d,
-                    hipLaunchKernelGGL((verify_box_kernel<5>), grid, dim3(VBLK), 0, st, B, m_max, d, A, b, mrows, lb, ub, status, basis8, centre, xfin, sc),
-                    hipLaunchKernelGGL((verify_box_kernel<9>), grid, dim3(VBLK), 0, st, B, m_max, d, A, b, mrows, lb, ub, status, basis8, centre, xfin, sc),
-                    hipLaunchKernelGGL((verify_box_kernel<17>), grid, dim3(VBLK), 0, st, B, m_max, d, A, b, mrows, lb, ub, status, basis8, centre, xfin, sc));
+    const Scratch sc = carve(scratch, T, m_max, parity);
+    const VArgs a{T, m_max, d, nullptr, A, b, mrows, lb, ub, status, basis8, centre, xfin};
+    launch_verify_kind<LP_BOXSIDE>(a, sc, st);
     hipLaunchKernelGGL((careful_kernel<LP_BOXSIDE>), dim3((unsigned)(CAREFUL_SLOTS / VBLK)), dim3(VBLK), 0, st, m_max, d,
                        (const double*)nullptr, A, b, mrows, lb, (double*)nullptr, status, ub, sc);
     return 0;

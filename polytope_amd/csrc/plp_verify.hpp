@@ -10,7 +10,7 @@
 //   certify()   From the final BASIS alone (the n rows / free variables that define the vertex -- handed over by the engine
 //               as masks, or read off its x: basis_from_x) and the ORIGINAL rows: M = those rows, x = M^-1 rhs and
 //               y = -M^-T c by LU with partial pivoting + iterative refinement with double-double residuals; then
-//                   primal  h_i - G_i.x >= -1e-10 max(|h_i|, |G_i|_inf max(1, |x|_inf))          for every row,
+//                   primal  h_i - G_i.x >= -1e-13 max(|h_i|, |G_i|_inf max(1, |x|_inf))          for every row,
 //                   dual    y_k |G_k|_inf >= -1e-12 |c|_inf on active rows, |y_k| <= 1e-12 |c|_inf on free variables:
 //               an optimal basis of the LP as given, its vertex recomputed to the last bits whatever path led there (the
 //               polished x replaces the engine's).  An unbounded answer is checked the same way: the vertex the engine
@@ -31,6 +31,12 @@
 
 #include "plp_dd.hpp"
 
+#if defined(__HIPCC__)
+#define PLP_UNROLL _Pragma("unroll")
+#else
+#define PLP_UNROLL
+#endif
+
 namespace plp {
 namespace verify {
 
@@ -39,7 +45,7 @@ constexpr int VNC = VNMAX + 1;    // + the phase-1 artificial
 constexpr int VW = 20;            // doubles per dictionary row in the careful engine's scratch: VNC columns, beta, spare
 constexpr double V_BIG = 1e9;     // optimum beyond V_BIG x scale(data): unbounded
 constexpr double V_TOL_DUAL = 1e-12;
-constexpr double V_TOL_PRIMAL = 1e-10;
+constexpr double V_TOL_PRIMAL = 1e-13;  // (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on the optimum of 235, seed 4 of verify_smoke)
 constexpr double C_TOL_D = 1e-12, C_TOL_PIV = 1e-12, C_TOL_FEAS = 1e-7, C_DEGEN = 1e-24;
 constexpr int C_BLAND_AFTER = 6;
 enum : int { V_OPT = 0, V_ITER = 1, V_INFEAS = 2, V_UNBND = 3, V_NUM = 4 };
@@ -92,134 +98,285 @@ struct LpView {
 };
 
 // ---------------------------------------------------------------------------------------------------- LU, refined solves
-// Cert<VN>: the certificate for LPs of up to VN columns (VN sizes the per-thread arrays: 5 / 9 / 17 on the device, so that
-// the small shapes do not pay the scratch memory of the large ones)
-template <int VN>
+// Cert<VN, ST>: the certificate for LPs of up to VN columns.  Its work arrays (the n x n factorisation, a dozen vectors) are
+// NOT private arrays -- indexed by run-time loop counters they would live in scratch memory, a dependent chain of global
+// round trips per element (measured: 10x the LP engines' own time) -- but views into a workspace the caller provides, element e
+// at ws[e * ST]: on the device one LP per lane with ST = 64 and the workspace in LDS (lane l at ws + l: consecutive lanes,
+// consecutive banks), on the host ST = 1.  ws_doubles() doubles per LP.
+template <int VN, int ST, int NF = 0>
 struct Cert {
+// NF > 0: every LP has exactly NF columns, known at compile time -- with ST = 1 and the workspace a local array the loops
+// below unroll completely and the arrays become registers (the device's small instances, n <= 5: one LP per lane, no LDS)
+static PLP_HD int ncols(const LpView& lp) { return NF ? NF : lp.n; }
+struct Vec {
+    double* p;
+    PLP_HD double& operator[](int e) const { return p[e * ST]; }
+};
+static constexpr int KC = VN + 7;                       // candidate rows kept by basis_from_x
+// workspace layout (in doubles): [LU / Q: VN * VN][M0: the basis matrix itself, VN * VN (before it: the candidate list, 2 KC)]
+// [rhs VN][z VN][y VN][t VN][rr VN][dz VN][v VN][perm VN]
+// [basis VN + 2: the basis list itself, as doubles -- >= 0 an active row, -1 - j a free variable; (unbounded) position, sign]
+// [x VN: the engine's point (a basis is read off it), or the values the free variables of the basis are held at]
+static constexpr int O_LU = 0, O_M0 = VN * VN, O_RHS = 2 * VN * VN, O_Z = O_RHS + VN, O_Y = O_Z + VN, O_T = O_Y + VN,
+                     O_RR = O_T + VN, O_DZ = O_RR + VN, O_V = O_DZ + VN, O_PERM = O_V + VN, O_BAS = O_PERM + VN,
+                     O_X = O_BAS + VN + 2, WS_DOUBLES = O_X + VN,
+                     O_CS = O_M0, O_CI = O_M0 + KC;   // (the candidate list is done with before the basis matrix is stored)
+static_assert(2 * KC <= VN * VN || VN < 5, "the candidate list shares the basis matrix' space");
+static PLP_HD constexpr int ws_doubles() { return WS_DOUBLES; }
+static PLP_HD Vec at(double* ws, int off) { return Vec{ws + off * ST}; }
+
+// v[idx], v[idx] = val at a run-time index (NF: a select chain over static indices)
+static PLP_HD double pick(Vec v, int n, int idx) {
+    if constexpr (NF > 0) {
+        double r = 0.0;
+        PLP_UNROLL
+        for (int i = 0; i < n; ++i) r = (i == idx) ? v[i] : r;
+        return r;
+    } else {
+        (void)n;
+        return v[idx];
+    }
+}
+static PLP_HD void put(Vec v, int n, int idx, double val) {
+    if constexpr (NF > 0) {
+        PLP_UNROLL
+        for (int i = 0; i < n; ++i)
+            if (i == idx) v[i] = val;
+    } else {
+        (void)n;
+        v[idx] = val;
+    }
+}
 // LU of the n x n matrix (row-major, stride VN) with partial pivoting; false: singular to working precision
-static PLP_HD bool lu_factor(int n, double* LU, int* perm) {
-    double big = 0.0;
+static PLP_HD bool lu_factor(int n, Vec LU, Vec perm, double* pivot_ratio) {
+    double big = 0.0, pmin = 1e300;
+    PLP_UNROLL
     for (int k = 0; k < n; ++k)
+        PLP_UNROLL
         for (int j = 0; j < n; ++j) big = fmax(big, fabs(LU[k * VN + j]));
     if (!(big > 0.0)) return false;
+    PLP_UNROLL
     for (int k = 0; k < n; ++k) perm[k] = k;
+    PLP_UNROLL
     for (int k = 0; k < n; ++k) {
         int p = k;
-        for (int i = k + 1; i < n; ++i)
-            if (fabs(LU[i * VN + k]) > fabs(LU[p * VN + k])) p = i;
-        if (!(fabs(LU[p * VN + k]) > 1e-13 * big)) return false;
-        if (p != k) {
+        double pv = fabs(LU[k * VN + k]);
+        PLP_UNROLL
+        for (int i = k + 1; i < n; ++i) {
+            const double a = fabs(LU[i * VN + k]);
+            if (a > pv) { pv = a; p = i; }
+        }
+        if (!(pv > 1e-13 * big)) return false;
+        pmin = fmin(pmin, pv);
+        if constexpr (NF > 0) {   // (static indices only: the arrays are registers)
+            PLP_UNROLL
+            for (int i = k + 1; i < n; ++i) {
+                if (i == p) {
+                    PLP_UNROLL
+                    for (int j = 0; j < n; ++j) {
+                        const double t = LU[k * VN + j];
+                        LU[k * VN + j] = LU[i * VN + j];
+                        LU[i * VN + j] = t;
+                    }
+                    const double t = perm[k];
+                    perm[k] = perm[i];
+                    perm[i] = t;
+                }
+            }
+        } else if (p != k) {
+            PLP_UNROLL
             for (int j = 0; j < n; ++j) {
                 const double t = LU[k * VN + j];
                 LU[k * VN + j] = LU[p * VN + j];
                 LU[p * VN + j] = t;
             }
-            const int t = perm[k];
+            const double t = perm[k];
             perm[k] = perm[p];
             perm[p] = t;
         }
         const double inv = 1.0 / LU[k * VN + k];
+        PLP_UNROLL
         for (int i = k + 1; i < n; ++i) {
             const double f = LU[i * VN + k] * inv;
             LU[i * VN + k] = f;
+            PLP_UNROLL
             for (int j = k + 1; j < n; ++j) LU[i * VN + j] = fma(-f, LU[k * VN + j], LU[i * VN + j]);
         }
     }
+    *pivot_ratio = pmin / big;
     return true;
 }
-static PLP_HD void lu_solve(int n, const double* LU, const int* perm, const double* r, double* z) {
-    double t[VN];
+// z = M^-1 r; t: n doubles of work space
+static PLP_HD void lu_solve(int n, Vec LU, Vec perm, Vec r, Vec z, Vec t) {
+    PLP_UNROLL
     for (int k = 0; k < n; ++k) {
-        double s = r[perm[k]];
+        double s = pick(r, n, (int)perm[k]);
+        PLP_UNROLL
         for (int j = 0; j < k; ++j) s = fma(-LU[k * VN + j], t[j], s);
         t[k] = s;
     }
+    PLP_UNROLL
     for (int k = n - 1; k >= 0; --k) {
         double s = t[k];
+        PLP_UNROLL
         for (int j = k + 1; j < n; ++j) s = fma(-LU[k * VN + j], z[j], s);
         z[k] = s / LU[k * VN + k];
     }
 }
-static PLP_HD void lu_solve_t(int n, const double* LU, const int* perm, const double* r, double* z) {
-    double t[VN];
+static PLP_HD void lu_solve_t(int n, Vec LU, Vec perm, Vec r, Vec z, Vec t) {
+    PLP_UNROLL
     for (int k = 0; k < n; ++k) {
         double s = r[k];
+        PLP_UNROLL
         for (int j = 0; j < k; ++j) s = fma(-LU[j * VN + k], t[j], s);
         t[k] = s / LU[k * VN + k];
     }
+    PLP_UNROLL
     for (int k = n - 1; k >= 0; --k) {
         double s = t[k];
+        PLP_UNROLL
         for (int j = k + 1; j < n; ++j) s = fma(-LU[j * VN + k], t[j], s);
         t[k] = s;
     }
-    for (int k = 0; k < n; ++k) z[perm[k]] = t[k];
+    PLP_UNROLL
+    for (int k = 0; k < n; ++k) put(z, n, (int)perm[k], t[k]);
 }
 
 // entry (k, j) of the basis matrix: row basis[k] of G, or e_j0 for the free variable j0 = -1 - basis[k]
-static PLP_HD double basis_entry(const LpView& lp, const int* basis, int k, int j) {
-    const int v = basis[k];
+static PLP_HD double basis_entry(const LpView& lp, Vec basis, int k, int j) {
+    const int v = (int)basis[k];
     return v >= 0 ? lp.g(v, j) : ((j == -1 - v) ? 1.0 : 0.0);
 }
-// z = M^-1 r (trans: M^-T r) with three rounds of refinement, residuals accumulated in double-double
-static PLP_HD void solve_refined(const LpView& lp, const int* basis, int n, const double* LU, const int* perm, const double* r,
-                          double* z, bool trans) {
-    double rr[VN], dz[VN];
-    if (trans) lu_solve_t(n, LU, perm, r, z);
-    else lu_solve(n, LU, perm, r, z);
-    for (int it = 0; it < 3; ++it) {
+// z = M^-1 r (trans: M^-T r) with up to `rounds` rounds of refinement, residuals accumulated in double-double against the
+// basis matrix kept beside its factorisation (ws[O_M0 ..): no global memory inside these dependent chains); a round whose
+// correction is below the last bits of z ends it.  rounds = 0 for a well-conditioned basis (smallest pivot above 1e-4 of the
+// largest entry): LU with partial pivoting is backward stable, the residuals of both systems are a few ulps of |M| |z| as they
+// stand -- which is all the certificate's conclusion (an optimal basis, its value) rests on; the refinement is for bases with
+// rows a hair apart, where it keeps the multipliers' signs and the vertex' coordinates meaningful.
+static PLP_HD void solve_refined(int n, double* ws, Vec r, Vec z, bool trans, int rounds) {
+    const Vec LU = at(ws, O_LU), M0 = at(ws, O_M0), perm = at(ws, O_PERM), t = at(ws, O_T), rr = at(ws, O_RR), dz = at(ws, O_DZ);
+    if (trans) lu_solve_t(n, LU, perm, r, z, t);
+    else lu_solve(n, LU, perm, r, z, t);
+    PLP_UNROLL
+    for (int it = 0; it < rounds; ++it) {
+        PLP_UNROLL
         for (int k = 0; k < n; ++k) {
             dd s = dd_make(r[k]);
-            for (int j = 0; j < n; ++j) {
-                const double mkj = trans ? basis_entry(lp, basis, j, k) : basis_entry(lp, basis, k, j);
-                s = dd_sub(s, two_prod(mkj, z[j]));
-            }
+            PLP_UNROLL
+            for (int j = 0; j < n; ++j) s = dd_sub(s, two_prod(trans ? M0[j * VN + k] : M0[k * VN + j], z[j]));
             rr[k] = dd_to_double(s);
         }
-        if (trans) lu_solve_t(n, LU, perm, rr, dz);
-        else lu_solve(n, LU, perm, rr, dz);
-        for (int j = 0; j < n; ++j) z[j] += dz[j];
+        if (trans) lu_solve_t(n, LU, perm, rr, dz, t);
+        else lu_solve(n, LU, perm, rr, dz, t);
+        double dmax = 0.0, zmax = 0.0;
+        PLP_UNROLL
+        for (int j = 0; j < n; ++j) {
+            const double zj = z[j] + dz[j];
+            z[j] = zj;
+            dmax = fmax(dmax, fabs(dz[j]));
+            zmax = fmax(zmax, fabs(zj));
+        }
+        if (!(dmax > 2e-16 * zmax)) break;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------- the certificate
-// status: V_OPT / V_UNBND as the engine reported it.  basis[0..n): >= 0 an active row, -1 - j the free variable x_j held at
-// xref[j] (xref == nullptr: 0); basis[n], basis[n + 1] (V_UNBND): position in the list of the variable the ray moves and its
-// sign.  true: certified; for V_OPT x[0..n) = the polished vertex, *fun = c.x.
-static PLP_HD bool certify(const LpView& lp, int status, const int* basis, const double* xref, double* x, double* fun) {
-    const int n = lp.n, m = lp.m;
-    double LU[VN * VN], rhs[VN], z[VN];
-    int perm[VN];
+// One row against a vertex z (xs = max(1, |z|_inf)): slack h_i - G_i.z >= -1e-13 max(|h_i|, |G_i|_inf xs).  A plain fma chain:
+// its rounding (n ulps of |G_i| |z|) is fifty times below the tolerance.
+static PLP_HD bool row_feasible(const LpView& lp, int i, Vec z, double xs) {
+    double s = lp.hh(i), gmax = 0.0;
+    PLP_UNROLL
+    for (int j = 0; j < ncols(lp); ++j) {
+        const double gij = lp.g(i, j);
+        s = fma(-gij, z[j], s);
+        gmax = fmax(gmax, fabs(gij));
+    }
+    return !(s < -V_TOL_PRIMAL * fmax(gmax * xs, fabs(lp.hh(i))));
+}
+
+// The vertex and the multipliers of a basis, everything of the certificate but the pass over all rows.
+// The basis list is in the workspace (O_BAS): >= 0 an active row, -1 - j the free variable x_j held at ws[O_X + j]
+// (have_xref false: at 0).
+// true: the basis matrix is regular and (want_dual) dual feasible; ws[O_Z ..) = the polished vertex, *fun = c.z,
+// *xs_out = max(1, |z|_inf).  (The factorisation stays in the workspace: the ray check of an unbounded answer uses it.)
+static PLP_HD bool vertex_and_dual(const LpView& lp, bool have_xref, bool want_dual, double* ws, double* fun, double* xs_out) {
+    const Vec basis = at(ws, O_BAS), xref = at(ws, O_X);
+    const int n = ncols(lp), m = lp.m;
+    const Vec LU = at(ws, O_LU), M0 = at(ws, O_M0), perm = at(ws, O_PERM), rhs = at(ws, O_RHS), z = at(ws, O_Z), y = at(ws, O_Y),
+              nc_ = at(ws, O_V);
     if (n > VN || n < 1) return false;
+    PLP_UNROLL
     for (int k = 0; k < n; ++k) {
-        const int v = basis[k];
+        const int v = (int)basis[k];
         if (v >= 0) {
             if (v >= m) return false;
             rhs[k] = lp.hh(v);
         } else {
             const int j0 = -1 - v;
             if (j0 < 0 || j0 >= n) return false;
-            rhs[k] = xref ? xref[j0] : 0.0;
+            rhs[k] = have_xref ? pick(xref, n, j0) : 0.0;
         }
-        for (int j = 0; j < n; ++j) LU[k * VN + j] = basis_entry(lp, basis, k, j);
+        PLP_UNROLL
+        for (int j = 0; j < n; ++j) {
+            const double e = basis_entry(lp, basis, k, j);
+            LU[k * VN + j] = e;
+            M0[k * VN + j] = e;
+        }
     }
-    if (!lu_factor(n, LU, perm)) return false;
-    const double cmax = lp.c_inf();
-    solve_refined(lp, basis, n, LU, perm, rhs, z, false);
+    double pr = 1.0;
+    if (!lu_factor(n, LU, perm, &pr)) return false;
+    const int rounds = pr < 1e-4 ? 3 : 0;
+    solve_refined(n, ws, rhs, z, false, rounds);
     double zmax = 0.0;
+    PLP_UNROLL
     for (int j = 0; j < n; ++j) {
         if (!(fabs(z[j]) < 1e300)) return false;
         zmax = fmax(zmax, fabs(z[j]));
     }
-    const double xs = zmax > 1.0 ? zmax : 1.0;
+    *xs_out = zmax > 1.0 ? zmax : 1.0;
+    dd f = dd_make(0.0);
+    PLP_UNROLL
+    for (int j = 0; j < n; ++j) f = dd_add(f, two_prod(lp.cc(j), z[j]));
+    *fun = dd_to_double(f);
+    if (!want_dual) return true;
+    // dual: M' y = -c
+    const double cmax = lp.c_inf();
+    PLP_UNROLL
+    for (int j = 0; j < n; ++j) nc_[j] = -lp.cc(j);
+    solve_refined(n, ws, nc_, y, true, rounds);
+    PLP_UNROLL
+    for (int k = 0; k < n; ++k) {
+        const double yk = y[k];
+        if (!(fabs(yk) < 1e300)) return false;
+        if (basis[k] >= 0.0) {
+            double gmax = 0.0;
+            PLP_UNROLL
+            for (int j = 0; j < n; ++j) gmax = fmax(gmax, fabs(M0[k * VN + j]));
+            if (yk * gmax < -V_TOL_DUAL * cmax) return false;
+        } else if (fabs(yk) > V_TOL_DUAL * cmax) return false;
+    }
+    return true;
+}
+
+// status: V_OPT / V_UNBND as the engine reported it; basis list in the workspace, entries n, n + 1 (V_UNBND): position in the list of the variable
+// the ray moves and its sign.  true: certified; for V_OPT x[0..n) = the polished vertex, *fun = c.x.
+static PLP_HD bool certify(const LpView& lp, int status, bool have_xref, double* ws, double* x, double* fun) {
+    const int n = ncols(lp), m = lp.m;
+    const Vec basis = at(ws, O_BAS);
+    double xs = 1.0, f = 0.0;
+    if (!vertex_and_dual(lp, have_xref, status != V_UNBND, ws, &f, &xs)) return false;
+    const Vec z = at(ws, O_Z);
     if (status == V_UNBND) {
-        const int e = basis[n];
-        double w[VN], ru[VN];
+        const int e = (int)basis[n];
+        const Vec w = at(ws, O_Y), ru = at(ws, O_V);
         if (e < 0 || e >= n) return false;
+        PLP_UNROLL
         for (int k = 0; k < n; ++k) ru[k] = 0.0;
-        ru[e] = basis[e] >= 0 ? -1.0 : (double)basis[n + 1];  // the slack of an active row grows / the free variable moves by its sign
-        solve_refined(lp, basis, n, LU, perm, ru, w, false);
+        ru[e] = basis[e] >= 0.0 ? -1.0 : basis[n + 1];  // the slack of an active row grows / the free variable moves by its sign
+        solve_refined(n, ws, ru, w, false, 3);
         dd cw = dd_make(0.0), cz = dd_make(0.0);
         double wmax = 0.0;
+        PLP_UNROLL
         for (int j = 0; j < n; ++j) {
             if (!(fabs(w[j]) < 1e300)) return false;
             wmax = fmax(wmax, fabs(w[j]));
@@ -228,9 +385,11 @@ static PLP_HD bool certify(const LpView& lp, int status, const int* basis, const
         }
         if (!(cw.hi < 0.0)) return false;
         const double big = V_BIG * lp.scale();
+        PLP_UNROLL
         for (int i = 0; i < m; ++i) {
             dd gw = dd_make(0.0), sl = dd_make(lp.hh(i));
             double gmax = 0.0;
+            PLP_UNROLL
             for (int j = 0; j < n; ++j) {
                 const double gij = lp.g(i, j);
                 gw = dd_add(gw, two_prod(gij, w[j]));
@@ -240,7 +399,8 @@ static PLP_HD bool certify(const LpView& lp, int status, const int* basis, const
             const double tol = fmax(gmax * xs, fabs(lp.hh(i)));
             if (sl.hi < -V_TOL_PRIMAL * tol) return false;  // the vertex itself must be feasible
             bool inb = false;                                // rows of the basis: G_k.w = 0 (or -1) by construction
-            for (int k = 0; k < n; ++k) inb = inb | (basis[k] == i);
+            PLP_UNROLL
+            for (int k = 0; k < n; ++k) inb = inb | ((int)basis[k] == i);
             if (inb || !(gw.hi > 1e-14 * gmax * wmax)) continue;  // (below the rounding of w: not a blocking row)
             if (dd_lt_d(sl, 0.0)) sl = dd_make(0.0);
             const dd t = dd_div(sl, gw);                     // the ray meets row i here ...
@@ -249,75 +409,145 @@ static PLP_HD bool certify(const LpView& lp, int status, const int* basis, const
         }
         return true;
     }
-    // dual: M' y = -c
-    double y[VN], nc_[VN];
-    for (int j = 0; j < n; ++j) nc_[j] = -lp.cc(j);
-    solve_refined(lp, basis, n, LU, perm, nc_, y, true);
-    for (int k = 0; k < n; ++k) {
-        if (!(fabs(y[k]) < 1e300)) return false;
-        if (basis[k] >= 0) {
-            const double gmax = lp.row_inf(basis[k]);
-            if (y[k] * gmax < -V_TOL_DUAL * cmax) return false;
-        } else if (fabs(y[k]) > V_TOL_DUAL * cmax) return false;
-    }
-    for (int i = 0; i < m; ++i) {
-        dd s = dd_make(lp.hh(i));
-        double gmax = 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double gij = lp.g(i, j);
-            s = dd_sub(s, two_prod(gij, z[j]));
-            gmax = fmax(gmax, fabs(gij));
-        }
-        const double tol = fmax(gmax * xs, fabs(lp.hh(i)));
-        if (s.hi < -V_TOL_PRIMAL * tol) return false;
-    }
-    dd f = dd_make(0.0);
-    for (int j = 0; j < n; ++j) {
-        f = dd_add(f, two_prod(lp.cc(j), z[j]));
-        x[j] = z[j];
-    }
-    *fun = dd_to_double(f);
+    PLP_UNROLL
+    for (int i = 0; i < m; ++i)
+        if (!row_feasible(lp, i, z, xs)) return false;
+    PLP_UNROLL
+    for (int j = 0; j < n; ++j) x[j] = z[j];
+    *fun = f;
     return true;
 }
 
-// A basis read off an engine's x (engines that do not hand over theirs): the rows whose slack at x is below 1e-9 of their
-// scale, in order of increasing slack, as long as they are linearly independent of the ones taken so far (modified
-// Gram-Schmidt; a copy of a taken row adds nothing to the cone they span); free variables x_j held at x_j complete it
-// where x lies on a face rather than at a vertex.  At a degenerate vertex the choice may not be the dual-feasible one: the
-// certificate then fails and the LP goes to the careful engine.  false: no basis (more than VN candidates ...).
-static PLP_HD bool basis_from_x(const LpView& lp, const double* x, int* basis) {
-    const int n = lp.n, m = lp.m;
-    double Q[VN * VN];  // orthonormal rows spanning the accepted rows
-    int nb = 0;
-    double xs = 1.0;
-    for (int j = 0; j < n; ++j) {
-        if (!(fabs(x[j]) < 1e300)) return false;
-        xs = fmax(xs, fabs(x[j]));
-    }
-    // candidates by increasing slack: repeated selection of the smallest slack above the last one taken (m is small)
-    double last = -1e300;
-    int lasti = -1;
-    for (int round = 0; round < m && nb < n; ++round) {
-        int bi = -1;
-        double bs = 1e300;
-        for (int i = 0; i < m; ++i) {
-            double s = lp.hh(i), gmax = 0.0;
-            for (int j = 0; j < n; ++j) {
-                const double gij = lp.g(i, j);
-                s = fma(-gij, x[j], s);
-                gmax = fmax(gmax, fabs(gij));
-            }
-            if (!(gmax > 0.0)) continue;
-            const double tol = fmax(gmax * xs, fabs(lp.hh(i)));
-            if (!(s <= 1e-9 * tol)) continue;
-            if (s < last || (s == last && i <= lasti)) continue;  // taken or looked at already
-            if (s < bs) { bs = s; bi = i; }
+// ---- a basis read off an engine's x (engines that do not hand over theirs).  Candidates: the rows whose slack at x is below
+// 1e-9 of their scale, kept sorted by (slack, row) in the workspace -- at most KC of them (more: no basis, the LP goes to
+// the careful engine).  cn: their number so far (KC + 1: overflow).
+static PLP_HD void cand_add(double* ws, int& cn, double s, int i) {
+    const Vec cs = at(ws, O_CS), ci = at(ws, O_CI);
+    if (cn >= KC) { cn = KC + 1; return; }
+    if constexpr (NF > 0) {   // (static indices only)
+        int pos = 0;
+        PLP_UNROLL
+        for (int k = 0; k < KC; ++k) pos += ((k < cn) & ((cs[k] < s) | ((cs[k] == s) & (ci[k] < (double)i)))) ? 1 : 0;
+        PLP_UNROLL
+        for (int k = KC - 1; k > 0; --k) {
+            if ((k > pos) & (k <= cn)) { cs[k] = cs[k - 1]; ci[k] = ci[k - 1]; }
         }
-        if (bi < 0) break;
-        last = bs;
-        lasti = bi;
-        double v[VN], nrm0 = 0.0, nrm1 = 0.0;
-        for (int j = 0; j < n; ++j) { v[j] = lp.g(bi, j); nrm0 = fma(v[j], v[j], nrm0); }
+        PLP_UNROLL
+        for (int k = 0; k < KC; ++k)
+            if (k == pos) { cs[k] = s; ci[k] = (double)i; }
+        ++cn;
+        return;
+    }
+    int k = cn++;
+    while (k > 0 && (cs[k - 1] > s || (cs[k - 1] == s && ci[k - 1] > (double)i))) {
+        cs[k] = cs[k - 1];
+        ci[k] = ci[k - 1];
+        --k;
+    }
+    cs[k] = s;
+    ci[k] = (double)i;
+}
+// slack of row i at x (plain fma chain) and whether the row is a candidate (xs = max(1, |x|_inf))
+static PLP_HD bool row_candidate(const LpView& lp, int i, Vec x, double xs, double* slack) {
+    double s = lp.hh(i), gmax = 0.0;
+    PLP_UNROLL
+    for (int j = 0; j < ncols(lp); ++j) {
+        const double gij = lp.g(i, j);
+        s = fma(-gij, x[j], s);
+        gmax = fmax(gmax, fabs(gij));
+    }
+    *slack = s;
+    return (gmax > 0.0) & (s <= 1e-9 * fmax(gmax * xs, fabs(lp.hh(i))));
+}
+// The candidates in order, as long as they are linearly independent of the ones taken so far (modified Gram-Schmidt; a copy
+// of a taken row adds nothing to the cone they span); free variables x_j held where they are complete the basis when x lies
+// on a face rather than at a vertex.  At a degenerate vertex the choice may not be the dual-feasible one: the certificate
+// then fails and the LP goes to the careful engine.  (Q shares the workspace of the factorisation, which comes after it.)
+static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
+    const int n = ncols(lp);
+    const Vec basis = at(ws, O_BAS);
+    const Vec Q = at(ws, O_LU), v = at(ws, O_V), ci = at(ws, O_CI);  // Q: orthonormal rows spanning the accepted rows
+    int nb = 0;
+    if (cn > KC) return false;
+    if constexpr (NF > 0) {   // the same with static indices only: rows of Q beyond nb are zero, "row nb" is a select
+        PLP_UNROLL
+        for (int e = 0; e < n * VN; ++e) Q[e] = 0.0;
+        PLP_UNROLL
+        for (int q0 = 0; q0 < KC; ++q0) {
+            if ((q0 < cn) & (nb < n)) {
+                const int bi = (int)ci[q0];
+                double nrm0 = 0.0, nrm1 = 0.0;
+                PLP_UNROLL
+                for (int j = 0; j < n; ++j) { const double g = lp.g(bi, j); v[j] = g; nrm0 = fma(g, g, nrm0); }
+                PLP_UNROLL
+                for (int q = 0; q < n; ++q) {   // (rows q >= nb of Q are zero: they change nothing)
+                    double dq = 0.0;
+                    PLP_UNROLL
+                    for (int j = 0; j < n; ++j) dq = fma(Q[q * VN + j], v[j], dq);
+                    PLP_UNROLL
+                    for (int j = 0; j < n; ++j) v[j] = fma(-dq, Q[q * VN + j], v[j]);
+                }
+                PLP_UNROLL
+                for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
+                if (nrm1 > 1e-12 * nrm0) {
+                    const double inv = 1.0 / sqrt(nrm1);
+                    PLP_UNROLL
+                    for (int q = 0; q < n; ++q) {
+                        if (q == nb) {
+                            PLP_UNROLL
+                            for (int j = 0; j < n; ++j) Q[q * VN + j] = v[j] * inv;
+                            basis[q] = (double)bi;
+                        }
+                    }
+                    ++nb;
+                }
+            }
+        }
+        PLP_UNROLL
+        for (int round = 0; round < n; ++round) {   // complete with free variables (unit vectors), most independent first
+            if (nb < n) {
+                int bj = -1;
+                double bn = 0.0;
+                PLP_UNROLL
+                for (int j0 = 0; j0 < n; ++j0) {
+                    double r2 = 1.0;
+                    PLP_UNROLL
+                    for (int q = 0; q < n; ++q) r2 = fma(-Q[q * VN + j0], Q[q * VN + j0], r2);
+                    if (r2 > bn) { bn = r2; bj = j0; }
+                }
+                if (bj < 0 || !(bn > 1e-12)) return false;
+                double nrm1 = 0.0;
+                PLP_UNROLL
+                for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
+                PLP_UNROLL
+                for (int q = 0; q < n; ++q) {
+                    double dq = 0.0;
+                    PLP_UNROLL
+                    for (int j = 0; j < n; ++j) dq = (j == bj) ? Q[q * VN + j] : dq;
+                    PLP_UNROLL
+                    for (int j = 0; j < n; ++j) v[j] = fma(-dq, Q[q * VN + j], v[j]);
+                }
+                PLP_UNROLL
+                for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
+                if (!(nrm1 > 1e-12)) return false;
+                const double inv = 1.0 / sqrt(nrm1);
+                PLP_UNROLL
+                for (int q = 0; q < n; ++q) {
+                    if (q == nb) {
+                        PLP_UNROLL
+                        for (int j = 0; j < n; ++j) Q[q * VN + j] = v[j] * inv;
+                        basis[q] = (double)(-1 - bj);
+                    }
+                }
+                ++nb;
+            }
+        }
+        return nb == n;
+    }
+    for (int q0 = 0; q0 < cn && nb < n; ++q0) {
+        const int bi = (int)ci[q0];
+        double nrm0 = 0.0, nrm1 = 0.0;
+        for (int j = 0; j < n; ++j) { const double g = lp.g(bi, j); v[j] = g; nrm0 = fma(g, g, nrm0); }
         for (int q = 0; q < nb; ++q) {
             double dq = 0.0;
             for (int j = 0; j < n; ++j) dq = fma(Q[q * VN + j], v[j], dq);
@@ -327,10 +557,9 @@ static PLP_HD bool basis_from_x(const LpView& lp, const double* x, int* basis) {
         if (!(nrm1 > 1e-12 * nrm0)) continue;  // (1e-6 of its length: dependent on the rows taken so far)
         const double inv = 1.0 / sqrt(nrm1);
         for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
-        basis[nb++] = bi;
+        basis[nb++] = (double)bi;
     }
-    // complete with free variables (unit vectors), most independent first
-    while (nb < n) {
+    while (nb < n) {  // complete with free variables (unit vectors), most independent first
         int bj = -1;
         double bn = 0.0;
         for (int j0 = 0; j0 < n; ++j0) {
@@ -339,7 +568,7 @@ static PLP_HD bool basis_from_x(const LpView& lp, const double* x, int* basis) {
             if (r2 > bn) { bn = r2; bj = j0; }
         }
         if (bj < 0 || !(bn > 1e-12)) return false;
-        double v[VN], nrm1 = 0.0;
+        double nrm1 = 0.0;
         for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
         for (int q = 0; q < nb; ++q) {
             const double dq = Q[q * VN + bj];
@@ -349,9 +578,33 @@ static PLP_HD bool basis_from_x(const LpView& lp, const double* x, int* basis) {
         if (!(nrm1 > 1e-12)) return false;
         const double inv = 1.0 / sqrt(nrm1);
         for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
-        basis[nb++] = -1 - bj;
+        basis[nb++] = (double)(-1 - bj);
     }
     return true;
+}
+static PLP_HD double x_scale(const LpView& lp, Vec x, bool* finite) {
+    double xs = 1.0;
+    *finite = true;
+    PLP_UNROLL
+    for (int j = 0; j < ncols(lp); ++j) {
+        if (!(fabs(x[j]) < 1e300)) *finite = false;
+        xs = fmax(xs, fabs(x[j]));
+    }
+    return xs;
+}
+// (the point: ws[O_X ..))
+static PLP_HD bool basis_from_x(const LpView& lp, double* ws) {
+    const Vec x = at(ws, O_X);
+    bool fin;
+    const double xs = x_scale(lp, x, &fin);
+    if (!fin) return false;
+    int cn = 0;
+    PLP_UNROLL
+    for (int i = 0; i < lp.m; ++i) {
+        double s;
+        if (row_candidate(lp, i, x, xs, &s)) cand_add(ws, cn, s, i);
+    }
+    return select_basis(lp, ws, cn);
 }
 };  // struct Cert
 

@@ -23,10 +23,27 @@ extern "C" {
 int plpv_certify_from_x(int kind, int m, int n, int side, const double* c, const double* G, const double* h,
                         const double* x_in, double* x_out, double* fun_out, int* basis_out) {
     const LpView lp = view(kind, m, n, side, c, G, h);
-    int basis[VNMAX + 2];
-    if (!Cert<VNMAX>::basis_from_x(lp, x_in, basis)) return -1;
-    if (basis_out) memcpy(basis_out, basis, sizeof(int) * n);
-    return Cert<VNMAX>::certify(lp, V_OPT, basis, x_in, x_out, fun_out) ? 1 : 0;
+    // (n <= 5: the instance with the column count fixed at compile time and static indices only -- what the device's
+    // one-LP-per-lane kernel instantiates, its arrays in registers; here it must give what the general instance gives)
+#define PLPV_FROM_X(CT)                                                                                    \
+    {                                                                                                      \
+        double ws[CT::WS_DOUBLES];                                                                         \
+        for (int j = 0; j < n; ++j) ws[CT::O_X + j] = x_in[j];                                             \
+        if (!CT::basis_from_x(lp, ws)) return -1;                                                          \
+        if (basis_out) for (int k = 0; k < n; ++k) basis_out[k] = (int)ws[CT::O_BAS + k];                  \
+        return CT::certify(lp, V_OPT, true, ws, x_out, fun_out) ? 1 : 0;                                   \
+    }
+    using C2 = Cert<2, 1, 2>;
+    using C3 = Cert<3, 1, 3>;
+    using C4 = Cert<4, 1, 4>;
+    using C5 = Cert<5, 1, 5>;
+    using CTG = Cert<VNMAX, 1>;
+    if (n == 2) PLPV_FROM_X(C2)
+    if (n == 3) PLPV_FROM_X(C3)
+    if (n == 4) PLPV_FROM_X(C4)
+    if (n == 5) PLPV_FROM_X(C5)
+    PLPV_FROM_X(CTG)
+#undef PLPV_FROM_X
 }
 
 // basis mode (status 0 / 3); basis[n + 2] as the oracle's plpo_lp_solve_raw hands it over
@@ -34,8 +51,16 @@ int plpv_certify_basis(int kind, int m, int n, int side, const double* c, const 
                        const int* basis, const double* xref, double* x_out, double* fun_out) {
     const LpView lp = view(kind, m, n, side, c, G, h);
     // (the small instance where it applies: what the device launches for these shapes)
-    if (n <= 5) return Cert<5>::certify(lp, status, basis, xref, x_out, fun_out) ? 1 : 0;
-    return Cert<VNMAX>::certify(lp, status, basis, xref, x_out, fun_out) ? 1 : 0;
+    if (n <= 5) {
+        double ws[Cert<5, 1>::WS_DOUBLES];
+        for (int k = 0; k < n + 2; ++k) ws[Cert<5, 1>::O_BAS + k] = basis[k];
+        for (int j = 0; j < n; ++j) ws[Cert<5, 1>::O_X + j] = xref ? xref[j] : 0.0;
+        return Cert<5, 1>::certify(lp, status, xref != nullptr, ws, x_out, fun_out) ? 1 : 0;
+    }
+    double ws[Cert<VNMAX, 1>::WS_DOUBLES];
+    for (int k = 0; k < n + 2; ++k) ws[Cert<VNMAX, 1>::O_BAS + k] = basis[k];
+    for (int j = 0; j < n; ++j) ws[Cert<VNMAX, 1>::O_X + j] = xref ? xref[j] : 0.0;
+    return Cert<VNMAX, 1>::certify(lp, status, xref != nullptr, ws, x_out, fun_out) ? 1 : 0;
 }
 
 int plpv_careful(int kind, int m, int n, int side, const double* c, const double* G, const double* h, double* x, double* fun,
