@@ -295,7 +295,8 @@ int plpo_lp_solve_raw(int m, int n, const double *c, const double *G, const doub
  *   M = the n rows that define the vertex (active rows; e_j for a free variable left at zero),
  *   x = M^-1 rhs and y = -M^-T c by LU with partial pivoting + iterative refinement (residuals in binary128),
  *   primal:  h_i - G_i.x >= -1e-13 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
- *   dual:    y_k |G_k|_inf >= -1e-11 |c|_inf on active rows, |y_k| <= 1e-11 |c|_inf on the free variables
+ *   dual:    y_k |G_k|_inf >= -1e-13 |c|_inf on active rows, |y_k| <= 1e-13 |c|_inf on the free variables (a multiplier
+ *            between that and the engine's own 1e-9 is judged by what it buys: plp_oracle_q.c, qrun)
  * -- an optimal basis of the LP as given, its vertex computed to the last bits whatever path led there.  An
  * unbounded answer is checked the same way (ray w = M^-1 (-/+ u_e): G_i.w <= 1e-12 |G_i| |w| for every row, c.w < 0).
  * What fails is solved again by plpo_lp_solve_q (binary128; plp_oracle_q.c): the oracle never returns an answer it
@@ -314,7 +315,7 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
  * |h_i| / |G_i|_inf). */
 #define PLPO_BIG 1e9
 #define PLPO_TOL_PRIMAL 1e-13   /* (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on an optimum of 235) */
-static double g_tol_dual = 1e-12;   /* plpo_set_tol_dual: experiments */
+static double g_tol_dual = 1e-13;   /* a multiplier below this is rounding; between it and the engine's 1e-9: binary128 judges it by what it buys */
 #define PLPO_TOL_DUAL g_tol_dual
 void plpo_set_tol_dual(double t) { g_tol_dual = t; }
 static double lp_scale(int m, int n, const double *c, const double *G, const double *h)

@@ -26,12 +26,16 @@ typedef __float128 qreal;
 #define QMAXM 256
 #define QMAXN 18
 /* Tolerances on the EQUILIBRATED dictionary (rows scaled to |G_i|_inf = 1, cost to |c|_inf = 1): the semantics of the
- * certificate in plp_oracle.c (lp_certify: dual 1e-12, primal 1e-10), not "exact".  An exact optimum is NOT what the
+ * certificate in plp_oracle.c (lp_certify: dual 1e-9, primal 1e-13), not "exact".  An exact optimum is NOT what the
  * reference computes on data with rows an ulp apart: a copy of the row x_0 <= 2 tilted by 1e-16 towards x_1 lets the
  * exact LP reach x_0 = 2.84 at x_1 = 1e16 (scripts/soak_lane.py family `dup`, seed 5 trial 6) where HiGHS and every
- * double-precision code answer 2; a coefficient below 1e-12 of its row is zero for all of them.  What binary128 buys
+ * double-precision code answer 2; a rate of change of the objective below 1e-9 per unit of distance is zero for all of them
+ * (Q_TOL_D = the double engine's TOL_D; tests/golden/g22 case 162: at 1e-12 this engine gave a sliver tilted by 5e-11 the
+ * Chebyshev radius 1.5, at a centre 6e10 away, where HiGHS says 2.5e-6).  What binary128 buys
  * is that the dictionary carries no rounding of its own at that level, whatever the basis' condition number. */
-#define Q_TOL_D 1e-12Q
+#define Q_TOL_D 1e-9Q
+#define Q_TOL_NOISE 1e-13Q   /* reduced costs between this and Q_TOL_D: judged by what they buy (qrun) */
+#define Q_TOL_GAIN 1e-10Q    /* ... an improvement above this (of max(1, |objective|)) within range */
 #define Q_TOL_PIV 1e-12Q
 #define Q_TOL_FEAS 1e-7Q
 #define Q_DEGEN 1e-24Q
@@ -84,7 +88,25 @@ static void qpivot(qdict_t *D, int r, int e)
     D->iters++;
 }
 
-static int qrun(qdict_t *D)
+/* ratio test of column e (entering upwards; negate: downwards): the leaving row (-1: none) and the step */
+static int qratio(const qdict_t *D, int e, int negate, int bland, qreal *step)
+{
+    int r = -1;
+    qreal rmin = 0.0Q;
+    for (int i = 0; i < D->m; ++i) {
+        if (!D->rowact[i]) continue;
+        const qreal a = negate ? -D->T[i][e] : D->T[i][e];
+        if (!(a > Q_TOL_PIV)) continue;
+        const qreal bi = D->beta[i] > 0.0Q ? D->beta[i] : 0.0Q;
+        const qreal q = bi / a;
+        if (r < 0 || q < rmin || (bland && q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
+    }
+    *step = rmin;
+    return r;
+}
+
+/* bigstep: PLPO_BIG times the scale of the data in the units of the equilibrated dictionary (how far a step may go and count) */
+static int qrun(qdict_t *D, double bigstep)
 {
     int ndeg = 0;
     for (;;) {
@@ -99,7 +121,26 @@ static int qrun(qdict_t *D)
             if (bland) { if (D->colvar[j] < bestid) { bestid = D->colvar[j]; e = j; } }
             else if (aj > best) { best = aj; e = j; }
         }
-        if (e < 0) return Q_OPT;
+        if (e < 0) {
+            /* no column above the engines' tolerance.  Those between the rounding level and it are judged by what they buy:
+             * the step they allow (cut at bigstep) times the rate, against Q_TOL_GAIN of max(1, |objective|)
+             * (polytope_amd/csrc/plp_verify.hpp: careful_run, the same rule) */
+            const qreal obj = fabsq(D->negz);
+            const qreal thr = Q_TOL_GAIN * (obj > 1.0Q ? obj : 1.0Q);
+            qreal gain = 0.0Q;
+            for (int j = 0; j < D->nc; ++j) {
+                if (D->coldead[j]) continue;
+                const qreal dj = D->cost[j], aj = fabsq(dj);
+                const int grey = QFREE(D, D->colvar[j]) ? (aj > Q_TOL_NOISE) : (dj < -Q_TOL_NOISE);
+                if (!grey) continue;
+                qreal step;
+                const int r = qratio(D, j, dj > 0.0Q, 0, &step);
+                const qreal t = (r < 0 || step > (qreal)bigstep) ? (qreal)bigstep : step;
+                const qreal gj = aj * t;
+                if (gj > thr && gj > gain) { gain = gj; e = j; }
+            }
+            if (e < 0) return Q_OPT;
+        }
         if (D->iters >= D->maxit) return Q_ITER;
         if (D->cost[e] > 0.0Q) {
             for (int i = 0; i < D->m; ++i) D->T[i][e] = -D->T[i][e];
@@ -107,16 +148,8 @@ static int qrun(qdict_t *D)
             if (D->carry) D->cost2[e] = -D->cost2[e];
             D->colsgn[e] = -D->colsgn[e];
         }
-        int r = -1;
-        qreal rmin = 0.0Q;
-        for (int i = 0; i < D->m; ++i) {
-            if (!D->rowact[i]) continue;
-            const qreal a = D->T[i][e];
-            if (!(a > Q_TOL_PIV)) continue;
-            const qreal bi = D->beta[i] > 0.0Q ? D->beta[i] : 0.0Q;
-            const qreal q = bi / a;
-            if (r < 0 || q < rmin || (bland && q == rmin && D->rowvar[i] < D->rowvar[r])) { rmin = q; r = i; }
-        }
+        qreal rmin;
+        const int r = qratio(D, e, 0, bland, &rmin);
         if (r < 0) return Q_UNBND;
         ndeg = (rmin <= Q_DEGEN) ? ndeg + 1 : 0;
         qpivot(D, r, e);
@@ -161,6 +194,13 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
     double cmax = 0.0;
     for (int j = 0; j < n; ++j) if (fabs(c[j]) > cmax) cmax = fabs(c[j]);
     for (int j = 0; j < n; ++j) d->cost[j] = cmax > 0.0 ? (qreal)c[j] / (qreal)cmax : 0.0Q;
+    double hs = 1.0;   /* max(1, max_i |h_i| / |G_i|_inf): plp_oracle.c's lp_scale without the cost */
+    for (int i = 0; i < m; ++i) {
+        double gmax = 0.0;
+        for (int j = 0; j < n; ++j) if (fabs(G[i * n + j]) > gmax) gmax = fabs(G[i * n + j]);
+        if (gmax > 0.0 && fabs(h[i]) > hs * gmax) hs = fabs(h[i]) / gmax;
+    }
+    const double bigstep = 1e9 * hs;
     int st;
     if (need_p1) {
         const int tc = n;
@@ -175,7 +215,7 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
             if (r0 < 0 || d->beta[i] < d->beta[r0]) r0 = i;
         }
         qpivot(d, r0, tc);
-        st = qrun(d);
+        st = qrun(d, bigstep);
         if (st != Q_OPT) { if (iters) *iters = d->iters; return st == Q_ITER ? Q_ITER : Q_NUM; }
         int rt = -1, ct = -1;
         for (int i = 0; i < m; ++i) if (d->rowvar[i] == Q_ID_T) rt = i;
@@ -196,7 +236,7 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
         for (int j = 0; j < d->nc; ++j) d->cost[j] = d->cost2[j];
         d->negz = d->negz2; d->carry = 0;
     }
-    st = qrun(d);
+    st = qrun(d, bigstep);
     if (iters) *iters = d->iters;
     if (st != Q_OPT) return st;
     qreal xq[QMAXN];

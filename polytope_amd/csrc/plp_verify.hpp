@@ -11,15 +11,23 @@
 //               as masks, or read off its x: basis_from_x) and the ORIGINAL rows: M = those rows, x = M^-1 rhs and
 //               y = -M^-T c by LU with partial pivoting + iterative refinement with double-double residuals; then
 //                   primal  h_i - G_i.x >= -1e-13 max(|h_i|, |G_i|_inf max(1, |x|_inf))          for every row,
-//                   dual    y_k |G_k|_inf >= -1e-12 |c|_inf on active rows, |y_k| <= 1e-12 |c|_inf on free variables:
+//                   dual    y_k |G_k|_inf >= -1e-13 |c|_inf on active rows, |y_k| <= 1e-13 |c|_inf on free variables:
 //               an optimal basis of the LP as given, its vertex recomputed to the last bits whatever path led there (the
 //               polished x replaces the engine's).  An unbounded answer is checked the same way: the vertex the engine
 //               stood on and the ray it left along, every row the ray runs into beyond the point where the objective
 //               passes BIG times the scale of the data.
 //   careful_solve()  What fails is solved again from scratch: the same textbook two-phase dictionary simplex, in
-//               double-double arithmetic on the row-equilibrated LP, tolerances 1e-12 (the certificate's).  Scalar code,
+//               double-double arithmetic on the row-equilibrated LP, with the certificate's tolerances.  Scalar code,
 //               one LP per thread, dictionary in global memory: slow (milliseconds) and rare (nothing on random, ragged,
 //               rescaled, flat or lattice data; ~5 % of the LPs of polytopes with rows 1e-16 .. 1e-5 rad apart).
+//   Tolerances.  The engines stop at reduced costs above -1e-9 (TOL_D): the rate at which the objective changes per unit of
+//   distance.  What such a rate is worth depends on how far the direction goes -- 1e-9 of the polytope's extent, which on a
+//   sliver that reaches 1e4 is 1e-5 of a box side of 3 (profiles/r05/soak_wide_r05l_*.log) -- so here a reduced cost between the
+//   rounding of the factorisation (1e-13) and 1e-9 is judged by what it BUYS: the careful engine (and the oracle's binary128
+//   twin) enter such a column when the step it allows, cut at BIG times the scale of the data, improves the objective by more
+//   than 1e-10 of max(1, |objective|); the certificate accepts no multiplier below -1e-13, so an answer with one in that zone
+//   goes to the careful engine.  Below 1e-13 a coefficient is zero: a copy of the row x_0 <= 2 tilted by 1e-16 towards x_1 lets
+//   the exact LP reach x_0 = 2.84 at x_1 = 1e16 where HiGHS and every double-precision code answer 2.
 //   An optimum beyond BIG = 1e9 times the scale of the data is reported UNBOUNDED -- what HiGHS does with such LPs
 //   (measured: box sides of exact value up to 1.5e9 come back as that value, beyond ~2e9 as +-inf).
 //
@@ -44,9 +52,11 @@ constexpr int VNMAX = 17;         // columns of an LP (d + 1)
 constexpr int VNC = VNMAX + 1;    // + the phase-1 artificial
 constexpr int VW = 20;            // doubles per dictionary row in the careful engine's scratch: VNC columns, beta, spare
 constexpr double V_BIG = 1e9;     // optimum beyond V_BIG x scale(data): unbounded
-constexpr double V_TOL_DUAL = 1e-12;
+constexpr double V_TOL_DUAL = 1e-13;  // a multiplier below this (of |c| / |G_k|) is rounding; see the note on tolerances below
 constexpr double V_TOL_PRIMAL = 1e-13;  // (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on the optimum of 235, seed 4 of verify_smoke)
-constexpr double C_TOL_D = 1e-12, C_TOL_PIV = 1e-12, C_TOL_FEAS = 1e-7, C_DEGEN = 1e-24;
+constexpr double C_TOL_D = 1e-9, C_TOL_PIV = 1e-12, C_TOL_FEAS = 1e-7, C_DEGEN = 1e-24;
+constexpr double C_TOL_NOISE = 1e-13;  // reduced costs between this and C_TOL_D: judged by what they buy (careful_run)
+constexpr double C_TOL_GAIN = 1e-10;   // ... an improvement above this (of max(1, |objective|)) within range
 constexpr int C_BLAND_AFTER = 6;
 enum : int { V_OPT = 0, V_ITER = 1, V_INFEAS = 2, V_UNBND = 3, V_NUM = 4 };
 enum : int { LP_GENERIC = 0, LP_CHEBY = 1, LP_BOXSIDE = 2 };
@@ -344,6 +354,15 @@ static PLP_HD bool vertex_and_dual(const LpView& lp, bool have_xref, bool want_d
     PLP_UNROLL
     for (int j = 0; j < n; ++j) nc_[j] = -lp.cc(j);
     solve_refined(n, ws, nc_, y, true, rounds);
+    if (rounds == 0) {   // a multiplier between -1e-9 and the tolerance: rounding of the plain solve, or real?  refine, then judge
+        bool grey = false;
+        PLP_UNROLL
+        for (int k = 0; k < n; ++k) {
+            const double yk = basis[k] >= 0.0 ? y[k] : -fabs(y[k]);
+            grey = grey | ((yk < 0.0) & (yk > -1e-9 * cmax));
+        }
+        if (grey) solve_refined(n, ws, nc_, y, true, 3);
+    }
     PLP_UNROLL
     for (int k = 0; k < n; ++k) {
         const double yk = y[k];
@@ -667,7 +686,29 @@ PLP_HD void careful_pivot(const CarefulMem& M, CarefulState& S, int r, int e) {
     S.iters++;
 }
 
-PLP_HD int careful_run(const CarefulMem& M, CarefulState& S) {
+// ratio test of column e (entering upwards): the leaving row (-1: none) and the step
+PLP_HD int careful_ratio(const CarefulMem& M, const CarefulState& S, int e, bool negate, bool bland, dd* step) {
+    int r = -1;
+    dd rmin = dd_make(0.0);
+    for (int i = 0; i < S.m; ++i) {
+        if (!M.ract(i)) continue;
+        dd a = M.get(i, e);
+        if (negate) a = dd_neg(a);
+        if (!dd_gt_d(a, C_TOL_PIV)) continue;
+        dd bi = M.get(i, VNC);
+        if (dd_lt_d(bi, 0.0)) bi = dd_make(0.0);
+        const dd q = dd_div(bi, a);
+        if (r < 0 || dd_lt(q, rmin) || (bland && dd_eq(q, rmin) && M.rv(i) < M.rv(r))) {
+            rmin = q;
+            r = i;
+        }
+    }
+    *step = rmin;
+    return r;
+}
+
+// `bigstep`: BIG times the scale of the data in the units of the (equilibrated) dictionary -- how far a step may go and count
+PLP_HD int careful_run(const CarefulMem& M, CarefulState& S, double bigstep) {
     int ndeg = 0;
     const int m = S.m;
     for (;;) {
@@ -687,7 +728,26 @@ PLP_HD int careful_run(const CarefulMem& M, CarefulState& S) {
                 e = j;
             }
         }
-        if (e < 0) return V_OPT;
+        if (e < 0) {
+            // no column above the engines' tolerance.  Those between the rounding level and it are judged by what they buy:
+            // the step they allow (cut at `bigstep`) times the rate, against C_TOL_GAIN of max(1, |objective|)
+            dd obj = dd_abs(M.get(m, VNC));
+            const double thr = C_TOL_GAIN * fmax(1.0, obj.hi);
+            double gain = 0.0;
+            for (int j = 0; j < S.nc; ++j) {
+                if (S.coldead[j]) continue;
+                const dd dj = M.get(m, j), aj = dd_abs(dj);
+                const bool fr = (unsigned)S.colvar[j] < (unsigned)S.n;
+                const bool grey = fr ? dd_gt_d(aj, C_TOL_NOISE) : dd_lt_d(dj, -C_TOL_NOISE);
+                if (!grey) continue;
+                dd step;
+                const int r = careful_ratio(M, S, j, dd_gt_d(dj, 0.0), false, &step);
+                const double t = r < 0 ? bigstep : fmin(step.hi, bigstep);
+                const double gj = aj.hi * t;
+                if (gj > thr && gj > gain) { gain = gj; e = j; }
+            }
+            if (e < 0) return V_OPT;
+        }
         if (S.iters >= S.maxit) return V_ITER;
         if (dd_gt_d(M.get(m, e), 0.0)) {  // free variable entering downwards: x := -x
             for (int i = 0; i < m; ++i) M.set(i, e, dd_neg(M.get(i, e)));
@@ -695,20 +755,8 @@ PLP_HD int careful_run(const CarefulMem& M, CarefulState& S) {
             if (S.carry) M.set(m + 1, e, dd_neg(M.get(m + 1, e)));
             S.colsgn[e] = -S.colsgn[e];
         }
-        int r = -1;
-        dd rmin = dd_make(0.0);
-        for (int i = 0; i < m; ++i) {
-            if (!M.ract(i)) continue;
-            const dd a = M.get(i, e);
-            if (!dd_gt_d(a, C_TOL_PIV)) continue;
-            dd bi = M.get(i, VNC);
-            if (dd_lt_d(bi, 0.0)) bi = dd_make(0.0);
-            const dd q = dd_div(bi, a);
-            if (r < 0 || dd_lt(q, rmin) || (bland && dd_eq(q, rmin) && M.rv(i) < M.rv(r))) {
-                rmin = q;
-                r = i;
-            }
-        }
+        dd rmin;
+        const int r = careful_ratio(M, S, e, false, bland, &rmin);
         if (r < 0) return V_UNBND;
         ndeg = !dd_gt_d(rmin, C_DEGEN) ? ndeg + 1 : 0;
         careful_pivot(M, S, r, e);
@@ -752,6 +800,7 @@ PLP_HD int careful_solve(const LpView& lp, const CarefulMem& M, double* x, doubl
         if (lp.hh(i) < 0.0) need_p1 = true;
     }
     const double cmax = lp.c_inf();
+    const double bigstep = V_BIG * (cmax > 0.0 ? lp.scale() / cmax : 1.0);   // (rows and cost are equilibrated: distances in |G_i|_inf units)
     for (int j = 0; j <= VNC; ++j) { M.set(m, j, zero); M.set(m + 1, j, zero); }
     for (int j = 0; j < n; ++j) M.set(m, j, cmax > 0.0 ? dd_div(dd_make(lp.cc(j)), dd_make(cmax)) : zero);
     int st;
@@ -769,7 +818,7 @@ PLP_HD int careful_solve(const LpView& lp, const CarefulMem& M, double* x, doubl
             if (r0 < 0 || dd_lt(M.get(i, VNC), M.get(r0, VNC))) r0 = i;
         }
         careful_pivot(M, S, r0, tc);
-        st = careful_run(M, S);
+        st = careful_run(M, S, bigstep);
         if (st != V_OPT) { if (iters_out) *iters_out = S.iters; return st == V_ITER ? V_ITER : V_NUM; }
         int rt = -1, ct = -1;
         for (int i = 0; i < m; ++i) if (M.rv(i) == C_ID_T) rt = i;
@@ -796,7 +845,7 @@ PLP_HD int careful_solve(const LpView& lp, const CarefulMem& M, double* x, doubl
         for (int j = 0; j <= VNC; ++j) M.set(m, j, M.get(m + 1, j));
         S.carry = 0;
     }
-    st = careful_run(M, S);
+    st = careful_run(M, S, bigstep);
     if (iters_out) *iters_out = S.iters;
     if (st != V_OPT) return st;
     // x_j = sgn * beta of the row that holds it (in units of the row's own scale: the free variables were not scaled)

@@ -8,6 +8,8 @@ and, at the full BASELINE sizes, size-independent properties.
 Bars: status / keep masks / booleans / indices exact; Chebyshev radii and objective values
 within 1e-9 (north_star); centres only validated as feasible (not unique).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -430,22 +432,105 @@ def test_cheby_vs_oracle(pa, oracle):
 
 def test_cheby_and_reduce_on_rows_a_hair_apart(pa, oracle):
     """tests/golden/twin_rows.npz (see tests/test_oracle_golden.py): the Chebyshev LP through every engine that takes the shape, and
-    the fused reduce (whose F1 it is: a wrong ball made one of these polytopes `empty`), against HiGHS's radius / the oracle."""
+    the fused reduce (whose F1 it is: a wrong ball made one of these polytopes `empty`).
+    Round 6: the stand-alone ball is a CERTIFIED answer (plp_verify.hip) and is held to 1e-9 of the oracle's certified one; the
+    fixture's radii are HiGHS's at its default tolerances, which on these rows are 1e-9 .. 3e-8 away from it (asserted per case
+    below: that is the reference's own accuracy here, not the kernel's).  The fused reduce's F1 is the uncertified engine
+    (parity: the oracle's reduce, same engine, 1e-9) and within 1e-7 of the certified ball."""
     import torch
     g = load_golden("twin_rows.npz")
     for name in "abc":
-        A, b, want = g["A_" + name], g["b_" + name], float(g["r_" + name])
+        A, b, highs = g["A_" + name], g["b_" + name], float(g["r_" + name])
+        so, want, _ = oracle.cheby(A, b)
+        assert so == 0 and abs(want - highs) <= 1e-7, (name, want, highs)   # HiGHS against the certified optimum
+        o = oracle.reduce(A, b)
         for B in (1, 300, 20000):         # (the dispatch changes engine with the batch size)
             At = torch.as_tensor(np.broadcast_to(A, (B,) + A.shape).copy()).cuda()
             bt = torch.as_tensor(np.broadcast_to(b, (B,) + b.shape).copy()).cuda()
             ch = pa.cheby_ball_batch(At, bt)
             assert int(ch["status"].abs().max()) == 0, (name, B)
-            assert float((ch["r"] - want).abs().max()) <= 1e-7, (name, B)
+            assert float((ch["r"] - want).abs().max()) <= 1e-9, (name, B, float((ch["r"] - want).abs().max()))
             rd = pa.reduce_batch(At, bt)
-            o = oracle.reduce(A, b)
             keep = rd["keep"].cpu().numpy().view(np.uint64)
             assert np.all(keep == np.uint64(o["mask"])) and np.all(rd["flags"].cpu().numpy() == o["flags"]), (name, B)
-            assert np.all(rd["nlp"].cpu().numpy() == o["nlp"]) and float((rd["r"] - want).abs().max()) <= 1e-7, (name, B)
+            assert np.all(rd["nlp"].cpu().numpy() == o["nlp"]) and float((rd["r"] - o["r"]).abs().max()) <= 1e-9, (name, B)
+            assert float((rd["r"] - want).abs().max()) <= 1e-7, (name, B)
+
+
+def _g22_cases():
+    g = load_golden("g22_bbox_dup.npz")
+    for i in range(len(g["m"])):
+        m, d = int(g["m"][i]), int(g["d"][i])
+        yield i, g, m, d, g["A"][i, :m * d].reshape(m, d).copy(), g["b"][i, :m].copy()
+
+
+def _sides_equal(a, o, ext, tol):
+    fa, fo = np.isfinite(a), np.isfinite(o)
+    return np.array_equal(fa, fo) and np.array_equal(a[~fa], o[~fo]) and bool(np.all(np.abs(a[fa] - o[fo]) <= tol * ext))
+
+
+def test_bbox_and_cheby_on_rows_a_hair_apart_reference_fixture(pa):
+    """g22 (tests/golden/make_golden_bbox_dup.py): the REFERENCE's bounding_box / cheby_ball on 640 polytopes with rows a hair
+    apart, slivers, elongated and shifted shapes, d = 2..16 -- where round 5's kernels were off by up to 7e-6 and put +-inf on
+    finite sides.  Every box the library returns (fused kernels + verifier; what it hands back: the generic LPs + verifier) within
+    1e-9 of the box's extent of the oracle's certified box, +-inf in the same places, on ALL cases; within 2e-9 of the reference's
+    own box on the cases where the fixture says the reference is within 1e-9 of the optimum (563 of 640; on the rest HiGHS's 1e-7
+    feasibility tolerance, or its treatment of extents beyond 1e9, shows -- recorded per case in the fixture, not a loosened
+    tolerance for all).  The same for the Chebyshev radius."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    n_ref = n_r = 0
+    try:
+        for i, g, m, d, A, b in _g22_cases():
+            ext = float(g["ext"][i])
+            ob = np.concatenate([g["ora_lb"][i, :d], g["ora_ub"][i, :d]])
+            if int(g["ora_bad"][i]) == 0:
+                lo, hi = pc.bounding_box(pc.Polytope(A, b, normalize=False))
+                mine = np.concatenate([lo.ravel(), hi.ravel()])
+                assert _sides_equal(mine, ob, ext, 1e-9), (i, str(g["fam"][i]), d, m, mine, ob)
+                if g["dev_box"][i] <= 1e-9:
+                    n_ref += 1
+                    assert _sides_equal(mine, np.concatenate([g["ref_lb"][i, :d], g["ref_ub"][i, :d]]), ext, 2e-9), i
+            r, _ = pc.cheby_ball(pc.Polytope(A, b, normalize=False))
+            assert abs(r - float(g["ora_r"][i])) <= 1e-9 * max(1.0, abs(float(g["ora_r"][i]))), (i, str(g["fam"][i]), r, float(g["ora_r"][i]))
+            if g["dev_r"][i] <= 1e-9:
+                n_r += 1
+                assert abs(r - float(g["ref_r"][i])) <= 2e-9 * max(1.0, abs(float(g["ref_r"][i]))), i
+    finally:
+        solvers.default_solver = old
+    assert n_ref >= 540 and n_r >= 570, (n_ref, n_r)
+
+
+def test_bbox_batches_on_rows_a_hair_apart(pa, oracle):
+    """g22 as BATCHES per shape through plp_bbox_batch / plp_cheby_batch (every fused kernel family: lanes, lane groups, one
+    polytope per wavefront and its small-batch form, with and without a stored dictionary) against the fixture's oracle values."""
+    import torch
+    g = load_golden("g22_bbox_dup.npz")
+    shapes = sorted(set(zip(g["d"].tolist(), g["m"].tolist())))
+    n_box = 0
+    for (d, m) in shapes:
+        sel = np.nonzero((g["d"] == d) & (g["m"] == m))[0]
+        A = np.stack([g["A"][i, :m * d].reshape(m, d) for i in sel])
+        b = np.stack([g["b"][i, :m] for i in sel])
+        for rep in (1, 40):   # (the dispatch changes kernel with the batch size)
+            At, bt = torch.as_tensor(np.tile(A, (rep, 1, 1))).cuda(), torch.as_tensor(np.tile(b, (rep, 1))).cuda()
+            bb = pa.bbox_batch(At, bt)
+            ch = pa.cheby_ball_batch(At, bt)
+            st, lb, ub = bb["status"].cpu().numpy(), bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
+            cs, cr = ch["status"].cpu().numpy(), ch["r"].cpu().numpy()
+            for k in range(len(sel) * rep):
+                i = sel[k % len(sel)]
+                want_r = float(g["ora_r"][i])
+                got_r = cr[k] if (cs[k] == 0 and cr[k] >= 0) else 0.0
+                assert abs(got_r - want_r) <= 1e-9 * max(1.0, want_r), (d, m, rep, k, got_r, want_r)
+                if st[k] != 0 or int(g["ora_bad"][i]) != 0:
+                    continue
+                n_box += 1
+                ob = np.concatenate([g["ora_lb"][i, :d], g["ora_ub"][i, :d]])
+                assert _sides_equal(np.concatenate([lb[k], ub[k]]), ob, float(g["ext"][i]), 1e-9), (d, m, rep, k, lb[k], ub[k], ob)
+    assert n_box >= 15000
 
 
 @pytest.mark.parametrize("variant", ["PLP_CHEBY_1ROW", "PLP_CHEBY_RETRY_ALL"])
@@ -1793,3 +1878,47 @@ def test_bench_kernel_full_size_repeatable_and_exact(pa, oracle):
     for k in list(range(0, 1500)) + list(range(98500, 100000)):   # full tiles at the front, half-size tiles at the end
         o = oracle.reduce(A[k], b[k])
         assert np.array_equal(keep[k], o["keep"]) and int(nlp[k]) == o["nlp"] and int(fl[k]) == o["flags"], k
+
+
+# ------------------------------------------------------------------------------ a slice of the soaks
+@pytest.mark.parametrize("fam", ["random", "ragged", "unbounded", "dup", "scaled", "flat", "lattice"])
+def test_soak_families_small(pa, oracle, fam):
+    """A slice of scripts/soak_lane.py / soak_wide.py in the suite the driver runs: ~3 000 polytopes per family over nine shapes
+    (d = 1..16, up to 64 rows: every kernel family of the dispatch), EVERY polytope against the oracle --
+      fused reduce: keep mask, flags, LP count exact, radius 1e-9 (LP counts that differ on a prefilter tie are classified by
+      scripts/soak_lane.py: prefilter_tie -- and must stay below one in a thousand);
+      stand-alone Chebyshev ball: status exact, radius 1e-9;
+      stand-alone bounding box: +-inf in the same places, finite sides within 1e-9 of the box's extent.
+    `dup` is the family bounding_box went wrong on in round 5 (rows 1e-16 .. 1e-5 rad apart, no dedupe in front of its LPs)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_lane as SL
+    rng = np.random.default_rng({"random": 11, "ragged": 12, "unbounded": 13, "dup": 14, "scaled": 15, "flat": 16, "lattice": 17}[fam])
+    n = n_tie = 0
+    for (d, m, B) in ((1, 6, 200), (2, 12, 500), (3, 16, 700), (3, 30, 400), (4, 22, 400), (6, 32, 300), (8, 64, 150), (12, 40, 150),
+                      (16, 64, 100)):
+        A, b, mr = SL.make(rng, B, m, d, fam)
+        At, bt, mt = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda(), torch.as_tensor(mr).cuda()
+        rd = pa.reduce_batch(At, bt, mt)
+        ch = pa.cheby_ball_batch(At, bt, m=mt)
+        bb = pa.bbox_batch(At, bt, mt)
+        keep = rd["keep"].cpu().numpy().view(np.uint64)
+        flags, nlp, r = rd["flags"].cpu().numpy(), rd["nlp"].cpu().numpy(), rd["r"].cpu().numpy()
+        cs, cr = ch["status"].cpu().numpy(), ch["r"].cpu().numpy()
+        st, lb, ub = bb["status"].cpu().numpy(), bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
+        for k in range(B):
+            Ak, bk = A[k, :mr[k]], b[k, :mr[k]]
+            o = oracle.reduce(Ak, bk)
+            same = int(keep[k]) == int(o["mask"]) and int(flags[k]) == int(o["flags"]) and abs(r[k] - o["r"]) <= 1e-9 * max(1.0, abs(o["r"]))
+            assert same, (fam, d, m, k, hex(int(keep[k])), hex(int(o["mask"])), int(flags[k]), o["flags"], r[k], o["r"])
+            if int(nlp[k]) != int(o["nlp"]):
+                assert SL.prefilter_tie(Ak, bk), (fam, d, m, k, int(nlp[k]), o["nlp"])
+                n_tie += 1
+            so, ro, _ = oracle.cheby(Ak, bk)
+            assert int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro))), (fam, d, m, k, int(cs[k]), so, cr[k], ro)
+            if st[k] == 0:
+                lo, hi, bad = oracle.bounding_box(Ak, bk)
+                assert bad == 0 and SL.box_equal(lb[k], ub[k], lo, hi), (fam, d, m, k, lb[k], lo, ub[k], hi)
+            n += 1
+    assert n_tie * 1000 <= n, (fam, n_tie, n)
