@@ -509,7 +509,10 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
     int basis[PLPO_MAXN + 2];
     int st = plpo_lp_solve_raw(m, n, c, G, h, x, fun, iters, basis);
     if (!g_certify || st == ST_INFEAS || m > PLPO_MAXM || n > PLPO_MAXN - 1 || n < 1) return st;
-    if ((st == ST_OPT || st == ST_UNBND) && lp_certify(m, n, c, G, h, basis, st, x, fun)) {
+    /* (an "unbounded" of the double engine is not certified by its ray any more: the HIP library has no ray to look at and sends
+     * every such LP to its careful engine -- the same flow here, or slivers end "unbounded" on one side and at a corner 1e8 away
+     * on the other; lp_certify keeps the ray check for tests) */
+    if (st == ST_OPT && lp_certify(m, n, c, G, h, basis, st, x, fun)) {
         ++g_cert_stat[0];
     } else {
         if (st == ST_NUM) {   /* non-finite input (the raw engine's argument check): nothing to solve */
@@ -523,7 +526,12 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
         if (sq != st) ++g_cert_stat[2];
         st = sq;
     }
-    if (st == ST_OPT && fabs(*fun) > PLPO_BIG * lp_scale(m, n, c, G, h)) st = ST_UNBND;
+    if (st == ST_OPT) {   /* out of range: the value, or the vertex (a sliver's corner 1e16 away: "unbounded" for HiGHS too) */
+        double cmax = 0.0, xmax = 0.0;
+        for (int j = 0; j < n; ++j) { if (fabs(c[j]) > cmax) cmax = fabs(c[j]); if (fabs(x[j]) > xmax) xmax = fabs(x[j]); }
+        const double sc = lp_scale(m, n, c, G, h);
+        if (fabs(*fun) > PLPO_BIG * sc || (cmax > 0.0 && xmax > PLPO_BIG * (sc / cmax))) st = ST_UNBND;
+    }
     if (st != ST_OPT) { for (int j = 0; j < n; ++j) x[j] = qnan; *fun = qnan; }
     return st;
 }

@@ -123,7 +123,8 @@ static int qrun(qdict_t *D, double bigstep)
         }
         if (e < 0) {
             /* no column above the engines' tolerance.  Those between the rounding level and it are judged by what they buy:
-             * the step they allow (cut at bigstep) times the rate, against Q_TOL_GAIN of max(1, |objective|)
+             * the step they allow times the rate, against Q_TOL_GAIN of max(1, |objective|), provided the step ends on a row
+             * and moves x by no more than bigstep
              * (polytope_amd/csrc/plp_verify.hpp: careful_run, the same rule) */
             const qreal obj = fabsq(D->negz);
             const qreal thr = Q_TOL_GAIN * (obj > 1.0Q ? obj : 1.0Q);
@@ -135,8 +136,13 @@ static int qrun(qdict_t *D, double bigstep)
                 if (!grey) continue;
                 qreal step;
                 const int r = qratio(D, j, dj > 0.0Q, 0, &step);
-                const qreal t = (r < 0 || step > (qreal)bigstep) ? (qreal)bigstep : step;
-                const qreal gj = aj * t;
+                if (r < 0) continue;   /* unbounded at a rate below the engines' tolerance: not a direction (HiGHS agrees) */
+                /* how far x moves per unit of the entering variable: the rows that hold the free variables (and itself, if free) */
+                qreal dx = QFREE(D, D->colvar[j]) ? 1.0Q : 0.0Q;
+                for (int i = 0; i < D->m; ++i)
+                    if (QFREE(D, D->rowvar[i]) && fabsq(D->T[i][j]) > dx) dx = fabsq(D->T[i][j]);
+                if (!(step * dx <= (qreal)bigstep)) continue;   /* the step leaves the range of the data: not taken either */
+                const qreal gj = aj * step;
                 if (gj > thr && gj > gain) { gain = gj; e = j; }
             }
             if (e < 0) return Q_OPT;

@@ -228,8 +228,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     if (s_ok[li] & (s_bad[li] == 0u)) {
         const Vec z = CT::at(ws, CT::O_Z);
         const double f = s_fun[li];
-        bool out = false;
-        if (fabs(f) > V_BIG * lp.c_inf()) out = range_rule(lp, V_OPT, f) != V_OPT;   // (the full scale only where it can matter)
+        const bool out = range_rule(lp, V_OPT, f, s_xs[li]) != V_OPT;
         if constexpr (KIND == LP_BOXSIDE) {
             const double pinf = __longlong_as_double(0x7ff0000000000000ll);
             ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)] = out ? ((side & 1) ? pinf : -pinf) : z[side >> 1];
@@ -275,7 +274,9 @@ __global__ __launch_bounds__(VBLK) void careful_kernel(int m_max, int n, const d
             lp.h = h + (size_t)p * m_max;
             lp.c = nullptr;
             int st = careful_solve(lp, M, xo, &f, nullptr);
-            st = range_rule(lp, st, f);
+            double xm = 0.0;
+            for (int j = 0; j < n; ++j) xm = fmax(xm, fabs(xo[j]));
+            st = range_rule(lp, st, f, xm);
             double* out = (side & 1) ? ub : x;
             const double pinf = __longlong_as_double(0x7ff0000000000000ll);
             const int kx = side >> 1;
@@ -291,7 +292,9 @@ __global__ __launch_bounds__(VBLK) void careful_kernel(int m_max, int n, const d
             lp.h = h + (size_t)p * m_max;
             lp.c = KIND == LP_GENERIC ? c + (size_t)p * n : nullptr;
             int st = careful_solve(lp, M, xo, &f, nullptr);
-            st = range_rule(lp, st, f);
+            double xm = 0.0;
+            for (int j = 0; j < n; ++j) xm = fmax(xm, fabs(xo[j]));
+            st = range_rule(lp, st, f, xm);
             const bool opt = st == V_OPT;
             if constexpr (KIND == LP_CHEBY) {
                 for (int j = 0; j < n - 1; ++j) x[(size_t)p * (n - 1) + j] = opt ? xo[j] : qnan();
@@ -393,8 +396,7 @@ __global__ __launch_bounds__(256) void verify_small_kernel(VArgs a, Scratch sc) 
         for (int i = 0; i < lp.m; ++i) ok = ok & CT::row_feasible(lp, i, z, zs);
     }
     if (ok) {
-        bool out = false;
-        if (fabs(f) > V_BIG * lp.c_inf()) out = range_rule(lp, V_OPT, f) != V_OPT;   // (the full scale only where it can matter)
+        const bool out = range_rule(lp, V_OPT, f, zs) != V_OPT;
         if constexpr (KIND == LP_BOXSIDE) {
             const double pinf = __longlong_as_double(0x7ff0000000000000ll);
             double zk = 0.0;

@@ -24,8 +24,9 @@
 //   distance.  What such a rate is worth depends on how far the direction goes -- 1e-9 of the polytope's extent, which on a
 //   sliver that reaches 1e4 is 1e-5 of a box side of 3 (profiles/r05/soak_wide_r05l_*.log) -- so here a reduced cost between the
 //   rounding of the factorisation (1e-13) and 1e-9 is judged by what it BUYS: the careful engine (and the oracle's binary128
-//   twin) enter such a column when the step it allows, cut at BIG times the scale of the data, improves the objective by more
-//   than 1e-10 of max(1, |objective|); the certificate accepts no multiplier below -1e-13, so an answer with one in that zone
+//   twin) enter such a column when the step it allows improves the objective by more than 1e-10 of max(1, |objective|) and
+//   moves x by no more than BIG times the scale of the data (a sliver's hair direction pays 5e-8 on a radius of 1.5 -- 2e9 away:
+//   HiGHS does not go there, nor do we); the certificate accepts no multiplier below -1e-13, so an answer with one in that zone
 //   goes to the careful engine.  Below 1e-13 a coefficient is zero: a copy of the row x_0 <= 2 tilted by 1e-16 towards x_1 lets
 //   the exact LP reach x_0 = 2.84 at x_1 = 1e16 where HiGHS and every double-precision code answer 2.
 //   An optimum beyond BIG = 1e9 times the scale of the data is reported UNBOUNDED -- what HiGHS does with such LPs
@@ -730,7 +731,8 @@ PLP_HD int careful_run(const CarefulMem& M, CarefulState& S, double bigstep) {
         }
         if (e < 0) {
             // no column above the engines' tolerance.  Those between the rounding level and it are judged by what they buy:
-            // the step they allow (cut at `bigstep`) times the rate, against C_TOL_GAIN of max(1, |objective|)
+            // the step they allow times the rate, against C_TOL_GAIN of max(1, |objective|) -- provided the step ends on a row
+            // and moves x by no more than `bigstep` (a direction that only pays beyond the range of the data is none)
             dd obj = dd_abs(M.get(m, VNC));
             const double thr = C_TOL_GAIN * fmax(1.0, obj.hi);
             double gain = 0.0;
@@ -742,8 +744,13 @@ PLP_HD int careful_run(const CarefulMem& M, CarefulState& S, double bigstep) {
                 if (!grey) continue;
                 dd step;
                 const int r = careful_ratio(M, S, j, dd_gt_d(dj, 0.0), false, &step);
-                const double t = r < 0 ? bigstep : fmin(step.hi, bigstep);
-                const double gj = aj.hi * t;
+                if (r < 0) continue;   // unbounded at a rate below the engines' tolerance: not a direction (HiGHS agrees)
+                // how far x moves per unit of the entering variable: the rows that hold the free variables (and itself, if free)
+                double dx = fr ? 1.0 : 0.0;
+                for (int i = 0; i < m; ++i)
+                    if ((unsigned)M.rv(i) < (unsigned)S.n) dx = fmax(dx, fabs(M.get(i, j).hi));
+                if (!(step.hi * dx <= bigstep)) continue;   // the step leaves the range of the data: not taken either
+                const double gj = aj.hi * step.hi;
                 if (gj > thr && gj > gain) { gain = gj; e = j; }
             }
             if (e < 0) return V_OPT;
@@ -864,9 +871,16 @@ PLP_HD int careful_solve(const LpView& lp, const CarefulMem& M, double* x, doubl
     return V_OPT;
 }
 
-// what every caller does with an optimum: out of range -> unbounded
-PLP_HD int range_rule(const LpView& lp, int status, double fun) {
-    return (status == V_OPT && fabs(fun) > V_BIG * lp.scale()) ? V_UNBND : status;
+// what every caller does with an optimum: out of range -> unbounded.  Out of range: the VALUE beyond BIG times the scale of
+// the data, or the VERTEX (xmax = |x|_inf) beyond BIG times the scale of the rows -- a sliver's far corner, 1e16 away, is where
+// the exact LP has its optimum and where HiGHS (and any double-precision code) says "unbounded".
+PLP_HD int range_rule(const LpView& lp, int status, double fun, double xmax) {
+    if (status != V_OPT) return status;
+    const double cmax = lp.c_inf();
+    if (!(fabs(fun) > V_BIG * cmax) && !(xmax > V_BIG)) return status;   // (the scale is at least |c|_inf: a pass over the rows only where it can matter)
+    const double sc = lp.scale();
+    if (fabs(fun) > V_BIG * sc) return V_UNBND;
+    return (cmax > 0.0 && xmax > V_BIG * (sc / cmax)) ? V_UNBND : status;
 }
 
 }  // namespace verify

@@ -77,8 +77,8 @@ def main():
             refb = SL.oracle_all(pool, "bbox", A, b, mr, chunk=16)
             nb = nc = nh = 0
             first = None
-            for k, (lo, hi, bd, so, ro) in enumerate(refb):
-                okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro)))
+            for k, (lo, hi, bd, so, ro, xn) in enumerate(refb):
+                okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro), xn))
                 nc += not okc
                 if not okc and first is None:
                     first = ("cheby", k, int(cs[k]), so, cr[k], ro)

@@ -28,8 +28,9 @@ def _task(args):
             out.append((int(o["mask"]), int(o["flags"]), int(o["nlp"]), float(o["r"])))
         else:
             lo, hi, bad = O.bounding_box(Ak, bk)
-            so, ro, _ = O.cheby(Ak, bk)
-            out.append((lo, hi, int(bad), int(so), float(ro)))
+            so, ro, xo = O.cheby(Ak, bk)
+            # (the ball's radius is known to 1e-9 of how far its centre lies: a sliver's centre 1e8 away is such a case)
+            out.append((lo, hi, int(bad), int(so), float(ro), float(np.max(np.abs(xo))) if so == 0 else 1.0))
     return out
 
 
@@ -52,21 +53,27 @@ def highs_radius_agrees(Ak, bk, r_mine):
     return rs.status == 0 and abs(-rs.fun - r_mine) <= 1e-6 * max(1.0, abs(r_mine))
 
 
-def box_equal(lb, ub, lo, hi, tol=1e-9):
+def box_equal(lb, ub, lo, hi, tol=1e-9, hair_unbounded_tol=None):
     """A box against the oracle's (round 6: both sides certified -- plp_verify.hpp / oracle lp_certify -- or re-solved in
     extended precision): +-inf in the same places, finite sides within `tol` of the box's EXTENT (the largest finite
-    coordinate, at least 1: a side of 1.5 of a sliver that reaches 1e6 elsewhere is known to 1e-16 x 1e6, not to 1e-16)."""
+    coordinate, at least 1: a side of 1.5 of a sliver that reaches 1e6 elsewhere is known to 1e-16 x 1e6, not to 1e-16).
+    hair_unbounded_tol (family `dup` only): the tolerance where the polytope is UNBOUNDED (an infinite side).  With rows a hair
+    apart a finite side of such a polytope is attained at vertices arbitrarily far out -- the hair's tilt, 1e-16, times the
+    distance -- and two certified answers differ by the certificate's tolerance on a multiplier (1e-13) times how far apart
+    their vertices lie: 4e-9 on a side of 3 in six of 3 M soaked polytopes (profiles/r06/soak_wide_*_73.log, trial 161)."""
     a, o = np.concatenate([lb, ub]), np.concatenate([lo, hi])
     fa, fo = np.isfinite(a), np.isfinite(o)
     if not np.array_equal(fa, fo) or not np.array_equal(a[~fa], o[~fo]):
         return False
+    if hair_unbounded_tol is not None and not fo.all():
+        tol = max(tol, hair_unbounded_tol)
     ext = max(1.0, float(np.max(np.abs(o[fo]), initial=1.0)))
     return bool(np.all(np.abs(a[fa] - o[fo]) <= tol * ext))
 
 
 def prefilter_tie(Ak, bk, margin=1e-6):
     """reduce()'s bounding-box prefilter (ref :1131-1134) drops a row when  sum_k max(a_k, 0) (u_k - l_k) - (b - a.l) < -1e-4.
-    True when some row of this polytope sits within `margin` of that threshold with the CERTIFIED box: which side it falls on
+    True when some row of this polytope sits within `margin` (of the box's extent) of that threshold with the CERTIFIED box: which side it falls on
     is then decided by the last digits of the box LPs -- the reference's (HiGHS: 1e-7 feasibility tolerance), the oracle's
     dictionary simplex and the kernels' walk each have their own -- and with it the number of redundancy LPs issued (nlp);
     the kept rows do not depend on it.  Classified, not counted, by the soaks."""
@@ -75,7 +82,8 @@ def prefilter_tie(Ak, bk, margin=1e-6):
     if bad or not (np.all(np.isfinite(lo)) and np.all(np.isfinite(hi))):
         return True
     val = ((Ak > 0) * Ak) @ (hi - lo) - (bk - Ak @ lo)
-    return bool(np.any(np.abs(val + 1e-4) < margin))
+    ext = max(1.0, float(np.max(np.abs(np.concatenate([lo, hi])))))   # (a sliver that reaches 7e7: its box is known to 1e-9 of THAT)
+    return bool(np.any(np.abs(val + 1e-4) < margin * ext))
 
 
 def make(rng, B, m, d, fam):
@@ -189,10 +197,10 @@ def main():
             st = bb["status"].cpu().numpy()
             lb, ub = bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
             refb = oracle_all(pool, "bbox", A[:nq], b[:nq], mrows[:nq])
-            for k, (lo, hi, bd, so, ro) in enumerate(refb):
+            for k, (lo, hi, bd, so, ro, _xn) in enumerate(refb):
                 if st[k] != 0:
                     continue
-                okb = bd == 0 and box_equal(lb[k], ub[k], lo, hi)
+                okb = bd == 0 and box_equal(lb[k], ub[k], lo, hi, hair_unbounded_tol=(1e-8 if fam == "dup" else None))
                 if not okb:
                     nbb += 1
                     first = first if first is not None else ("bbox", k, lb[k], lo, ub[k], hi, bd)

@@ -65,20 +65,21 @@ def main():
         ch = pa.cheby_ball_batch(At, bt, m=mt)
         torch.cuda.synchronize()
         cs, cr = ch["status"].cpu().numpy(), ch["r"].cpu().numpy()
+        cxn = np.nan_to_num(np.abs(ch["xc"].cpu().numpy()).max(axis=1), nan=1.0)   # how far the ball's centre lies
         nq = min(B, 1500)
         bb = pa.bbox_batch(At[:nq], bt[:nq], mt[:nq])
         refb = SL.oracle_all(pool, "bbox", A[:nq], b[:nq], mrows[:nq], chunk=16)
         if bb is not None:
             torch.cuda.synchronize()
             st, lb, ub = bb["status"].cpu().numpy(), bb["lb"].cpu().numpy(), bb["ub"].cpu().numpy()
-        for k, (lo, hi, bd, so, ro) in enumerate(refb):
-            okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro)))
+        for k, (lo, hi, bd, so, ro, xn) in enumerate(refb):
+            okc = int(cs[k]) == so and (so != 0 or abs(cr[k] - ro) <= 1e-9 * max(1.0, abs(ro), xn, cxn[k]))
             if not okc:
                 nc += 1
                 first = first if first is not None else ("cheby", k, int(cs[k]), so, cr[k], ro)
             if bb is None or st[k] != 0:
                 continue
-            okb = bd == 0 and SL.box_equal(lb[k], ub[k], lo, hi)
+            okb = bd == 0 and SL.box_equal(lb[k], ub[k], lo, hi, hair_unbounded_tol=(1e-8 if fam == "dup" else None))
             if not okb:
                 nbb += 1
                 first = first if first is not None else ("bbox", k, lb[k], lo, ub[k], hi, bd)

@@ -71,7 +71,10 @@ int plpv_careful(int kind, int m, int n, int side, const double* c, const double
     std::vector<int> ri(m + 2);
     CarefulMem M{hi.data(), lo.data(), ri.data(), 1};
     double f = 0.0;
-    const int st = range_rule(lp, careful_solve(lp, M, x, &f, iters), f);
+    int st = careful_solve(lp, M, x, &f, iters);
+    double xm = 0.0;
+    if (st == V_OPT) for (int j = 0; j < n; ++j) xm = fmax(xm, fabs(x[j]));
+    st = range_rule(lp, st, f, xm);
     *fun = f;
     return st;
 }
