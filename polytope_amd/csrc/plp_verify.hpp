@@ -32,7 +32,7 @@
 //   An optimum beyond BIG = 1e9 times the scale of the data is reported UNBOUNDED -- what HiGHS does with such LPs
 //   (measured: box sides of exact value up to 1.5e9 come back as that value, beyond ~2e9 as +-inf).
 //
-// oracle/plp_oracle.c (lp_certify, binary128 residuals) and oracle/plp_oracle_q.c (binary128 dictionary) are the test-side
+// oracle/plp_oracle.c (lp_certify, binary128 residuals) and its binary128 dictionary engine beside it are the test-side
 // restatement of the same two steps.  Everything here compiles for the host too: tests/cabi/verify_host.cpp runs both
 // steps against the oracle's on the CPU (tests/test_verify_host.py).
 #pragma once
