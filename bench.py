@@ -196,6 +196,123 @@ def end_to_end(torch, pa, A, b, dev, reps=10):
 _ORACLE_AB = None
 
 
+
+def secondary(torch, pa, dev):
+    """The other BASELINE configs, driver-timed beside the headline (rank 0, N = 1, about three seconds in all; never `value`).
+    Each with its own roofline figure (algorithmic flops / bytes) and a parity sample against the oracle:
+      C3  1 M points x 10 k polytopes (d = 6, m = 16), Region.contains semantics (polytope/polytope.py:206-218, :732-746)
+      C5  quickhull's distance / first-facet assignment / furthest point, 1 M points, d = 8, F = 9 / 64 / 512
+          (polytope/quickhull.py:117-121, :224-245, :87-102)
+      C4  the 1000-cell grid in d = 4: all 499 500 pair LPs of find_adjacent_regions (polytope/prop2partition.py:46-63), and
+          region_diff of the fixture polytope against 500 cells (polytope/polytope.py:2117-2282; tests/golden/g12: 234 pieces)
+      fused reduce at the far end of the envelope, (64,16) x 5 000 (polytope/polytope.py:1053-1163)"""
+    import itertools
+    from oracle import oracle as O
+    from polytope_amd import synth
+    out = {}
+
+    def timeit(fn, reps, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        return ms[len(ms) // 2]
+
+    # ---- C3
+    P, N, d, m = 10000, 1000000, 6, 16
+    A, b, X = synth.containment_workload(P, N, d=d, m=m, seed=0)
+    At, bt, Xt = (torch.as_tensor(v).to(dev) for v in (A, b, X))
+    got = pa.contains_batch(At, bt, Xt, 1e-7)
+    ms = timeit(lambda: pa.contains_batch(At, bt, Xt, 1e-7), reps=3)
+    flops = 2.0 * m * d * N * P
+    rng = np.random.default_rng(0)
+    pts = rng.choice(N, 1500, replace=False)     # 1 500 points against ALL polytopes on the oracle
+    want = O.contains(A, b, np.ascontiguousarray(X[:, pts].T), region=True)
+    out["C3_contains"] = {"workload": "1M points x 10k polytopes, d=6, m=16 (BASELINE configs[2])", "ms": ms,
+                          "tests_per_s": N * P / (ms * 1e-3), "points_inside": int(got.sum().item()),
+                          "roofline": {"bound": "fp64-valu", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                                       "frac": flops / (ms * 1e-3) / 1e12 / 78.6},
+                          "parity": {"oracle_points": 1500, "equal": bool(np.array_equal(got.cpu().numpy()[pts].astype(bool), want.astype(bool)))}}
+    del At, bt, Xt, got
+    # ---- C5
+    c5 = {}
+    for F in (9, 64, 512):
+        X, nrm, off = synth.quickhull_workload(N, d=8, F=F, seed=0)
+        Xt, nt, ot = (torch.as_tensor(v).to(dev) for v in (X, nrm, off))
+        res = pa.assign_batch(Xt, nt, ot, 1e-7)
+        ms = timeit(lambda: pa.assign_batch(Xt, nt, ot, 1e-7), reps=5)
+        by = 8 * 8 * N + 12 * N + 8 * F * 9
+        k = 20000                                  # the first 20 000 points on the oracle: facet ids, distances bit for bit
+        fop, dist, _am, _mx = O.assign(X[:k], nrm, off, 1e-7)
+        same = bool(np.array_equal(res["facet"][:k].cpu().numpy(), fop) and
+                    np.array_equal(res["dist"][:k].cpu().numpy().view(np.int64), dist.view(np.int64)))
+        c5["F=%d" % F] = {"ms": ms, "point_facet_evals_per_s": N * F / (ms * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "parity": {"oracle_points": k, "bitwise_equal": same}}
+        del Xt
+    out["C5_assign"] = dict(workload="1M points, d=8 (BASELINE configs[4])", **c5)
+    # ---- C4
+    import polytope_amd.polytope as pc
+    from polytope_amd import prop2partition as p2p
+    from polytope_amd import solvers
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    try:
+        shape = (10, 10, 5, 2)
+        cells, index = [], []
+        for idx in itertools.product(*[range(n) for n in shape]):
+            cells.append(pc.box2poly([[idx[k] / shape[k], (idx[k] + 1) / shape[k]] for k in range(4)]))
+            index.append(idx)
+        index = np.array(index)
+        p2p.adjacency_matrix_dense(cells)
+        t0 = time.perf_counter()
+        adj = p2p.adjacency_matrix_dense(cells)
+        t_adj = time.perf_counter() - t0
+        want = (np.abs(index[:, None, :] - index[None, :, :]).max(axis=2) <= 1).astype(np.int8)
+        c4 = {"workload": "1000-cell 10x10x5x2 grid, d=4 (BASELINE configs[3])",
+              "adjacency_pairs": 499500, "adjacency_ms": t_adj * 1e3, "pair_lps_per_s": 499500 / t_adj,
+              "adjacency_equals_grid_neighbourhood": bool(np.array_equal(adj, want))}
+        gpath = os.path.join(ROOT, "tests", "golden", "g12_config4.npz")
+        if os.path.exists(gpath):
+            g = np.load(gpath, allow_pickle=False)
+            Pp = pc.Polytope(g["c4_PA"], g["c4_Pb"], normalize=False)
+            pc.region_diff(Pp.copy(), pc.Region(cells[:500]), _order=g["c4_order"])
+            t0 = time.perf_counter()
+            D = pc.region_diff(Pp.copy(), pc.Region(cells[:500]), _order=g["c4_order"])
+            t_diff = time.perf_counter() - t0
+            c4.update(region_diff_ms=t_diff * 1e3, region_diff_pieces=len(D), reference_pieces=234,
+                      reference_lps=int(g["c4_diff_nlp"]), lps_per_s_reference_count=int(g["c4_diff_nlp"]) / t_diff)
+        out["C4_region"] = c4
+    finally:
+        solvers.default_solver = old
+    # ---- fused reduce (64,16) x 5000
+    B, m, d = 5000, 64, 16
+    A, b = synth.random_hpolytopes(B, m, d, seed=2)
+    At, bt = torch.as_tensor(A).to(dev), torch.as_tensor(b).to(dev)
+    res = pa.reduce_batch(At, bt)
+    ms = timeit(lambda: pa.reduce_batch(At, bt), reps=5)
+    nlp = int(res["nlp"].sum().item())
+    by = B * (8 * m * (d + 1) + 12)
+    keep, flags, nl, r = (res[k].cpu().numpy() for k in ("keep", "flags", "nlp", "r"))
+    ok = True
+    for k in range(48):                            # 48 polytopes (3 400 LPs) on the oracle
+        o = O.reduce(A[k], b[k])
+        ok = ok and (int(keep[k]) & (2 ** 64 - 1)) == int(o["mask"]) and int(flags[k]) == o["flags"] and int(nl[k]) == o["nlp"] \
+            and abs(r[k] - o["r"]) <= 1e-9
+    out["reduce_64x16"] = {"workload": "fused reduce of 5000 random H-polytopes, m=64, d=16", "ms": ms, "lps": nlp,
+                           "lp_per_s": nlp / (ms * 1e-3),
+                           "roofline": {"bound": "hbm", "achieved": by / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "parity": {"oracle_polytopes": 48, "equal": bool(ok)}}
+    return out
+
 def _oracle_chunk(args):
     from oracle import oracle as O
     lo, cnt = args
@@ -310,6 +427,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-batch parity check against the oracle")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the `secondary` object (BASELINE configs 3-5 and the "
+                    "(64,16) fused reduce, about three seconds)")
     ap.add_argument("--batches", type=int, default=6, help="distinct 100k-polytope batches the steps rotate over "
                     "(6 x 52.4 MB > 256 MiB Infinity Cache: every step reads its input from HBM)")
     ap.add_argument("--regions", type=int, default=5, help="timed regions (each: barrier + synchronize, the steps, "
@@ -582,6 +701,9 @@ def main():
     ranks_seen, exchange_ms = None, None
     if multi:
         ranks_seen = int(allred(1, torch.int64))
+        if ranks_seen != world:   # a collective layer that does not see every rank measures something else: refuse the number
+            raise SystemExit("bench.py: the all-reduce over the process group counted %d ranks, %d were launched (backend %s)"
+                             % (ranks_seen, world, args.backend))
         # what ONE exchange of a group costs on its own (all-gather of G x 24 B x polytopes per rank, nothing overlapping it)
         src = head["ex"].big[0]
         src = src.cpu() if args.backend == "gloo" else src
@@ -743,6 +865,10 @@ def main():
             line["end_to_end"] = end_to_end(torch, pa, A, b, dev)
         if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(A, b, head["first"][0]["nlp"].cpu().numpy())
+        if not multi and not args.no_secondary:
+            t_sec = time.perf_counter()
+            line["secondary"] = secondary(torch, pa, dev)
+            line["secondary"]["seconds"] = time.perf_counter() - t_sec
         print(json.dumps(line), flush=True)
     if multi:
         dist.destroy_process_group()
