@@ -207,6 +207,7 @@ def secondary(torch, pa, dev):
           region_diff of the fixture polytope against 500 cells (polytope/polytope.py:2117-2282; tests/golden/g12: 234 pieces)
       fused reduce at the far end of the envelope, (64,16) x 5 000 (polytope/polytope.py:1053-1163)"""
     import itertools
+    import numpy as np
     from oracle import oracle as O
     from polytope_amd import synth
     out = {}
