@@ -70,17 +70,27 @@ def cpu_baseline(A, b, nlp_gpu):
         out["scipy_linprog_1proc_lp_per_s"] = cnt / t1
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-        chunks = [(A[k], b[k]) for k in range(ns, ns + 8 * ncpu)]
+        # the all-cores sample: a pilot of two tasks per worker gives the rate, the timed sample is sized for ~12 s of it
+        # (tasks of 4 polytopes = 64 LPs, ~40 ms: the pool's dispatch is noise)
+        per_task = 4
+        avail = (A.shape[0] - ns) // per_task
+        mk = lambda lo, hi: [[(A[k], b[k]) for k in range(ns + t * per_task, ns + (t + 1) * per_task)] for t in range(lo, hi)]
         with mp.get_context("fork").Pool(ncpu) as pool:
-            pool.map(_scipy_chunk, chunks[:ncpu], chunksize=1)  # start the workers, import scipy
+            pool.map(_scipy_chunk, mk(0, min(ncpu, avail)), chunksize=1)  # start the workers, import scipy: not timed
+            t0 = time.perf_counter()
+            pilot = pool.map(_scipy_chunk, mk(0, min(2 * ncpu, avail)), chunksize=1)
+            rate = sum(pilot) / (time.perf_counter() - t0)
+            ntask = int(min(avail, max(2 * ncpu, 12.0 * rate / (M_ROWS * per_task))))
+            chunks = mk(0, ntask)
             t0 = time.perf_counter()
             res = pool.map(_scipy_chunk, chunks, chunksize=1)
             t2 = time.perf_counter() - t0
         out["value"] = sum(res) / t2
         out["cores"] = ncpu
         out["sample"] = ("scipy.optimize.linprog (HiGHS), called as polytope/solvers.py:152-154, on the F2 LPs of %d "
-                         "polytopes of batch 0 over %d processes (%d LPs, %.1f s); 1 process: %d LPs, %.1f s"
-                         % (len(chunks), ncpu, sum(res), t2, cnt, t1))
+                         "polytopes of batch 0 over %d processes (%d LPs, %.1f s, workers started and scipy imported before "
+                         "the clock, BLAS pools held to one thread); 1 process: %d LPs, %.1f s"
+                         % (len(chunks) * per_task, ncpu, sum(res), t2, cnt, t1))
     except Exception as e:  # report, never fail the bench on the baseline
         out["scipy_error"] = repr(e)
     n = 40000
@@ -325,14 +335,22 @@ def _oracle_chunk(args):
 
 
 def _scipy_chunk(args):
+    """the F2 LPs of a few polytopes on one worker process; BLAS / OpenMP pools held to one thread (one process per core)"""
     from scipy.optimize import linprog
-    Ak, bk = args
+    try:
+        from threadpoolctl import threadpool_limits
+        lim = threadpool_limits(limits=1)
+    except Exception:
+        lim = None
     cnt = 0
-    for row in range(Ak.shape[0]):
-        h = bk.copy()
-        h[row] += 0.1
-        linprog(-Ak[row], Ak, h, None, None, bounds=(None, None))
-        cnt += 1
+    for Ak, bk in args:
+        for row in range(Ak.shape[0]):
+            h = bk.copy()
+            h[row] += 0.1
+            linprog(-Ak[row], Ak, h, None, None, bounds=(None, None))
+            cnt += 1
+    if lim is not None:
+        lim.restore_original_limits()
     return cnt
 
 
