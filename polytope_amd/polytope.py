@@ -1973,18 +1973,13 @@ def extreme(poly1):
 
 # ====================================================================================== small callers of the path
 def is_interior(r0, r1, abs_tol=ABS_TOL):
-    """The reference's `is_interior` (ref :1888-1909), reproduced as written there: every polytope of r1 is
-    enlarged by abs_tol, and the function returns True as soon as one of the enlarged polytopes is NOT a
-    subset of r0, False otherwise."""
-    if isinstance(r0, Polytope):
-        r0 = Region([r0])
-    if isinstance(r1, Polytope):
-        r1 = Region([r1])
-    for p in r1:
-        dummy = Polytope(p.A.copy(), p.b.copy() + abs_tol)
-        if not dummy <= r0:
-            return True
-    return False
+    """`is_interior` of the reference (ref :1888-1909), whose return value is the opposite of its name: True as soon as some
+    member of r1, grown by abs_tol on every facet, sticks out of r0; False when every grown member stays inside.  Kept that way
+    (drop-in); the grown members are built with the constructor, as there (rows re-normalised), and tested one at a time in
+    order, so the first one that sticks out ends the call."""
+    outer = r0 if isinstance(r0, Region) else Region([r0])
+    inner = r1.list_poly if isinstance(r1, Region) else [r1]
+    return any(not (Polytope(q.A.copy(), q.b.copy() + abs_tol) <= outer) for q in inner)
 
 
 def separate(reg1, abs_tol=ABS_TOL):

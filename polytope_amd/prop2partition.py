@@ -397,17 +397,19 @@ class Partition(pc._NoDeviceState):
         return True
 
     def preserves(self, other):
-        """Return True if it refines the closure of `other` under complement (ref :209-228): every element lies in
-        each of its annotated `supersets` and meets no other element of `other`."""
-        for item in self._elements:
-            # item subset of these sets
-            for superset in item.supersets:
-                if not item <= superset:
-                    return False
-            # item subset of the complements of these sets
-            for other_set in set(other).difference(item.supersets):
-                if item.intersect(other_set):
-                    return False
+        """Does this partition respect `other` together with the complements of its elements (ref :209-228)?  Each element
+        carries, as `.supersets`, the elements of `other` it is meant to lie inside; it must be a subset of every one of those
+        and have an empty (zero-volume) intersection with every remaining element of `other`.
+        Same calls in the same order as the reference makes them (`<=`, then `intersect` + truth value per remaining set,
+        iterating a `set` difference), because both go through sampled volumes; only the bookkeeping is written differently."""
+        every = set(other)
+        for element in self._elements:
+            inside = element.supersets
+            if any(not (element <= big) for big in inside):
+                return False
+            outside = every.difference(inside)
+            if any(bool(element.intersect(far)) for far in outside):
+                return False
         return True
 
 
