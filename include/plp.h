@@ -143,6 +143,17 @@ int plp_reduce_batch_dev(plp_ctx *ctx, void *stream, int64_t B, int m_max, int d
 int plp_reduce_counters(plp_ctx *ctx, void *stream, uint64_t *simplex_runs, int reset);
 
 /*
+ * The verifier behind plp_lp_solve_batch / plp_cheby_batch / plp_bbox_batch (round 6; csrc/plp_verify.hpp says why): every
+ * answer of the LP engines is certified against the original rows from its final basis -- its vertex recomputed, its
+ * multipliers' signs checked, every row tested -- and what does not certify (or is reported unbounded / at a limit) is
+ * solved again by a careful double-double engine.  This call returns, for the LAST verified batch issued on `stream`
+ * through `ctx`, how many of its LPs went to the careful engine (0 on random, ragged, rescaled, flat or lattice data;
+ * ~5 % of the LPs of polytopes with rows 1e-16 .. 1e-5 rad apart; every unbounded LP).  It blocks until that batch is done.
+ * PLP_VERIFY=0 in the environment switches the verifier off (A/B measurements: the answers then are the engines' own).
+ */
+int plp_verify_counters(plp_ctx *ctx, void *stream, int64_t *careful_lps);
+
+/*
  * The same for polytopes of ANY row count whose rows and dictionary fit the LDS of a CU (about 500 rows at d = 16,
  * 2000 at d = 3): `reduce` has no row limit in the reference (polytope/polytope.py:1053-1163), Polytope.intersect
  * stacks m1 + m2 rows (:268-275) and region_diff's leaves as many as the search collected (:2276).

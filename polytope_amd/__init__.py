@@ -31,6 +31,7 @@ from .prop2partition import (  # noqa: F401
 from . import polytope, prop2partition, quickhull  # noqa: F401,E402  (submodules, as `polytope.polytope` etc.)
 from .batch import (  # noqa: F401
     lpsolve_batch, cheby_ball_batch, bbox_batch, reduce_batch, contains_batch, assign_batch, adjacent_pairs, keep_to_bool,
+    verify_careful_lps, lp_histograms,
 )
 
 __version__ = "0.1.0"

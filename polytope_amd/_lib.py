@@ -40,6 +40,7 @@ SIGNATURES = {
     "plp_reduce_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_reduce_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_reduce_counters": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "plp_verify_counters": (C.c_int, [_vp, _vp, _vp]),
     "plp_reduce_wide_batch": (C.c_int, [_vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_reduce_wide_batch_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "plp_contains": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int64, _vp, C.c_double, C.c_int, _vp]),

@@ -266,6 +266,39 @@ def reduce_simplex_runs(device=None, reset=False, stream=None):
     return int(out.value)
 
 
+def verify_careful_lps(device=None, stream=None):
+    """How many LPs of the LAST lpsolve_batch / cheby_ball_batch / bbox_batch call did not pass the verifier's certificate (or
+    were reported unbounded / at a limit) and were solved again by the careful double-double engine (include/plp.h:
+    plp_verify_counters).  `stream`: a torch stream (default: torch's current stream when torch is loaded with a GPU; calls
+    with numpy arrays run on the context's own stream, which the library falls back to).  Blocks until that batch is done."""
+    lib = _lib.load()
+    ctx = _lib.context(device)
+    if stream is None:
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(ctx.device)
+    sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
+    out = C.c_int64(0)
+    _lib.check(lib.plp_verify_counters(ctx.handle, sp, C.cast(C.byref(out), C.c_void_p)), "plp_verify_counters")
+    return int(out.value)
+
+
+def lp_histograms(result):
+    """Status and pivot-count histograms of an lpsolve_batch result (counters): dict(status={code: count},
+    iters=(edges, counts) over the engines' pivot counts -- LPs the careful engine re-solved keep the engine's count)."""
+    st = result["status"]
+    it = result.get("iters")
+    st = st.cpu().numpy() if hasattr(st, "cpu") else np.asarray(st)
+    codes, cnt = np.unique(st, return_counts=True)
+    out = {"status": {int(c): int(n) for c, n in zip(codes, cnt)}}
+    if it is not None:
+        it = it.cpu().numpy() if hasattr(it, "cpu") else np.asarray(it)
+        edges = np.array([0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 1 << 30])
+        out["iters"] = (edges.tolist(), np.histogram(it, bins=edges)[0].tolist())
+    return out
+
+
 def keep_to_bool(keep, m_max):
     """uint64 keep masks (one word per polytope, or [B, W] words for more than 64 rows) -> bool[B, m_max]."""
     keep = np.asarray(keep).astype(np.uint64)

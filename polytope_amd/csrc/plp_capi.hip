@@ -511,6 +511,25 @@ static int verify_cheby_answers(plp_ctx* ctx, hipStream_t st, int64_t B, int m_m
     return check_launch("verify_x_kernel");
 }
 
+int plp_verify_counters(plp_ctx* ctx, void* stream, int64_t* careful_lps) {
+    if (!ctx || !careful_lps) return fail(PLP_EINVAL, "NULL pointer");
+    *careful_lps = 0;
+    auto it = ctx->vf_scratch.find(stream);
+    if (it == ctx->vf_scratch.end()) {   // (host-pointer calls run on the context's own stream)
+        stream = (void*)ctx->stream;
+        it = ctx->vf_scratch.find(stream);
+    }
+    if (it == ctx->vf_scratch.end() || !it->second.p || it->second.calls == 0) return PLP_OK;   // nothing verified on this stream yet
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    // the list counter of the last launch: the two counters (64 B apart) are used in turn, the last call took (calls - 1) & 1
+    unsigned cnt = 0;
+    const char* base = static_cast<const char*>(it->second.p) + (((it->second.calls - 1) & 1u) ? 64 : 0);
+    HIP_TRY(hipMemcpy(&cnt, base, sizeof(cnt), hipMemcpyDeviceToHost));
+    *careful_lps = (int64_t)cnt;
+    return PLP_OK;
+}
+
 // ------------------------------------------------------------------------------- lp_solve
 int plp_lp_solve_batch_dev(plp_ctx* ctx, void* stream, int64_t B, int m_max, int n, const double* c,
                            const double* G, const double* h, const int32_t* m, double* x, double* fun,

@@ -1923,3 +1923,32 @@ def test_soak_families_small(pa, oracle, fam):
                 assert bad == 0 and SL.box_equal(lb[k], ub[k], lo, hi, hair_unbounded_tol=(1e-8 if fam == "dup" else None)), (fam, d, m, k, lb[k], lo, ub[k], hi)
             n += 1
     assert n_tie * 1000 <= n, (fam, n_tie, n)
+
+
+def test_verifier_counters_and_histograms(pa):
+    """plp_verify_counters / lp_histograms (counters): on random polytopes every answer certifies -- nothing
+    goes to the careful engine --, on rows a hair apart and on unbounded LPs some do; the status / pivot histograms add up."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_lane as SL
+    rng = np.random.default_rng(5)
+    for fam, expect_zero in (("random", True), ("dup", False), ("unbounded", False)):
+        A, b, mr = SL.make(rng, 2000, 20, 4, fam)
+        At, bt = torch.as_tensor(A).cuda(), torch.as_tensor(b).cuda()
+        pa.cheby_ball_batch(At, bt)
+        n_ch = pa.verify_careful_lps()
+        pa.bbox_batch(At, bt)
+        n_bb = pa.verify_careful_lps()
+        c = torch.as_tensor(rng.standard_normal((2000, 4))).cuda()
+        res = pa.lpsolve_batch(c, At, bt)
+        n_lp = pa.verify_careful_lps()
+        h = pa.lp_histograms(res)
+        assert sum(h["status"].values()) == 2000 and sum(h["iters"][1]) == 2000
+        if expect_zero:
+            assert (n_ch, n_bb, n_lp) == (0, 0, 0), (fam, n_ch, n_bb, n_lp)
+            assert h["status"] == {0: 2000}
+        else:
+            assert n_ch + n_bb + n_lp > 0, fam
+        if fam == "unbounded":
+            assert n_lp >= h["status"].get(3, 0) > 0      # every unbounded LP is the careful engine's verdict
