@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libplp_oracle.so")
 
 RF_EMPTY, RF_EARLY, RF_MINREP, RF_LPFAIL = 1, 2, 4, 8
+RF_F1OPEN = 32   # RF_EMPTY because the Chebyshev LP did not end optimal (polytope_amd/csrc/plp_common.hpp)
 
 
 def build(force=False):

@@ -600,6 +600,7 @@ int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb
 #define RF_EARLY 2    /* returned at neq <= nx+1 (minrep stays False)             */
 #define RF_MINREP 4   /* went through the redundancy LPs (minrep = True)          */
 #define RF_LPFAIL 8   /* a bounding-box LP came back with status 1/4 (RuntimeError) */
+#define RF_F1OPEN 32  /* RF_EMPTY because the Chebyshev LP did not end optimal (unbounded / a limit): polytope_amd/csrc/plp_common.hpp */
 
 /* reduce (polytope.py:1053-1163) on ONE polytope that is not already minrep.
  * keep: bit i set <=> input row i survives.  bout[i] = b value of row i as the
@@ -618,7 +619,7 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     int st = cheby_impl(m, d, A, b, r, xc, NULL, 0);   /* the fused kernels' engine: not certified (see lp_certify) */
     ++*nlp;
     if (!(st == ST_OPT && *r >= 0.0)) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; }
-    if (!(*r > abs_tol)) return RF_EMPTY;
+    if (!(*r > abs_tol)) return RF_EMPTY | ((st != ST_OPT && st != ST_INFEAS) ? RF_F1OPEN : 0);
     /* :1087-1089 drop rows with b == inf */
     for (int i = 0; i < m; ++i) if (b[i] != INFINITY) idx[neq++] = i;
     /* :1094-1110 parallel-row dedupe */

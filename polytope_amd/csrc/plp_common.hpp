@@ -18,7 +18,14 @@ enum : int {
     RF_EARLY = 2,   // returned at neq <= nx+1, minrep stays False               (:1114-1116,:1136-1138)
     RF_MINREP = 4,  // went through the redundancy LPs, minrep = True            (:1161-1163)
     RF_LPFAIL = 8,  // a bounding-box LP ended with status 1/4 (RuntimeError)    (:1378-1384)
-    RF_RETRY = 16   // internal: redo this polytope with the general engine (second pass of launch_reduce)
+    RF_RETRY = 16,  // internal: redo this polytope with the general engine (second pass of launch_reduce)
+    // RF_EMPTY because the Chebyshev LP did NOT end optimal (unbounded, or a limit) rather than with a radius below the
+    // tolerance.  For a half-space or a cone that is the reference's verdict too (cheby_ball returns 0 for every status but 0,
+    // :1289-1297) -- but on rows a hair apart the engine's pivot tolerance (TOL_PIV) can call a bounded ball unbounded
+    // (tests/golden/g23, case 33: the reference reduces that polytope, the engine called it empty).  The fused kernels run
+    // unverified; with this flag the caller re-examines the few polytopes concerned through the verified stand-alone LPs
+    // (polytope_amd/polytope.py: _reduce_many).
+    RF_F1OPEN = 32
 };
 
 // tolerances of the simplex core (identical in oracle/plp_oracle.c)

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, 
         if (lane < d) R.xc[lane] = xcl;
         const bool ball = (S.status == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
         const bool fulldim = ball & (rr > abs_tol);
-        int flags = fulldim ? 0 : RF_EMPTY;
+        int flags = fulldim ? 0 : (RF_EMPTY | (((S.status != ST_OPT) & (S.status != ST_INFEAS)) ? RF_F1OPEN : 0));
         int nlp = 1;
         int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
         int neq = 0;

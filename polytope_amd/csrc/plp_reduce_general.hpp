@@ -66,7 +66,7 @@ __device__ __forceinline__ void reduce_general_tile(unsigned char* smem_raw, con
     // ---------------------------------------------------------------- F1: Chebyshev ball
     double xc[D];
     double rr = 0.0;
-    bool ball, fulldim;
+    bool ball, fulldim, f1open = false;
     {
         Simplex<D + 1, false, true> S;
         S.reset(D + 1, m, i);
@@ -89,6 +89,7 @@ __device__ __forceinline__ void reduce_general_tile(unsigned char* smem_raw, con
         else if (infeasible0) { S.mode = M_DONE; S.status = ST_INFEAS; }
         S.run(g);
         const bool ok = S.status == ST_OPT;
+        f1open = valid && !ok && S.status != ST_INFEAS;   // (RF_F1OPEN, plp_common.hpp)
         const double mine = S.x_value();
         const bool holds = S.holds_x();
 #pragma unroll
@@ -123,7 +124,7 @@ __device__ __forceinline__ void reduce_general_tile(unsigned char* smem_raw, con
         }
         live = grp_ballot(has_row && !removed, g);
     }
-    int flags = fulldim ? 0 : RF_EMPTY;
+    int flags = fulldim ? 0 : (RF_EMPTY | (f1open ? RF_F1OPEN : 0));
     int nlp = 1;
     uint64_t keep = 0ull;
     int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs

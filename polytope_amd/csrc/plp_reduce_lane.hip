@@ -160,7 +160,7 @@ __device__ __forceinline__ void reduce_lane_tile(
     const int m = valid ? (mrows ? (mrows + tile)[gib] : m_max) : 0;
     double xc[D];
     double rr = 0.0;
-    bool ball, fulldim;
+    bool ball, fulldim, f1open = false;
     uint64_t live = 0ull;
     unsigned has = 0u;
     bool retry = force_retry != 0;
@@ -207,6 +207,7 @@ __device__ __forceinline__ void reduce_lane_tile(
 #endif
         retry = retry | (valid & (S.status == ST_RETRY));
         const bool ok = S.status == ST_OPT;
+        f1open = valid & !ok & (S.status != ST_INFEAS);   // (RF_F1OPEN, plp_common.hpp)
 #pragma unroll
         for (int j = 0; j <= D; ++j) {
             bool found;
@@ -303,7 +304,7 @@ __device__ __forceinline__ void reduce_lane_tile(
         }
     };
     zero_dead(((unsigned)(live >> row0) & RMASK));
-    int flags = fulldim ? 0 : RF_EMPTY;
+    int flags = fulldim ? 0 : (RF_EMPTY | (f1open ? RF_F1OPEN : 0));
     int nlp = 1;
     uint64_t keep = 0ull;
     int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs

@@ -345,7 +345,7 @@ __device__ __forceinline__ void reduce_r_tile(
         const int m = valid ? (mrows ? mrows[pg] : m_max) : 0;
         double xc[D];
         double rr = 0.0;
-        bool ball, fulldim;
+        bool ball, fulldim, f1open = false;
         uint64_t live = 0ull;
         unsigned has = 0u;
         // an F2/F3 LP needed Bland's rule: the whole polytope goes to the general kernel
@@ -401,6 +401,7 @@ __device__ __forceinline__ void reduce_r_tile(
             }
             ball = (st1 == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
             fulldim = ball & (rr > abs_tol);
+            f1open = valid & (st1 != ST_OPT) & (st1 != ST_INFEAS);   // (RF_F1OPEN, plp_common.hpp)
         } else
         {
 #if PLP_R_FAST
@@ -468,6 +469,7 @@ __device__ __forceinline__ void reduce_r_tile(
             S.run(g);
 #endif
             const bool ok = S.status == ST_OPT;
+            f1open = valid & !ok & (S.status != ST_INFEAS);   // (RF_F1OPEN, plp_common.hpp)
 #pragma unroll
             for (int j = 0; j <= D; ++j) {
                 bool found;
@@ -589,7 +591,7 @@ __device__ __forceinline__ void reduce_r_tile(
             }
         };
         zero_dead(((unsigned)(live >> row0) & RMASK));
-        int flags = fulldim ? 0 : RF_EMPTY;
+        int flags = fulldim ? 0 : (RF_EMPTY | (f1open ? RF_F1OPEN : 0));
         int nlp = 1;
         uint64_t keep = 0ull;
         int stage = 0;  // 0 done, 1 needs the box, 2 needs the redundancy LPs
@@ -1418,7 +1420,7 @@ __global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_ws
 #pragma unroll
             for (int k = 0; k < D; ++k) { xc_out[pg * D + k] = ball1 ? xc1[k] : qnan; sxc[k] = xc1[k]; }
             sxc[D] = rr1;
-            s32[3] = (ball1 ? 1u : 0u) | (full1 ? 2u : 0u);
+            s32[3] = (ball1 ? 1u : 0u) | (full1 ? 2u : 0u) | (((st1 != ST_OPT) & (st1 != ST_INFEAS)) ? 4u : 0u);   // bit 2: RF_F1OPEN
         }
     } else {
         // ------------------------------------------------------------ dedupe (:1094-1110): the partners j in NW - 1 ranges
@@ -1465,7 +1467,7 @@ __global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_ws
         myan[lane] = sk;
         zero_dead(((live >> lane) & 1ull) != 0ull);
     }
-    int flags = fulldim ? 0 : RF_EMPTY;
+    int flags = fulldim ? 0 : (RF_EMPTY | ((s32[3] & 4u) ? RF_F1OPEN : 0));
     int nlp = 1;
     uint64_t keep = 0ull;
     int stage = 0;

@@ -36,6 +36,7 @@ _F64 = np.dtype(np.float64)
 ABS_TOL = 1e-7
 
 _RF_EMPTY, _RF_EARLY, _RF_MINREP, _RF_LPFAIL = 1, 2, 4, 8
+_RF_F1OPEN = 32   # empty because the fused kernel's Chebyshev LP did not end optimal (csrc/plp_common.hpp): re-examined below
 _MAX_ROWS, _MAX_DIM = 64, 16
 _RDIFF_NATIVE = True   # region_diff's search in the library (False: the host loop over batched calls, for A/B runs)
 
@@ -907,8 +908,26 @@ def _reduce_many(polys, abs_tol):
     A, b, ms = _pack(polys)
     res = reduce_batch(A, b, m=ms, abs_tol=abs_tol)
     masks = keep_to_bool(res["keep"], A.shape[1])
+    # The fused kernels run unverified.  A polytope they call empty because their Chebyshev LP ended UNBOUNDED (or at a limit)
+    # is a half-space or a cone as a rule -- the reference's verdict too (ref :1289-1297) -- but on rows a hair apart the
+    # engine's pivot tolerance can call a bounded ball unbounded (tests/golden/g23).  Those few get the verified stand-alone
+    # ball (one batch), and where that one is full-dimensional the reference's own LP loop on the verified LPs.
+    redo = {}
+    opened = [k for k in range(len(polys)) if int(res["flags"][k]) & _RF_F1OPEN]
+    if opened:
+        from .batch import cheby_ball_batch
+        sub = cheby_ball_batch(A[opened], b[opened], m=ms[opened])
+        for j, k in enumerate(opened):
+            rj = float(sub["r"][j])
+            if int(sub["status"][j]) == 0 and rj > abs_tol:
+                p = polys[k]
+                p._chebR, p._chebXc, p.fulldim = np.double(rj), np.array(sub["xc"][j], dtype=float), True
+                redo[k] = _reduce_lp_loop(p, 1, abs_tol)
     out = []
     for k, p in enumerate(polys):
+        if k in redo:
+            out.append(redo[k])
+            continue
         fl = int(res["flags"][k])
         if fl & _RF_LPFAIL:
             raise RuntimeError("bounding_box: an LP of the box prefilter of `reduce` ended with status 1 or 4")

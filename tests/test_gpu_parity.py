@@ -1952,3 +1952,43 @@ def test_verifier_counters_and_histograms(pa):
             assert n_ch + n_bb + n_lp > 0, fam
         if fam == "unbounded":
             assert n_lp >= h["status"].get(3, 0) > 0      # every unbounded LP is the careful engine's verdict
+
+
+def test_reduce_on_rows_a_hair_apart_reference_fixture(pa):
+    """g23 (tests/golden/make_golden_reduce_dup.py): the REFERENCE's reduce() on 336 polytopes with rows a hair apart, elongated
+    and shifted ones, d = 2..8 -- the engines' absolute tolerances against the real reference, not the oracle that shares them.
+    Through the public reduce() on the 'hip' backend: the same rows kept (rows that coincide to 1e-12 stand for one another),
+    the same emptiness verdict -- including the polytope whose Chebyshev LP the fused kernel ends "unbounded" (RF_F1OPEN: the
+    host layer consults the verified ball and reduces it through the verified LPs) --, on every case the reference itself is
+    consistent on (not: one polytope where HiGHS ends a redundancy LP with "numerical difficulties" and drops a facet)."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    from test_oracle_golden import _twin_classes
+    g = load_golden("g23_reduce_dup.npz")
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    n = 0
+    try:
+        for i in range(len(g["m"])):
+            if not g["pinned"][i]:
+                continue
+            m, d = int(g["m"][i]), int(g["d"][i])
+            A, b = g["A"][i, :m * d].reshape(m, d).copy(), g["b"][i, :m].copy()
+            q = pc.reduce(pc.Polytope(A, b, normalize=False))
+            assert (q.A.size == 0) == bool(g["empty"][i]), (i, str(g["fam"][i]))
+            if g["empty"][i]:
+                continue
+            # which input rows came back (rows are renormalised by the constructor)
+            nrm = np.sqrt((A * A).sum(1))
+            An, bn = A / nrm[:, None], b / nrm
+            keep = np.zeros(m, bool)
+            for a, bb in zip(q.A, q.b):
+                cand = np.nonzero((np.abs(An - a).max(1) < 1e-12) & (np.abs(bn - bb) < 1e-9 * max(1.0, abs(bb))))[0]
+                assert cand.size, (i, a, bb)
+                keep[cand[0]] = True
+            assert np.array_equal(_twin_classes(A, b, keep), _twin_classes(A, b, g["keep"][i, :m])), (
+                i, str(g["fam"][i]), d, m, np.nonzero(keep)[0], np.nonzero(g["keep"][i, :m])[0])
+            n += 1
+    finally:
+        solvers.default_solver = old
+    assert n >= 300
