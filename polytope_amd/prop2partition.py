@@ -66,22 +66,26 @@ def _pair_shapes_ok(members):
     return 1 <= d <= 16 and all(p.A.shape[1] == d and 1 <= p.A.shape[0] <= 32 for p in members)
 
 
+def _members_key(regions):
+    """identity of every element AND of every member polytope inside an element Region"""
+    return tuple((id(r), tuple(id(p) for p in r.list_poly)) if isinstance(r, pc.Region) else id(r) for r in regions)
+
+
 def _flat_members(regions, owner=None):
     """(members, first, pair kernels applicable) of `regions`; remembered on `owner` -- the object whose element list
-    `regions` is -- keyed by the identity of EVERY element, and the entry keeps the elements alive (an id cannot be handed
-    out again while its object lives), so an element replaced at the same length is seen.  Member lists edited inside an
-    element Region are caught one level down: polytope._table_of compares the packed rows' content."""
+    `regions` is -- keyed by the identity of EVERY element and of every member polytope inside an element Region, and the
+    entry keeps the elements and members alive (an id cannot be handed out again while its object lives): an element
+    replaced at the same length, or a member replaced inside an element (`reg.list_poly[k] = q`), gives another key.
+    (Rows edited in place inside a member are caught one level down: polytope._table_of compares the packed rows' content.)"""
     if owner is not None and regions:
-        key = tuple(id(r) for r in regions)
+        key = _members_key(regions)
         hit = owner.__dict__.get("_p2p_flat")
-        if hit is not None and hit[0] == key and \
-                all(len(r.list_poly) == n for r, n in zip(hit[2], hit[3]) if n is not None):
+        if hit is not None and hit[0] == key:
             return hit[1]
     members, first = _members_of(regions)
     out = (members, first, _pair_shapes_ok(members))
     if owner is not None and regions:
-        owner.__dict__["_p2p_flat"] = (key, out, list(regions),
-                                       [len(r.list_poly) if isinstance(r, pc.Region) else None for r in regions])
+        owner.__dict__["_p2p_flat"] = (key, out, list(regions), list(members))
     return out
 
 
