@@ -27,7 +27,7 @@ done
 if [[ " $GROUPS_ " == *" bench "* ]]; then
   echo "== bench.py: kernel trace + SQ counters (one pass per set)"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o kt -- \
-      python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-parity > "$OUT/bench_trace.log" 2>&1)
+      python "$OLDPWD/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --no-parity --no-secondary > "$OUT/bench_trace.log" 2>&1)
   tail -1 "$OUT/bench_trace.log" | cut -c1-400
   i=0
   for set_ in "FETCH_SIZE" "WRITE_SIZE" \
@@ -38,7 +38,7 @@ if [[ " $GROUPS_ " == *" bench "* ]]; then
       "GRBM_GUI_ACTIVE GRBM_COUNT"; do
     i=$((i+1))
     (cd /tmp && timeout 900 rocprofv3 --pmc $set_ --kernel-trace --output-format csv -d "$OUT/bench_pmc_$i" -o p -- \
-        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-parity --regions 1 --min-region-ms 0 > "$OUT/bench_pmc_$i.log" 2>&1)
+        python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-parity --no-secondary --regions 1 --min-region-ms 0 > "$OUT/bench_pmc_$i.log" 2>&1)
   done
 fi
 # compact summaries (the raw csv files of a trace run are large)

@@ -575,6 +575,20 @@ def test_config4_full_size_region_diff_and_adjacency():
                 inD |= q.contains(X, abs_tol=0)
                 assert float(pcm.cheby_ball(q)[0]) > 1e-7
             assert not np.any(inD & ~inP)
+        # (iii) as SETS (the public call against the reference's 234 pieces).  They are not the same set and cannot
+        # be: neither is P \\ sub -- the reference's decomposition depends on the order of its tied cells, misses 0.105 of the true
+        # difference's volume of 1.339 and covers 0.009 outside it (scripts/debug/c4_set_check.py, 2 M seeded points through the
+        # containment kernel).  What is asserted: the public call's pieces miss and overshoot the TRUE difference by no more,
+        # in total, than the reference's own pieces do (measured: 0.080 against 0.114).
+        insub = sub.contains(X, abs_tol=0)
+        truth = inP & ~insub
+        err = []
+        for Dk in (D2, D):        # D reproduces the reference's pieces (i)
+            inD = np.zeros(X.shape[1], bool)
+            for q in _pieces(pcm, Dk):
+                inD |= q.contains(X, abs_tol=0)
+            err.append(float(np.mean(truth ^ inD)))
+        assert err[0] <= err[1] * 1.05 and err[1] > 0.0, err
         D3 = pcm.region_diff(P.copy(), sub)   # deterministic
         assert [q.A.shape for q in _pieces(pcm, D3)] == [q.A.shape for q in _pieces(pcm, D2)]
         # adjacency
