@@ -158,6 +158,24 @@ static PLP_HD void put(Vec v, int n, int idx, double val) {
         v[idx] = val;
     }
 }
+// dst[doff + j] -= f * src[soff + j] for j0 <= j < j1, four at a time with the loads ahead of the stores: through the views
+// the compiler cannot tell that a store to dst does not feed the next load of src (the workspace is one array), and an
+// element-by-element loop pays an LDS round trip per element
+static PLP_HD void row_axpy(Vec dst, int doff, Vec src, int soff, double f, int j0, int j1) {
+    int j = j0;
+    if constexpr (NF == 0) {
+        for (; j + 4 <= j1; j += 4) {
+            const double s0 = src[soff + j], s1 = src[soff + j + 1], s2 = src[soff + j + 2], s3 = src[soff + j + 3];
+            const double d0 = dst[doff + j], d1 = dst[doff + j + 1], d2 = dst[doff + j + 2], d3 = dst[doff + j + 3];
+            dst[doff + j] = fma(-f, s0, d0);
+            dst[doff + j + 1] = fma(-f, s1, d1);
+            dst[doff + j + 2] = fma(-f, s2, d2);
+            dst[doff + j + 3] = fma(-f, s3, d3);
+        }
+    }
+    PLP_UNROLL
+    for (; j < j1; ++j) dst[doff + j] = fma(-f, src[soff + j], dst[doff + j]);
+}
 // LU of the n x n matrix (row-major, stride VN) with partial pivoting; false: singular to working precision
 static PLP_HD bool lu_factor(int n, Vec LU, Vec perm, double* pivot_ratio) {
     double big = 0.0, pmin = 1e300;
@@ -210,8 +228,7 @@ static PLP_HD bool lu_factor(int n, Vec LU, Vec perm, double* pivot_ratio) {
         for (int i = k + 1; i < n; ++i) {
             const double f = LU[i * VN + k] * inv;
             LU[i * VN + k] = f;
-            PLP_UNROLL
-            for (int j = k + 1; j < n; ++j) LU[i * VN + j] = fma(-f, LU[k * VN + j], LU[i * VN + j]);
+            row_axpy(LU, i * VN, LU, k * VN, f, k + 1, n);
         }
     }
     *pivot_ratio = pmin / big;
@@ -489,6 +506,14 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
     const Vec Q = at(ws, O_LU), v = at(ws, O_V), ci = at(ws, O_CI);  // Q: orthonormal rows spanning the accepted rows
     int nb = 0;
     if (cn > KC) return false;
+    if (cn == n) {
+        // exactly n candidates -- a non-degenerate vertex, the generic case -- ARE the basis; should they be dependent, the
+        // factorisation says so (vertex_and_dual: singular) and the LP goes to the careful engine.  Saves the O(n^3)
+        // orthogonalisation, the largest term of the certificate at n = 17.
+        PLP_UNROLL
+        for (int k = 0; k < n; ++k) basis[k] = ci[k];
+        return true;
+    }
     if constexpr (NF > 0) {   // the same with static indices only: rows of Q beyond nb are zero, "row nb" is a select
         PLP_UNROLL
         for (int e = 0; e < n * VN; ++e) Q[e] = 0.0;
@@ -571,7 +596,7 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
         for (int q = 0; q < nb; ++q) {
             double dq = 0.0;
             for (int j = 0; j < n; ++j) dq = fma(Q[q * VN + j], v[j], dq);
-            for (int j = 0; j < n; ++j) v[j] = fma(-dq, Q[q * VN + j], v[j]);
+            row_axpy(v, 0, Q, q * VN, dq, 0, n);
         }
         for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
         if (!(nrm1 > 1e-12 * nrm0)) continue;  // (1e-6 of its length: dependent on the rows taken so far)
@@ -590,10 +615,7 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
         if (bj < 0 || !(bn > 1e-12)) return false;
         double nrm1 = 0.0;
         for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
-        for (int q = 0; q < nb; ++q) {
-            const double dq = Q[q * VN + bj];
-            for (int j = 0; j < n; ++j) v[j] = fma(-dq, Q[q * VN + j], v[j]);
-        }
+        for (int q = 0; q < nb; ++q) row_axpy(v, 0, Q, q * VN, Q[q * VN + bj], 0, n);
         for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
         if (!(nrm1 > 1e-12)) return false;
         const double inv = 1.0 / sqrt(nrm1);
