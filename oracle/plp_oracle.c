@@ -294,7 +294,7 @@ int plpo_lp_solve_raw(int m, int n, const double *c, const double *G, const doub
  * checked against the ORIGINAL rows, from the final basis alone:
  *   M = the n rows that define the vertex (active rows; e_j for a free variable left at zero),
  *   x = M^-1 rhs and y = -M^-T c by LU with partial pivoting + iterative refinement (residuals in binary128),
- *   primal:  h_i - G_i.x >= -1e-13 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
+ *   primal:  h_i - G_i.x >= -2e-14 * max(|h_i|, |G_i|_inf * max(1, |x|_inf))   for every row,
  *   dual:    y_k |G_k|_inf >= -1e-13 |c|_inf on active rows, |y_k| <= 1e-13 |c|_inf on the free variables (a multiplier
  *            between that and the engine's own 1e-9 is judged by what it buys: plp_oracle_q.c, qrun)
  * -- an optimal basis of the LP as given, its vertex computed to the last bits whatever path led there.  An
@@ -314,7 +314,7 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
  * this oracle and the HIP library apply it to the certified / re-solved value.  scale = |c|_inf * max(1, max_i
  * |h_i| / |G_i|_inf). */
 #define PLPO_BIG 1e9
-#define PLPO_TOL_PRIMAL 1e-13   /* (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on an optimum of 235) */
+#define PLPO_TOL_PRIMAL 2e-14   /* (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on an optimum of 235) */
 static double g_tol_dual = 1e-13;   /* a multiplier below this is rounding; between it and the engine's 1e-9: binary128 judges it by what it buys */
 #define PLPO_TOL_DUAL g_tol_dual
 void plpo_set_tol_dual(double t) { g_tol_dual = t; }

@@ -10,7 +10,7 @@
 //   certify()   From the final BASIS alone (the n rows / free variables that define the vertex -- handed over by the engine
 //               as masks, or read off its x: basis_from_x) and the ORIGINAL rows: M = those rows, x = M^-1 rhs and
 //               y = -M^-T c by LU with partial pivoting + iterative refinement with double-double residuals; then
-//                   primal  h_i - G_i.x >= -1e-13 max(|h_i|, |G_i|_inf max(1, |x|_inf))          for every row,
+//                   primal  h_i - G_i.x >= -2e-14 max(|h_i|, |G_i|_inf max(1, |x|_inf))          for every row,
 //                   dual    y_k |G_k|_inf >= -1e-13 |c|_inf on active rows, |y_k| <= 1e-13 |c|_inf on free variables:
 //               an optimal basis of the LP as given, its vertex recomputed to the last bits whatever path led there (the
 //               polished x replaces the engine's).  An unbounded answer is checked the same way: the vertex the engine
@@ -54,7 +54,7 @@ constexpr int VNC = VNMAX + 1;    // + the phase-1 artificial
 constexpr int VW = 20;            // doubles per dictionary row in the careful engine's scratch: VNC columns, beta, spare
 constexpr double V_BIG = 1e9;     // optimum beyond V_BIG x scale(data): unbounded
 constexpr double V_TOL_DUAL = 1e-13;  // a multiplier below this (of |c| / |G_k|) is rounding; see the note on tolerances below
-constexpr double V_TOL_PRIMAL = 1e-13;  // (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on the optimum of 235, seed 4 of verify_smoke)
+constexpr double V_TOL_PRIMAL = 2e-14;  // (ten ulps of |G_i| |x|: the fma chain itself is good to n / 2 ulps; 1e-13 left 1.2e-9 of a sliver's 2.6e7; 1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on the optimum of 235, seed 4 of verify_smoke)
 constexpr double C_TOL_D = 1e-9, C_TOL_PIV = 1e-12, C_TOL_FEAS = 1e-7, C_DEGEN = 1e-24;
 constexpr double C_TOL_NOISE = 1e-13;  // reduced costs between this and C_TOL_D: judged by what they buy (careful_run)
 constexpr double C_TOL_GAIN = 1e-10;   // ... an improvement above this (of max(1, |objective|)) within range
@@ -309,8 +309,8 @@ static PLP_HD void solve_refined(int n, double* ws, Vec r, Vec z, bool trans, in
 }
 
 // ---------------------------------------------------------------------------------------------------- the certificate
-// One row against a vertex z (xs = max(1, |z|_inf)): slack h_i - G_i.z >= -1e-13 max(|h_i|, |G_i|_inf xs).  A plain fma chain:
-// its rounding (n ulps of |G_i| |z|) is fifty times below the tolerance.
+// One row against a vertex z (xs = max(1, |z|_inf)): slack h_i - G_i.z >= -2e-14 max(|h_i|, |G_i|_inf xs).  A plain fma chain:
+// its rounding (n / 2 ulps of |G_i| |z| at worst, typically one or two) stays below the tolerance.
 static PLP_HD bool row_feasible(const LpView& lp, int i, Vec z, double xs) {
     double s = lp.hh(i), gmax = 0.0;
     PLP_UNROLL
