@@ -185,34 +185,63 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         }
     }
     __syncthreads();
-    // ---- leader: basis, factorisation, vertex, multipliers
-    if ((gl == 0) & ((s_mode[li] == 1) | (s_mode[li] == 2))) {
-        bool have = true;
-        if (s_mode[li] == 1) {
-            const Vec cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
-            int cn = s_cn[li];
-            if (cn > CT::KC) cn = CT::KC + 1;
-            else {   // in place, by (slack, row): the order the host version inserts in
-                for (int k = 1; k < cn; ++k) {
-                    const double sk = cs[k], ik = ci[k];
-                    int q = k;
-                    while (q > 0 && (cs[q - 1] > sk || (cs[q - 1] == sk && ci[q - 1] > ik))) {
-                        cs[q] = cs[q - 1];
-                        ci[q] = ci[q - 1];
-                        --q;
-                    }
-                    cs[q] = sk;
-                    ci[q] = ik;
+    // ---- leader: the basis
+    if ((gl == 0) & (s_mode[li] == 1)) {
+        const Vec cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
+        int cn = s_cn[li];
+        if (cn > CT::KC) cn = CT::KC + 1;
+        else {   // in place, by (slack, row): the order the host version inserts in
+            for (int k = 1; k < cn; ++k) {
+                const double sk = cs[k], ik = ci[k];
+                int q = k;
+                while (q > 0 && (cs[q - 1] > sk || (cs[q - 1] == sk && ci[q - 1] > ik))) {
+                    cs[q] = cs[q - 1];
+                    ci[q] = ci[q - 1];
+                    --q;
                 }
+                cs[q] = sk;
+                ci[q] = ik;
             }
-            have = CT::select_basis(lp, ws, cn);
         }
+        if (!CT::select_basis(lp, ws, cn)) s_mode[li] = 3;
+    }
+    __syncthreads();
+    // ---- the basis matrix, a row per lane in turn; its factorisation with the row updates of an elimination step shared by
+    // the LP's lanes (the leader finds the pivot and swaps, a barrier, every lane takes every GSL-th row below it, a barrier)
+    const bool fac = (s_mode[li] == 1) | (s_mode[li] == 2);   // (the same for the lanes of an LP; the barriers are workgroup-wide)
+    if (fac) {
+        bool okr = true;
+        for (int k = gl; k < n; k += GSL) okr = okr & CT::basis_row(lp, true, ws, k);
+        if (!okr) atomicOr(&s_bad[li], 2u);
+    }
+    __syncthreads();
+    double big = 0.0, pmin = 1e300;
+    bool live = fac && !(s_bad[li] & 2u);
+    if (live & (gl == 0)) {
+        big = CT::lu_begin(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM));
+        if (!(big > 0.0)) atomicOr(&s_bad[li], 2u);
+    }
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        live = fac && !(s_bad[li] & 2u);
+        if (live & (gl == 0)) {
+            double pv;
+            if (CT::lu_pivot(n, k, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), big, &pv)) pmin = fmin(pmin, pv);
+            else atomicOr(&s_bad[li], 2u);
+        }
+        __syncthreads();
+        if (fac && !(s_bad[li] & 2u)) CT::lu_rows(n, k, CT::at(ws, CT::O_LU), gl, GSL);
+        __syncthreads();
+    }
+    // ---- leader: vertex, value, multipliers
+    if ((gl == 0) & fac) {
         double f = 0.0, zs = 1.0;
-        if (have && CT::vertex_and_dual(lp, true, true, ws, &f, &zs)) {
+        if (!(s_bad[li] & 2u) && CT::vertex_and_dual_finish(lp, true, ws, pmin / big, &f, &zs)) {
             s_xs[li] = zs;
             s_fun[li] = f;
             s_ok[li] = 1;
         }
+        s_bad[li] = 0u;
     }
     __syncthreads();
     // ---- pass 2: every row against the polished vertex

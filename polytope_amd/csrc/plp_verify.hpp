@@ -162,6 +162,11 @@ static PLP_HD void put(Vec v, int n, int idx, double val) {
 // the compiler cannot tell that a store to dst does not feed the next load of src (the workspace is one array), and an
 // element-by-element loop pays an LDS round trip per element
 static PLP_HD void row_axpy(Vec dst, int doff, Vec src, int soff, double f, int j0, int j1) {
+    if constexpr (NF > 0) {   // (registers: a plain loop that unrolls)
+        PLP_UNROLL
+        for (int j = j0; j < j1; ++j) dst[doff + j] = fma(-f, src[soff + j], dst[doff + j]);
+        return;
+    }
     int j = j0;
     if constexpr (NF == 0) {
         for (; j + 4 <= j1; j += 4) {
@@ -176,7 +181,71 @@ static PLP_HD void row_axpy(Vec dst, int doff, Vec src, int soff, double f, int 
     PLP_UNROLL
     for (; j < j1; ++j) dst[doff + j] = fma(-f, src[soff + j], dst[doff + j]);
 }
-// LU of the n x n matrix (row-major, stride VN) with partial pivoting; false: singular to working precision
+// LU of the n x n matrix (row-major, stride VN) with partial pivoting, in steps so that the lanes of an LP can share the row
+// updates (plp_verify.hip: the leader runs lu_begin / lu_pivot, every lane lu_rows on its rows, a barrier between them):
+//   lu_begin: the largest entry (0: the matrix is zero), perm = identity
+//   lu_pivot(k): pivot search in column k, row swap; false: singular to working precision; *pv = |pivot|
+//   lu_rows(k, first, step): rows i = k + 1 + first, + step, ...: the multiplier and the update of the row
+static PLP_HD double lu_begin(int n, Vec LU, Vec perm) {
+    double big = 0.0;
+    PLP_UNROLL
+    for (int k = 0; k < n; ++k)
+        PLP_UNROLL
+        for (int j = 0; j < n; ++j) big = fmax(big, fabs(LU[k * VN + j]));
+    PLP_UNROLL
+    for (int k = 0; k < n; ++k) perm[k] = k;
+    return big;
+}
+static PLP_HD bool lu_pivot(int n, int k, Vec LU, Vec perm, double big, double* pv_out) {
+    int p = k;
+    double pv = fabs(LU[k * VN + k]);
+    PLP_UNROLL
+    for (int i = k + 1; i < n; ++i) {
+        const double a = fabs(LU[i * VN + k]);
+        if (a > pv) { pv = a; p = i; }
+    }
+    *pv_out = pv;
+    if (!(pv > 1e-13 * big)) return false;
+    if constexpr (NF > 0) {   // (static indices only: the arrays are registers)
+        PLP_UNROLL
+        for (int i = k + 1; i < n; ++i) {
+            if (i == p) {
+                PLP_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    const double t = LU[k * VN + j];
+                    LU[k * VN + j] = LU[i * VN + j];
+                    LU[i * VN + j] = t;
+                }
+                const double t = perm[k];
+                perm[k] = perm[i];
+                perm[i] = t;
+            }
+        }
+    } else if (p != k) {
+        PLP_UNROLL
+        for (int j = 0; j < n; ++j) {
+            const double t = LU[k * VN + j];
+            LU[k * VN + j] = LU[p * VN + j];
+            LU[p * VN + j] = t;
+        }
+        const double t = perm[k];
+        perm[k] = perm[p];
+        perm[p] = t;
+    }
+    return true;
+}
+static PLP_HD void lu_rows(int n, int k, Vec LU, int first, int step) {
+    const double inv = 1.0 / LU[k * VN + k];
+    PLP_UNROLL
+    for (int i = k + 1 + first; i < n; i += step) {
+        const double f = LU[i * VN + k] * inv;
+        LU[i * VN + k] = f;
+        row_axpy(LU, i * VN, LU, k * VN, f, k + 1, n);
+    }
+}
+// The whole factorisation on one lane.  Written out, not as a loop over the steps above: through their pointer / by-step
+// interface the register instance (NF > 0) no longer has its workspace split into registers -- all of it goes to scratch
+// memory (measured: the small verify kernel 60 -> 100 us per 100 000 LPs).
 static PLP_HD bool lu_factor(int n, Vec LU, Vec perm, double* pivot_ratio) {
     double big = 0.0, pmin = 1e300;
     PLP_UNROLL
@@ -308,51 +377,78 @@ static PLP_HD void solve_refined(int n, double* ws, Vec r, Vec z, bool trans, in
     }
 }
 
+// h_i - G_i.v (a plain fma chain in column order) and |G_i|_inf.  In the instances whose column count is a run-time value the
+// loop does not unroll and every element would wait for the one before it -- a global-memory round trip each; four loads are
+// issued ahead of their fmas instead (the chain itself is unchanged: same operations, same order).
+static PLP_HD double row_slack(const LpView& lp, int i, Vec v, double* gmax_out) {
+    const int n = ncols(lp);
+    double s = lp.hh(i), gmax = 0.0;
+    int j = 0;
+    if constexpr (NF == 0) {
+        for (; j + 4 <= n; j += 4) {
+            const double g0 = lp.g(i, j), g1 = lp.g(i, j + 1), g2 = lp.g(i, j + 2), g3 = lp.g(i, j + 3);
+            const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
+            s = fma(-g0, v0, s);
+            s = fma(-g1, v1, s);
+            s = fma(-g2, v2, s);
+            s = fma(-g3, v3, s);
+            gmax = fmax(fmax(gmax, fmax(fabs(g0), fabs(g1))), fmax(fabs(g2), fabs(g3)));
+        }
+    }
+    PLP_UNROLL
+    for (; j < n; ++j) {
+        const double gij = lp.g(i, j);
+        s = fma(-gij, v[j], s);
+        gmax = fmax(gmax, fabs(gij));
+    }
+    *gmax_out = gmax;
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------------- the certificate
 // One row against a vertex z (xs = max(1, |z|_inf)): slack h_i - G_i.z >= -2e-14 max(|h_i|, |G_i|_inf xs).  A plain fma chain:
 // its rounding (n / 2 ulps of |G_i| |z| at worst, typically one or two) stays below the tolerance.
 static PLP_HD bool row_feasible(const LpView& lp, int i, Vec z, double xs) {
-    double s = lp.hh(i), gmax = 0.0;
-    PLP_UNROLL
-    for (int j = 0; j < ncols(lp); ++j) {
-        const double gij = lp.g(i, j);
-        s = fma(-gij, z[j], s);
-        gmax = fmax(gmax, fabs(gij));
-    }
+    double gmax;
+    const double s = row_slack(lp, i, z, &gmax);
     return !(s < -V_TOL_PRIMAL * fmax(gmax * xs, fabs(lp.hh(i))));
 }
 
-// The vertex and the multipliers of a basis, everything of the certificate but the pass over all rows.
-// The basis list is in the workspace (O_BAS): >= 0 an active row, -1 - j the free variable x_j held at ws[O_X + j]
-// (have_xref false: at 0).
-// true: the basis matrix is regular and (want_dual) dual feasible; ws[O_Z ..) = the polished vertex, *fun = c.z,
-// *xs_out = max(1, |z|_inf).  (The factorisation stays in the workspace: the ray check of an unbounded answer uses it.)
-static PLP_HD bool vertex_and_dual(const LpView& lp, bool have_xref, bool want_dual, double* ws, double* fun, double* xs_out) {
-    const Vec basis = at(ws, O_BAS), xref = at(ws, O_X);
+// row k of the basis matrix (both copies) and of its right-hand side; false: an index out of range
+static PLP_HD bool basis_row(const LpView& lp, bool have_xref, double* ws, int k) {
+    const Vec basis = at(ws, O_BAS), xref = at(ws, O_X), LU = at(ws, O_LU), M0 = at(ws, O_M0), rhs = at(ws, O_RHS);
     const int n = ncols(lp), m = lp.m;
-    const Vec LU = at(ws, O_LU), M0 = at(ws, O_M0), perm = at(ws, O_PERM), rhs = at(ws, O_RHS), z = at(ws, O_Z), y = at(ws, O_Y),
-              nc_ = at(ws, O_V);
-    if (n > VN || n < 1) return false;
-    PLP_UNROLL
-    for (int k = 0; k < n; ++k) {
-        const int v = (int)basis[k];
-        if (v >= 0) {
-            if (v >= m) return false;
-            rhs[k] = lp.hh(v);
-        } else {
-            const int j0 = -1 - v;
-            if (j0 < 0 || j0 >= n) return false;
-            rhs[k] = have_xref ? pick(xref, n, j0) : 0.0;
-        }
-        PLP_UNROLL
-        for (int j = 0; j < n; ++j) {
-            const double e = basis_entry(lp, basis, k, j);
-            LU[k * VN + j] = e;
-            M0[k * VN + j] = e;
+    const int v = (int)basis[k];
+    if (v >= 0) {
+        if (v >= m) return false;
+        rhs[k] = lp.hh(v);
+    } else {
+        const int j0 = -1 - v;
+        if (j0 < 0 || j0 >= n) return false;
+        rhs[k] = have_xref ? pick(xref, n, j0) : 0.0;
+    }
+    int j = 0;
+    if constexpr (NF == 0) {   // (four loads in flight: see row_slack)
+        for (; j + 4 <= n; j += 4) {
+            const double e0 = basis_entry(lp, basis, k, j), e1 = basis_entry(lp, basis, k, j + 1);
+            const double e2 = basis_entry(lp, basis, k, j + 2), e3 = basis_entry(lp, basis, k, j + 3);
+            LU[k * VN + j] = e0; LU[k * VN + j + 1] = e1; LU[k * VN + j + 2] = e2; LU[k * VN + j + 3] = e3;
+            M0[k * VN + j] = e0; M0[k * VN + j + 1] = e1; M0[k * VN + j + 2] = e2; M0[k * VN + j + 3] = e3;
         }
     }
-    double pr = 1.0;
-    if (!lu_factor(n, LU, perm, &pr)) return false;
+    PLP_UNROLL
+    for (; j < n; ++j) {
+        const double e = basis_entry(lp, basis, k, j);
+        LU[k * VN + j] = e;
+        M0[k * VN + j] = e;
+    }
+    return true;
+}
+// what follows the factorisation (pr = smallest pivot / largest entry): vertex, value, multipliers
+static PLP_HD bool vertex_and_dual_finish(const LpView& lp, bool want_dual, double* ws, double pr, double* fun, double* xs_out) {
+    const Vec basis = at(ws, O_BAS);
+    const int n = ncols(lp);
+    const Vec M0 = at(ws, O_M0), rhs = at(ws, O_RHS), z = at(ws, O_Z), y = at(ws, O_Y), nc_ = at(ws, O_V);
     const int rounds = pr < 1e-4 ? 3 : 0;
     solve_refined(n, ws, rhs, z, false, rounds);
     double zmax = 0.0;
@@ -393,6 +489,17 @@ static PLP_HD bool vertex_and_dual(const LpView& lp, bool have_xref, bool want_d
         } else if (fabs(yk) > V_TOL_DUAL * cmax) return false;
     }
     return true;
+}
+
+static PLP_HD bool vertex_and_dual(const LpView& lp, bool have_xref, bool want_dual, double* ws, double* fun, double* xs_out) {
+    const int n = ncols(lp);
+    if (n > VN || n < 1) return false;
+    PLP_UNROLL
+    for (int k = 0; k < n; ++k)
+        if (!basis_row(lp, have_xref, ws, k)) return false;
+    double pr = 1.0;
+    if (!lu_factor(n, at(ws, O_LU), at(ws, O_PERM), &pr)) return false;
+    return vertex_and_dual_finish(lp, want_dual, ws, pr, fun, xs_out);
 }
 
 // status: V_OPT / V_UNBND as the engine reported it; basis list in the workspace, entries n, n + 1 (V_UNBND): position in the list of the variable
@@ -486,13 +593,8 @@ static PLP_HD void cand_add(double* ws, int& cn, double s, int i) {
 }
 // slack of row i at x (plain fma chain) and whether the row is a candidate (xs = max(1, |x|_inf))
 static PLP_HD bool row_candidate(const LpView& lp, int i, Vec x, double xs, double* slack) {
-    double s = lp.hh(i), gmax = 0.0;
-    PLP_UNROLL
-    for (int j = 0; j < ncols(lp); ++j) {
-        const double gij = lp.g(i, j);
-        s = fma(-gij, x[j], s);
-        gmax = fmax(gmax, fabs(gij));
-    }
+    double gmax;
+    const double s = row_slack(lp, i, x, &gmax);
     *slack = s;
     return (gmax > 0.0) & (s <= 1e-9 * fmax(gmax * xs, fabs(lp.hh(i))));
 }
@@ -604,23 +706,37 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
         for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
         basis[nb++] = (double)bi;
     }
-    while (nb < n) {  // complete with free variables (unit vectors), most independent first
-        int bj = -1;
-        double bn = 0.0;
-        for (int j0 = 0; j0 < n; ++j0) {
-            double r2 = 1.0;  // |e_j0 - Q'Q e_j0|^2 = 1 - sum_q Q[q][j0]^2
-            for (int q = 0; q < nb; ++q) r2 = fma(-Q[q * VN + j0], Q[q * VN + j0], r2);
-            if (r2 > bn) { bn = r2; bj = j0; }
+    if (nb < n) {  // complete with free variables (unit vectors), most independent first
+        // |e_j - Q'Q e_j|^2 = 1 - sum_q Q[q][j]^2, kept up to date as rows join (recomputed from scratch per step it was the
+        // largest term of the certificate for an optimum on a FACE -- every box LP of a box: 0.46 ms per 5 000 LPs at n = 16)
+        const Vec r2 = at(ws, O_T);
+        for (int j = 0; j < n; ++j) {
+            double r = 1.0;
+            for (int q = 0; q < nb; ++q) r = fma(-Q[q * VN + j], Q[q * VN + j], r);
+            r2[j] = r;
         }
-        if (bj < 0 || !(bn > 1e-12)) return false;
-        double nrm1 = 0.0;
-        for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
-        for (int q = 0; q < nb; ++q) row_axpy(v, 0, Q, q * VN, Q[q * VN + bj], 0, n);
-        for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
-        if (!(nrm1 > 1e-12)) return false;
-        const double inv = 1.0 / sqrt(nrm1);
-        for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
-        basis[nb++] = (double)(-1 - bj);
+        while (nb < n) {
+            int bj = -1;
+            double bn = 0.0;
+            for (int j0 = 0; j0 < n; ++j0) {
+                const double r = r2[j0];
+                if (r > bn) { bn = r; bj = j0; }
+            }
+            if (bj < 0 || !(bn > 1e-12)) return false;
+            double nrm1 = 0.0;
+            for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
+            for (int q = 0; q < nb; ++q) row_axpy(v, 0, Q, q * VN, Q[q * VN + bj], 0, n);
+            for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
+            if (!(nrm1 > 1e-12)) return false;
+            const double inv = 1.0 / sqrt(nrm1);
+            for (int j = 0; j < n; ++j) {
+                const double qj = v[j] * inv;
+                Q[nb * VN + j] = qj;
+                r2[j] = fma(-qj, qj, r2[j]);
+            }
+            r2[bj] = 0.0;
+            basis[nb++] = (double)(-1 - bj);
+        }
     }
     return true;
 }
