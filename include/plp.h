@@ -50,6 +50,10 @@ extern "C" {
 #define PLP_RF_EARLY 2  /* returned at neq <= nx+1, minrep stays False             (:1114-1116, :1136-1138) */
 #define PLP_RF_MINREP 4 /* all redundancy LPs done, minrep = True                  (:1161-1163) */
 #define PLP_RF_LPFAIL 8 /* a bounding-box LP ended 1/4: reference raises RuntimeError (:1378-1384) */
+/* set beside PLP_RF_EMPTY when the verdict is the ENGINE's, not the polytope's: the fused kernel's Chebyshev LP ended neither
+ * optimal nor infeasible, or "optimal" at a centre that violates a row (rows a hair apart).  The fused reduce is not verified:
+ * ask plp_cheby_batch (verified) about such a polytope, as polytope_amd.polytope.reduce does. */
+#define PLP_RF_F1OPEN 32
 
 typedef struct plp_ctx plp_ctx;
 

@@ -600,6 +600,7 @@ int plpo_bounding_box(int m, int d, const double *A, const double *b, double *lb
 #define RF_EARLY 2    /* returned at neq <= nx+1 (minrep stays False)             */
 #define RF_MINREP 4   /* went through the redundancy LPs (minrep = True)          */
 #define RF_LPFAIL 8   /* a bounding-box LP came back with status 1/4 (RuntimeError) */
+#define PLPO_TOL_CENTRE 1e-6
 #define RF_F1OPEN 32  /* RF_EMPTY because the Chebyshev LP did not end optimal (unbounded / a limit): polytope_amd/csrc/plp_common.hpp */
 
 /* reduce (polytope.py:1053-1163) on ONE polytope that is not already minrep.
@@ -618,6 +619,19 @@ int plpo_reduce(int m, int d, const double *A, const double *b, double abs_tol,
     /* :1081 is_fulldim -> cheby_ball -> F1 */
     int st = cheby_impl(m, d, A, b, r, xc, NULL, 0);   /* the fused kernels' engine: not certified (see lp_certify) */
     ++*nlp;
+    if (st == ST_OPT && *r >= 0.0) {
+        /* The fused kernels start every later LP from this centre (centre-relative coordinates, ray presolve): an "optimal"
+         * centre that violates a row of the polytope -- the raw engine next to twin rows: tests/golden/found/lane93_t21_k20730.npz,
+         * radius right, centre 5 outside -- is refused by them and by this function alike (centre_off, csrc/plp_common.hpp). */
+        double xs = 1.0;
+        for (int k = 0; k < d; ++k) xs = fmax(xs, fabs(xc[k]));
+        for (int i = 0; i < m; ++i) {
+            double s = 0.0, n2 = 0.0;
+            for (int k = 0; k < d; ++k) { s = fma(A[i * d + k], xc[k], s); n2 = n2 + A[i * d + k] * A[i * d + k]; }
+            const double inv = 1.0 / sqrt(n2);
+            if (isfinite(inv) && (b[i] - s) * inv < -PLPO_TOL_CENTRE * fmax(fabs(b[i]) * inv, xs)) { st = ST_NUM; break; }
+        }
+    }
     if (!(st == ST_OPT && *r >= 0.0)) { *r = 0.0; for (int k = 0; k < d; ++k) xc[k] = NAN; }
     if (!(*r > abs_tol)) return RF_EMPTY | ((st != ST_OPT && st != ST_INFEAS) ? RF_F1OPEN : 0);
     /* :1087-1089 drop rows with b == inf */

@@ -25,6 +25,9 @@ enum : int {
     // (tests/golden/g23, case 33: the reference reduces that polytope, the engine called it empty).  The fused kernels run
     // unverified; with this flag the caller re-examines the few polytopes concerned through the verified stand-alone LPs
     // (polytope_amd/polytope.py: _reduce_many).
+    // Also set when the engine called its Chebyshev LP optimal at a centre that VIOLATES a row of the polytope (centre_off
+    // below; tests/golden/found/lane93_t21_k20730.npz: radius right, centre 5 outside -- a pivot next to twin rows): the
+    // presolve and the walks of F2 / F3 start from that centre, so nothing of the fused answer is usable.
     RF_F1OPEN = 32
 };
 
@@ -40,6 +43,20 @@ constexpr double TOL_D = 1e-9;      // reduced-cost tolerance
 // agrees with HiGHS (600 `dup` polytopes of (37,8): 4 wrong balls -> 0, largest difference 2e-8).
 constexpr double TOL_PIV = 1e-7;
 constexpr double TOL_FEAS = 1e-7;   // phase-1 infeasibility accepted (HiGHS primal tolerance)
+// The fused reduce's F1 answer is checked where the centre is first used: row i with raw = b_i - a_i.xc fails when
+// raw / |a_i| < -TOL_CENTRE max(|b_i| / |a_i|, max(1, |xc|_inf)) -- far above anything a healthy answer shows (1e-12) and far
+// below what a broken pivot leaves (1e-2 .. 10); identical in oracle/plp_oracle.c (plpo_reduce).
+constexpr double TOL_CENTRE = 1e-6;
+__host__ __device__ __forceinline__ bool centre_off(double raw, double inv_nrm, double bi, double xs) {
+    return isfinite(inv_nrm) & (raw * inv_nrm < -TOL_CENTRE * fmax(fabs(bi) * inv_nrm, xs));
+}
+template <int D>
+__host__ __device__ __forceinline__ double centre_scale(const double* xc) {
+    double xs = 1.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) xs = fmax(xs, fabs(xc[k]));
+    return xs;
+}
 constexpr double DEGEN_EPS = 1e-12; // step length regarded as degenerate
 constexpr int BLAND_AFTER = 6;      // consecutive degenerate pivots before Bland's rule
 

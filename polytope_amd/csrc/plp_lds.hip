@@ -640,7 +640,19 @@ __global__ __launch_bounds__(64) void reduce_lds_kernel(long long B, int m_max, 
         }
         const double rr = lds_x_of(D, m, d, lane);
         if (lane < d) R.xc[lane] = xcl;
-        const bool ball = (S.status == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        bool ball = (S.status == ST_OPT) & (rr >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        __syncthreads();
+        {   // a centre that violates a row (centre_off, plp_common.hpp) is no centre: RF_F1OPEN
+            double xs = 1.0;
+            for (int k = 0; k < d; ++k) xs = fmax(xs, fabs(R.xc[k]));
+            bool off = false;
+            for (int i = lane; i < m; i += 64) {
+                double sk = 0.0;
+                for (int k = 0; k < d; ++k) sk = fma(R.A[i * d + k], R.xc[k], sk);
+                off = off | centre_off(R.b[i] - sk, R.s[i], R.b[i], xs);
+            }
+            if (ball & (__ballot(off) != 0)) { ball = false; S.status = ST_NUM; }
+        }
         const bool fulldim = ball & (rr > abs_tol);
         int flags = fulldim ? 0 : (RF_EMPTY | (((S.status != ST_OPT) & (S.status != ST_INFEAS)) ? RF_F1OPEN : 0));
         int nlp = 1;

@@ -100,6 +100,14 @@ __device__ __forceinline__ void reduce_general_tile(unsigned char* smem_raw, con
             if (j < D) xc[j < D ? j : 0] = xj; else rr = xj;
         }
         ball = ok && rr >= 0.0;        // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        {   // a centre that violates a row (centre_off, plp_common.hpp) is no centre: RF_F1OPEN
+            double sk = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sk = fma(a[k], xc[k], sk);
+            if (ball && grp_ballot(has_row && centre_off(bi - sk, an_i, bi, centre_scale<D>(xc)), g) != 0) {
+                ball = false; f1open = true;
+            }
+        }
         fulldim = ball && rr > abs_tol;
     }
     // ---------------------------------------------------------------- dedupe (:1094-1110)

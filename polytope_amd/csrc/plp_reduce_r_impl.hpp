@@ -567,13 +567,25 @@ __device__ __forceinline__ void reduce_r_tile(
         }
         // dictionary translated to the Chebyshev centre: beta_i = b_i - a_i.xc.  s_i = a_i.xc replaces
         // 1/||a_i|| in LDS (only the owner lane touches its rows' slots from here on).
+        bool off = false;   // a row the centre violates (centre_off, plp_common.hpp)
+        const double xs = centre_scale<D>(xc);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             double sk = 0.0;
 #pragma unroll
             for (int kk = 0; kk < D; ++kk)
                 sk = fma(((has >> k) & 1u) ? myA[(row0 + k) * D + kk] : 0.0, ball ? xc[kk] : 0.0, sk);
+            const double bk = ((has >> k) & 1u) ? myb[row0 + k] : 0.0;
+            off = off | ((((has >> k) & 1u) != 0u) & centre_off(bk - sk, myan[row0 + k], bk, xs));
             myan[row0 + k] = sk;
+        }
+        if (ball & (grp_ballot(off, g) != 0)) {   // F1 "optimal" outside the polytope: nothing below may start from it
+            ball = false; fulldim = false; f1open = true;
+            if (valid & (g.gl == 0) & (!SPLIT || grp == 0)) {
+                r_out[tile + gib] = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) xc_out[(tile + gib) * D + k] = qnan;
+            }
         }
         // Rows that dropped out (never present, or removed by the dedupe) are zeroed in LDS -- A, b and
         // s -- so that the LP set-ups below load their rows without masking.  Only the owner lane writes
@@ -1413,8 +1425,17 @@ __global__ __launch_bounds__(64 * NW, PLP_REDUCE_WSPLIT_WAVES(D)) void reduce_ws
             const double xj = ob ? wide::uniform_lane(mine, __ffsll((long long)ob) - 1) : 0.0;
             if (j < D) xc1[j < D ? j : 0] = xj; else rr1 = xj;
         }
-        const bool ball1 = (st1 == ST_OPT) & (rr1 >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
-        const bool full1 = ball1 & (rr1 > abs_tol);
+        bool ball1 = (st1 == ST_OPT) & (rr1 >= 0.0);  // cheby_ball: status 0 and r >= 0 (:1289-1293)
+        bool full1 = ball1 & (rr1 > abs_tol);
+        {   // a centre that violates a row (centre_off, plp_common.hpp) is no centre: RF_F1OPEN
+            double sk = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) sk = fma(has ? myA[lane * D + kk] : 0.0, xc1[kk], sk);
+            const double bk = has ? myb[lane] : 0.0;
+            if (ball1 & (__ballot(has & centre_off(bk - sk, myan[lane], bk, centre_scale<D>(xc1))) != 0)) {
+                ball1 = false; full1 = false; st1 = ST_NUM;
+            }
+        }
         if (lane == 0) {
             r_out[pg] = ball1 ? rr1 : 0.0;
 #pragma unroll

@@ -47,7 +47,7 @@ ABS_TOL = 1e-7
 STRICT_REFERENCE_QUIRKS = True
 
 _RF_EMPTY, _RF_EARLY, _RF_MINREP, _RF_LPFAIL = 1, 2, 4, 8
-_RF_F1OPEN = 32   # empty because the fused kernel's Chebyshev LP did not end optimal (csrc/plp_common.hpp): re-examined below
+_RF_F1OPEN = 32   # empty because the fused kernel's Chebyshev LP did not end optimal, or ended outside the polytope (csrc/plp_common.hpp): re-examined below
 _MAX_ROWS, _MAX_DIM = 64, 16
 _RDIFF_NATIVE = True   # region_diff's search in the library (False: the host loop over batched calls, for A/B runs)
 

@@ -82,6 +82,16 @@ def main():
                 recs.append(dict(fam=fam, A=A, b=b, keep=k0[0], empty=k0[1], minrep=k0[2], r=k0[3], r_tight=k1[3],
                                  lp_trouble=k0[4] + k1[4],
                                  pinned=bool((k0[0] == k1[0]).all() and k0[1] == k1[1] and k0[2] == k1[2] and k0[4] + k1[4] == 0)))
+    # polytopes the soaks found (tests/golden/found/*.npz: inputs only), family "found"
+    import glob
+    for f in sorted(glob.glob(os.path.join(HERE, "found", "*.npz"))):
+        z = np.load(f)
+        A, b = z["A"], z["b"]
+        k0 = reference_reduce(A, b, False)
+        k1 = reference_reduce(A, b, True)
+        recs.append(dict(fam="found", A=A, b=b, keep=k0[0], empty=k0[1], minrep=k0[2], r=k0[3], r_tight=k1[3],
+                         lp_trouble=k0[4] + k1[4],
+                         pinned=bool((k0[0] == k1[0]).all() and k0[1] == k1[1] and k0[2] == k1[2] and k0[4] + k1[4] == 0)))
     mmax = max(r["A"].shape[0] for r in recs)
     dmax = max(r["A"].shape[1] for r in recs)
 
