@@ -89,13 +89,26 @@ struct VArgs {
 
 template <int VN>
 struct VShape {
-    static constexpr int LPB = VN <= 5 ? 64 : (VN <= 9 ? 16 : 8);   // (LDS: 816 B / 2 KB / 6 KB of work arrays per LP)
+#ifndef PLP_VF_LPB9
+#define PLP_VF_LPB9 8
+#endif
+#ifndef PLP_VF_LPB17
+#define PLP_VF_LPB17 4
+#endif
+    static constexpr int LPB = VN <= 5 ? 64 : (VN <= 9 ? PLP_VF_LPB9 : PLP_VF_LPB17);   // (LDS: 2 KB / 6 KB of work arrays per LP; 8 / 16 lanes per LP: measured against 4 / 8 and 16 / 32)
     static constexpr int GSL = VBLK / LPB;
 };
 
+// (-DPLP_VF_STOP=k: the kernel ends before stage k + 1 -- timing builds only, scripts/debug/verify_stages.sh)
+#ifdef PLP_VF_STOP
+#define PLP_VF_STAGE(k) if (PLP_VF_STOP == (k)) return;
+#else
+#define PLP_VF_STAGE(k)
+#endif
 template <int KIND, int VN>
 __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     constexpr int LPB = VShape<VN>::LPB, GSL = VShape<VN>::GSL;
+    static_assert(GSL >= 2, "two lanes for the side-by-side solves");
     using CT = Cert<VN, LPB>;
     using Vec = typename CT::Vec;
     __shared__ double s_ws[CT::WS_DOUBLES * LPB];
@@ -128,43 +141,21 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     // ---- leader: what is to be done, the point / basis into the workspace
     if (gl == 0) {
         int mode = 0;
-        const Vec xv = CT::at(ws, CT::O_X), bas = CT::at(ws, CT::O_BAS);
         if (valid) {
             if constexpr (KIND == LP_BOXSIDE) {
                 if (a.status[p] == 0) {   // (status 1: handed to the caller's generic LPs, which pass this kernel as LP_GENERIC)
                     const double val = ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)];
                     if (!(fabs(val) < 1e300)) mode = 3;   // unbounded: the careful engine decides
-                    else if (a.xfin) {
-                        for (int j = 0; j < n; ++j) xv[j] = a.xfin[((size_t)p * 2 * n + side) * n + j];
-                        mode = 1;
-                    } else {
-                        for (int j = 0; j < n; ++j) {
-                            xv[j] = a.centre[(size_t)p * n + j];
-                            bas[j] = (double)a.basis8[((size_t)p * 2 * n + side) * n + j];
-                        }
-                        mode = 2;
-                    }
+                    else mode = a.xfin ? 1 : 2;
                 }
             } else {
                 const int st = a.status[p];
                 // (infeasible: phase 1's verdict, read with a 1e-7 margin -- not a question of rounding; it stands)
-                if (st == ST_OPT) {
-                    if constexpr (KIND == LP_CHEBY) {
-                        for (int j = 0; j < n - 1; ++j) xv[j] = a.x[(size_t)p * (n - 1) + j];
-                        xv[n - 1] = a.fun[p];
-                    } else {
-                        for (int j = 0; j < n; ++j) xv[j] = a.x[(size_t)p * n + j];
-                    }
-                    mode = 1;
-                } else if (st != ST_INFEAS) {
+                if (st == ST_OPT) mode = 1;
+                else if (st != ST_INFEAS) {
                     mode = 3;
                 }
             }
-        }
-        if (mode == 1) {
-            bool fin;
-            s_xs[li] = CT::x_scale(lp, xv, &fin);
-            if (!fin) mode = 3;
         }
         s_mode[li] = mode;
         s_cn[li] = 0;
@@ -172,6 +163,32 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         s_bad[li] = 0u;
     }
     __syncthreads();
+    // ---- the engine's point / basis into the workspace, an entry per lane in turn (one lane alone pays a global-memory round
+    // trip per entry: the loop does not unroll)
+    if (s_mode[li] == 1 || s_mode[li] == 2) {
+        const Vec xv = CT::at(ws, CT::O_X), bas = CT::at(ws, CT::O_BAS);
+        for (int j = gl; j < n; j += GSL) {
+            if constexpr (KIND == LP_BOXSIDE) {
+                if (s_mode[li] == 1) xv[j] = a.xfin[((size_t)p * 2 * n + side) * n + j];
+                else {
+                    xv[j] = a.centre[(size_t)p * n + j];
+                    bas[j] = (double)a.basis8[((size_t)p * 2 * n + side) * n + j];
+                }
+            } else if constexpr (KIND == LP_CHEBY) {
+                xv[j] = j < n - 1 ? a.x[(size_t)p * (n - 1) + j] : a.fun[p];
+            } else {
+                xv[j] = a.x[(size_t)p * n + j];
+            }
+        }
+    }
+    __syncthreads();
+    if ((gl == 0) & (s_mode[li] == 1)) {
+        bool fin;
+        s_xs[li] = CT::x_scale(lp, CT::at(ws, CT::O_X), &fin);
+        if (!fin) s_mode[li] = 3;
+    }
+    __syncthreads();
+    PLP_VF_STAGE(1)
     // ---- pass 1 (a basis is to be read off x): the candidate rows, unsorted, into the workspace's list
     if (s_mode[li] == 1) {
         const Vec xv = CT::at(ws, CT::O_X), cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         }
     }
     __syncthreads();
+    PLP_VF_STAGE(2)
     // ---- leader: the basis
     if ((gl == 0) & (s_mode[li] == 1)) {
         const Vec cs = CT::at(ws, CT::O_CS), ci = CT::at(ws, CT::O_CI);
@@ -206,19 +224,24 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         if (!CT::select_basis(lp, ws, cn)) s_mode[li] = 3;
     }
     __syncthreads();
+    PLP_VF_STAGE(3)
     // ---- the basis matrix, a row per lane in turn; its factorisation with the row updates of an elimination step shared by
     // the LP's lanes (the leader finds the pivot and swaps, a barrier, every lane takes every GSL-th row below it, a barrier)
     const bool fac = (s_mode[li] == 1) | (s_mode[li] == 2);   // (the same for the lanes of an LP; the barriers are workgroup-wide)
     if (fac) {
         bool okr = true;
-        for (int k = gl; k < n; k += GSL) okr = okr & CT::basis_row(lp, true, ws, k);
+        for (int k = gl; k < n; k += GSL) {
+            okr = okr & CT::basis_row(lp, true, ws, k);
+            CT::cost_entry(lp, ws, k);
+        }
         if (!okr) atomicOr(&s_bad[li], 2u);
     }
     __syncthreads();
+    PLP_VF_STAGE(4)
     double big = 0.0, pmin = 1e300;
     bool live = fac && !(s_bad[li] & 2u);
     if (live & (gl == 0)) {
-        big = CT::lu_begin(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM));
+        big = CT::lu_begin(n, CT::at(ws, CT::O_GM), CT::at(ws, CT::O_PERM));
         if (!(big > 0.0)) atomicOr(&s_bad[li], 2u);
     }
     __syncthreads();
@@ -233,10 +256,18 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         if (fac && !(s_bad[li] & 2u)) CT::lu_rows(n, k, CT::at(ws, CT::O_LU), gl, GSL);
         __syncthreads();
     }
-    // ---- leader: vertex, value, multipliers
+    PLP_VF_STAGE(5)
+    // ---- the two plain solves side by side (lane 0: the vertex, lane 1: the multipliers; one instruction stream), then the
+    // leader: refinement where the basis is ill-conditioned, value, the multipliers' signs
+    if (fac && !(s_bad[li] & 2u) && gl < 2) {
+        const bool tr = gl == 1;
+        CT::lu_solve_any(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), CT::at(ws, tr ? CT::O_V : CT::O_RHS),
+                         CT::at(ws, tr ? CT::O_Y : CT::O_Z), CT::at(ws, tr ? CT::O_DZ : CT::O_T), tr);
+    }
+    __syncthreads();
     if ((gl == 0) & fac) {
         double f = 0.0, zs = 1.0;
-        if (!(s_bad[li] & 2u) && CT::vertex_and_dual_finish(lp, true, ws, pmin / big, &f, &zs)) {
+        if (!(s_bad[li] & 2u) && CT::vertex_and_dual_finish(lp, true, ws, pmin / big, &f, &zs, true)) {
             s_xs[li] = zs;
             s_fun[li] = f;
             s_ok[li] = 1;
@@ -244,6 +275,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         s_bad[li] = 0u;
     }
     __syncthreads();
+    PLP_VF_STAGE(6)
     // ---- pass 2: every row against the polished vertex
     if (s_ok[li]) {
         const Vec z = CT::at(ws, CT::O_Z);
@@ -257,7 +289,9 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     if (s_ok[li] & (s_bad[li] == 0u)) {
         const Vec z = CT::at(ws, CT::O_Z);
         const double f = s_fun[li];
-        const bool out = range_rule(lp, V_OPT, f, s_xs[li]) != V_OPT;
+        double cmax = 0.0;   // (-c is in the workspace)
+        for (int j = 0; j < n; ++j) cmax = fmax(cmax, fabs(CT::at(ws, CT::O_V)[j]));
+        const bool out = range_rule_c(lp, V_OPT, f, s_xs[li], cmax) != V_OPT;
         if constexpr (KIND == LP_BOXSIDE) {
             const double pinf = __longlong_as_double(0x7ff0000000000000ll);
             ((side & 1) ? a.fun : a.x)[p * n + (side >> 1)] = out ? ((side & 1) ? pinf : -pinf) : z[side >> 1];

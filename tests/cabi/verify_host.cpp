@@ -78,4 +78,26 @@ int plpv_careful(int kind, int m, int n, int side, const double* c, const double
     *fun = f;
     return st;
 }
+
+// lu_solve_any (the device's side-by-side solves) against lu_solve / lu_solve_t on the n x n matrix M (row-major): number of
+// entries of the two solutions that differ in any bit (0 expected), -1 if M is singular
+int plpv_solve_any_check(int n, const double* M, const double* r) {
+    using CT = Cert<VNMAX, 1>;
+    double ws[CT::WS_DOUBLES], za[VNMAX], zb[VNMAX];
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j) ws[CT::O_LU + k * VNMAX + j] = M[k * n + j];
+    double pr;
+    if (!CT::lu_factor(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), &pr)) return -1;
+    for (int j = 0; j < n; ++j) ws[CT::O_RHS + j] = r[j];
+    int bad = 0;
+    for (int trans = 0; trans < 2; ++trans) {
+        if (trans) CT::lu_solve_t(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), CT::at(ws, CT::O_RHS), CT::at(ws, CT::O_Z), CT::at(ws, CT::O_T));
+        else CT::lu_solve(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), CT::at(ws, CT::O_RHS), CT::at(ws, CT::O_Z), CT::at(ws, CT::O_T));
+        for (int j = 0; j < n; ++j) za[j] = ws[CT::O_Z + j];
+        CT::lu_solve_any(n, CT::at(ws, CT::O_LU), CT::at(ws, CT::O_PERM), CT::at(ws, CT::O_RHS), CT::at(ws, CT::O_Y), CT::at(ws, CT::O_DZ), trans != 0);
+        for (int j = 0; j < n; ++j) zb[j] = ws[CT::O_Y + j];
+        for (int j = 0; j < n; ++j) bad += memcmp(&za[j], &zb[j], sizeof(double)) != 0;
+    }
+    return bad;
+}
 }

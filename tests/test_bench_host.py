@@ -44,5 +44,6 @@ def test_gpus_n_without_a_launcher_starts_n_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-parity"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode != 0
-    assert p.stderr.count("needs a MI355X") == 2, p.stderr[-2000:]
-    assert "stopping the other ranks" in p.stderr or p.stderr.count("needs a MI355X") == 2
+    # (each rank says so; on a loaded host the launcher may stop the slower one before it got to say it)
+    n = p.stderr.count("needs a MI355X")
+    assert n == 2 or (n == 1 and "stopping the other ranks" in p.stderr), p.stderr[-2000:]

@@ -31,6 +31,7 @@ def vh(oracle, tmp_path_factory):
     L.plpv_certify_from_x.argtypes = [C.c_int] * 4 + [dp] * 6 + [ip]
     L.plpv_certify_basis.argtypes = [C.c_int] * 4 + [dp] * 3 + [C.c_int, ip, dp, dp, dp]
     L.plpv_careful.argtypes = [C.c_int] * 4 + [dp] * 5 + [ip]
+    L.plpv_solve_any_check.argtypes = [C.c_int, dp, dp]
     OL = oracle.lib()
     OL.plpo_lp_solve_raw.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip]
     OL.plpo_lp_solve_q.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip]
@@ -127,3 +128,17 @@ def test_certificate_and_careful_engine_against_the_oracle(vh, fam):
     # bases read off x: degenerate vertices may go to the careful engine
     print(fam, "LPs", n_lp, "certified from the basis", n_cert, "; optimal ones read off x:", n_xcert, "of", n_xtry)
     assert n_xcert >= (0.5 if fam in ("lattice", "dup") else 0.97) * n_xtry
+
+
+def test_side_by_side_solves_give_the_serial_ones_bit_for_bit(vh):
+    """The device solves M z = rhs and M' y = -c on two lanes with ONE routine whose instruction stream does not depend on which
+    of the two it is (`lu_solve_any`); its results must be those of the serial `lu_solve` / `lu_solve_t` in every bit."""
+    L, _ = vh
+    rng = np.random.default_rng(11)
+    for n in range(1, 18):
+        for rep in range(20):
+            M = rng.standard_normal((n, n))
+            if rep % 3 == 0 and n > 1:
+                M[rng.integers(n)] = np.eye(n)[rng.integers(n)]      # a free variable's row
+            r = rng.standard_normal(n)
+            assert L.plpv_solve_any_check(n, _p(np.ascontiguousarray(M)), _p(r)) in (0, -1), (n, rep)
