@@ -48,6 +48,9 @@ constexpr double TOL_FEAS = 1e-7;   // phase-1 infeasibility accepted (HiGHS pri
 // below what a broken pivot leaves (1e-2 .. 10); identical in oracle/plp_oracle.c (plpo_reduce).
 constexpr double TOL_CENTRE = 1e-6;
 __host__ __device__ __forceinline__ bool centre_off(double raw, double inv_nrm, double bi, double xs) {
+#if defined(PLP_NO_CENTRE_CHECK)   // (A/B builds only: what the test costs)
+    return false;
+#endif
     return isfinite(inv_nrm) & (raw * inv_nrm < -TOL_CENTRE * fmax(fabs(bi) * inv_nrm, xs));
 }
 template <int D>

@@ -283,25 +283,38 @@ __device__ __forceinline__ void reduce_lane_tile(
     // The LPs below live in centre-relative coordinates: a_i.x' <= beta_i, beta_i = max(b_i - a_i.xc, 0), which replaces
     // 1/||a_i|| in LDS -- every LP of the polytope reads it as it is (the lane-group kernels keep s_i = a_i.xc and form
     // b_i - s_i in every LP set-up: the same number)
-    bool off = false;   // a row the centre violates (centre_off, plp_common.hpp)
-    const double xs = centre_scale<D>(xc);
+    // A centre that violates a row (centre_off, plp_common.hpp) is no centre.  An interior centre leaves every b_i - a_i.xc
+    // positive, so the test proper runs only in a wavefront that saw a negative one (one compare per row otherwise: the full
+    // test on every row cost the bench 1.0 %, same-box A/B).
+    double raw[R];
+    bool neg = false;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         double sk = 0.0;
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) sk = fma(((has >> k) & 1u) ? OA(k, kk) : 0.0, ball ? xc[kk] : 0.0, sk);
-        const double bk = ((has >> k) & 1u) ? OB(k) : 0.0;
-        off = off | ((((has >> k) & 1u) != 0u) & centre_off(bk - sk, ON(k), bk, xs));
-        ON(k) = fmax(bk - sk, 0.0);
+        raw[k] = (((has >> k) & 1u) ? OB(k) : 0.0) - sk;
+        neg = neg | (raw[k] < 0.0);
     }
-    if (ball & (grp_ballot(off, g) != 0)) {   // F1 "optimal" outside the polytope: nothing below may start from it
-        ball = false; fulldim = false; f1open = true;
-        if (!BBOX && (valid & (g.gl == 0))) {
-            (r_out + tile)[gib] = 0.0;
+    if (__any(neg & ball)) {
+        bool off = false;
+        const double xs = centre_scale<D>(xc);
 #pragma unroll
-            for (int k = 0; k < D; ++k) (xc_out + tile * D)[gib * D + k] = qnan;
+        for (int k = 0; k < R; ++k) {
+            const double bk = ((has >> k) & 1u) ? OB(k) : 0.0;
+            off = off | ((((has >> k) & 1u) != 0u) & centre_off(raw[k], ON(k), bk, xs));
+        }
+        if (ball & (grp_ballot(off, g) != 0)) {   // F1 "optimal" outside the polytope: nothing below may start from it
+            ball = false; fulldim = false; f1open = true;
+            if (!BBOX && (valid & (g.gl == 0))) {
+                (r_out + tile)[gib] = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) (xc_out + tile * D)[gib * D + k] = qnan;
+            }
         }
     }
+#pragma unroll
+    for (int k = 0; k < R; ++k) ON(k) = fmax(raw[k], 0.0);
     // rows that dropped out (never present, or removed by the dedupe / the prefilter) are zeroed -- A, b and s -- by their
     // owner lane: a zero row never stops a ray and passes every presolve test
     auto zero_dead = [&](unsigned alive) {

@@ -651,6 +651,9 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
     const Vec Q = at(ws, O_LU), v = at(ws, O_V), ci = at(ws, O_CI);  // Q: orthonormal rows spanning the accepted rows
     int nb = 0;
     if (cn > KC) return false;
+#if defined(PLP_SB_STOP)
+    if (PLP_SB_STOP == 0) return false;   // (timing builds)
+#endif
     if (cn == n) {
         // exactly n candidates -- a non-degenerate vertex, the generic case -- ARE the basis; should they be dependent, the
         // factorisation says so (vertex_and_dual: singular) and the LP goes to the careful engine.  Saves the O(n^3)
@@ -759,6 +762,9 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
         for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
         basis[nb++] = (double)bi;
     }
+#if defined(PLP_SB_STOP)
+    if (PLP_SB_STOP == 1) return false;   // (timing builds)
+#endif
     if (nb < n && 2 * nb <= n) {
         // Few rows, many free variables (an optimum on a face: every LP whose cost is a coordinate, every box LP of a box): the
         // free variables are the columns that elimination with column pivoting on the nb accepted rows does NOT pivot on -- any
