@@ -44,6 +44,8 @@ constexpr int LANE_MAX_ITERS = 48;   // steps + drops of one LP before it is han
 // it by t a.d, a few 1e-11; a projected gradient below LANE_TOL_D |c| counts as zero: the optimum is off by no more than that
 // times the distance left.  (1e-9 for both, the first version, showed as 2e-10 on 3 of 120 000 box LPs at d = 4.)
 constexpr double LANE_TOL_D = 1e-11, LANE_TOL_PIV = 1e-11;
+// what cancellation leaves of a multiplier's numerator, as a multiple of the sum of its terms' magnitudes (walk4: 64 ulps)
+constexpr double LANE_M_NOISE = 64 * 2.220446049250313e-16;
 
 struct Lp3 {
     double x0, x1, x2;     // x' (relative to the Chebyshev centre)
@@ -323,6 +325,7 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
     if (go && !(cn1 > 0.0)) S.status = ST_OPT;
     while (ANY(S.status < 0)) {
         const bool run = S.status < 0;
+        bool dropped = false;   // this pass ended by taking a row off the list (no step)
         double d0 = -c0, d1 = -c1, d2 = -c2, d3 = -c3;
         double n00 = 0, n01 = 0, n02 = 0, n03 = 0, n10 = 0, n11 = 0, n12 = 0, n13 = 0;
         double n20 = 0, n21 = 0, n22 = 0, n23 = 0, n30 = 0, n31 = 0, n32 = 0, n33 = 0;
@@ -414,38 +417,40 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
                 if (S.nact == 0) {
                     S.status = ST_OPT;
                 } else if (S.nact <= 3) {
+                    // The m_j are sums of products that cancel (m_j = 0 for a row the cost does not lean on): what is left of
+                    // the cancellation -- a few ulps of the terms -- is NOT a negative multiplier, however small det makes the
+                    // tolerance (three rows of norms 2.3 / 0.1 / 2.2, det 2.7e-6: m_1 = 1.6e-16 against a tolerance of 2.7e-17;
+                    // scripts/soak_lane.py, seed 112, family `scaled`).  Hence the floor under each tolerance.
                     const double tol = LANE_TOL_D * det * cn1;
+                    double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+                    if (S.nact == 2) {
+                        f0 = fabs(r0 * g11) + fabs(r1 * g01);
+                        f1 = fabs(r1 * g00) + fabs(r0 * g01);
+                    } else if (S.nact == 3) {
+                        const double B00 = fabs(g11 * g22) + g12 * g12, B01 = fabs(g02 * g12) + fabs(g01 * g22), B02 = fabs(g01 * g12) + fabs(g02 * g11);
+                        const double B11 = fabs(g00 * g22) + g02 * g02, B12 = fabs(g01 * g02) + fabs(g00 * g12), B22 = fabs(g00 * g11) + g01 * g01;
+                        f0 = B00 * fabs(r0) + B01 * fabs(r1) + B02 * fabs(r2);
+                        f1 = B01 * fabs(r0) + B11 * fabs(r1) + B12 * fabs(r2);
+                        f2 = B02 * fabs(r0) + B12 * fabs(r1) + B22 * fabs(r2);
+                    }
                     const double a0 = -m0 * w0, a1 = S.nact >= 2 ? -m1 * w1 : 0.0, a2 = S.nact >= 3 ? -m2 * w2 : 0.0;
-                    if (a0 >= -tol && a1 >= -tol && a2 >= -tol) {
+                    const double t0 = fmax(tol, LANE_M_NOISE * f0 * w0), t1 = fmax(tol, LANE_M_NOISE * f1 * w1), t2 = fmax(tol, LANE_M_NOISE * f2 * w2);
+                    if (a0 >= -t0 && a1 >= -t1 && a2 >= -t2) {
                         S.status = ST_OPT;
                     } else {
+                        // The row furthest below its tolerance goes.  The pass ends there: the next one forms the direction on
+                        // the remaining rows with the care the top of the loop takes (second projection where the cost lies
+                        // nearly in their span).  Written out here as  sum k_j n_j - dd c  it was, for a cost PARALLEL to a row
+                        // that stays (a box LP against its own box row), what rounding leaves of a zero vector -- 1e-15 long,
+                        // and the walk followed it for t = 1.8e15 to another facet (same polytope: box value 0.02 for -1.26).
                         int j = 0;
-                        double am = a0;
-                        if (a1 < am) { am = a1; j = 1; }
-                        if (a2 < am) { am = a2; j = 2; }
-                        // remove row j from the list; the direction is the projection onto the remaining rows
-                        if (j == 0) { S.w0 = S.w1; n00 = n10; n01 = n11; n02 = n12; n03 = n13; }
-                        if (j <= 1) { S.w1 = S.w2; n10 = n20; n11 = n21; n12 = n22; n13 = n23; }
+                        double am = a0 + t0;
+                        if (a1 + t1 < am) { am = a1 + t1; j = 1; }
+                        if (a2 + t2 < am) { am = a2 + t2; j = 2; }
+                        if (j == 0) S.w0 = S.w1;
+                        if (j <= 1) S.w1 = S.w2;
                         S.nact -= 1;
-                        if (S.nact == 0) {
-                            d0 = -c0; d1 = -c1; d2 = -c2; d3 = -c3;
-                        } else {
-                            const double h00 = dot4(n00, n01, n02, n03, n00, n01, n02, n03);
-                            const double q0 = dot4(c0, c1, c2, c3, n00, n01, n02, n03);
-                            double dd = h00, k0 = q0, k1 = 0.0;
-                            if (S.nact == 2) {
-                                const double h11 = dot4(n10, n11, n12, n13, n10, n11, n12, n13);
-                                const double h01 = dot4(n00, n01, n02, n03, n10, n11, n12, n13);
-                                const double q1 = dot4(c0, c1, c2, c3, n10, n11, n12, n13);
-                                dd = fma(h00, h11, -(h01 * h01));
-                                k0 = fma(q0, h11, -(q1 * h01));
-                                k1 = fma(q1, h00, -(q0 * h01));
-                            }
-                            d0 = fma(k1, n10, fma(k0, n00, -(dd * c0)));
-                            d1 = fma(k1, n11, fma(k0, n01, -(dd * c1)));
-                            d2 = fma(k1, n12, fma(k0, n02, -(dd * c2)));
-                            d3 = fma(k1, n13, fma(k0, n03, -(dd * c3)));
-                        }
+                        dropped = true;
                     }
                 } else {
                     // a vertex: u_j = gcross(the other three rows) is orthogonal to them, N^-1[:, j] = u_j / (n_j.u_j),
@@ -491,7 +496,11 @@ PLP_LANE_FN void walk4(Lp4& S, const double c0, const double c1, const double c2
                 }
             }
         }
-        const bool step = S.status < 0;
+        if (dropped) {   // (counts as a pass: a chain of drops ends like a chain of steps)
+            ++S.iters;
+            if (S.iters >= LANE_MAX_ITERS) S.status = ST_RETRY;
+        }
+        const bool step = (S.status < 0) & !dropped;
         const double dn1 = fabs(d0) + fabs(d1) + fabs(d2) + fabs(d3);
         const double tolp = LANE_TOL_PIV * dn1;
         double bs = 1.0, bd = 0.0;

@@ -641,9 +641,9 @@ static PLP_HD bool row_candidate(const LpView& lp, int i, Vec x, double xs, doub
     *slack = s;
     return (gmax > 0.0) & (s <= 1e-9 * fmax(gmax * xs, fabs(lp.hh(i))));
 }
-// The candidates in order, as long as they are linearly independent of the ones taken so far (modified Gram-Schmidt; a copy
-// of a taken row adds nothing to the cone they span); free variables x_j held where they are complete the basis when x lies
-// on a face rather than at a vertex.  At a degenerate vertex the choice may not be the dual-feasible one: the certificate
+// The candidates in order, as long as they are linearly independent of the ones taken so far (a copy of a taken row adds
+// nothing to the cone they span: elimination with column pivoting in the LDS instances, modified Gram-Schmidt in the register
+// ones); free variables x_j held where they are complete the basis when x lies on a face rather than at a vertex.  At a degenerate vertex the choice may not be the dual-feasible one: the certificate
 // then fails and the LP goes to the careful engine.  (Q shares the workspace of the factorisation, which comes after it.)
 static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
     const int n = ncols(lp);
@@ -651,9 +651,6 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
     const Vec Q = at(ws, O_LU), v = at(ws, O_V), ci = at(ws, O_CI);  // Q: orthonormal rows spanning the accepted rows
     int nb = 0;
     if (cn > KC) return false;
-#if defined(PLP_SB_STOP)
-    if (PLP_SB_STOP == 0) return false;   // (timing builds)
-#endif
     if (cn == n) {
         // exactly n candidates -- a non-degenerate vertex, the generic case -- ARE the basis; should they be dependent, the
         // factorisation says so (vertex_and_dual: singular) and the LP goes to the careful engine.  Saves the O(n^3)
@@ -737,89 +734,46 @@ static PLP_HD bool select_basis(const LpView& lp, double* ws, int cn) {
         }
         return nb == n;
     }
+    // One elimination with column pivoting over the candidates in their order: a row is reduced by the rows taken so far (it
+    // keeps zeros in their pivot columns), what is left of it outside those columns decides -- below 1e-6 of the row: dependent
+    // (a twin of a taken row adds nothing to the cone), otherwise taken, its largest entry there the next pivot column.  The
+    // columns that are never pivoted on are the free variables.  O(nb^2 n / 2) on the leader lane, no dot products; it replaced
+    // a modified Gram-Schmidt plus a separate completion (0.18 of the 0.25 ms a generic (64,16) LP batch spent in this kernel).
+    const Vec taken = at(ws, O_T), pcol = at(ws, O_RR);
+    (void)v;
+    for (int j = 0; j < n; ++j) taken[j] = 0.0;
     for (int q0 = 0; q0 < cn && nb < n; ++q0) {
         const int bi = (int)ci[q0];
-        double nrm0 = 0.0, nrm1 = 0.0;
+        double rmax = 0.0;
         {   // (the row from global memory, four loads in flight: see row_slack)
             int j = 0;
             for (; j + 4 <= n; j += 4) {
                 const double g0 = lp.g(bi, j), g1 = lp.g(bi, j + 1), g2 = lp.g(bi, j + 2), g3 = lp.g(bi, j + 3);
-                v[j] = g0; v[j + 1] = g1; v[j + 2] = g2; v[j + 3] = g3;
-                nrm0 = fma(g0, g0, nrm0);
-                nrm0 = fma(g1, g1, nrm0);
-                nrm0 = fma(g2, g2, nrm0);
-                nrm0 = fma(g3, g3, nrm0);
+                Q[nb * VN + j] = g0; Q[nb * VN + j + 1] = g1; Q[nb * VN + j + 2] = g2; Q[nb * VN + j + 3] = g3;
+                rmax = fmax(fmax(rmax, fmax(fabs(g0), fabs(g1))), fmax(fabs(g2), fabs(g3)));
             }
-            for (; j < n; ++j) { const double g = lp.g(bi, j); v[j] = g; nrm0 = fma(g, g, nrm0); }
+            for (; j < n; ++j) { const double g = lp.g(bi, j); Q[nb * VN + j] = g; rmax = fmax(rmax, fabs(g)); }
         }
         for (int q = 0; q < nb; ++q) {
-            const double dq = -dot_sub(-0.0, Q, q * VN, 1, v, 0, n);   // (sum_j Q[q][j] v[j], the fmas in index order)
-            row_axpy(v, 0, Q, q * VN, dq, 0, n);
+            const int cq = (int)pcol[q];
+            const double f = Q[nb * VN + cq] / Q[q * VN + cq];
+            row_axpy(Q, nb * VN, Q, q * VN, f, 0, n);
+            Q[nb * VN + cq] = 0.0;
         }
-        nrm1 = -dot_sub(-0.0, v, 0, 1, v, 0, n);
-        if (!(nrm1 > 1e-12 * nrm0)) continue;  // (1e-6 of its length: dependent on the rows taken so far)
-        const double inv = 1.0 / sqrt(nrm1);
-        for (int j = 0; j < n; ++j) Q[nb * VN + j] = v[j] * inv;
+        int pj = -1;
+        double pa = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double a = fabs(Q[nb * VN + j]);
+            if ((taken[j] == 0.0) & (a > pa)) { pa = a; pj = j; }
+        }
+        if (pj < 0 || !(pa > 1e-6 * rmax)) continue;
+        taken[pj] = 1.0;
+        pcol[nb] = (double)pj;
         basis[nb++] = (double)bi;
     }
-#if defined(PLP_SB_STOP)
-    if (PLP_SB_STOP == 1) return false;   // (timing builds)
-#endif
-    if (nb < n && 2 * nb <= n) {
-        // Few rows, many free variables (an optimum on a face: every LP whose cost is a coordinate, every box LP of a box): the
-        // free variables are the columns that elimination with column pivoting on the nb accepted rows does NOT pivot on -- any
-        // complement of a non-singular nb x nb block completes the basis, and this one costs O(nb^2 n) where adding unit vectors
-        // one by one costs O((n - nb) nb n) in dependent LDS round trips (0.26 of 0.33 ms per 5 000 LPs of (64,16) with c = e_0).
-        // Q is done with afterwards (the factorisation takes its space): eliminated in place; taken columns are marked in r2.
-        const Vec taken = at(ws, O_T);
-        for (int j = 0; j < n; ++j) taken[j] = 0.0;
-        for (int k = 0; k < nb; ++k) {
-            int pj = -1;
-            double pa = 0.0;
-            for (int j = 0; j < n; ++j) {
-                const double a = fabs(Q[k * VN + j]);
-                if ((taken[j] == 0.0) & (a > pa)) { pa = a; pj = j; }
-            }
-            if (pj < 0 || !(pa > 1e-9)) return false;   // (orthonormal rows: a pivot this small means the growth got out of hand)
-            taken[pj] = 1.0;
-            const double inv = 1.0 / Q[k * VN + pj];
-            for (int i = k + 1; i < nb; ++i) row_axpy(Q, i * VN, Q, k * VN, Q[i * VN + pj] * inv, 0, n);
-        }
-        for (int j = 0; j < n; ++j)
-            if (taken[j] == 0.0) basis[nb++] = (double)(-1 - j);
-        return nb == n;
-    }
-    if (nb < n) {  // few free variables: unit vectors one by one, the most independent of the rows taken so far first
-        // |e_j - Q'Q e_j|^2 = 1 - sum_q Q[q][j]^2, kept up to date as rows join
-        const Vec r2 = at(ws, O_T);
-        for (int j = 0; j < n; ++j) {
-            double r = 1.0;
-            for (int q = 0; q < nb; ++q) r = fma(-Q[q * VN + j], Q[q * VN + j], r);
-            r2[j] = r;
-        }
-        while (nb < n) {
-            int bj = -1;
-            double bn = 0.0;
-            for (int j0 = 0; j0 < n; ++j0) {
-                const double r = r2[j0];
-                if (r > bn) { bn = r; bj = j0; }
-            }
-            if (bj < 0 || !(bn > 1e-12)) return false;
-            double nrm1 = 0.0;
-            for (int j = 0; j < n; ++j) v[j] = (j == bj) ? 1.0 : 0.0;
-            for (int q = 0; q < nb; ++q) row_axpy(v, 0, Q, q * VN, Q[q * VN + bj], 0, n);
-            for (int j = 0; j < n; ++j) nrm1 = fma(v[j], v[j], nrm1);
-            if (!(nrm1 > 1e-12)) return false;
-            const double inv = 1.0 / sqrt(nrm1);
-            for (int j = 0; j < n; ++j) {
-                const double qj = v[j] * inv;
-                Q[nb * VN + j] = qj;
-                r2[j] = fma(-qj, qj, r2[j]);
-            }
-            r2[bj] = 0.0;
-            basis[nb++] = (double)(-1 - bj);
-        }
-    }
+    for (int j = 0; j < n; ++j)
+        if (taken[j] == 0.0) basis[nb++] = (double)(-1 - j);
+    if (nb != n) return false;
     return true;
 }
 static PLP_HD double x_scale(const LpView& lp, Vec x, bool* finite) {

@@ -245,3 +245,33 @@ def test_walk4_stays_on_its_planes_when_the_cost_is_nearly_in_their_span(lane, o
             worst = max(worst, abs(xc[it >> 1] + x[it >> 1] - (hi if it & 1 else lo)[it >> 1]))
     # (the oracle's own simplex stops at reduced costs below an absolute 1e-9: it is the looser side on these rows)
     assert worst <= 5e-9, worst
+
+
+def test_walk_in_r4_on_rows_of_very_different_lengths(lane, oracle):
+    """Rows scaled by e^-2.5 .. e^2.5 (scripts/soak_lane.py, family `scaled`) in R^4.  Found by the soak (seed 112, a (19,4)
+    polytope, tests/golden/found/lane112_t11_k25610.npz): three active rows of norms 2.3 / 0.1 / 2.2, det of their Gram matrix
+    2.7e-6, and the cancellation residue of a zero multiplier (1.6e-16) fell below -LANE_TOL_D det: the row was dropped, the
+    direction on the two that stayed -- the cost parallel to one of them -- was rounding noise, and the walk followed it for
+    t = 1.8e15: box value +0.02 where the optimum is -1.26, two facets removed by the prefilter."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import soak_lane as SL
+    z = np.load(os.path.join(root, "tests", "golden", "found", "lane112_t11_k25610.npz"))
+    A, b = z["A"], z["b"]
+    st, r, xc = oracle.cheby(A, b)
+    assert st == 0 and r > 0.5
+    beta = np.maximum(b - A @ xc, 0.0)
+    for k in range(4):
+        for sgn in (1.0, -1.0):
+            c = np.zeros(4)
+            c[k] = sgn
+            sw, x = lane.solve_one4(A, beta, c)
+            so, xo, fo, _ = oracle.lp_solve(c, A, beta)
+            assert sw == so == 0 and abs(float(c @ x) - fo) <= 1e-10 * max(1.0, abs(fo)), (k, sgn, sw, float(c @ x), so, fo)
+    rng = np.random.default_rng(12)
+    for m in (9, 12, 16):
+        A, b, _ = SL.make(rng, 4000, m, 4, "scaled")
+        s = lane(A, b)
+        assert s["status_diff"] == 0 and s["max_diff"] <= 1e-10 and s["retry"] <= s["lps"] // 2000 + 2, s
