@@ -314,6 +314,8 @@ int plpo_lp_solve_q(int m, int n, const double *c, const double *G, const double
  * this oracle and the HIP library apply it to the certified / re-solved value.  scale = |c|_inf * max(1, max_i
  * |h_i| / |G_i|_inf). */
 #define PLPO_BIG 1e9
+#define PLPO_FAR 1e4            /* a certificate counts at a vertex within this many times the data's scale: see plpo_lp_solve */
+#define PLPO_SMALL_ENTRY 1e-9   /* HiGHS's small_matrix_value: see plpo_lp_solve */
 #define PLPO_TOL_PRIMAL 2e-14   /* (1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on an optimum of 235) */
 static double g_tol_dual = 1e-13;   /* a multiplier below this is rounding; between it and the engine's 1e-9: binary128 judges it by what it buys */
 #define PLPO_TOL_DUAL g_tol_dual
@@ -507,12 +509,37 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
 {
     static const double qnan = NAN;
     int basis[PLPO_MAXN + 2];
+    /* HiGHS -- the reference's solver behind scipy.optimize.linprog (solvers.py:152-158) -- treats matrix entries of magnitude
+     * <= 1e-9 as ZERO (its `small_matrix_value`; checked here on this image: min x0 s.t. -x0 + eps x1 <= 2, |x1| <= 1e6 gives
+     * -2 - 1e6 eps down to eps = 1.0000001e-9 and -2 from 1e-9 on).  So does this function, as the HIP library's verifier and
+     * careful engine do (LpView::g, csrc/plp_verify.hpp): a row tilted by 1e-16 from its twin is that twin for the reference,
+     * not a plane that meets it 1e16 away. */
+    double Gc[PLPO_MAXM * PLPO_MAXN];
+    if (g_certify && m <= PLPO_MAXM && n <= PLPO_MAXN && m >= 0 && n >= 1) {
+        for (int k = 0; k < m * n; ++k) Gc[k] = fabs(G[k]) <= PLPO_SMALL_ENTRY ? 0.0 : G[k];
+        G = Gc;
+    }
     int st = plpo_lp_solve_raw(m, n, c, G, h, x, fun, iters, basis);
     if (!g_certify || st == ST_INFEAS || m > PLPO_MAXM || n > PLPO_MAXN - 1 || n < 1) return st;
     /* (an "unbounded" of the double engine is not certified by its ray any more: the HIP library has no ray to look at and sends
      * every such LP to its careful engine -- the same flow here, or slivers end "unbounded" on one side and at a corner 1e8 away
      * on the other; lp_certify keeps the ray check for tests) */
-    if (st == ST_OPT && lp_certify(m, n, c, G, h, basis, st, x, fun)) {
+    int certified = st == ST_OPT && lp_certify(m, n, c, G, h, basis, st, x, fun);
+    if (certified) {
+        /* a certificate counts at a vertex within PLPO_FAR times the data's scale: its row test allows 2e-14 of |G_i| |x|, which
+         * 4e9 out is 1e-4 (LpView::far_vertex, csrc/plp_verify.hpp); far vertices go to binary128 */
+        double xmax = 0.0, hs = 1.0;
+        for (int j = 0; j < n; ++j) if (fabs(x[j]) > xmax) xmax = fabs(x[j]);
+        if (xmax > PLPO_FAR) {
+            for (int i = 0; i < m; ++i) {
+                double gm = 0.0;
+                for (int j = 0; j < n; ++j) if (fabs(G[i * n + j]) > gm) gm = fabs(G[i * n + j]);
+                if (gm > 0.0 && fabs(h[i]) > hs * gm) hs = fabs(h[i]) / gm;
+            }
+            if (xmax > PLPO_FAR * hs) certified = 0;
+        }
+    }
+    if (certified) {
         ++g_cert_stat[0];
     } else {
         if (st == ST_NUM) {   /* non-finite input (the raw engine's argument check): nothing to solve */
@@ -526,11 +553,13 @@ int plpo_lp_solve(int m, int n, const double *c, const double *G, const double *
         if (sq != st) ++g_cert_stat[2];
         st = sq;
     }
-    if (st == ST_OPT) {   /* out of range: the value, or the vertex (a sliver's corner 1e16 away: "unbounded" for HiGHS too) */
-        double cmax = 0.0, xmax = 0.0;
-        for (int j = 0; j < n; ++j) { if (fabs(c[j]) > cmax) cmax = fabs(c[j]); if (fabs(x[j]) > xmax) xmax = fabs(x[j]); }
+    if (st == ST_OPT) {
+        /* Out of range: the VALUE.  (Until the entries below 1e-9 were dropped as HiGHS drops them, a far VERTEX counted too --
+         * for the corners 1e16 away that rows an ulp apart define.  Those are gone with the entries; and where the optimal face
+         * is long -- the ball of an unbounded polytope can slide along it -- which of its vertices an engine ends on is an accident
+         * of its path, the value is not: tests/golden/found/wide104_t132_k295.npz, radius 3 with the centre 4e9 away.) */
         const double sc = lp_scale(m, n, c, G, h);
-        if (fabs(*fun) > PLPO_BIG * sc || (cmax > 0.0 && xmax > PLPO_BIG * (sc / cmax))) st = ST_UNBND;
+        if (fabs(*fun) > PLPO_BIG * sc) st = ST_UNBND;
     }
     if (st != ST_OPT) { for (int j = 0; j < n; ++j) x[j] = qnan; *fun = qnan; }
     return st;

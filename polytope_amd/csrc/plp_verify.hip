@@ -286,7 +286,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     }
     __syncthreads();
     if ((gl != 0) | (s_mode[li] == 0)) return;
-    if (s_ok[li] & (s_bad[li] == 0u)) {
+    if (s_ok[li] & (s_bad[li] == 0u) & !lp.far_vertex(s_xs[li])) {
         const Vec z = CT::at(ws, CT::O_Z);
         const double f = s_fun[li];
         double cmax = 0.0;   // (-c is in the workspace)
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256) void verify_small_kernel(VArgs a, Scratch sc) 
     if (ok) {
         for (int i = 0; i < lp.m; ++i) ok = ok & CT::row_feasible(lp, i, z, zs);
     }
+    if (ok) ok = !lp.far_vertex(zs);
     if (ok) {
         const bool out = range_rule(lp, V_OPT, f, zs) != V_OPT;
         if constexpr (KIND == LP_BOXSIDE) {

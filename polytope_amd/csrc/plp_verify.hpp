@@ -53,6 +53,8 @@ constexpr int VNMAX = 17;         // columns of an LP (d + 1)
 constexpr int VNC = VNMAX + 1;    // + the phase-1 artificial
 constexpr int VW = 20;            // doubles per dictionary row in the careful engine's scratch: VNC columns, beta, spare
 constexpr double V_BIG = 1e9;     // optimum beyond V_BIG x scale(data): unbounded
+constexpr double V_SMALL_ENTRY = 1e-9;   // matrix entries HiGHS drops (LpView::g)
+constexpr double V_FAR = 1e4;            // a certificate counts at a vertex within V_FAR x the data's scale (LpView::far_vertex)
 constexpr double V_TOL_DUAL = 1e-13;  // a multiplier below this (of |c| / |G_k|) is rounding; see the note on tolerances below
 constexpr double V_TOL_PRIMAL = 2e-14;  // (ten ulps of |G_i| |x|: the fma chain itself is good to n / 2 ulps; 1e-13 left 1.2e-9 of a sliver's 2.6e7; 1e-10 let through a vertex 1e-8 outside a twin row: 7e-7 on the optimum of 235, seed 4 of verify_smoke)
 constexpr double C_TOL_D = 1e-9, C_TOL_PIV = 1e-12, C_TOL_FEAS = 1e-7, C_DEGEN = 1e-24;
@@ -71,15 +73,20 @@ struct LpView {
     const double* G;  // generic: G; otherwise A (m x d, d = n - 1 for LP_CHEBY)
     const double* h;
     const double* c;  // generic only
+    // HiGHS -- the reference's solver (solvers.py:152-158) -- takes matrix entries of magnitude <= 1e-9 for ZERO (its
+    // small_matrix_value; checked on this image, oracle/plp_oracle.c: plpo_lp_solve): the LP this view describes is the LP with
+    // those entries dropped -- a row tilted by 1e-16 from its twin IS that twin, not a plane that meets it 1e16 away.  (The
+    // norms of F1 are formed by numpy from the full rows before HiGHS sees them: from the undropped entries here too.)
+    static PLP_HD double kept(double v) { return fabs(v) <= V_SMALL_ENTRY ? 0.0 : v; }
     PLP_HD double g(int i, int j) const {
         if (kind == LP_CHEBY) {
             const int d = n - 1;
-            if (j < d) return G[(long)i * d + j];
+            if (j < d) return kept(G[(long)i * d + j]);
             double s = 0.0;
             for (int k = 0; k < d; ++k) s = s + G[(long)i * d + k] * G[(long)i * d + k];
-            return sqrt(s);
+            return kept(sqrt(s));
         }
-        return G[(long)i * n + j];
+        return kept(G[(long)i * n + j]);
     }
     PLP_HD double hh(int i) const { return h[i]; }
     PLP_HD double cc(int j) const {
@@ -97,15 +104,22 @@ struct LpView {
         for (int j = 0; j < n; ++j) cm = fmax(cm, fabs(cc(j)));
         return cm;
     }
-    // |c|_inf * max(1, max_i |h_i| / |G_i|_inf): what "out of range" is measured against
-    PLP_HD double scale() const {
+    // max(1, max_i |h_i| / |G_i|_inf): how far from the origin the data puts its planes
+    PLP_HD double h_scale() const {
         double hs = 1.0;
         for (int i = 0; i < m; ++i) {
             const double gm = row_inf(i);
             if (gm > 0.0 && fabs(hh(i)) > hs * gm) hs = fabs(hh(i)) / gm;
         }
-        return c_inf() * hs;
+        return hs;
     }
+    // |c|_inf * h_scale(): what "out of range" is measured against
+    PLP_HD double scale() const { return c_inf() * h_scale(); }
+    // A certificate is taken from a vertex within V_FAR x h_scale() only.  Its row test allows 2e-14 of |G_i| |x|: at a vertex
+    // 4e9 out -- where the free variables of a basis were held at a Chebyshev centre that had slid along an unbounded face -- that
+    // is 1e-4, and a box side of -3.0000001 passed against a row that puts it at -3.000000025 (tests/golden/found/
+    // wide104_t132_k295.npz).  Far vertices are for the careful engine, whose arithmetic has the digits.
+    PLP_HD bool far_vertex(double xmax) const { return xmax > V_FAR && xmax > V_FAR * h_scale(); }
 };
 
 // ---------------------------------------------------------------------------------------------------- LU, refined solves
@@ -1046,22 +1060,18 @@ PLP_HD int careful_solve(const LpView& lp, const CarefulMem& M, double* x, doubl
 }
 
 // what every caller does with an optimum: out of range -> unbounded.  Out of range: the VALUE beyond BIG times the scale of
-// the data, or the VERTEX (xmax = |x|_inf) beyond BIG times the scale of the rows -- a sliver's far corner, 1e16 away, is where
-// the exact LP has its optimum and where HiGHS (and any double-precision code) says "unbounded".
+// the data.  (xmax = |x|_inf is no longer looked at: a far vertex counted while rows an ulp apart still met 1e16 away; with the
+// entries below 1e-9 dropped as HiGHS drops them those corners are gone, and on a long optimal face -- the ball of an unbounded
+// polytope slides along it -- the vertex an engine ends on is an accident of its path, the value is not.)
 PLP_HD int range_rule_c(const LpView& lp, int status, double fun, double xmax, double cmax) {   // cmax = |c|_inf
+    (void)xmax;
     if (status != V_OPT) return status;
-    if (!(fabs(fun) > V_BIG * cmax) && !(xmax > V_BIG)) return status;
-    const double sc = lp.scale();
-    if (fabs(fun) > V_BIG * sc) return V_UNBND;
-    return (cmax > 0.0 && xmax > V_BIG * (sc / cmax)) ? V_UNBND : status;
+    if (!(fabs(fun) > V_BIG * cmax)) return status;   // (the scale is at least |c|_inf: a pass over the rows only where it can matter)
+    return fabs(fun) > V_BIG * lp.scale() ? V_UNBND : status;
 }
 PLP_HD int range_rule(const LpView& lp, int status, double fun, double xmax) {
     if (status != V_OPT) return status;
-    const double cmax = lp.c_inf();
-    if (!(fabs(fun) > V_BIG * cmax) && !(xmax > V_BIG)) return status;   // (the scale is at least |c|_inf: a pass over the rows only where it can matter)
-    const double sc = lp.scale();
-    if (fabs(fun) > V_BIG * sc) return V_UNBND;
-    return (cmax > 0.0 && xmax > V_BIG * (sc / cmax)) ? V_UNBND : status;
+    return range_rule_c(lp, status, fun, xmax, lp.c_inf());
 }
 
 }  // namespace verify

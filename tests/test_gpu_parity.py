@@ -503,6 +503,41 @@ def test_bbox_and_cheby_on_rows_a_hair_apart_reference_fixture(pa):
     assert n_ref >= 540 and n_r >= 570, (n_ref, n_r)
 
 
+def test_polytopes_the_soaks_found(pa, oracle):
+    """tests/golden/found/*.npz: the polytopes on which a soak campaign of 25 M found the library and the oracle apart (DESIGN.md
+    4.8, "what the last soak campaign found"): the fused reduce against the oracle's (keep mask, flags, LP count exact; as single
+    polytopes and inside a batch large enough for the lane kernels), the stand-alone ball and box against the certified oracle."""
+    import glob
+    import torch
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "found", "*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        z = np.load(f)
+        A, b = z["A"], z["b"]
+        m, d = A.shape
+        ref = oracle.reduce(A, b)
+        for B in (1, 36000 if d <= 4 else 300):
+            At = torch.as_tensor(np.repeat(A[None], B, 0)).cuda()
+            bt = torch.as_tensor(np.repeat(b[None], B, 0)).cuda()
+            rd = pa.reduce_batch(At, bt)
+            keep = rd["keep"].cpu().numpy().view(np.uint64)
+            assert set(int(k) for k in keep) == {ref["mask"]}, (f, B, hex(int(keep[0])), hex(ref["mask"]))
+            assert set(rd["flags"].cpu().numpy().tolist()) == {ref["flags"]} and set(rd["nlp"].cpu().numpy().tolist()) == {ref["nlp"]}, (f, B)
+        At, bt = torch.as_tensor(A[None]).cuda(), torch.as_tensor(b[None]).cuda()
+        ch = pa.cheby_ball_batch(At, bt)
+        st, r, _ = oracle.cheby(A, b)
+        assert int(ch["status"][0]) == st, (f, int(ch["status"][0]), st)
+        if st == 0:
+            assert abs(float(ch["r"][0]) - r) <= 1e-9 * max(1.0, abs(r)), (f, float(ch["r"][0]), r)
+        bb = pa.bbox_batch(At, bt)
+        lo, hi, bad = oracle.bounding_box(A, b)[:3]
+        if bb is not None and int(bb["status"][0]) == 0 and bad == 0:
+            fin = np.isfinite(np.concatenate([lo, hi]))
+            ext = max(1.0, float(np.abs(np.concatenate([lo, hi])[fin]).max())) if fin.any() else 1.0
+            assert _sides_equal(np.concatenate([bb["lb"][0].cpu().numpy(), bb["ub"][0].cpu().numpy()]), np.concatenate([lo, hi]), ext, 1e-9), (
+                f, bb["lb"][0].cpu().numpy(), lo, bb["ub"][0].cpu().numpy(), hi)
+
+
 def test_bbox_batches_on_rows_a_hair_apart(pa, oracle):
     """g22 as BATCHES per shape through plp_bbox_batch / plp_cheby_batch (every fused kernel family: lanes, lane groups, one
     polytope per wavefront and its small-batch form, with and without a stored dictionary) against the fixture's oracle values."""
