@@ -100,6 +100,48 @@ def prefilter_tie(Ak, bk, margin=1e-6):
     return bool(np.any(np.abs(val + 1e-4) < margin * ext))
 
 
+def _classes(A, b, keep):
+    """the kept rows as classes: rows that coincide to 1e-12 stand for one another (tests/test_oracle_golden.py: _twin_classes)"""
+    nrm = np.sqrt((A * A).sum(1))
+    An, bn = A / nrm[:, None], b / nrm
+    rep = np.arange(len(b))
+    for i in range(len(b)):
+        for j in range(i):
+            if np.abs(An[i] - An[j]).max() < 1e-12 and abs(bn[i] - bn[j]) < 1e-12 * max(1.0, abs(bn[i])):
+                rep[i] = rep[j]
+                break
+    return np.unique(rep[np.asarray(keep, bool)])
+
+
+def public_reduce_agrees(Ak, bk, oracle_mask):
+    """RF_F1OPEN (flags & 32) in the fused kernel's answer and not in the oracle's: the kernel's Chebyshev LP ended "unbounded", at
+    a limit, or at a centre outside the polytope where the oracle's did not (the two engines are restatements of one another, not
+    bit-for-bit twins on rows a hair apart).  The flag MEANS "not answered here": polytope_amd.polytope.reduce re-examines such a
+    polytope through the verified LPs.  So does this check: the product's public reduce() must keep the rows the oracle keeps."""
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    try:
+        q = pc.reduce(pc.Polytope(Ak.copy(), bk.copy(), normalize=False))
+    finally:
+        solvers.default_solver = old
+    m = len(bk)
+    want = np.array([(oracle_mask >> i) & 1 for i in range(m)], bool)
+    if q.A.size == 0:
+        return not want.any()
+    nrm = np.sqrt((Ak * Ak).sum(1))
+    An, bn = Ak / nrm[:, None], bk / nrm
+    keep = np.zeros(m, bool)
+    for a, bb in zip(q.A, q.b):
+        dist = np.abs(An - a).max(1) + np.abs(bn - bb) / max(1.0, abs(bb))
+        best = int(np.argmin(dist))
+        if dist[best] > 1e-9:
+            return False
+        keep[best] = True
+    return np.array_equal(_classes(Ak, bk, keep), _classes(Ak, bk, want))
+
+
 def make(rng, B, m, d, fam):
     A = rng.standard_normal((B, m, d))
     A /= np.linalg.norm(A, axis=2, keepdims=True)
@@ -160,6 +202,7 @@ def main():
     n_oracle_off = 0   # answers on nearly duplicated rows where HiGHS sides with the kernel against the oracle
     n_cond = 0         # boxes that differ by less than the conditioning of rows a hair apart allows (hair_tol)
     n_tie = 0          # polytopes whose LP count alone differs, a row sitting on the prefilter's threshold (prefilter_tie)
+    n_open = 0         # polytopes the fused kernel handed back (RF_F1OPEN) where the oracle's engine answered; public reduce() checked
     t0 = time.time()
     for trial in range(trials):
         d = int(rng.choice([1, 2, 3, 3, 3, 4, 4]))
@@ -200,6 +243,9 @@ def main():
                     and prefilter_tie(A[k, :mrows[k]], b[k, :mrows[k]]):
                 ok = True          # only the LP count differs, and a row sits on the prefilter's threshold (see prefilter_tie)
                 n_tie += 1
+            if not ok and (int(flags[k]) & 32) and not (fl & 32) and public_reduce_agrees(A[k, :mrows[k]], b[k, :mrows[k]], mk):
+                ok = True          # the kernel handed the polytope back (RF_F1OPEN); the public reduce() keeps the oracle's rows
+                n_open += 1
             if not ok:
                 nb += 1
                 first = first if first is not None else (k, hex(int(keep[k])), hex(mk), int(flags[k]), fl, int(nlp[k]), nl, r[k], rr)
@@ -229,7 +275,8 @@ def main():
             flush=True)
     print("LANE SOAK %s: %d polytopes, %d mismatches, %.0f s  (radii on nearly duplicated rows where HiGHS sides with the fused "
           "kernel against the oracle's raw engine: %d; LP counts that differ on a prefilter tie: %d; boxes within the conditioning of "
-          "rows a hair apart: %d)" % ("FAILED" if bad else "OK", npoly, bad, time.time() - t0, n_oracle_off, n_tie, n_cond), flush=True)
+          "rows a hair apart: %d; handed back by the fused kernel (RF_F1OPEN) and right through the public reduce(): %d)" % (
+              "FAILED" if bad else "OK", npoly, bad, time.time() - t0, n_oracle_off, n_tie, n_cond, n_open), flush=True)
     pool.close()
     return 1 if bad else 0
 

@@ -28,7 +28,7 @@ def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
     fams = ["random", "ragged", "unbounded", "dup", "scaled", "flat", "lattice"]
-    bad = npoly = n_off = n_tie = n_cond = 0
+    bad = npoly = n_off = n_tie = n_cond = n_open = 0
     t0 = time.time()
     for trial in range(trials):
         d = int(rng.choice([4, 5, 5, 6, 6, 7, 8, 8, 9, 10, 12, 13, 14, 16]))
@@ -57,6 +57,9 @@ def main():
                     and SL.prefilter_tie(A[k, :mrows[k]], b[k, :mrows[k]]):
                 ok = True          # only the LP count differs, and a row sits on the prefilter's threshold (soak_lane.prefilter_tie)
                 n_tie += 1
+            if not ok and (int(flags[k]) & 32) and not (fl & 32) and SL.public_reduce_agrees(A[k, :mrows[k]], b[k, :mrows[k]], mk):
+                ok = True          # the kernel handed the polytope back (RF_F1OPEN); the public reduce() keeps the oracle's rows
+                n_open += 1
             if not ok:
                 nb += 1
                 first = first if first is not None else (k, hex(int(keep[k])), hex(mk), int(flags[k]), fl, int(nlp[k]), nl, r[k], rr)
@@ -92,7 +95,8 @@ def main():
             trial, d, m, B, fam, nb, nc, nbb, "" if first is None else first), flush=True)
     print("WIDE SOAK %s: %d polytopes, %d mismatches, %.0f s  (radii on nearly duplicated rows where HiGHS sides with the fused kernel "
           "against the oracle's raw engine: %d; LP counts that differ on a prefilter tie: %d; boxes within the conditioning of rows a hair "
-          "apart: %d)" % ("FAILED" if bad else "OK", npoly, bad, time.time() - t0, n_off, n_tie, n_cond), flush=True)
+          "apart: %d; handed back by the fused kernel (RF_F1OPEN) and right through the public reduce(): %d)" % (
+              "FAILED" if bad else "OK", npoly, bad, time.time() - t0, n_off, n_tie, n_cond, n_open), flush=True)
     pool.close()
     return 1 if bad else 0
 

@@ -9,6 +9,7 @@ Bars: status / keep masks / booleans / indices exact; Chebyshev radii and object
 within 1e-9 (north_star); centres only validated as feasible (not unique).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -521,8 +522,16 @@ def test_polytopes_the_soaks_found(pa, oracle):
             bt = torch.as_tensor(np.repeat(b[None], B, 0)).cuda()
             rd = pa.reduce_batch(At, bt)
             keep = rd["keep"].cpu().numpy().view(np.uint64)
+            fl = set(rd["flags"].cpu().numpy().tolist())
+            if fl == {33} and not (ref["flags"] & 32):
+                # handed back (RF_F1OPEN: the kernel's Chebyshev LP did not end where the oracle's did): "not answered here" --
+                # the public reduce(), which re-examines such a polytope through the verified LPs, must keep the oracle's rows
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+                import soak_lane as SL
+                assert SL.public_reduce_agrees(A, b, ref["mask"]), (f, B)
+                continue
             assert set(int(k) for k in keep) == {ref["mask"]}, (f, B, hex(int(keep[0])), hex(ref["mask"]))
-            assert set(rd["flags"].cpu().numpy().tolist()) == {ref["flags"]} and set(rd["nlp"].cpu().numpy().tolist()) == {ref["nlp"]}, (f, B)
+            assert fl == {ref["flags"]} and set(rd["nlp"].cpu().numpy().tolist()) == {ref["nlp"]}, (f, B)
         At, bt = torch.as_tensor(A[None]).cuda(), torch.as_tensor(b[None]).cuda()
         ch = pa.cheby_ball_batch(At, bt)
         st, r, _ = oracle.cheby(A, b)
