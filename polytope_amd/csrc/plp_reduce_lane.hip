@@ -284,25 +284,35 @@ __device__ __forceinline__ void reduce_lane_tile(
     // 1/||a_i|| in LDS -- every LP of the polytope reads it as it is (the lane-group kernels keep s_i = a_i.xc and form
     // b_i - s_i in every LP set-up: the same number)
     // A centre that violates a row (centre_off, plp_common.hpp) is no centre.  An interior centre leaves every b_i - a_i.xc
-    // positive, so the test proper runs only in a wavefront that saw a negative one (one compare per row otherwise: the full
-    // test on every row cost the bench 1.0 %, same-box A/B).
-    double raw[R];
+    // positive, so the test proper runs only in a wavefront that saw a negative one, and forms everything it needs again
+    // from the rows (nothing is kept for it across the branch: four doubles held for it were an 8-byte spill store per lane in the hot
+    // path -- WRITE_SIZE 6.2 -> 10.2 MB per launch).  The hot path pays one compare per row (+0.3 % on the bench step; the full
+    // test on every row: +1.0 %, same-box A/B).
     bool neg = false;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         double sk = 0.0;
 #pragma unroll
         for (int kk = 0; kk < D; ++kk) sk = fma(((has >> k) & 1u) ? OA(k, kk) : 0.0, ball ? xc[kk] : 0.0, sk);
-        raw[k] = (((has >> k) & 1u) ? OB(k) : 0.0) - sk;
-        neg = neg | (raw[k] < 0.0);
+        const double raw = (((has >> k) & 1u) ? OB(k) : 0.0) - sk;
+        neg = neg | (raw < 0.0);
+        ON(k) = fmax(raw, 0.0);
     }
     if (__any(neg & ball)) {
         bool off = false;
         const double xs = centre_scale<D>(xc);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const double bk = ((has >> k) & 1u) ? OB(k) : 0.0;
-            off = off | ((((has >> k) & 1u) != 0u) & centre_off(raw[k], ON(k), bk, xs));
+            const bool hk = ((has >> k) & 1u) != 0u;
+            double sk = 0.0, nrm2 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < D; ++kk) {
+                const double v = hk ? OA(k, kk) : 0.0;
+                sk = fma(v, ball ? xc[kk] : 0.0, sk);
+                nrm2 = nrm2 + v * v;
+            }
+            const double bk = hk ? OB(k) : 0.0;
+            off = off | (hk & centre_off(bk - sk, 1.0 / sqrt(nrm2), bk, xs));   // (1 / |a|: the value F1's set-up stored)
         }
         if (ball & (grp_ballot(off, g) != 0)) {   // F1 "optimal" outside the polytope: nothing below may start from it
             ball = false; fulldim = false; f1open = true;
@@ -313,8 +323,6 @@ __device__ __forceinline__ void reduce_lane_tile(
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < R; ++k) ON(k) = fmax(raw[k], 0.0);
     // rows that dropped out (never present, or removed by the dedupe / the prefilter) are zeroed -- A, b and s -- by their
     // owner lane: a zero row never stops a ray and passes every presolve test
     auto zero_dead = [&](unsigned alive) {
