@@ -779,8 +779,8 @@ def main():
             if tj.get("kernel") != kname:
                 raise KeyError("counters of another kernel")
             traffic = tj["hbm_bytes_per_launch"]
-            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_busy_frac_measured", "effective_clock_GHz", "source")
-                    if k in tj}
+            valu = {k: tj[k] for k in ("valu_insts_per_launch", "valu_busy_frac_measured", "busy_frac_basis", "effective_clock_GHz", "source")
+                    if tj.get(k) is not None}
             traffic_src = "profiles/latest_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
         except Exception:
             pass

@@ -286,7 +286,7 @@ __device__ __forceinline__ void reduce_lane_tile(
     // A centre that violates a row (centre_off, plp_common.hpp) is no centre.  An interior centre leaves every b_i - a_i.xc
     // positive, so the test proper runs only in a wavefront that saw a negative one, and forms everything it needs again
     // from the rows (nothing is kept for it across the branch: four doubles held for it were an 8-byte spill store per lane in the hot
-    // path -- WRITE_SIZE 6.2 -> 10.2 MB per launch).  The hot path pays one compare per row (+0.3 % on the bench step; the full
+    // path -- WRITE_SIZE 6.2 -> 10.2 MB per launch).  The hot path pays one compare per row (+0.4 % on the bench step; the full
     // test on every row: +1.0 %, same-box A/B).
     bool neg = false;
 #pragma unroll

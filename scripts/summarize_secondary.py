@@ -95,8 +95,15 @@ if vals:
     if "SQ_ACTIVE_INST_VALU" in vals and "SQ_INSTS_VALU" in vals:
         d["quad_cycles_per_valu_inst_measured"] = vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_INSTS_VALU"]
     if "SQ_ACTIVE_INST_VALU" in vals and "GRBM_GUI_ACTIVE" in vals:
-        # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles summed over all SIMDs (1024)
+        # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles summed over all SIMDs (1024).  The cycles they are divided by:
+        # GRBM_GUI_ACTIVE of the same dispatch -- unless that window is visibly not the kernel's (an effective clock beyond the
+        # part's 2.4 GHz: the counter spans more than the dispatch; r06c: 8.5 GHz), then the traced duration at 2.4 GHz.
         simd_cycles = 1024 * d["kernel_cycles_per_xcd"]
+        d["busy_frac_basis"] = "GRBM_GUI_ACTIVE"
+        if not (1.0 <= d["effective_clock_GHz"] <= 2.45):
+            simd_cycles = 1024 * kfull["avg_ns"] * 2.4
+            d["busy_frac_basis"] = "traced duration at 2.4 GHz (GRBM_GUI_ACTIVE spans more than the dispatch: %.2f GHz)" % d["effective_clock_GHz"]
+            d["effective_clock_GHz"] = None
         d["valu_busy_frac_measured"] = vals["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles
         if "SQ_WAVE_CYCLES" in vals:
             d["mean_resident_waves_per_simd"] = vals["SQ_WAVE_CYCLES"] * 4 / simd_cycles
@@ -114,7 +121,7 @@ if vals:
                   "hbm_write_bytes": d["hbm_write_bytes"], "rocprof_avg_kernel_ns": kfull["avg_ns"],
                   "valu_insts_per_launch": vals.get("SQ_INSTS_VALU"),
                   "valu_busy_frac_measured": d.get("valu_busy_frac_measured"),
-                  "effective_clock_GHz": d.get("effective_clock_GHz"),
+                  "effective_clock_GHz": d.get("effective_clock_GHz"), "busy_frac_basis": d.get("busy_frac_basis"),
                   "source": "profiles/%s/%s_reduce_counters.json" % (rnd, tag)}
         json.dump(latest, open(os.path.join(root, "profiles", "latest_traffic.json"), "w"), indent=1)
     print(json.dumps(out["derived"], indent=1))
