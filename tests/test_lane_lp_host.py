@@ -275,3 +275,41 @@ def test_walk_in_r4_on_rows_of_very_different_lengths(lane, oracle):
         A, b, _ = SL.make(rng, 4000, m, 4, "scaled")
         s = lane(A, b)
         assert s["status_diff"] == 0 and s["max_diff"] <= 1e-10 and s["retry"] <= s["lps"] // 2000 + 2, s
+
+
+def test_walk_in_r3_on_half_infinite_prisms(lane, oracle):
+    """walk3 (the bench kernel's engine) where walk4 failed (above): unbounded polytopes -- half-infinite prisms -- with rows
+    scaled by e^-2.5 .. e^2.5 and near-copies of rows (nearly degenerate vertices), costs orthogonal to the unbounded edge (a finite
+    optimum attained along a ray: a multiplier that is zero up to rounding must not send the walk down that ray as "unbounded")
+    and general ones.  Status equal to the oracle's on every LP, optimum within 1e-10."""
+    rng = np.random.default_rng(31)
+    n_lp = 0
+    for trial in range(900):
+        u = rng.standard_normal(3)
+        u /= np.linalg.norm(u)
+        m = int(rng.integers(5, 16))
+        N = rng.standard_normal((m, 3))
+        N -= np.outer(N @ u, u)
+        N /= np.linalg.norm(N, axis=1)[:, None]
+        b = 0.5 + rng.random(m)
+        N[0], b[0] = -u, 1.0
+        if trial % 3 >= 1:
+            N *= np.exp(rng.uniform(-2.5, 2.5, m))[:, None]
+            b *= np.linalg.norm(N, axis=1)
+        if trial % 3 == 2:
+            N[rng.integers(1, m)] = N[rng.integers(1, m)] * (1 + 1e-3 * rng.standard_normal())
+        A16, b16 = np.zeros((16, 3)), np.zeros(16)
+        A16[:m], b16[:m] = N, b
+        for rep in range(6):
+            c = rng.standard_normal(3)
+            if rep < 4:
+                c -= (c @ u) * u
+            sw, x = lane.solve_one(A16, b16, c)
+            so, xo, fo, _ = oracle.lp_solve(c, N, b)
+            n_lp += 1
+            if sw == 5:      # handed back
+                continue
+            assert sw == so, (trial, rep, sw, so)
+            if sw == 0:
+                assert abs(float(c @ x) - fo) <= 1e-10 * max(1.0, abs(fo)), (trial, rep, float(c @ x), fo)
+    assert n_lp == 5400
