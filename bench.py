@@ -70,7 +70,7 @@ def cpu_baseline(A, b, nlp_gpu):
         out["scipy_linprog_1proc_lp_per_s"] = cnt / t1
         os.environ.setdefault("OMP_NUM_THREADS", "1")
         os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
-        # the all-cores sample: a pilot of two tasks per worker gives the rate, the timed sample is sized for ~12 s of it
+        # the all-cores sample: a pilot of two tasks per worker gives the rate, the timed sample is sized for >= 10 s of clock
         # (tasks of 4 polytopes = 64 LPs, ~40 ms: the pool's dispatch is noise)
         per_task = 4
         avail = (A.shape[0] - ns) // per_task
@@ -80,7 +80,7 @@ def cpu_baseline(A, b, nlp_gpu):
             t0 = time.perf_counter()
             pilot = pool.map(_scipy_chunk, mk(0, min(2 * ncpu, avail)), chunksize=1)
             rate = sum(pilot) / (time.perf_counter() - t0)
-            ntask = int(min(avail, max(2 * ncpu, 12.0 * rate / (M_ROWS * per_task))))
+            ntask = int(min(avail, max(2 * ncpu, 16.0 * rate / (M_ROWS * per_task))))   # (the pilot runs ~1.3 x the sample's rate: 16 s of it is >= 10 s of clock)
             chunks = mk(0, ntask)
             t0 = time.perf_counter()
             res = pool.map(_scipy_chunk, chunks, chunksize=1)
