@@ -504,6 +504,36 @@ def test_bbox_and_cheby_on_rows_a_hair_apart_reference_fixture(pa):
     assert n_ref >= 540 and n_r >= 570, (n_ref, n_r)
 
 
+def test_small_matrix_entries_as_the_references_solver_reads_them_gpu(pa):
+    """g24: the reference's lpsolve / bounding_box on LPs with one entry eps on a ladder around 1e-9 and a lever of 1e3 / 1e6 behind
+    it (HiGHS takes |entry| <= 1e-9 for zero) -- through the product's public lpsolve(solver='hip'), its batch form, and
+    bounding_box on the 'hip' backend: the reference's answer on every one."""
+    import torch
+    import polytope_amd.polytope as pc
+    from polytope_amd import solvers
+    from test_oracle_golden import _g24_check
+    g = load_golden("g24_small_entries.npz")
+    old = solvers.default_solver
+    solvers.default_solver = "hip"
+    try:
+        for i in range(len(g["kind"])):
+            def lp(c, G, h):
+                r = solvers.lpsolve(c, G, h, solver="hip")
+                return int(r["status"]), float(r["fun"]) if r["status"] == 0 else float("nan")
+
+            def bb(A, b):
+                lo, hi = pc.bounding_box(pc.Polytope(A.copy(), b.copy(), normalize=False))
+                return float(lo[0, 0]), float(hi[0, 0])
+            _g24_check(i, g, lp, bb)
+    finally:
+        solvers.default_solver = old
+    lev = np.nonzero(g["kind"] == "lever")[0]
+    res = pa.lpsolve_batch(torch.as_tensor(g["c"][lev]).cuda(), torch.as_tensor(g["G"][lev]).cuda(), torch.as_tensor(g["h"][lev]).cuda())
+    st, fun = res["status"].cpu().numpy(), res["fun"].cpu().numpy()
+    assert np.array_equal(st, g["status"][lev])
+    assert np.all(np.abs(fun - g["fun"][lev]) <= 1e-9 * np.maximum(1.0, np.abs(g["fun"][lev])))
+
+
 def test_polytopes_the_soaks_found(pa, oracle):
     """tests/golden/found/*.npz: the polytopes on which a soak campaign of 25 M found the library and the oracle apart (DESIGN.md
     4.8, "what the last soak campaign found"): the fused reduce against the oracle's (keep mask, flags, LP count exact; as single
