@@ -51,7 +51,7 @@ __host__ __device__ __forceinline__ bool centre_off(double raw, double inv_nrm, 
 #if defined(PLP_NO_CENTRE_CHECK)   // (A/B builds only: what the test costs)
     return false;
 #endif
-    return isfinite(inv_nrm) & (raw * inv_nrm < -TOL_CENTRE * fmax(fabs(bi) * inv_nrm, xs));
+    return isfinite(inv_nrm) && (raw * inv_nrm < -TOL_CENTRE * fmax(fabs(bi) * inv_nrm, xs));
 }
 template <int D>
 __host__ __device__ __forceinline__ double centre_scale(const double* xc) {

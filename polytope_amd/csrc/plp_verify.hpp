@@ -628,7 +628,7 @@ static PLP_HD void cand_add(double* ws, int& cn, double s, int i) {
     if constexpr (NF > 0) {   // (static indices only)
         int pos = 0;
         PLP_UNROLL
-        for (int k = 0; k < KC; ++k) pos += ((k < cn) & ((cs[k] < s) | ((cs[k] == s) & (ci[k] < (double)i)))) ? 1 : 0;
+        for (int k = 0; k < KC; ++k) pos += ((k < cn) && ((cs[k] < s) || ((cs[k] == s) && (ci[k] < (double)i)))) ? 1 : 0;
         PLP_UNROLL
         for (int k = KC - 1; k > 0; --k) {
             if ((k > pos) & (k <= cn)) { cs[k] = cs[k - 1]; ci[k] = ci[k - 1]; }
