@@ -1472,11 +1472,16 @@ def _renormalised(p, ops):
     changed = False
     k = 0
     quiet = 0
-    while k < len(ops) and quiet < 3:
+    only_p = "R" not in ops    # (a pass that changes nothing is followed by passes that change nothing: one quiet pass ends it)
+    while k < len(ops) and quiet < (1 if only_p else 3):
         if ops[k] == "P":
             norms = np.sqrt(np.add.reduce(A * A, 1))
             if not np.minimum.reduce(norms) > 1e-10:
                 return p.copy()   # (a row the constructor would drop: not a piece of a difference; the plain copy)
+            if np.all(norms == 1.0):      # scaling by exactly 1: nothing moves (box rows; most rows after a pass or two)
+                quiet += 1
+                k += 1
+                continue
             scale = 1 / norms
             A2, b2 = A * scale[:, None], b * scale
         else:
