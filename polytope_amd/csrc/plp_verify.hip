@@ -117,6 +117,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
     __shared__ int s_ok[LPB];
     __shared__ unsigned s_bad[LPB];
     __shared__ double s_xs[LPB], s_fun[LPB];
+    __shared__ unsigned long long s_hs[LPB];   // bits of max(1, max_i |h_i| / |G_i|_inf), gathered by pass 2
     const int li = threadIdx.x / GSL, gl = threadIdx.x % GSL;
     const long long t = (long long)blockIdx.x * LPB + li;
     const bool valid = t < a.T;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         s_cn[li] = 0;
         s_ok[li] = 0;
         s_bad[li] = 0u;
+        s_hs[li] = (unsigned long long)__double_as_longlong(1.0);
     }
     __syncthreads();
     // ---- the engine's point / basis into the workspace, an entry per lane in turn (one lane alone pays a global-memory round
@@ -281,12 +283,14 @@ __global__ __launch_bounds__(VBLK) void verify_kernel(VArgs a, Scratch sc) {
         const Vec z = CT::at(ws, CT::O_Z);
         const double zs = s_xs[li];
         bool bad = false;
-        for (int i = gl; i < lp.m; i += GSL) bad = bad | !CT::row_feasible(lp, i, z, zs);
+        double hs = 1.0;
+        for (int i = gl; i < lp.m; i += GSL) bad = bad | !CT::row_feasible_hs(lp, i, z, zs, &hs);
         if (bad) atomicOr(&s_bad[li], 1u);
+        if (hs > 1.0) atomicMax(&s_hs[li], (unsigned long long)__double_as_longlong(hs));   // (positive doubles order like their bits)
     }
     __syncthreads();
     if ((gl != 0) | (s_mode[li] == 0)) return;
-    if (s_ok[li] & (s_bad[li] == 0u) & !lp.far_vertex(s_xs[li])) {
+    if (s_ok[li] & (s_bad[li] == 0u) & !LpView::far_vertex_hs(s_xs[li], __longlong_as_double((long long)s_hs[li]))) {
         const Vec z = CT::at(ws, CT::O_Z);
         const double f = s_fun[li];
         double cmax = 0.0;   // (-c is in the workspace)
@@ -456,9 +460,10 @@ __global__ __launch_bounds__(256) void verify_small_kernel(VArgs a, Scratch sc) 
     else if (mode == 2) ok = true;
     if (ok) ok = CT::vertex_and_dual(lp, true, true, ws, &f, &zs);
     if (ok) {
-        for (int i = 0; i < lp.m; ++i) ok = ok & CT::row_feasible(lp, i, z, zs);
+        double hs = 1.0;
+        for (int i = 0; i < lp.m; ++i) ok = ok & CT::row_feasible_hs(lp, i, z, zs, &hs);
+        if (ok) ok = !LpView::far_vertex_hs(zs, hs);
     }
-    if (ok) ok = !lp.far_vertex(zs);
     if (ok) {
         const bool out = range_rule(lp, V_OPT, f, zs) != V_OPT;
         if constexpr (KIND == LP_BOXSIDE) {

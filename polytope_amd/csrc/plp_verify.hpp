@@ -120,6 +120,8 @@ struct LpView {
     // is 1e-4, and a box side of -3.0000001 passed against a row that puts it at -3.000000025 (tests/golden/found/
     // wide104_t132_k295.npz).  Far vertices are for the careful engine, whose arithmetic has the digits.
     PLP_HD bool far_vertex(double xmax) const { return xmax > V_FAR && xmax > V_FAR * h_scale(); }
+    // the same with h_scale() handed in (the device's row passes gather it as they go: max(1, max_i |h_i| / |G_i|_inf))
+    static PLP_HD bool far_vertex_hs(double xmax, double hs) { return xmax > V_FAR && xmax > V_FAR * hs; }
 };
 
 // ---------------------------------------------------------------------------------------------------- LU, refined solves
@@ -460,6 +462,16 @@ static PLP_HD bool row_feasible(const LpView& lp, int i, Vec z, double xs) {
     double gmax;
     const double s = row_slack(lp, i, z, &gmax);
     return !(s < -V_TOL_PRIMAL * fmax(gmax * xs, fabs(lp.hh(i))));
+}
+// the same, and the row's share of LpView::h_scale() into *hs (the pass has the row in hand: far_vertex_hs needs no pass of its own --
+// on data 1e5 from the origin every vertex is beyond V_FAR, and a leader lane walking all m x n entries for the scale doubled
+// the kernel's time there)
+static PLP_HD bool row_feasible_hs(const LpView& lp, int i, Vec z, double xs, double* hs) {
+    double gmax;
+    const double s = row_slack(lp, i, z, &gmax);
+    const double ah = fabs(lp.hh(i));
+    if (gmax > 0.0 && ah > *hs * gmax) *hs = ah / gmax;
+    return !(s < -V_TOL_PRIMAL * fmax(gmax * xs, ah));
 }
 
 // row k of the basis matrix (both copies) and of its right-hand side; false: an index out of range
